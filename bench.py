@@ -1,0 +1,188 @@
+#!/usr/bin/env python3
+"""bench.py — positive-edges/sec of the LightGCN train step on MI355X (BASELINE.json metric).
+
+A "step" is one pass of the hot path over one batch: K-layer propagate forward, on-device
+sampling of B positive edges + negatives, fused BPR forward/backward, K-layer propagate backward,
+dense Adam over the whole table (run_pipeline_lightgcn.py:117-159).  Workload at N=1 is
+BASELINE.json configs[1]: synthetic bipartite 1M users x 100K items, 10M edges, LightGCN 3-layer
+D=128 (SURVEY §8d "C2": symmetric adjacency nnz=20M, B=16384).  At N>1 every rank owns its own
+1M-user / 10M-edge shard of a weak-scaled graph (items replicated, one RCCL all-reduce of the
+item rows per layer), so per-GPU work is fixed: "scaling": "weak".
+
+Launch: python bench.py --gpus 1 --steps K --warmup W
+        python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy rate
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--users", type=int, default=1_000_000)
+    ap.add_argument("--items", type=int, default=100_000)
+    ap.add_argument("--edges", type=int, default=10_000_000)
+    ap.add_argument("--dim", type=int, default=128)
+    ap.add_argument("--layers", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=16384)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=2)
+    return ap.parse_args()
+
+
+def spmm_bytes(nnz: int, n_rows: int, d: int) -> int:
+    """Algorithmic bytes of one propagate launch: int32 col + fp32 val per entry, the
+    row pointer, one gathered fp32 row per entry (no reuse credit), one stored row per output row."""
+    return nnz * 8 + (n_rows + 1) * 4 + nnz * d * 4 + n_rows * d * 4
+
+
+def cpu_baseline(ei, spec, args, table0):
+    """The oracle's CPU port of the same step, timed on this box's host cores (rank 0, N=1 only)."""
+    import torch as t
+    from oracle import lightgcn_ref as R
+    U, I = spec.num_users, spec.num_items
+    cores = R.clib().ref_num_threads()
+    t.set_num_threads(cores)
+    r, c = R.bipartite_edges(ei[0], ei[1], U)
+    rowptr, cs, _ = R.sparse_tensor_csr(r, c, U + I, U + I)
+    val = R.gcn_norm_csr(rowptr, cs)
+    port = R.CpuTrainPort(table0, rowptr, cs, val, U, args.layers, 1e-3, 1e-6)
+    g = t.Generator().manual_seed(1)
+    E = ei.shape[1]
+
+    def batch():
+        e = t.randint(0, E, (args.batch,), generator=g)
+        return ei[0][e], ei[1][e], t.randint(0, I, (args.batch,), generator=g)  # negatives pre-drawn
+
+    port.step(batch())  # warm-up (page-faults the buffers)
+    t0 = time.perf_counter()
+    for _ in range(args.cpu_steps):
+        port.step(batch())
+    dt = (time.perf_counter() - t0) / args.cpu_steps
+    return {"value": args.batch / dt, "unit": "positive-edges/s", "cores": int(cores), "kind": "port",
+            "sample": f"{args.cpu_steps} full model-only train steps (fwd+BPR+bwd+Adam, negatives pre-drawn) of the "
+                      f"same graph and batch size with oracle/ (C/OpenMP restatement of torch_sparse spmm_cpu + "
+                      f"torch CPU ops), {dt:.2f} s/step"}
+
+
+def main():
+    args = parse_args()
+    import torch as t
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N>1")
+    if not t.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product has no CPU path")
+    t.cuda.set_device(local_rank)
+    dev = t.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from laplace_amd import ops, synthetic as S
+    from laplace_amd.interactions import Interactions
+    from laplace_amd.model.lightgcn import LightGCN
+    from laplace_amd.trainer import LightGCNTrainer
+
+    spec = S.SyntheticSpec(args.users, args.items, args.edges, seed=1)
+    if world > 1:
+        spec = S.shard_spec(spec, rank)
+    t_gen = time.perf_counter()
+    ei = S.generate(spec)
+    t_gen = time.perf_counter() - t_gen
+    U, I, D, K, B = spec.num_users, spec.num_items, args.dim, args.layers, args.batch
+
+    t.manual_seed(1234 + rank)
+    model = LightGCN(U, I, embedding_dim=D, num_iterations=K)
+    table0 = model.table().clone() if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
+    model.to(dev)
+    inter = Interactions(ei.to(dev), U, I)
+    adj = inter.adjacency("bipartite")
+    if world == 1:
+        trainer = LightGCNTrainer(model, adj, inter, lr=1e-3, Lambda=1e-6, batch_size=B, seed=7)
+    else:
+        from laplace_amd.dist import ShardedLightGCNTrainer
+        trainer = ShardedLightGCNTrainer(model, inter, lr=1e-3, Lambda=1e-6, batch_size=B, seed=7 + rank)
+    nnz, n_rows = trainer.adj_fwd.nnz, trainer.adj_fwd.n_rows
+    t.cuda.synchronize()
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        t.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        trainer.step()
+    sync()
+    ops.SPMM_EVENTS = []  # (start, end) HIP events around every propagate launch, on the launch stream
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = trainer.step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    events, ops.SPMM_EVENTS = ops.SPMM_EVENTS, None
+    loss_val = float(loss)
+
+    if world > 1:
+        tt = t.tensor([elapsed], device=dev, dtype=t.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt)
+
+    if rank == 0:
+        spmm_ms = [s.elapsed_time(e) for s, e in events]
+        avg_ms = sum(spmm_ms) / max(len(spmm_ms), 1)
+        algo = spmm_bytes(nnz, n_rows, D)
+        achieved = algo / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tf):
+            try:
+                traffic = json.load(open(tf)).get("spmm_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "positive-edges/sec (train step)",
+            "value": world * B * args.steps / elapsed,
+            "unit": "positive-edges/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"LightGCN train step, synthetic bipartite {U}x{I} users x items per GPU, "
+                                   f"{args.edges} edges per GPU (symmetric adjacency nnz={nnz}), "
+                                   f"{K}-layer D={D}, batch {B} positive edges per GPU, on-device sampling, "
+                                   f"BPR + dense Adam; BASELINE.json configs[1]",
+                       "parallelism": "1 GPU" if world == 1 else f"user-sharded x{world}, items replicated, "
+                                                                 f"RCCL all-reduce of item rows per layer"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "mi_spmm_csr_f32 (spmm_items_kernel + spmm_rows_kernel + spmm_fixup_kernel)",
+                         "algorithmic_bytes_per_launch": algo, "avg_launch_ms": avg_ms,
+                         "launches_timed": len(spmm_ms)},
+            "loss": loss_val, "graph_gen_s": round(t_gen, 1),
+        }
+        if table0 is not None:
+            out["cpu_baseline"] = cpu_baseline(ei, spec, args, table0)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,205 @@
+/*
+ * laplace_hip.h — C ABI of liblaplace_hip.so, the MI355X (gfx950) hot path of the
+ * laplace GNN link-prediction engine.
+ *
+ * The reference (dream-faster/laplace-gnn-recommendation) has no FFI of its own: its
+ * hot path reaches native code only through third-party wheels (torch_sparse,
+ * torch_scatter, PyG).  Each entry point below replaces one of those call sites; the
+ * "replaces:" line cites the reference file:line (paths relative to the reference root)
+ * whose work it does.  INTEGRATION.md shows the ctypes binding a reference maintainer
+ * would add at each site.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer owned by the caller unless marked "host";
+ *  - every function enqueues on `stream` (a hipStream_t passed as void*) and returns
+ *    without synchronising, except the *_plan_build / *_count functions, which say so;
+ *  - return value: 0 = success; >0 = hipError_t from the runtime; <0 = MI_ERR_* below;
+ *  - no global mutable state: the library is re-entrant and thread-safe;
+ *  - node / edge indices inside the library are int32 (n, nnz < 2^31 is checked);
+ *    edge lists coming from the reference's tensors are int64 and converted once
+ *    in mi_coo_to_csr_i32;
+ *  - floating point is fp32 end to end (the reference's dtype); no reduced precision.
+ */
+#ifndef LAPLACE_HIP_H
+#define LAPLACE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI_ABI_VERSION 1
+
+#define MI_ERR_BAD_ARG      (-1)  /* null pointer, negative size, misaligned buffer   */
+#define MI_ERR_TOO_LARGE    (-2)  /* a size does not fit int32 indexing                */
+#define MI_ERR_WORKSPACE    (-3)  /* workspace smaller than *_workspace_bytes says     */
+#define MI_ERR_UNSUPPORTED  (-4)  /* feature width / k outside the compiled kernels    */
+
+typedef void* mi_stream_t; /* hipStream_t */
+
+int         mi_abi_version(void);
+const char* mi_error_string(int code); /* host string, static storage */
+
+/* ------------------------------------------------------------------------------------
+ * K4  COO -> sorted CSR.
+ * replaces: torch_sparse.SparseTensor(row=, col=, sparse_sizes=) at
+ *           data/lightgcn_loader.py:65-79 (sort by row*N+col, no duplicate merging,
+ *           rowptr = ind2ptr(row)).
+ * row/col: int64[nnz] as the reference's edge_index rows.  Outputs: rowptr int32[n_rows+1],
+ * col_out int32[nnz] (sorted by (row, col)), perm int32[nnz] (perm[p] = index of the
+ * input edge now at position p; nullable).
+ * ---------------------------------------------------------------------------------- */
+size_t mi_coo_to_csr_workspace_bytes(int64_t n_rows, int64_t nnz);
+int    mi_coo_to_csr_i32(int64_t n_rows, int64_t n_cols, int64_t nnz,
+                         const int64_t* row, const int64_t* col,
+                         int32_t* rowptr, int32_t* col_out, int32_t* perm,
+                         void* ws, size_t ws_bytes, mi_stream_t stream);
+
+/* CSR(A) -> CSR(A^T).  replaces: SparseTensor.csr2csc()/colptr used by the backward of
+ * torch_sparse.matmul (autograd through model/lightgcn.py:64).  perm_t[q] = position in
+ * A of the entry now at position q of A^T (so val_t = val[perm_t]). */
+size_t mi_csr_transpose_workspace_bytes(int64_t n_rows, int64_t nnz);
+int    mi_csr_transpose_i32(int64_t n_rows, int64_t n_cols, int64_t nnz,
+                            const int32_t* rowptr, const int32_t* col,
+                            int32_t* rowptr_t, int32_t* col_t, int32_t* perm_t,
+                            void* ws, size_t ws_bytes, mi_stream_t stream);
+
+/* out[i] = src[idx[i]] — used to permute edge values. */
+int mi_gather_f32(int64_t n, const float* src, const int32_t* idx, float* out,
+                  mi_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * K3  gcn_norm on a square CSR.
+ * replaces: torch_geometric gcn_norm(SparseTensor, add_self_loops=False) at
+ *           model/lightgcn.py:56:  deg = rowsum(A); dis = deg^-1/2 (inf -> 0);
+ *           val[p] = (val[p] * dis[row]) * dis[col[p]].
+ * val_in nullable (= all ones, SparseTensor without value).  dis_out float[n] is written
+ * (deg^-1/2) and may be reused by the caller.
+ * ---------------------------------------------------------------------------------- */
+int mi_gcn_norm_csr_f32(int64_t n, int64_t nnz, const int32_t* rowptr, const int32_t* col,
+                        const float* val_in, float* val_out, float* dis_out,
+                        mi_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * K1/K2  CSR SpMM with fused epilogue — the LightGCN propagate.
+ * replaces: torch_sparse.matmul(adj_t, x) at model/lightgcn.py:87 (called K times per
+ *           forward at :63-65, and K times on A^T in backward), plus the
+ *           stack/mean at model/lightgcn.py:67-68 through the epilogue.
+ *
+ *   acc[r,:] = sum_{p in [rowptr[r], rowptr[r+1])} val[p] * X[col[p], :]
+ *   if (Y) Y[r,:] = acc
+ *   if (S) S[r,:] = scale * ((addend ? addend[r,:] : 0) + acc)
+ *
+ * d (feature width) must be a multiple of 4 and <= 512; X, Y, addend, S rows are
+ * 16-byte aligned with leading dimensions ld* (in floats, multiples of 4).  S may alias
+ * addend (in-place running sum).  Y/S must not alias X.
+ *
+ * Rows longer than the plan's chunk are split over several wavefronts and reduced in a
+ * fixed order (no float atomics): results are bitwise reproducible run to run.
+ * The plan depends only on rowptr; build it once per adjacency.
+ * ---------------------------------------------------------------------------------- */
+typedef struct mi_spmm_plan {
+    int32_t  chunk;        /* nnz per work item of a split row                       */
+    int32_t  n_long_rows;  /* rows with more than `chunk` entries                    */
+    int32_t  n_items;      /* work items over all long rows                          */
+    int32_t  reserved;
+    int32_t* long_rows;    /* device int32[n_long_rows]                              */
+    int32_t* item_ptr;     /* device int32[n_long_rows+1]: items of long row i       */
+    int32_t* items;        /* device int32[4*n_items]: row, begin, end, slot         */
+} mi_spmm_plan;
+
+/* Upper bounds for the plan arrays, so the caller can allocate before building. */
+int mi_spmm_plan_bounds(int64_t n_rows, int64_t nnz, int32_t chunk,
+                        int64_t* max_long_rows, int64_t* max_items);
+/* Fills plan->long_rows/item_ptr/items (caller-allocated to the bounds above) and the
+ * counts.  SYNCHRONISES `stream` (reads two counters back); setup-time only. */
+size_t mi_spmm_plan_workspace_bytes(int64_t n_rows);
+int    mi_spmm_plan_build(int64_t n_rows, const int32_t* rowptr, int32_t chunk,
+                          mi_spmm_plan* plan, void* ws, size_t ws_bytes,
+                          mi_stream_t stream);
+/* Bytes of partial-sum workspace mi_spmm_csr_f32 needs for this plan and width. */
+size_t mi_spmm_workspace_bytes(const mi_spmm_plan* plan, int64_t d);
+
+int mi_spmm_csr_f32(int64_t n_rows, int64_t d,
+                    const int32_t* rowptr, const int32_t* col, const float* val,
+                    const float* X, int64_t ldx,
+                    float* Y, int64_t ldy,
+                    const float* addend, int64_t lda,
+                    float* S, int64_t lds, float scale,
+                    const mi_spmm_plan* plan, void* ws, size_t ws_bytes,
+                    mi_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * K9  mini-batch sampler: B positive edges with replacement + one structured negative
+ *     each, entirely on device.
+ * replaces: sample_mini_batch at data/lightgcn_loader.py:95-112
+ *           (structured_negative_sampling over all E edges on the CPU, then
+ *           random.choices(range(E), k=B)).
+ * Edge e = Philox(seed, step, slot b) mod nnz of the *train* CSR (rows = users, cols =
+ * item ids in [0, n_items)); the negative for edge e is drawn from [0, neg_range) by
+ * Philox keyed on (seed, step, e) — the same edge drawn twice in one step gets the same
+ * negative, as in the reference — and redrawn while it is a neighbour of the user
+ * (binary search in the user's sorted CSR row).  `quirk_user_rows`: when non-zero,
+ * also rejects negative 0 for user u if user u-1 has an edge to item `neg_range`
+ * (the reference's row*num_nodes+col key collision).
+ * row_of_edge int32[nnz] is the expanded row index (mi_csr_expand_rows).
+ * Outputs int64[B] each (the reference's index dtype).
+ * ---------------------------------------------------------------------------------- */
+int mi_csr_expand_rows(int64_t n_rows, const int32_t* rowptr, int32_t* row_of_edge,
+                       int64_t nnz, mi_stream_t stream);
+int mi_sample_bpr_batch(int64_t batch, int64_t nnz,
+                        const int32_t* rowptr, const int32_t* col,
+                        const int32_t* row_of_edge,
+                        int64_t neg_range, int32_t quirk_user_rows,
+                        uint64_t seed, uint64_t step,
+                        int64_t* users, int64_t* pos, int64_t* neg,
+                        mi_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * a7+a8  fused batch gather + BPR loss forward/backward.
+ * replaces: the six index_selects at run_pipeline_lightgcn.py:133-144 and bpr_loss at
+ *           utils/metrics_lightgcn.py:9-45, and their autograd backward.
+ *   x_b  = <u_b,p_b> - <u_b,n_b>          (rows of final_emb)
+ *   loss = -mean_b softplus(x_b) + lambda * sum_b (|u0_b|^2+|p0_b|^2+|n0_b|^2)   (rows of e0)
+ * final_emb / e0: [n_users + n_items, d] tables (item i is row n_users + i).
+ * loss_out: device float[1], written (fixed-order reduction).
+ * When g_final is non-null (dense [n, d], zeroed by the caller) it receives
+ *   g_final[row,:] += g_scale * dL/dfinal[row,:]
+ * and reg_w (float[n], zeroed by the caller; nullable) receives, per occurrence of a
+ * node in the batch, reg_w[row] += 2*lambda*reg_scale, so that the L2 term's gradient is
+ * reg_w[row] * e0[row,:] (applied by mi_adam_dense_f32 or by the caller).
+ * Repeated users/items in a batch are combined with float atomics (order-dependent in
+ * the last bits); everything else is deterministic.
+ * ---------------------------------------------------------------------------------- */
+size_t mi_bpr_workspace_bytes(int64_t batch);
+int    mi_bpr_fwd_bwd_f32(int64_t batch, int64_t d, int64_t n_users,
+                          const int64_t* users, const int64_t* pos, const int64_t* neg,
+                          const float* final_emb, int64_t ldf,
+                          const float* e0, int64_t lde,
+                          float lambda, float g_scale, float reg_scale,
+                          float* loss_out,
+                          float* g_final, int64_t ldg,
+                          float* reg_w,
+                          void* ws, size_t ws_bytes, mi_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * a9  dense Adam step (torch.optim.Adam semantics, no weight decay, no amsgrad).
+ * replaces: optimizer.step() at run_pipeline_lightgcn.py:159.
+ *   g   = grad[i] + (reg_w ? reg_w[row(i)] * p[i] : 0)
+ *   m   = b1*m + (1-b1)*g ; v = b2*v + (1-b2)*g*g
+ *   p  -= step_size * m / (sqrt(v)/sqrt(bc2) + eps)
+ * step_size = lr / (1 - b1^t), bc2_sqrt = sqrt(1 - b2^t) are computed by the host in
+ * double.  n_rows x d row-major, ld in floats.
+ * ---------------------------------------------------------------------------------- */
+int mi_adam_dense_f32(int64_t n_rows, int64_t d,
+                      float* p, int64_t ldp, const float* grad, int64_t ldgr,
+                      float* m, float* v, const float* reg_w,
+                      float beta1, float beta2, float step_size, float bc2_sqrt, float eps,
+                      mi_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LAPLACE_HIP_H */

@@ -1,0 +1,82 @@
+"""ctypes binding of liblaplace_hip.so (include/laplace_hip.h).  Fails loudly, never falls back."""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int32, c_int64, c_size_t, c_uint64, c_void_p
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG_DIR, "liblaplace_hip.so")
+
+MI_ABI_VERSION = 1
+
+
+class MiError(RuntimeError):
+    pass
+
+
+class SpmmPlanStruct(Structure):
+    _fields_ = [
+        ("chunk", c_int32), ("n_long_rows", c_int32), ("n_items", c_int32), ("reserved", c_int32),
+        ("long_rows", c_void_p), ("item_ptr", c_void_p), ("items", c_void_p),
+    ]
+
+
+P = c_void_p
+_PROTOTYPES = {
+    # name: (restype, [argtypes])
+    "mi_abi_version": (c_int32, []),
+    "mi_error_string": (c_char_p, [c_int32]),
+    "mi_coo_to_csr_workspace_bytes": (c_size_t, [c_int64, c_int64]),
+    "mi_coo_to_csr_i32": (c_int32, [c_int64, c_int64, c_int64, P, P, P, P, P, P, c_size_t, P]),
+    "mi_csr_transpose_workspace_bytes": (c_size_t, [c_int64, c_int64]),
+    "mi_csr_transpose_i32": (c_int32, [c_int64, c_int64, c_int64, P, P, P, P, P, P, c_size_t, P]),
+    "mi_gather_f32": (c_int32, [c_int64, P, P, P, P]),
+    "mi_gcn_norm_csr_f32": (c_int32, [c_int64, c_int64, P, P, P, P, P, P]),
+    "mi_spmm_plan_bounds": (c_int32, [c_int64, c_int64, c_int32, POINTER(c_int64), POINTER(c_int64)]),
+    "mi_spmm_plan_workspace_bytes": (c_size_t, [c_int64]),
+    "mi_spmm_plan_build": (c_int32, [c_int64, P, c_int32, POINTER(SpmmPlanStruct), P, c_size_t, P]),
+    "mi_spmm_workspace_bytes": (c_size_t, [POINTER(SpmmPlanStruct), c_int64]),
+    "mi_spmm_csr_f32": (c_int32, [c_int64, c_int64, P, P, P, P, c_int64, P, c_int64, P, c_int64, P, c_int64,
+                                  c_float, POINTER(SpmmPlanStruct), P, c_size_t, P]),
+    "mi_csr_expand_rows": (c_int32, [c_int64, P, P, c_int64, P]),
+    "mi_sample_bpr_batch": (c_int32, [c_int64, c_int64, P, P, P, c_int64, c_int32, c_uint64, c_uint64,
+                                      P, P, P, P]),
+    "mi_bpr_workspace_bytes": (c_size_t, [c_int64]),
+    "mi_bpr_fwd_bwd_f32": (c_int32, [c_int64, c_int64, c_int64, P, P, P, P, c_int64, P, c_int64,
+                                     c_float, c_float, c_float, P, P, c_int64, P, P, c_size_t, P]),
+    "mi_adam_dense_f32": (c_int32, [c_int64, c_int64, P, c_int64, P, c_int64, P, P, P,
+                                    c_float, c_float, c_float, c_float, c_float, P]),
+}
+
+_LIB = None
+
+
+def lib() -> ctypes.CDLL:
+    """Load (once) and return the shared library; raises MiError if it is not built."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise MiError(
+                f"{LIB_PATH} is missing: build it with `python -c \"import __graft_entry__ as g; g.build()\"` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _PROTOTYPES.items():
+            fn = getattr(handle, name)  # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        got = handle.mi_abi_version()
+        if got != MI_ABI_VERSION:
+            raise MiError(f"ABI mismatch: library {got}, binding {MI_ABI_VERSION}")
+        _LIB = handle
+    return _LIB
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = lib().mi_error_string(int(rc))
+        raise MiError(f"{what} failed with code {rc}: {msg.decode() if msg else '?'}")
+
+
+def exported_symbols() -> list[str]:
+    return sorted(_PROTOTYPES)

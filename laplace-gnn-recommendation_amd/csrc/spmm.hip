@@ -1,0 +1,375 @@
+// K1 / K2: CSR SpMM with fused epilogue — the LightGCN propagate (model/lightgcn.py:63-68,87).
+//
+//   acc[r,:] = sum_p val[p] * X[col[p],:]
+//   Y[r,:]   = acc                               (optional)
+//   S[r,:]   = scale * (addend[r,:] + acc)        (optional; the running layer sum / mean)
+//
+// HBM-bound gather (0.49 flop/byte at D=128): the design is about keeping many whole-row
+// 16-byte-per-lane loads in flight per wavefront, not about arithmetic.
+//
+// Mapping (wave64): a row of D floats is covered by LPR = D/4 lanes of float4, so one load
+// instruction fetches NB = 64/LPR neighbour rows at once (D=128: 2 rows, 1 KiB per
+// instruction).  (col,val) pairs are read 64 at a time, coalesced, one per lane, and handed to
+// the sub-groups with ds_bpermute (__shfl); UNROLL independent row loads per lane are issued
+// before the first fma.  The NB partial sums are combined with log2(NB) DPP/xor steps at the
+// end.  One wavefront owns one destination row; rows longer than plan->chunk are cut into
+// chunk-sized work items whose partial sums are reduced in item order by a fix-up kernel, so
+// there are no float atomics and results are bitwise reproducible.
+#include "common.hpp"
+#include <rocprim/rocprim.hpp>
+
+namespace {
+
+constexpr int kWavesPerBlock = 4;
+constexpr int kBlock = kWavesPerBlock * MI_WAVE;
+
+struct Epilogue {
+    float4* Y;            int64_t ldy4;
+    const float4* addend; int64_t lda4;
+    float4* S;            int64_t lds4;
+    float scale;
+};
+
+// Accumulates entries [beg, end) of one row into acc (valid in lanes of sub-group 0 after
+// the final cross-sub-group reduce).
+template <int LPR, int VPL, int UNROLL>
+__device__ __forceinline__ void wave_accumulate(const int32_t* __restrict__ col,
+                                                const float* __restrict__ val,
+                                                const float4* __restrict__ X4, int64_t ldx4, int d4,
+                                                int32_t beg, int32_t end, float4 (&acc)[VPL]) {
+    constexpr int NB = MI_WAVE / LPR;
+    const int lane = mi_lane();
+    const int g = lane / LPR;
+    const int li = lane % LPR;
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) acc[v] = mi_f4_zero();
+
+    for (int32_t base = beg; base < end; base += MI_WAVE) {
+        const int n = min((int32_t)MI_WAVE, end - base);
+        int32_t my_c = 0;
+        float my_v = 0.f;
+        if (lane < n) {
+            my_c = col[base + lane];
+            my_v = val[base + lane];
+        }
+        for (int j = 0; j < n; j += NB * UNROLL) {
+            float w[UNROLL];
+            float4 x[UNROLL][VPL];
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) {
+                const int idx = j + u * NB + g;
+                const int32_t c = __shfl(my_c, idx & (MI_WAVE - 1), MI_WAVE);
+                w[u] = __shfl(my_v, idx & (MI_WAVE - 1), MI_WAVE);
+                const bool ok = idx < n;
+                const float4* src = X4 + (int64_t)c * ldx4;
+#pragma unroll
+                for (int v = 0; v < VPL; ++v) {
+                    const int e = li + v * LPR;
+                    x[u][v] = (ok && e < d4) ? src[e] : mi_f4_zero();
+                }
+                if (!ok) w[u] = 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u)
+#pragma unroll
+                for (int v = 0; v < VPL; ++v) mi_f4_fma(acc[v], w[u], x[u][v]);
+        }
+    }
+#pragma unroll
+    for (int m = MI_WAVE / 2; m >= LPR; m >>= 1)
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) acc[v] = mi_f4_add(acc[v], mi_f4_shfl_xor(acc[v], m));
+}
+
+template <int LPR, int VPL>
+__device__ __forceinline__ void apply_epilogue(const Epilogue& ep, int64_t r, int d4,
+                                               const float4 (&acc)[VPL], const float4 (&a)[VPL]) {
+    const int lane = mi_lane();
+    if (lane >= LPR) return;
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) {
+        const int e = lane + v * LPR;
+        if (e >= d4) continue;
+        if (ep.Y) ep.Y[r * ep.ldy4 + e] = acc[v];
+        if (ep.S) {
+            float4 o;
+            o.x = ep.scale * (a[v].x + acc[v].x);
+            o.y = ep.scale * (a[v].y + acc[v].y);
+            o.z = ep.scale * (a[v].z + acc[v].z);
+            o.w = ep.scale * (a[v].w + acc[v].w);
+            ep.S[r * ep.lds4 + e] = o;
+        }
+    }
+}
+
+template <int LPR, int VPL>
+__device__ __forceinline__ void load_addend(const Epilogue& ep, int64_t r, int d4, float4 (&a)[VPL]) {
+    const int lane = mi_lane();
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) {
+        const int e = lane + v * LPR;
+        a[v] = (ep.S && ep.addend && lane < LPR && e < d4) ? ep.addend[r * ep.lda4 + e] : mi_f4_zero();
+    }
+}
+
+// One wavefront per row; rows with more than `chunk` entries are left to the split path.
+template <int LPR, int VPL, int UNROLL>
+__global__ __launch_bounds__(kBlock) void spmm_rows_kernel(int64_t n_rows, int d4,
+                                                           const int32_t* __restrict__ rowptr,
+                                                           const int32_t* __restrict__ col,
+                                                           const float* __restrict__ val,
+                                                           const float4* __restrict__ X4, int64_t ldx4,
+                                                           Epilogue ep, int32_t chunk) {
+    const int64_t r = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x / MI_WAVE);
+    if (r >= n_rows) return;
+    const int32_t beg = rowptr[r], end = rowptr[r + 1];
+    if (end - beg > chunk) return;
+    float4 a[VPL], acc[VPL];
+    load_addend<LPR, VPL>(ep, r, d4, a);
+    wave_accumulate<LPR, VPL, UNROLL>(col, val, X4, ldx4, d4, beg, end, acc);
+    apply_epilogue<LPR, VPL>(ep, r, d4, acc, a);
+}
+
+// Split rows: one wavefront per work item (row, begin, end, slot) -> partial[slot, :].
+template <int LPR, int VPL, int UNROLL>
+__global__ __launch_bounds__(kBlock) void spmm_items_kernel(int32_t n_items, int d4,
+                                                            const int32_t* __restrict__ items,
+                                                            const int32_t* __restrict__ col,
+                                                            const float* __restrict__ val,
+                                                            const float4* __restrict__ X4, int64_t ldx4,
+                                                            float4* __restrict__ partial) {
+    const int32_t it = blockIdx.x * kWavesPerBlock + (threadIdx.x / MI_WAVE);
+    if (it >= n_items) return;
+    const int32_t beg = items[4 * it + 1], end = items[4 * it + 2], slot = items[4 * it + 3];
+    float4 acc[VPL];
+    wave_accumulate<LPR, VPL, UNROLL>(col, val, X4, ldx4, d4, beg, end, acc);
+    const int lane = mi_lane();
+    if (lane < LPR) {
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) {
+            const int e = lane + v * LPR;
+            if (e < d4) partial[(int64_t)slot * d4 + e] = acc[v];
+        }
+    }
+}
+
+// One 256-thread block per split row.  Its 4 wavefronts x NB sub-groups stride over the row's
+// partial sums (several loads in flight each), then combine through LDS in a fixed order, so the
+// result does not depend on scheduling.  Wave 0 applies the epilogue.
+template <int LPR, int VPL>
+__global__ __launch_bounds__(kBlock) void spmm_fixup_kernel(int32_t n_long, int d4,
+                                                            const int32_t* __restrict__ long_rows,
+                                                            const int32_t* __restrict__ item_ptr,
+                                                            const float4* __restrict__ partial,
+                                                            Epilogue ep) {
+    constexpr int NB = MI_WAVE / LPR;
+    constexpr int NSG = NB * kWavesPerBlock;  // sub-groups per block
+    __shared__ float4 red[kWavesPerBlock][VPL][LPR];
+    const int32_t i = blockIdx.x;
+    if (i >= n_long) return;
+    const int64_t r = long_rows[i];
+    const int32_t sb = item_ptr[i], se = item_ptr[i + 1];
+    const int lane = mi_lane();
+    const int wave = threadIdx.x / MI_WAVE;
+    const int g = lane / LPR, li = lane % LPR;
+    const int sg = wave * NB + g;
+    float4 acc[VPL];
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) acc[v] = mi_f4_zero();
+    for (int32_t s = sb + sg; s < se; s += NSG * 4) {
+        float4 x[4][VPL];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int v = 0; v < VPL; ++v) {
+                const int e = li + v * LPR;
+                const int32_t ss = s + u * NSG;
+                x[u][v] = (ss < se && e < d4) ? partial[(int64_t)ss * d4 + e] : mi_f4_zero();
+            }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int v = 0; v < VPL; ++v) acc[v] = mi_f4_add(acc[v], x[u][v]);
+    }
+#pragma unroll
+    for (int m = MI_WAVE / 2; m >= LPR; m >>= 1)
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) acc[v] = mi_f4_add(acc[v], mi_f4_shfl_xor(acc[v], m));
+    if (lane < LPR) {
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) red[wave][v][lane] = acc[v];
+    }
+    __syncthreads();
+    if (wave != 0) return;
+    float4 a[VPL];
+    load_addend<LPR, VPL>(ep, r, d4, a);
+    if (lane < LPR) {
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) {
+            float4 t = red[0][v][lane];
+#pragma unroll
+            for (int w = 1; w < kWavesPerBlock; ++w) t = mi_f4_add(t, red[w][v][lane]);
+            acc[v] = t;
+        }
+    }
+    apply_epilogue<LPR, VPL>(ep, r, d4, acc, a);
+}
+
+// ---- plan construction --------------------------------------------------------------------
+__global__ void plan_flags_kernel(int64_t n_rows, const int32_t* __restrict__ rowptr, int32_t chunk,
+                                  int32_t* __restrict__ is_long, int32_t* __restrict__ n_it) {
+    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r > n_rows) return;
+    int32_t deg = (r < n_rows) ? rowptr[r + 1] - rowptr[r] : 0;
+    bool lg = deg > chunk;
+    is_long[r] = lg ? 1 : 0;
+    n_it[r] = lg ? (deg + chunk - 1) / chunk : 0;
+}
+
+__global__ void plan_fill_kernel(int64_t n_rows, const int32_t* __restrict__ rowptr, int32_t chunk,
+                                 const int32_t* __restrict__ long_off, const int32_t* __restrict__ item_off,
+                                 int32_t* __restrict__ long_rows, int32_t* __restrict__ item_ptr,
+                                 int32_t* __restrict__ items) {
+    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r > n_rows) return;
+    if (r == n_rows) {  // sentinel: item_ptr[n_long] = n_items
+        item_ptr[long_off[r]] = item_off[r];
+        return;
+    }
+    const int32_t b = rowptr[r], e = rowptr[r + 1];
+    if (e - b <= chunk) return;
+    const int32_t li = long_off[r], io = item_off[r];
+    long_rows[li] = (int32_t)r;
+    item_ptr[li] = io;
+    int32_t k = 0;
+    for (int32_t p = b; p < e; p += chunk, ++k) {
+        items[4 * (io + k) + 0] = (int32_t)r;
+        items[4 * (io + k) + 1] = p;
+        items[4 * (io + k) + 2] = min(p + chunk, e);
+        items[4 * (io + k) + 3] = io + k;
+    }
+}
+
+template <int LPR, int VPL>
+int launch_spmm(int64_t n_rows, int d4, const int32_t* rowptr, const int32_t* col, const float* val,
+                const float4* X4, int64_t ldx4, const Epilogue& ep, const mi_spmm_plan* plan,
+                float4* partial, hipStream_t s) {
+    constexpr int UNROLL = (VPL == 1) ? 4 : 2;
+    const int32_t chunk = plan ? plan->chunk : INT32_MAX;
+    if (plan && plan->n_items > 0) {
+        dim3 gi((unsigned)mi_ceil_div(plan->n_items, kWavesPerBlock));
+        hipLaunchKernelGGL((spmm_items_kernel<LPR, VPL, UNROLL>), gi, dim3(kBlock), 0, s, plan->n_items, d4,
+                           plan->items, col, val, X4, ldx4, partial);
+    }
+    dim3 gr((unsigned)mi_ceil_div(n_rows, kWavesPerBlock));
+    hipLaunchKernelGGL((spmm_rows_kernel<LPR, VPL, UNROLL>), gr, dim3(kBlock), 0, s, n_rows, d4, rowptr, col,
+                       val, X4, ldx4, ep, chunk);
+    if (plan && plan->n_long_rows > 0) {
+        dim3 gf((unsigned)plan->n_long_rows);
+        hipLaunchKernelGGL((spmm_fixup_kernel<LPR, VPL>), gf, dim3(kBlock), 0, s, plan->n_long_rows, d4,
+                           plan->long_rows, plan->item_ptr, partial, ep);
+    }
+    return mi_launch_status();
+}
+
+}  // namespace
+
+extern "C" {
+
+int mi_spmm_plan_bounds(int64_t n_rows, int64_t nnz, int32_t chunk, int64_t* max_long_rows,
+                        int64_t* max_items) {
+    MI_CHECK_ARG(n_rows >= 0 && nnz >= 0 && chunk > 0 && max_long_rows && max_items);
+    int64_t ml = nnz / ((int64_t)chunk + 1);  // each long row holds > chunk entries
+    if (ml > n_rows) ml = n_rows;
+    *max_long_rows = ml;
+    *max_items = nnz / chunk + ml;  // sum ceil(deg/chunk) <= nnz/chunk + n_long
+    return 0;
+}
+
+size_t mi_spmm_plan_workspace_bytes(int64_t n_rows) {
+    size_t n = (size_t)n_rows + 1;
+    return 4 * mi_align_up(n * 4, 256) + ((size_t)16 << 20);
+}
+
+int mi_spmm_plan_build(int64_t n_rows, const int32_t* rowptr, int32_t chunk, mi_spmm_plan* plan,
+                       void* ws, size_t ws_bytes, mi_stream_t stream) {
+    MI_CHECK_ARG(n_rows >= 0 && rowptr && chunk > 0 && plan && ws);
+    if (n_rows >= INT32_MAX) return MI_ERR_TOO_LARGE;
+    hipStream_t s = (hipStream_t)stream;
+    plan->chunk = chunk;
+    plan->n_long_rows = 0;
+    plan->n_items = 0;
+    plan->reserved = 0;
+    const int64_t n1 = n_rows + 1;
+    MiArena arena(ws, ws_bytes);
+    int32_t* is_long = arena.take<int32_t>(n1);
+    int32_t* n_it = arena.take<int32_t>(n1);
+    int32_t* long_off = arena.take<int32_t>(n1);
+    int32_t* item_off = arena.take<int32_t>(n1);
+    if (!is_long || !n_it || !long_off || !item_off) return MI_ERR_WORKSPACE;
+    dim3 g((unsigned)mi_ceil_div(n1, 256));
+    hipLaunchKernelGGL(plan_flags_kernel, g, dim3(256), 0, s, n_rows, rowptr, chunk, is_long, n_it);
+    size_t tmp_bytes = 0;
+    MI_HIP(rocprim::exclusive_scan(nullptr, tmp_bytes, is_long, long_off, 0, (size_t)n1,
+                                   rocprim::plus<int32_t>(), s));
+    char* tmp = arena.take<char>(tmp_bytes ? tmp_bytes : 1);
+    if (!tmp) return MI_ERR_WORKSPACE;
+    MI_HIP(rocprim::exclusive_scan(tmp, tmp_bytes, is_long, long_off, 0, (size_t)n1,
+                                   rocprim::plus<int32_t>(), s));
+    MI_HIP(rocprim::exclusive_scan(tmp, tmp_bytes, n_it, item_off, 0, (size_t)n1,
+                                   rocprim::plus<int32_t>(), s));
+    int32_t totals[2] = {0, 0};
+    MI_HIP(hipMemcpyAsync(&totals[0], long_off + n_rows, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    MI_HIP(hipMemcpyAsync(&totals[1], item_off + n_rows, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    MI_HIP(hipStreamSynchronize(s));
+    plan->n_long_rows = totals[0];
+    plan->n_items = totals[1];
+    if (totals[0] > 0) {
+        MI_CHECK_ARG(plan->long_rows && plan->item_ptr && plan->items);
+        hipLaunchKernelGGL(plan_fill_kernel, g, dim3(256), 0, s, n_rows, rowptr, chunk, long_off, item_off,
+                           plan->long_rows, plan->item_ptr, plan->items);
+        MI_HIP(hipStreamSynchronize(s));  // ws may be released by the caller on return
+    }
+    return mi_launch_status();
+}
+
+size_t mi_spmm_workspace_bytes(const mi_spmm_plan* plan, int64_t d) {
+    if (!plan || plan->n_items <= 0) return 0;
+    return mi_align_up((size_t)plan->n_items * (size_t)d * sizeof(float), 256);
+}
+
+int mi_spmm_csr_f32(int64_t n_rows, int64_t d, const int32_t* rowptr, const int32_t* col,
+                    const float* val, const float* X, int64_t ldx, float* Y, int64_t ldy,
+                    const float* addend, int64_t lda, float* S, int64_t lds, float scale,
+                    const mi_spmm_plan* plan, void* ws, size_t ws_bytes, mi_stream_t stream) {
+    MI_CHECK_ARG(n_rows >= 0 && d > 0 && rowptr);
+    if (n_rows == 0) return 0;
+    if (d % 4 != 0 || d > 512) return MI_ERR_UNSUPPORTED;
+    if (n_rows >= INT32_MAX) return MI_ERR_TOO_LARGE;
+    MI_CHECK_ARG(X && (Y || S));
+    MI_CHECK_ARG(ldx % 4 == 0 && ldx >= d && mi_aligned16(X));
+    MI_CHECK_ARG(!Y || (ldy % 4 == 0 && ldy >= d && mi_aligned16(Y) && Y != X));
+    MI_CHECK_ARG(!S || (lds % 4 == 0 && lds >= d && mi_aligned16(S) && S != X));
+    MI_CHECK_ARG(!addend || (lda % 4 == 0 && lda >= d && mi_aligned16(addend)));
+    float4* partial = nullptr;
+    if (plan && plan->n_items > 0) {
+        if (!ws || ws_bytes < mi_spmm_workspace_bytes(plan, d)) return MI_ERR_WORKSPACE;
+        MI_CHECK_ARG(mi_aligned16(ws));
+        partial = reinterpret_cast<float4*>(ws);
+    }
+    Epilogue ep;
+    ep.Y = reinterpret_cast<float4*>(Y);                 ep.ldy4 = ldy / 4;
+    ep.addend = reinterpret_cast<const float4*>(addend); ep.lda4 = lda / 4;
+    ep.S = reinterpret_cast<float4*>(S);                 ep.lds4 = lds / 4;
+    ep.scale = scale;
+    const float4* X4 = reinterpret_cast<const float4*>(X);
+    const int d4 = (int)(d / 4);
+    hipStream_t s = (hipStream_t)stream;
+    if (d4 <= 8)   return launch_spmm<8, 1>(n_rows, d4, rowptr, col, val, X4, ldx / 4, ep, plan, partial, s);
+    if (d4 <= 16)  return launch_spmm<16, 1>(n_rows, d4, rowptr, col, val, X4, ldx / 4, ep, plan, partial, s);
+    if (d4 <= 32)  return launch_spmm<32, 1>(n_rows, d4, rowptr, col, val, X4, ldx / 4, ep, plan, partial, s);
+    if (d4 <= 64)  return launch_spmm<64, 1>(n_rows, d4, rowptr, col, val, X4, ldx / 4, ep, plan, partial, s);
+    return launch_spmm<64, 2>(n_rows, d4, rowptr, col, val, X4, ldx / 4, ep, plan, partial, s);
+}
+
+}  // extern "C"

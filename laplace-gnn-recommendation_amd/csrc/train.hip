@@ -1,0 +1,251 @@
+// LightGCN training-step kernels other than the propagate:
+//   K9   mi_sample_bpr_batch   data/lightgcn_loader.py:95-112 (+ PyG structured_negative_sampling)
+//   a7/8 mi_bpr_fwd_bwd_f32    run_pipeline_lightgcn.py:133-155, utils/metrics_lightgcn.py:9-45
+//   a9   mi_adam_dense_f32     run_pipeline_lightgcn.py:157-159 (torch.optim.Adam)
+#include "common.hpp"
+
+namespace {
+
+constexpr int kBlock = 256;
+
+// ------------------------------------------------------------------ sampler ------------
+// Domain tags keep the edge-pick stream and the negative stream apart.
+constexpr uint32_t kTagEdge = 0x45444745u;  // "EDGE"
+constexpr uint32_t kTagNeg = 0x4E454721u;   // "NEG!"
+constexpr int kMaxNegAttempts = 4096;
+
+__device__ __forceinline__ bool csr_contains(const int32_t* __restrict__ rowptr,
+                                             const int32_t* __restrict__ col, int64_t r,
+                                             int32_t key) {
+    int32_t lo = rowptr[r], hi = rowptr[r + 1];
+    const int32_t end = hi;
+    while (lo < hi) {
+        int32_t mid = (lo + hi) >> 1;
+        if (col[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    return lo < end && col[lo] == key;
+}
+
+__global__ void sample_bpr_kernel(int64_t batch, int64_t nnz, const int32_t* __restrict__ rowptr,
+                                  const int32_t* __restrict__ col,
+                                  const int32_t* __restrict__ row_of_edge, int64_t neg_range,
+                                  int32_t quirk, uint64_t seed, uint64_t step,
+                                  int64_t* __restrict__ users, int64_t* __restrict__ pos,
+                                  int64_t* __restrict__ neg) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= batch) return;
+    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    const uint32_t s0 = (uint32_t)step, s1 = (uint32_t)(step >> 32);
+    MiPhilox r = mi_philox4x32((uint32_t)b, (uint32_t)((uint64_t)b >> 32), s0, s1 ^ kTagEdge, k0, k1);
+    const uint64_t e = (((uint64_t)r.c[0] << 32) | r.c[1]) % (uint64_t)nnz;
+    const int64_t u = row_of_edge[e];
+    const int32_t p = col[e];
+    int32_t cand = 0;
+    for (int t = 0; t < kMaxNegAttempts; ++t) {
+        MiPhilox q = mi_philox4x32((uint32_t)e, (uint32_t)t, s0, s1 ^ kTagNeg, k0, k1);
+        cand = (int32_t)((((uint64_t)q.c[0] << 32) | q.c[1]) % (uint64_t)neg_range);
+        bool hit = csr_contains(rowptr, col, u, cand);
+        // reference key collision: (u-1, item neg_range) aliases (u, 0) in row*num_nodes+col
+        if (!hit && quirk && cand == 0 && u > 0) hit = csr_contains(rowptr, col, u - 1, (int32_t)neg_range);
+        if (!hit) break;
+    }
+    users[b] = u;
+    pos[b] = p;
+    neg[b] = cand;
+}
+
+// ------------------------------------------------------------------ BPR ----------------
+__device__ __forceinline__ float softplus_ref(float x) {  // torch softplus, beta=1, threshold=20
+    return x > 20.f ? x : log1pf(expf(x));
+}
+__device__ __forceinline__ float softplus_grad_ref(float x) {  // torch softplus_backward
+    if (x > 20.f) return 1.f;
+    float z = expf(x);
+    return z / (z + 1.f);
+}
+
+// One wavefront per batch slot.  Each lane covers d/64 (rounded up) strided elements.
+__global__ __launch_bounds__(kBlock) void bpr_slot_kernel(
+    int64_t batch, int d, int64_t n_users, const int64_t* __restrict__ users,
+    const int64_t* __restrict__ pos, const int64_t* __restrict__ neg,
+    const float* __restrict__ fin, int64_t ldf, const float* __restrict__ e0, int64_t lde,
+    float inv_batch, float g_scale, float reg_coef /* = lambda*reg_scale */,
+    float* __restrict__ softplus_out, float* __restrict__ reg_out,
+    float* __restrict__ g_final, int64_t ldg, float* __restrict__ reg_w) {
+    const int64_t b = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / MI_WAVE;
+    if (b >= batch) return;
+    const int lane = mi_lane();
+    const int64_t u = users[b], p = n_users + pos[b], n = n_users + neg[b];
+    const float* uf = fin + u * ldf;
+    const float* pf = fin + p * ldf;
+    const float* nf = fin + n * ldf;
+    const float* u0 = e0 + u * lde;
+    const float* p0 = e0 + p * lde;
+    const float* n0 = e0 + n * lde;
+    float sp = 0.f, sn = 0.f, rg = 0.f;
+    for (int k = lane; k < d; k += MI_WAVE) {
+        float a = uf[k];
+        sp = fmaf(a, pf[k], sp);
+        sn = fmaf(a, nf[k], sn);
+        float x0 = u0[k], x1 = p0[k], x2 = n0[k];
+        rg = fmaf(x0, x0, rg);
+        rg = fmaf(x1, x1, rg);
+        rg = fmaf(x2, x2, rg);
+    }
+    sp = mi_wave_sum(sp);
+    sn = mi_wave_sum(sn);
+    rg = mi_wave_sum(rg);
+    const float x = sp - sn;
+    if (lane == 0) {
+        softplus_out[b] = softplus_ref(x);
+        reg_out[b] = rg;
+    }
+    if (g_final) {
+        // loss = -mean softplus(x)  =>  dL/dx = -sigmoid'(x)/B
+        const float coef = -softplus_grad_ref(x) * inv_batch * g_scale;
+        float* gu = g_final + u * ldg;
+        float* gp = g_final + p * ldg;
+        float* gn = g_final + n * ldg;
+        for (int k = lane; k < d; k += MI_WAVE) {
+            float a = uf[k], pk = pf[k], nk = nf[k];
+            atomicAdd(gu + k, coef * (pk - nk));
+            atomicAdd(gp + k, coef * a);
+            atomicAdd(gn + k, -coef * a);
+        }
+    }
+    if (reg_w && lane == 0) {
+        const float w = 2.0f * reg_coef;
+        atomicAdd(reg_w + u, w);
+        atomicAdd(reg_w + p, w);
+        atomicAdd(reg_w + n, w);
+    }
+}
+
+// Single block, fixed order: loss = -sum(softplus)/B + lambda*sum(reg).
+__global__ __launch_bounds__(1024) void bpr_finish_kernel(int64_t batch,
+                                                          const float* __restrict__ softplus_v,
+                                                          const float* __restrict__ reg_v,
+                                                          float inv_batch, float lambda,
+                                                          float* __restrict__ loss_out) {
+    __shared__ float sh_a[1024];
+    __shared__ float sh_b[1024];
+    const int t = threadIdx.x;
+    const int64_t per = (batch + 1023) / 1024;
+    float a = 0.f, r = 0.f;
+    for (int64_t i = t * per; i < min(batch, (t + 1) * per); ++i) {
+        a += softplus_v[i];
+        r += reg_v[i];
+    }
+    sh_a[t] = a;
+    sh_b[t] = r;
+    __syncthreads();
+    for (int s = 512; s > 0; s >>= 1) {
+        if (t < s) {
+            sh_a[t] += sh_a[t + s];
+            sh_b[t] += sh_b[t + s];
+        }
+        __syncthreads();
+    }
+    if (t == 0) loss_out[0] = -sh_a[0] * inv_batch + lambda * sh_b[0];
+}
+
+// ------------------------------------------------------------------ Adam ---------------
+__global__ __launch_bounds__(kBlock) void adam_kernel(int64_t n_rows, int d4, float4* __restrict__ p,
+                                                      int64_t ldp4, const float4* __restrict__ g,
+                                                      int64_t ldg4, float4* __restrict__ m,
+                                                      float4* __restrict__ v,
+                                                      const float* __restrict__ reg_w, float b1, float b2,
+                                                      float step_size, float bc2_sqrt, float eps) {
+    const int64_t total = n_rows * d4;
+    const float omb1 = 1.f - b1, omb2 = 1.f - b2;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / d4;
+        const int c = (int)(i - r * d4);
+        float4 pp = p[r * ldp4 + c];
+        float4 gg = g[r * ldg4 + c];
+        float4 mm = m[i];
+        float4 vv = v[i];
+        if (reg_w) {
+            const float w = reg_w[r];
+            gg.x = fmaf(w, pp.x, gg.x);
+            gg.y = fmaf(w, pp.y, gg.y);
+            gg.z = fmaf(w, pp.z, gg.z);
+            gg.w = fmaf(w, pp.w, gg.w);
+        }
+#define MI_ADAM_1(f)                                              \
+        mm.f = b1 * mm.f + omb1 * gg.f;                           \
+        vv.f = b2 * vv.f + omb2 * gg.f * gg.f;                    \
+        pp.f = pp.f - step_size * (mm.f / (sqrtf(vv.f) / bc2_sqrt + eps));
+        MI_ADAM_1(x) MI_ADAM_1(y) MI_ADAM_1(z) MI_ADAM_1(w)
+#undef MI_ADAM_1
+        p[r * ldp4 + c] = pp;
+        m[i] = mm;
+        v[i] = vv;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int mi_sample_bpr_batch(int64_t batch, int64_t nnz, const int32_t* rowptr, const int32_t* col,
+                        const int32_t* row_of_edge, int64_t neg_range, int32_t quirk_user_rows,
+                        uint64_t seed, uint64_t step, int64_t* users, int64_t* pos, int64_t* neg,
+                        mi_stream_t stream) {
+    MI_CHECK_ARG(batch >= 0);
+    if (batch == 0) return 0;
+    MI_CHECK_ARG(nnz > 0 && neg_range > 0 && rowptr && col && row_of_edge && users && pos && neg);
+    if (nnz >= INT32_MAX || neg_range >= INT32_MAX) return MI_ERR_TOO_LARGE;
+    dim3 g((unsigned)mi_ceil_div(batch, kBlock));
+    hipLaunchKernelGGL(sample_bpr_kernel, g, dim3(kBlock), 0, (hipStream_t)stream, batch, nnz, rowptr, col,
+                       row_of_edge, neg_range, quirk_user_rows, seed, step, users, pos, neg);
+    return mi_launch_status();
+}
+
+size_t mi_bpr_workspace_bytes(int64_t batch) {
+    return 2 * mi_align_up((size_t)(batch > 0 ? batch : 1) * sizeof(float), 256);
+}
+
+int mi_bpr_fwd_bwd_f32(int64_t batch, int64_t d, int64_t n_users, const int64_t* users,
+                       const int64_t* pos, const int64_t* neg, const float* final_emb, int64_t ldf,
+                       const float* e0, int64_t lde, float lambda, float g_scale, float reg_scale,
+                       float* loss_out, float* g_final, int64_t ldg, float* reg_w, void* ws,
+                       size_t ws_bytes, mi_stream_t stream) {
+    MI_CHECK_ARG(batch > 0 && d > 0 && n_users >= 0);
+    MI_CHECK_ARG(users && pos && neg && final_emb && e0 && loss_out && ws);
+    MI_CHECK_ARG(ldf >= d && lde >= d && (!g_final || ldg >= d));
+    if (ws_bytes < mi_bpr_workspace_bytes(batch)) return MI_ERR_WORKSPACE;
+    MiArena arena(ws, ws_bytes);
+    float* spv = arena.take<float>(batch);
+    float* rgv = arena.take<float>(batch);
+    hipStream_t s = (hipStream_t)stream;
+    const float inv_b = 1.0f / (float)batch;
+    dim3 g((unsigned)mi_ceil_div(batch * MI_WAVE, kBlock));
+    hipLaunchKernelGGL(bpr_slot_kernel, g, dim3(kBlock), 0, s, batch, (int)d, n_users, users, pos, neg,
+                       final_emb, ldf, e0, lde, inv_b, g_scale, reg_scale * lambda, spv, rgv, g_final, ldg,
+                       reg_w);
+    hipLaunchKernelGGL(bpr_finish_kernel, dim3(1), dim3(1024), 0, s, batch, spv, rgv, inv_b, lambda, loss_out);
+    return mi_launch_status();
+}
+
+int mi_adam_dense_f32(int64_t n_rows, int64_t d, float* p, int64_t ldp, const float* grad,
+                      int64_t ldgr, float* m, float* v, const float* reg_w, float beta1, float beta2,
+                      float step_size, float bc2_sqrt, float eps, mi_stream_t stream) {
+    MI_CHECK_ARG(n_rows >= 0 && d > 0);
+    if (n_rows == 0) return 0;
+    MI_CHECK_ARG(p && grad && m && v);
+    if (d % 4 != 0) return MI_ERR_UNSUPPORTED;
+    MI_CHECK_ARG(ldp % 4 == 0 && ldgr % 4 == 0 && ldp >= d && ldgr >= d);
+    MI_CHECK_ARG(mi_aligned16(p) && mi_aligned16(grad) && mi_aligned16(m) && mi_aligned16(v));
+    const int64_t total = n_rows * (d / 4);
+    int64_t blocks = mi_ceil_div(total, kBlock);
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, n_rows,
+                       (int)(d / 4), reinterpret_cast<float4*>(p), ldp / 4,
+                       reinterpret_cast<const float4*>(grad), ldgr / 4, reinterpret_cast<float4*>(m),
+                       reinterpret_cast<float4*>(v), reg_w, beta1, beta2, step_size, bc2_sqrt, eps);
+    return mi_launch_status();
+}
+
+}  // extern "C"

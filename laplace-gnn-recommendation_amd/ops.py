@@ -1,0 +1,275 @@
+"""Tensor-level wrappers over the C ABI (include/laplace_hip.h).
+
+PyTorch is plumbing here: device memory, the current HIP stream, dtype/shape checks.  Every
+function requires GPU tensors and raises otherwise — there is no CPU path in the product.
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+from dataclasses import dataclass, field
+from typing import Optional, Tuple
+
+import torch as t
+from torch import Tensor
+
+from . import _lib
+from ._lib import SpmmPlanStruct, check
+
+DEFAULT_CHUNK = 256  # nnz per work item of a split (hub) row
+
+# bench.py sets this to a list to collect (start, end) HIP events around every propagate launch,
+# recorded on the stream the kernels are launched on.  None = no timing overhead.
+SPMM_EVENTS = None
+
+
+def _stream() -> int:
+    return t.cuda.current_stream().cuda_stream
+
+
+def _ptr(x: Optional[Tensor]) -> Optional[int]:
+    if x is None:
+        return None
+    return x.data_ptr() if x.numel() > 0 else None
+
+
+def _need(x: Tensor, dtype: t.dtype, name: str, contiguous: bool = True) -> None:
+    if not isinstance(x, Tensor):
+        raise TypeError(f"{name}: expected a tensor, got {type(x)}")
+    if not x.is_cuda:
+        raise _lib.MiError(f"{name}: tensor is on {x.device}; the HIP path needs a GPU tensor (no CPU fallback)")
+    if x.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {x.dtype}")
+    if contiguous and not x.is_contiguous():
+        raise ValueError(f"{name}: must be contiguous")
+
+
+def _rows_ok(x: Tensor, name: str) -> int:
+    """Checks a 2-D fp32 row-major matrix with unit inner stride; returns its leading dimension."""
+    _need(x, t.float32, name, contiguous=False)
+    if x.dim() != 2 or (x.shape[1] > 1 and x.stride(1) != 1):
+        raise ValueError(f"{name}: expected a row-major 2-D matrix, got shape {tuple(x.shape)} strides {x.stride()}")
+    return x.stride(0) if x.shape[0] > 1 else max(x.shape[1], x.stride(0))
+
+
+def _ws(nbytes: int, device) -> Tensor:
+    return t.empty(max(int(nbytes), 256), dtype=t.uint8, device=device)
+
+
+# --------------------------------------------------------------------------------------
+# CSR container
+# --------------------------------------------------------------------------------------
+@dataclass
+class SpmmPlan:
+    struct: SpmmPlanStruct
+    long_rows: Optional[Tensor]
+    item_ptr: Optional[Tensor]
+    items: Optional[Tensor]
+    partial: dict = field(default_factory=dict)  # d -> workspace tensor
+
+    @property
+    def n_long_rows(self) -> int:
+        return int(self.struct.n_long_rows)
+
+    @property
+    def n_items(self) -> int:
+        return int(self.struct.n_items)
+
+
+@dataclass
+class DeviceCSR:
+    """Sorted CSR on the GPU: int32 rowptr/col, optional fp32 val, optional perm to the input order."""
+    n_rows: int
+    n_cols: int
+    rowptr: Tensor
+    col: Tensor
+    val: Optional[Tensor] = None
+    perm: Optional[Tensor] = None
+    plan: Optional[SpmmPlan] = None
+
+    @property
+    def nnz(self) -> int:
+        return int(self.col.numel())
+
+    @property
+    def device(self):
+        return self.rowptr.device
+
+
+def coo_to_csr(row: Tensor, col: Tensor, n_rows: int, n_cols: int, want_perm: bool = True) -> DeviceCSR:
+    """K4 — replaces SparseTensor(row=, col=, sparse_sizes=) (data/lightgcn_loader.py:65-79)."""
+    _need(row, t.int64, "row")
+    _need(col, t.int64, "col")
+    if row.shape != col.shape or row.dim() != 1:
+        raise ValueError("row/col must be 1-D tensors of equal length")
+    nnz = row.numel()
+    dev = row.device
+    rowptr = t.empty(n_rows + 1, dtype=t.int32, device=dev)
+    col_out = t.empty(nnz, dtype=t.int32, device=dev)
+    perm = t.empty(nnz, dtype=t.int32, device=dev) if want_perm else None
+    L = _lib.lib()
+    ws = _ws(L.mi_coo_to_csr_workspace_bytes(n_rows, nnz), dev)
+    check(L.mi_coo_to_csr_i32(n_rows, n_cols, nnz, _ptr(row), _ptr(col), _ptr(rowptr), _ptr(col_out),
+                              _ptr(perm), ws.data_ptr(), ws.numel(), _stream()), "mi_coo_to_csr_i32")
+    return DeviceCSR(n_rows, n_cols, rowptr, col_out, None, perm)
+
+
+def csr_transpose(a: DeviceCSR) -> DeviceCSR:
+    """CSR(A) -> CSR(A^T); values follow through perm_t (replaces csr2csc of torch_sparse)."""
+    dev = a.device
+    rowptr_t = t.empty(a.n_cols + 1, dtype=t.int32, device=dev)
+    col_t = t.empty(a.nnz, dtype=t.int32, device=dev)
+    perm_t = t.empty(a.nnz, dtype=t.int32, device=dev)
+    L = _lib.lib()
+    ws = _ws(L.mi_csr_transpose_workspace_bytes(a.n_rows, a.nnz), dev)
+    check(L.mi_csr_transpose_i32(a.n_rows, a.n_cols, a.nnz, _ptr(a.rowptr), _ptr(a.col), _ptr(rowptr_t),
+                                 _ptr(col_t), _ptr(perm_t), ws.data_ptr(), ws.numel(), _stream()),
+          "mi_csr_transpose_i32")
+    val_t = gather_f32(a.val, perm_t) if a.val is not None else None
+    return DeviceCSR(a.n_cols, a.n_rows, rowptr_t, col_t, val_t, perm_t)
+
+
+def gather_f32(src: Tensor, idx: Tensor) -> Tensor:
+    _need(src, t.float32, "src")
+    _need(idx, t.int32, "idx")
+    out = t.empty(idx.numel(), dtype=t.float32, device=src.device)
+    check(_lib.lib().mi_gather_f32(idx.numel(), _ptr(src), _ptr(idx), _ptr(out), _stream()), "mi_gather_f32")
+    return out
+
+
+def gcn_norm(a: DeviceCSR, val_in: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
+    """K3 — gcn_norm(adj, add_self_loops=False) (model/lightgcn.py:56). Returns (val, deg^-1/2)."""
+    if a.n_rows != a.n_cols:
+        raise ValueError("gcn_norm needs a square adjacency")
+    if val_in is not None:
+        _need(val_in, t.float32, "val_in")
+    val = t.empty(a.nnz, dtype=t.float32, device=a.device)
+    dis = t.empty(a.n_rows, dtype=t.float32, device=a.device)
+    check(_lib.lib().mi_gcn_norm_csr_f32(a.n_rows, a.nnz, _ptr(a.rowptr), _ptr(a.col), _ptr(val_in),
+                                         _ptr(val), _ptr(dis), _stream()), "mi_gcn_norm_csr_f32")
+    return val, dis
+
+
+def build_spmm_plan(a: DeviceCSR, chunk: int = DEFAULT_CHUNK) -> SpmmPlan:
+    L = _lib.lib()
+    ml, mi = ctypes.c_int64(0), ctypes.c_int64(0)
+    check(L.mi_spmm_plan_bounds(a.n_rows, a.nnz, chunk, ctypes.byref(ml), ctypes.byref(mi)), "mi_spmm_plan_bounds")
+    dev = a.device
+    long_rows = t.empty(max(ml.value, 1), dtype=t.int32, device=dev)
+    item_ptr = t.empty(max(ml.value, 1) + 1, dtype=t.int32, device=dev)
+    items = t.empty(4 * max(mi.value, 1), dtype=t.int32, device=dev)
+    st = SpmmPlanStruct()
+    st.long_rows, st.item_ptr, st.items = long_rows.data_ptr(), item_ptr.data_ptr(), items.data_ptr()
+    ws = _ws(L.mi_spmm_plan_workspace_bytes(a.n_rows), dev)
+    check(L.mi_spmm_plan_build(a.n_rows, _ptr(a.rowptr), chunk, ctypes.byref(st), ws.data_ptr(), ws.numel(),
+                               _stream()), "mi_spmm_plan_build")
+    # shrink to what is used (keeps the pointers valid: slices share storage)
+    nl, ni = int(st.n_long_rows), int(st.n_items)
+    return SpmmPlan(st, long_rows[:max(nl, 1)], item_ptr[:max(nl, 1) + 1], items[:4 * max(ni, 1)])
+
+
+def spmm(a: DeviceCSR, X: Tensor, *, Y: Optional[Tensor] = None, addend: Optional[Tensor] = None,
+         S: Optional[Tensor] = None, scale: float = 1.0) -> None:
+    """K1/K2 — acc = A @ X; Y = acc (optional); S = scale * (addend + acc) (optional)."""
+    if a.val is None:
+        raise ValueError("spmm needs edge values (run gcn_norm or set val)")
+    d = X.shape[1]
+    ldx = _rows_ok(X, "X")
+    if X.shape[0] != a.n_cols:
+        raise ValueError(f"X has {X.shape[0]} rows, adjacency has {a.n_cols} columns")
+    for name, m in (("Y", Y), ("addend", addend), ("S", S)):
+        if m is not None and (m.shape[0] != a.n_rows or m.shape[1] != d):
+            raise ValueError(f"{name} must be [{a.n_rows}, {d}], got {tuple(m.shape)}")
+    if Y is None and S is None:
+        raise ValueError("spmm needs an output (Y and/or S)")
+    ldy = _rows_ok(Y, "Y") if Y is not None else 0
+    lda = _rows_ok(addend, "addend") if addend is not None else 0
+    lds = _rows_ok(S, "S") if S is not None else 0
+    if a.plan is None:
+        a.plan = build_spmm_plan(a)
+    plan = a.plan
+    L = _lib.lib()
+    ws_ptr, ws_bytes = None, 0
+    if plan.n_items > 0:
+        if d not in plan.partial:
+            plan.partial[d] = _ws(L.mi_spmm_workspace_bytes(ctypes.byref(plan.struct), d), a.device)
+        ws_ptr, ws_bytes = plan.partial[d].data_ptr(), plan.partial[d].numel()
+    col_ptr = _ptr(a.col) if a.nnz else a.rowptr.data_ptr()
+    val_ptr = _ptr(a.val) if a.nnz else a.rowptr.data_ptr()
+    ev = None
+    if SPMM_EVENTS is not None:
+        ev = (t.cuda.Event(enable_timing=True), t.cuda.Event(enable_timing=True))
+        ev[0].record()
+    check(L.mi_spmm_csr_f32(a.n_rows, d, _ptr(a.rowptr), col_ptr, val_ptr, X.data_ptr(), ldx,
+                            _ptr(Y), ldy, _ptr(addend), lda, _ptr(S), lds, float(scale),
+                            ctypes.byref(plan.struct), ws_ptr, ws_bytes, _stream()), "mi_spmm_csr_f32")
+    if ev is not None:
+        ev[1].record()
+        SPMM_EVENTS.append(ev)
+
+
+def expand_rows(a: DeviceCSR) -> Tensor:
+    out = t.empty(a.nnz, dtype=t.int32, device=a.device)
+    check(_lib.lib().mi_csr_expand_rows(a.n_rows, _ptr(a.rowptr), _ptr(out), a.nnz, _stream()),
+          "mi_csr_expand_rows")
+    return out
+
+
+def sample_bpr_batch(r: DeviceCSR, row_of_edge: Tensor, batch: int, neg_range: int, seed: int, step: int,
+                     quirk: bool = False, out: Optional[Tuple[Tensor, Tensor, Tensor]] = None
+                     ) -> Tuple[Tensor, Tensor, Tensor]:
+    """K9 — replaces sample_mini_batch (data/lightgcn_loader.py:95-112) on device."""
+    if r.nnz == 0:
+        raise ValueError("cannot sample from an empty edge set")
+    if neg_range <= 0:
+        raise ValueError("neg_range must be positive")
+    dev = r.device
+    if out is None:
+        out = tuple(t.empty(batch, dtype=t.int64, device=dev) for _ in range(3))
+    users, pos, neg = out
+    check(_lib.lib().mi_sample_bpr_batch(batch, r.nnz, _ptr(r.rowptr), _ptr(r.col), _ptr(row_of_edge),
+                                         int(neg_range), 1 if quirk else 0, int(seed) & (2**64 - 1),
+                                         int(step) & (2**64 - 1), _ptr(users), _ptr(pos), _ptr(neg),
+                                         _stream()), "mi_sample_bpr_batch")
+    return users, pos, neg
+
+
+def bpr_fwd_bwd(users: Tensor, pos: Tensor, neg: Tensor, final_emb: Tensor, e0: Tensor, n_users: int,
+                lambda_val: float, *, g_final: Optional[Tensor] = None, reg_w: Optional[Tensor] = None,
+                g_scale: float = 1.0, reg_scale: float = 1.0, loss_out: Optional[Tensor] = None) -> Tensor:
+    """a7+a8 — batch gather + bpr_loss (utils/metrics_lightgcn.py:9-45) forward and backward."""
+    for n, x in (("users", users), ("pos", pos), ("neg", neg)):
+        _need(x, t.int64, n)
+    batch = users.numel()
+    d = final_emb.shape[1]
+    ldf = _rows_ok(final_emb, "final_emb")
+    lde = _rows_ok(e0, "e0")
+    ldg = _rows_ok(g_final, "g_final") if g_final is not None else 0
+    if reg_w is not None:
+        _need(reg_w, t.float32, "reg_w")
+    dev = final_emb.device
+    if loss_out is None:
+        loss_out = t.empty(1, dtype=t.float32, device=dev)
+    L = _lib.lib()
+    ws = _ws(L.mi_bpr_workspace_bytes(batch), dev)
+    check(L.mi_bpr_fwd_bwd_f32(batch, d, n_users, _ptr(users), _ptr(pos), _ptr(neg), final_emb.data_ptr(), ldf,
+                               e0.data_ptr(), lde, float(lambda_val), float(g_scale), float(reg_scale),
+                               loss_out.data_ptr(), _ptr(g_final), ldg, _ptr(reg_w), ws.data_ptr(),
+                               ws.numel(), _stream()), "mi_bpr_fwd_bwd_f32")
+    return loss_out
+
+
+def adam_step(p: Tensor, grad: Tensor, m: Tensor, v: Tensor, *, step: int, lr: float, beta1: float = 0.9,
+              beta2: float = 0.999, eps: float = 1e-8, reg_w: Optional[Tensor] = None) -> None:
+    """a9 — dense Adam (torch.optim.Adam semantics) in one pass."""
+    ldp = _rows_ok(p, "p")
+    ldg = _rows_ok(grad, "grad")
+    _need(m, t.float32, "m")
+    _need(v, t.float32, "v")
+    if m.shape != p.shape or v.shape != p.shape or grad.shape != p.shape:
+        raise ValueError("p, grad, m, v must have equal shapes")
+    bc1 = 1.0 - beta1 ** step
+    bc2 = 1.0 - beta2 ** step
+    check(_lib.lib().mi_adam_dense_f32(p.shape[0], p.shape[1], p.data_ptr(), ldp, grad.data_ptr(), ldg,
+                                       m.data_ptr(), v.data_ptr(), _ptr(reg_w), beta1, beta2, lr / bc1,
+                                       math.sqrt(bc2), eps, _stream()), "mi_adam_dense_f32")

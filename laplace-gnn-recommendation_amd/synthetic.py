@@ -1,0 +1,92 @@
+"""Seeded synthetic user-item graphs with the shapes SURVEY §8(d) names (C1, C2, C4 shards).
+
+Generation is host-side numpy so that the GPU run and the CPU baseline see the very same edges.
+User degrees: clipped log-normal rescaled to the edge budget; item popularity: Zipf(s) over a
+seeded permutation of item ids; (user, item) pairs are distinct.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, replace
+
+import numpy as np
+import torch as t
+
+
+@dataclass
+class SyntheticSpec:
+    num_users: int
+    num_items: int
+    num_edges: int
+    seed: int
+    deg_sigma: float = 1.0
+    deg_min: int = 1
+    deg_max: int = 2000
+    zipf_s: float = 1.05
+    item_perm_seed: int = 12345  # shared by all shards of one graph: same popular items everywhere
+
+
+C1 = SyntheticSpec(943, 1682, 100_000, seed=0, deg_sigma=1.0, deg_min=20, deg_max=737, zipf_s=1.0)
+C2 = SyntheticSpec(1_000_000, 100_000, 10_000_000, seed=1)
+
+
+def shard_spec(spec: SyntheticSpec, rank: int) -> SyntheticSpec:
+    """Spec of rank `rank`'s user shard of a weak-scaled graph: same items, its own users/edges."""
+    return replace(spec, seed=spec.seed * 1000 + 17 * rank + (1 if rank else 0))
+
+
+def item_popularity(spec: SyntheticSpec) -> np.ndarray:
+    ranks = np.arange(1, spec.num_items + 1, dtype=np.float64)
+    p = ranks ** (-spec.zipf_s)
+    p /= p.sum()
+    perm = np.random.default_rng(spec.item_perm_seed).permutation(spec.num_items)
+    out = np.empty_like(p)
+    out[perm] = p
+    return out
+
+
+def user_degrees(spec: SyntheticSpec, rng: np.random.Generator) -> np.ndarray:
+    mean = spec.num_edges / spec.num_users
+    mu = np.log(max(mean, 1.0)) - 0.5 * spec.deg_sigma ** 2
+    d = rng.lognormal(mu, spec.deg_sigma, spec.num_users)
+    d = np.clip(d, spec.deg_min, spec.deg_max)
+    d = d * (spec.num_edges / d.sum())
+    return np.clip(np.rint(d), spec.deg_min, min(spec.deg_max, spec.num_items)).astype(np.int64)
+
+
+def generate(spec: SyntheticSpec) -> t.Tensor:
+    """Returns edge_index int64 [2, E]: row 0 = user id in [0, U), row 1 = item id in [0, I)."""
+    rng = np.random.default_rng(spec.seed)
+    U, I, E = spec.num_users, spec.num_items, spec.num_edges
+    if E > U * I:
+        raise ValueError("more edges requested than distinct pairs exist")
+    p = item_popularity(spec)
+    cdf = np.cumsum(p)
+    cdf[-1] = 1.0
+    deg = user_degrees(spec, rng)
+    keys = np.empty(0, dtype=np.int64)
+    have = np.zeros(U, dtype=np.int64)
+    for _ in range(16):
+        deficit = np.maximum(deg - have, 0)
+        if keys.size >= E and deficit.sum() == 0:
+            break
+        n_draw = np.where(deficit > 0, np.ceil(deficit * 1.25).astype(np.int64) + 1, 0)
+        if keys.size < E and n_draw.sum() == 0:  # degrees met but edge budget not: spread the rest
+            extra = rng.integers(0, U, size=int((E - keys.size) * 1.2) + 16)
+            n_draw = np.bincount(extra, minlength=U)
+        u = np.repeat(np.arange(U, dtype=np.int64), n_draw)
+        i = np.searchsorted(cdf, rng.random(u.size), side="right").astype(np.int64)
+        np.minimum(i, I - 1, out=i)
+        keys = np.unique(np.concatenate([keys, u * I + i]))
+        have = np.bincount(keys // I, minlength=U)
+    if keys.size < E:
+        raise RuntimeError(f"generator produced {keys.size} < {E} distinct edges")
+    if keys.size > E:  # trim uniformly, but never a user's only edge
+        u_of = keys // I
+        first = np.ones(keys.size, dtype=bool)
+        first[1:] = u_of[1:] != u_of[:-1]
+        prio = rng.random(keys.size)
+        prio[first] = -1.0
+        keep = np.argpartition(prio, E - 1)[:E]
+        keys = keys[keep]
+    keys = keys[rng.permutation(keys.size)]  # edge order carries no structure (a raw transaction log)
+    return t.from_numpy(np.stack([keys // I, keys % I]))

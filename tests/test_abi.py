@@ -1,0 +1,77 @@
+"""The C-ABI library loads without a GPU and exports exactly what include/laplace_hip.h declares."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch as t
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "laplace_hip.h")
+
+
+def _declared():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(mi_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_declares_functions():
+    names = _declared()
+    assert "mi_spmm_csr_f32" in names and "mi_coo_to_csr_i32" in names and len(names) >= 15
+
+
+def test_library_exports_every_declared_symbol():
+    from laplace_amd import _lib
+    handle = ctypes.CDLL(_lib.LIB_PATH)
+    for name in _declared():
+        assert hasattr(handle, name), f"{name} declared in laplace_hip.h but not exported"
+
+
+def test_binding_covers_header_exactly():
+    from laplace_amd import _lib
+    assert _lib.exported_symbols() == _declared()
+    L = _lib.lib()
+    assert L.mi_abi_version() == _lib.MI_ABI_VERSION
+    assert L.mi_error_string(0) == b"success"
+    assert b"workspace" in L.mi_error_string(-3)
+
+
+def test_size_queries_run_without_gpu():
+    from laplace_amd import _lib
+    L = _lib.lib()
+    assert L.mi_coo_to_csr_workspace_bytes(1000, 5000) >= 5000 * 24
+    assert L.mi_bpr_workspace_bytes(128) >= 2 * 128 * 4
+    ml, mi = ctypes.c_int64(), ctypes.c_int64()
+    assert L.mi_spmm_plan_bounds(10, 1000, 256, ctypes.byref(ml), ctypes.byref(mi)) == 0
+    assert ml.value == 3 and mi.value == 1000 // 256 + 3
+    assert L.mi_spmm_plan_bounds(10, 1000, 0, ctypes.byref(ml), ctypes.byref(mi)) == -1  # MI_ERR_BAD_ARG
+
+
+def test_ops_refuse_cpu_tensors():
+    """No CPU fallback: handing the product a CPU tensor is an error, not a slow path."""
+    from laplace_amd import ops, _lib
+    from laplace_amd.sparse import SparseTensor
+    row, col = t.tensor([0, 1]), t.tensor([1, 0])
+    with pytest.raises(_lib.MiError):
+        ops.coo_to_csr(row, col, 2, 2)
+    with pytest.raises(_lib.MiError):
+        SparseTensor(row=row, col=col, sparse_sizes=(2, 2)).csr()
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from laplace_amd import _lib
+    monkeypatch.setattr(_lib, "_LIB", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(_lib.MiError, match="no CPU fallback"):
+        _lib.lib()
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "laplace-gnn-recommendation_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f
+                assert "liboracle_ref" not in text, f

@@ -1,0 +1,406 @@
+"""GPU parity tests for the LightGCN hot path: HIP kernels (through the C ABI) vs the oracle.
+
+Bars: bit-exact for integer / index work; fp32 embeddings within 1e-4 absolute (north_star), in
+practice asserted tighter where the arithmetic allows; top-K indices exact.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch as t
+
+from oracle import lightgcn_ref as R
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def _ops():
+    from laplace_amd import ops
+    return ops
+
+
+def _rand_graph(n_rows, n_cols, nnz, seed):
+    g = t.Generator().manual_seed(seed)
+    return t.randint(0, n_rows, (nnz,), generator=g), t.randint(0, n_cols, (nnz,), generator=g)
+
+
+# ---------------------------------------------------------------------------- K4: CSR build
+@pytest.mark.parametrize("n_rows,n_cols,nnz", [(1, 1, 1), (7, 5, 0), (37, 91, 400), (1000, 1000, 20000), (3, 200000, 5000)])
+def test_coo_to_csr_bit_exact(n_rows, n_cols, nnz):
+    ops = _ops()
+    row, col = _rand_graph(n_rows, n_cols, nnz, seed=nnz + n_rows)
+    if nnz > 10:  # force duplicates and an empty leading row
+        row[:5], col[:5] = row[5], col[5]
+    a = ops.coo_to_csr(row.to(DEV), col.to(DEV), n_rows, n_cols)
+    rowptr, col_s, _ = R.sparse_tensor_csr(row, col, n_rows, n_cols)
+    assert t.equal(a.rowptr.cpu().long(), rowptr)
+    assert t.equal(a.col.cpu().long(), col_s)
+    perm = a.perm.cpu().long()
+    assert sorted(perm.tolist()) == list(range(nnz))
+    assert t.equal(row[perm] * n_cols + col[perm], rowptr.new_tensor(
+        (t.repeat_interleave(t.arange(n_rows), rowptr[1:] - rowptr[:-1]) * n_cols + col_s).tolist()))
+
+
+def test_csr_transpose_bit_exact():
+    ops = _ops()
+    row, col = _rand_graph(300, 170, 6000, seed=3)
+    a = ops.coo_to_csr(row.to(DEV), col.to(DEV), 300, 170)
+    a.val = t.rand(a.nnz, device=DEV)
+    at = ops.csr_transpose(a)
+    rowptr_t, col_t, _ = R.sparse_tensor_csr(col, row, 170, 300)
+    assert t.equal(at.rowptr.cpu().long(), rowptr_t) and t.equal(at.col.cpu().long(), col_t)
+    # values follow their entries: dense check
+    dense = t.zeros(300, 170)
+    ar = t.repeat_interleave(t.arange(300), (a.rowptr[1:] - a.rowptr[:-1]).cpu().long())
+    dense.index_put_((ar, a.col.cpu().long()), a.val.cpu(), accumulate=True)
+    dense_t = t.zeros(170, 300)
+    atr = t.repeat_interleave(t.arange(170), (at.rowptr[1:] - at.rowptr[:-1]).cpu().long())
+    dense_t.index_put_((atr, at.col.cpu().long()), at.val.cpu(), accumulate=True)
+    assert t.allclose(dense.T, dense_t, atol=1e-6)
+
+
+# ---------------------------------------------------------------------------- K3: gcn_norm
+def test_gcn_norm_matches_oracle():
+    ops = _ops()
+    n = 500
+    row, col = _rand_graph(n, n, 7000, seed=11)
+    row[row == 17] = 18  # an empty row -> deg 0 -> dis 0 (inf masked)
+    a = ops.coo_to_csr(row.to(DEV), col.to(DEV), n, n)
+    val, dis = ops.gcn_norm(a)
+    rowptr, col_s, _ = R.sparse_tensor_csr(row, col, n, n)
+    want = R.gcn_norm_csr(rowptr, col_s)
+    assert t.allclose(val.cpu(), want, rtol=3e-7, atol=0)
+    assert float(dis[17]) == 0.0
+    # weighted variant
+    w = t.rand(7000) + 0.5
+    a.val = ops.gather_f32(w.to(DEV), a.perm)
+    val_w, _ = ops.gcn_norm(a, a.val)
+    want_w = R.gcn_norm_csr(rowptr, col_s, w[R.sparse_tensor_csr(row, col, n, n)[2]])
+    assert t.allclose(val_w.cpu(), want_w, rtol=1e-6, atol=0)
+
+
+# ---------------------------------------------------------------------------- K1: SpMM
+def _csr_with_vals(row, col, n_rows, n_cols, seed):
+    ops = _ops()
+    a = ops.coo_to_csr(row.to(DEV), col.to(DEV), n_rows, n_cols)
+    g = t.Generator().manual_seed(seed)
+    a.val = (t.rand(a.nnz, generator=g) - 0.3).to(DEV)
+    return a
+
+
+def _oracle_spmm(a, X):
+    return R.spmm_c(a.rowptr.cpu(), a.col.cpu(), a.val.cpu(), X.cpu())
+
+
+@pytest.mark.parametrize("d", [4, 32, 64, 96, 128, 256, 320, 512])
+def test_spmm_feature_widths(d):
+    ops = _ops()
+    n_rows, n_cols = 777, 431  # not multiples of 64
+    row, col = _rand_graph(n_rows, n_cols, 9000, seed=d)
+    row[row == 5] = 6  # empty row
+    a = _csr_with_vals(row, col, n_rows, n_cols, seed=d)
+    X = t.randn(n_cols, d, generator=t.Generator().manual_seed(d)).to(DEV)
+    Y = t.full((n_rows, d), float("nan"), device=DEV)
+    ops.spmm(a, X, Y=Y)
+    want = _oracle_spmm(a, X)
+    assert t.allclose(Y.cpu(), want, atol=2e-5, rtol=1e-5)
+    assert float(Y[5].abs().max()) == 0.0
+
+
+def test_spmm_hub_rows_split_path_and_determinism():
+    """One 100K-degree row, a few mid hubs, many short rows; result independent of scheduling."""
+    ops = _ops()
+    n, d = 3000, 128
+    g = t.Generator().manual_seed(0)
+    hub = t.stack([t.full((100_000,), 7), t.randint(0, n, (100_000,), generator=g)])
+    mid = t.stack([t.randint(10, 14, (3000,), generator=g), t.randint(0, n, (3000,), generator=g)])
+    rest = t.stack(_rand_graph(n, n, 20000, seed=1))
+    ei = t.cat([hub, mid, rest], dim=1)
+    a = _csr_with_vals(ei[0], ei[1], n, n, seed=2)
+    a.val = a.val * 0.01
+    a.plan = ops.build_spmm_plan(a, chunk=256)
+    assert a.plan.n_long_rows >= 5 and a.plan.n_items >= 100_000 // 256
+    X = t.randn(n, d, generator=g).to(DEV)
+    Y1, Y2 = t.empty(n, d, device=DEV), t.empty(n, d, device=DEV)
+    ops.spmm(a, X, Y=Y1)
+    ops.spmm(a, X, Y=Y2)
+    assert t.equal(Y1, Y2)  # no atomics: bitwise reproducible
+    want = _oracle_spmm(a, X)
+    assert t.allclose(Y1.cpu(), want, atol=5e-4, rtol=1e-4)  # 100K-term fp32 sums, different order
+    # against float64 accumulation the HIP path must be at least as good as the sequential oracle
+    L = R.clib()
+    y64 = t.empty(n, d, dtype=t.float64)
+    rp, c, v, Xc = a.rowptr.cpu(), a.col.cpu(), a.val.cpu(), X.cpu()
+    L.ref_spmm_csr_f64acc(n, d, rp.data_ptr(), c.data_ptr(), v.data_ptr(), Xc.data_ptr(), d, y64.data_ptr(), d)
+    err_hip = (Y1.cpu().double() - y64).abs().max()
+    err_seq = (want.double() - y64).abs().max()
+    assert err_hip <= max(2 * err_seq, 1e-5)
+    # a different chunk size changes only rounding
+    a.plan = ops.build_spmm_plan(a, chunk=1000)
+    Y3 = t.empty(n, d, device=DEV)
+    ops.spmm(a, X, Y=Y3)
+    assert t.allclose(Y3, Y1, atol=5e-4, rtol=1e-4)
+
+
+def test_spmm_epilogue_forms_and_strides():
+    ops = _ops()
+    n, d = 1500, 64
+    row, col = _rand_graph(n, n, 30000, seed=21)
+    a = _csr_with_vals(row, col, n, n, seed=22)
+    big = t.randn(n, 2 * d + 8, device=DEV)
+    X = big[:, 4:4 + d]  # 16-byte aligned start, leading dimension 2d+8
+    add = t.randn(n, d, device=DEV)
+    Y, S = t.empty(n, d, device=DEV), t.empty(n, d, device=DEV)
+    ops.spmm(a, X, Y=Y, addend=add, S=S, scale=0.25)
+    want = _oracle_spmm(a, X.contiguous())
+    assert t.allclose(Y.cpu(), want, atol=2e-5, rtol=1e-5)
+    assert t.allclose(S.cpu(), 0.25 * (add.cpu() + want), atol=2e-5, rtol=1e-5)
+    # in-place running sum: S aliases addend
+    run = add.clone()
+    ops.spmm(a, X, addend=run, S=run, scale=1.0)
+    assert t.allclose(run.cpu(), add.cpu() + want, atol=2e-5, rtol=1e-5)
+    # S without addend
+    S2 = t.empty(n, d, device=DEV)
+    ops.spmm(a, X, S=S2, scale=2.0)
+    assert t.allclose(S2.cpu(), 2.0 * want, atol=4e-5, rtol=1e-5)
+
+
+def test_spmm_rejects_bad_arguments():
+    ops = _ops()
+    from laplace_amd._lib import MiError
+    row, col = _rand_graph(10, 10, 30, seed=1)
+    a = _csr_with_vals(row, col, 10, 10, seed=1)
+    X = t.randn(10, 8, device=DEV)
+    with pytest.raises(MiError):
+        ops.spmm(a, X, Y=X)  # aliasing
+    with pytest.raises(ValueError):
+        ops.spmm(a, t.randn(9, 8, device=DEV), Y=t.empty(10, 8, device=DEV))
+    with pytest.raises(MiError):
+        ops.spmm(a, t.randn(10, 6, device=DEV), Y=t.empty(10, 6, device=DEV))  # d % 4 != 0
+
+
+def test_spmm_empty_adjacency():
+    ops = _ops()
+    a = ops.coo_to_csr(t.empty(0, dtype=t.int64, device=DEV), t.empty(0, dtype=t.int64, device=DEV), 6, 6)
+    a.val = t.empty(0, device=DEV)
+    X = t.randn(6, 16, device=DEV)
+    S = t.empty(6, 16, device=DEV)
+    ops.spmm(a, X, addend=X, S=S, scale=0.5)
+    assert t.allclose(S, 0.5 * X)
+
+
+# ---------------------------------------------------------------------------- LightGCN.forward
+def _model_and_graph(U, I, E, D, K, seed, compat):
+    from laplace_amd.interactions import Interactions
+    from laplace_amd.model.lightgcn import LightGCN
+    g = t.Generator().manual_seed(seed)
+    ei = t.stack([t.randint(0, U, (E,), generator=g), t.randint(0, I, (E,), generator=g)])
+    t.manual_seed(seed)
+    model = LightGCN(U, I, embedding_dim=D, num_iterations=K)
+    inter = Interactions(ei, U, I)
+    adj = inter.adjacency(compat)
+    return model, inter, adj, ei
+
+
+@pytest.mark.parametrize("compat", ["reference", "bipartite"])
+@pytest.mark.parametrize("D,K", [(64, 2), (32, 4), (128, 3), (64, 1), (64, 0)])
+def test_lightgcn_forward_parity(compat, D, K):
+    U, I, E = 943, 1682, 20000
+    model, inter, adj, ei = _model_and_graph(U, I, E, D, K, seed=7, compat=compat)
+    uw, iw = model.users_emb.weight.detach().clone(), model.items_emb.weight.detach().clone()
+    model.to(DEV)
+    outs = model(adj.to(DEV))
+    row, col, _ = adj.coo()
+    want = R.lightgcn_forward(uw, iw, row, col, K)
+    for got, ref in zip(outs, want):
+        assert (got.detach().cpu() - ref).abs().max() <= 1e-4  # north_star tolerance
+        assert t.allclose(got.detach().cpu(), ref, atol=2e-6)    # what fp32 actually gives
+    assert outs[1] is model.users_emb.weight and outs[3] is model.items_emb.weight
+    if compat == "reference":  # item rows never receive messages
+        assert t.allclose(outs[2].detach().cpu(), iw / (K + 1), atol=1e-7)
+
+
+def test_lightgcn_forward_add_self_loops():
+    model, inter, adj, ei = _model_and_graph(50, 70, 600, 32, 2, seed=9, compat="bipartite")
+    model.add_self_loops = True
+    uw, iw = model.users_emb.weight.detach().clone(), model.items_emb.weight.detach().clone()
+    model.to(DEV)
+    uf, _, itf, _ = model(adj.to(DEV))
+    row, col, _ = adj.coo()
+    wu, _, wi, _ = R.lightgcn_forward(uw, iw, row, col, 2, add_self_loops=True)
+    assert t.allclose(uf.detach().cpu(), wu, atol=2e-6) and t.allclose(itf.detach().cpu(), wi, atol=2e-6)
+
+
+@pytest.mark.parametrize("compat", ["reference", "bipartite"])
+def test_lightgcn_autograd_backward_parity(compat):
+    """loss.backward() through the HIP propagate == torch autograd through the oracle."""
+    U, I, E, D, K = 300, 500, 6000, 64, 3
+    model, inter, adj, ei = _model_and_graph(U, I, E, D, K, seed=13, compat=compat)
+    uw = model.users_emb.weight.detach().clone().requires_grad_(True)
+    iw = model.items_emb.weight.detach().clone().requires_grad_(True)
+    g = t.Generator().manual_seed(5)
+    B = 256
+    ui, pi, ni = (t.randint(0, U, (B,), generator=g), t.randint(0, I, (B,), generator=g),
+                  t.randint(0, I, (B,), generator=g))
+    row, col, _ = adj.coo()
+    uf, u0, itf, i0 = R.lightgcn_forward(uw, iw, row, col, K)
+    loss_ref = R.bpr_loss(uf[ui], u0[ui], itf[pi], i0[pi], itf[ni], i0[ni], 1e-3)
+    loss_ref.backward()
+
+    from laplace_amd.utils.metrics_lightgcn import bpr_loss
+    model.to(DEV)
+    uf, u0, itf, i0 = model(adj.to(DEV))
+    uid, pid, nid = ui.to(DEV), pi.to(DEV), ni.to(DEV)
+    loss = bpr_loss(uf[uid], u0[uid], itf[pid], i0[pid], itf[nid], i0[nid], 1e-3)
+    loss.backward()
+    assert abs(float(loss) - float(loss_ref)) < 1e-6
+    assert t.allclose(model.users_emb.weight.grad.cpu(), uw.grad, atol=1e-7, rtol=1e-4)
+    assert t.allclose(model.items_emb.weight.grad.cpu(), iw.grad, atol=1e-7, rtol=1e-4)
+
+
+# ---------------------------------------------------------------------------- K9: sampler
+def test_sampler_bit_exact_vs_philox_oracle():
+    ops = _ops()
+    from laplace_amd.interactions import Interactions
+    U, I, E = 200, 90, 3000
+    g = t.Generator().manual_seed(3)
+    keys = t.randperm(U * I, generator=g)[:E]
+    ei = t.stack([keys // I, keys % I])
+    inter = Interactions(ei.to(DEV), U, I)
+    r = inter.csr()
+    roe = inter.row_of_edge()
+    rowptr, col_s, _ = R.sparse_tensor_csr(ei[0], ei[1], U, I)
+    assert t.equal(r.rowptr.cpu().long(), rowptr) and t.equal(r.col.cpu().long(), col_s)
+    assert t.equal(roe.cpu().long(), t.repeat_interleave(t.arange(U), rowptr[1:] - rowptr[:-1]))
+    neg_range = int(ei[1].max())  # reference: num_nodes = max(col)
+    for quirk in (False, True):
+        for step in (0, 1, 12345678901):
+            us, ps, ns = ops.sample_bpr_batch(r, roe, 512, neg_range, seed=0xDEADBEEFCAFE, step=step, quirk=quirk)
+            wu, wp, wn = R.sample_bpr_batch_philox(rowptr, col_s, 512, neg_range, seed=0xDEADBEEFCAFE, step=step,
+                                                   quirk=quirk)
+            assert t.equal(us.cpu(), wu) and t.equal(ps.cpu(), wp) and t.equal(ns.cpu(), wn)
+    # structural properties on a bigger draw
+    us, ps, ns = ops.sample_bpr_batch(r, roe, 20000, neg_range, seed=1, step=2)
+    us, ps, ns = us.cpu(), ps.cpu(), ns.cpu()
+    pos_keys = set((ei[0] * I + ei[1]).tolist())
+    assert all(k in pos_keys for k in (us * I + ps).tolist())
+    assert not any(k in pos_keys for k in (us * I + ns).tolist())
+    assert int(ns.min()) >= 0 and int(ns.max()) < neg_range
+
+
+# ---------------------------------------------------------------------------- a7/a8: BPR
+def test_bpr_kernel_matches_reference_golden(golden_dir):
+    """Loss and gradients of the fused kernel vs the reference's bpr_loss + autograd (golden)."""
+    ops = _ops()
+    for case in t.load(os.path.join(golden_dir, "bpr_loss.pt"), weights_only=False):
+        uf, u0, pf, p0, nf, n0 = case["inputs"]
+        B, D = uf.shape
+        if D % 4:
+            continue
+        # lay the six gathered blocks out as tables: users rows [0,B), pos items [B,2B), neg [2B,3B)
+        final = t.cat([uf, pf, nf]).to(DEV)
+        e0 = t.cat([u0, p0, n0]).to(DEV)
+        users = t.arange(B, device=DEV)
+        pos = t.arange(B, device=DEV)          # item ids -> rows n_users + id
+        neg = t.arange(B, 2 * B, device=DEV)
+        g_final = t.zeros(3 * B, D, device=DEV)
+        reg_w = t.zeros(3 * B, device=DEV)
+        loss = ops.bpr_fwd_bwd(users, pos, neg, final, e0, B, case["lambda"], g_final=g_final, reg_w=reg_w)
+        assert abs(float(loss) - float(case["loss"])) <= 1e-6 * max(1.0, abs(float(case["loss"])))
+        gu, g_u0, gp, g_p0, gn, g_n0 = case["grads"]
+        want_final = t.cat([gu, gp, gn])
+        assert t.allclose(g_final.cpu(), want_final, atol=1e-7, rtol=2e-5)
+        want_e0 = t.cat([g_u0, g_p0, g_n0])
+        assert t.allclose((reg_w[:, None] * e0).cpu(), want_e0, atol=1e-9, rtol=2e-5)
+
+
+def test_bpr_kernel_repeated_nodes_accumulate():
+    ops = _ops()
+    U, I, D, B = 5, 6, 32, 64
+    g = t.Generator().manual_seed(1)
+    final = t.randn(U + I, D, generator=g).requires_grad_(True)
+    e0 = t.randn(U + I, D, generator=g).requires_grad_(True)
+    users, pos, neg = (t.randint(0, U, (B,), generator=g), t.randint(0, I, (B,), generator=g),
+                       t.randint(0, I, (B,), generator=g))
+    loss_ref = R.bpr_loss(final[users], e0[users], final[U + pos], e0[U + pos], final[U + neg], e0[U + neg], 1e-2)
+    loss_ref.backward()
+    gf = t.zeros(U + I, D, device=DEV)
+    rw = t.zeros(U + I, device=DEV)
+    loss = ops.bpr_fwd_bwd(users.to(DEV), pos.to(DEV), neg.to(DEV), final.detach().to(DEV), e0.detach().to(DEV), U,
+                           1e-2, g_final=gf, reg_w=rw, g_scale=0.5)
+    assert abs(float(loss) - float(loss_ref)) < 1e-5
+    assert t.allclose(gf.cpu(), 0.5 * final.grad, atol=1e-6, rtol=1e-4)
+    assert t.allclose((rw[:, None].cpu() * e0.detach()), e0.grad, atol=1e-7, rtol=1e-5)
+
+
+# ---------------------------------------------------------------------------- a9: Adam
+def test_adam_matches_torch_optim():
+    ops = _ops()
+    n, d = 257, 64
+    g = t.Generator().manual_seed(2)
+    p_ref = t.nn.Parameter(t.randn(n, d, generator=g) * 0.1)
+    opt = t.optim.Adam([p_ref], lr=1e-3)
+    p = p_ref.detach().clone().to(DEV)
+    m, v = t.zeros_like(p), t.zeros_like(p)
+    for step in range(1, 8):
+        grad = t.randn(n, d, generator=g) * (10.0 ** -(step % 4))
+        grad[step::7] = 0.0  # rows with exactly zero gradient must not move
+        p_ref.grad = grad.clone()
+        opt.step()
+        ops.adam_step(p, grad.to(DEV), m, v, step=step, lr=1e-3)
+        assert t.allclose(p.cpu(), p_ref.detach(), atol=2e-7, rtol=1e-6), step
+    st = opt.state[p_ref]
+    assert t.allclose(m.cpu(), st["exp_avg"], atol=1e-8, rtol=1e-5)
+    assert t.allclose(v.cpu(), st["exp_avg_sq"], atol=1e-12, rtol=1e-5)
+
+
+# ---------------------------------------------------------------------------- whole train step
+@pytest.mark.parametrize("compat", ["reference", "bipartite"])
+def test_trainer_ten_steps_match_reference_loop(compat):
+    """10 iterations of run_pipeline_lightgcn.py:117-159 (same batches): fused HIP step vs the
+    oracle's forward/bpr/backward/torch.optim.Adam.  Embeddings within 1e-4 (north_star)."""
+    from laplace_amd.trainer import LightGCNTrainer
+    U, I, E, D, K, B = 400, 600, 8000, 64, 3, 128
+    model, inter, adj, ei = _model_and_graph(U, I, E, D, K, seed=21, compat=compat)
+    uw = t.nn.Parameter(model.users_emb.weight.detach().clone())
+    iw = t.nn.Parameter(model.items_emb.weight.detach().clone())
+    opt = t.optim.Adam([uw, iw], lr=1e-3)
+    sched = t.optim.lr_scheduler.ExponentialLR(opt, gamma=0.95)
+    row, col, _ = adj.coo()
+    model.to(DEV)
+    tr = LightGCNTrainer(model, adj.to(DEV), inter.to(DEV), lr=1e-3, Lambda=1e-6, batch_size=B, seed=5)
+    g = t.Generator().manual_seed(99)
+    for it in range(10):
+        batch = (t.randint(0, U, (B,), generator=g), t.randint(0, I, (B,), generator=g),
+                 t.randint(0, I, (B,), generator=g))
+        loss_ref = R.train_step(uw, iw, opt, row, col, K, batch, 1e-6)
+        loss = tr.step(tuple(x.to(DEV) for x in batch))
+        assert abs(float(loss) - loss_ref) < 1e-5, it
+        if it % 4 == 0 and it != 0:
+            sched.step()
+            tr.decay_lr(0.95)
+    assert (model.users_emb.weight.detach().cpu() - uw.detach()).abs().max() <= 1e-4
+    assert (model.items_emb.weight.detach().cpu() - iw.detach()).abs().max() <= 1e-4
+    uf, _, itf, _ = model(adj.to(DEV))
+    wu, _, wi, _ = R.lightgcn_forward(uw.detach(), iw.detach(), row, col, K)
+    assert (uf.detach().cpu() - wu).abs().max() <= 1e-4 and (itf.detach().cpu() - wi).abs().max() <= 1e-4
+
+
+def test_trainer_on_device_sampling_trains():
+    """With the on-device sampler the BPR objective (unbounded below) goes down."""
+    from laplace_amd.trainer import LightGCNTrainer
+    from laplace_amd.interactions import Interactions
+    from laplace_amd.model.lightgcn import LightGCN
+    from laplace_amd import synthetic as S
+    spec = S.SyntheticSpec(2000, 500, 30000, seed=8)
+    ei = S.generate(spec)
+    t.manual_seed(0)
+    model = LightGCN(spec.num_users, spec.num_items, 64, 3).to(DEV)
+    inter = Interactions(ei.to(DEV), spec.num_users, spec.num_items)
+    tr = LightGCNTrainer(model, inter.adjacency("bipartite"), inter, lr=1e-2, Lambda=1e-6, batch_size=1024, seed=1)
+    losses = [float(tr.step()) for _ in range(60)]
+    assert np.isfinite(losses).all()
+    assert np.mean(losses[-10:]) < np.mean(losses[:10]) - 0.05
+    assert tr.step_count == 60

@@ -1,0 +1,102 @@
+"""Host-side logic that needs no GPU: config surface, synthetic graphs, adjacency index math."""
+import dataclasses
+import os
+
+import numpy as np
+import pytest
+import torch as t
+
+
+def _load(golden_dir, name):
+    return t.load(os.path.join(golden_dir, name), weights_only=False)
+
+
+def test_config_surface_matches_reference(golden_dir):
+    from laplace_amd import config as C
+    g = _load(golden_dir, "config_defaults.pt")
+    assert [f.name for f in dataclasses.fields(C.Config)] == g["Config_fields"]
+    assert [f.name for f in dataclasses.fields(C.LightGCNConfig)] == g["LightGCNConfig_fields"]
+    assert C.embedding_range_dict == g["embedding_range_dict"]
+    for k, v in g["lightgcn_config"].items():
+        assert getattr(C.lightgcn_config, k) == v, k
+    for k, v in g["link_pred_config"].items():
+        ours = getattr(C.link_pred_config, k)
+        if isinstance(v, list):
+            ours = [list(x) if isinstance(x, tuple) else x for x in ours]
+        assert ours == v, k
+    C.link_pred_config.check_validity()
+
+
+def test_constants():
+    from laplace_amd.utils.constants import Constants
+    assert Constants.edge_key == ("customer", "buys", "article")
+    assert Constants.rev_edge_key == ("article", "rev_buys", "customer")
+
+
+def test_synthetic_c1_shape_and_determinism():
+    from laplace_amd import synthetic as S
+    e1, e2 = S.generate(S.C1), S.generate(S.C1)
+    assert t.equal(e1, e2)
+    assert e1.shape == (2, 100_000) and e1.dtype == t.int64
+    assert int(e1[0].max()) < 943 and int(e1[1].max()) < 1682 and int(e1.min()) >= 0
+    keys = e1[0] * 1682 + e1[1]
+    assert keys.unique().numel() == 100_000  # distinct pairs
+    deg = t.bincount(e1[0], minlength=943)
+    assert int(deg.min()) >= 1
+
+
+def test_synthetic_small_power_law():
+    from laplace_amd import synthetic as S
+    spec = S.SyntheticSpec(5000, 800, 40_000, seed=4)
+    e = S.generate(spec)
+    di = t.bincount(e[1], minlength=800).double()
+    assert di.max() > 20 * di.median().clamp(min=1)  # Zipf head
+    other = S.generate(S.shard_spec(spec, 1))
+    assert not t.equal(e, other)
+    # same popular items in every shard
+    top_a = set(di.topk(10).indices.tolist())
+    top_b = set(t.bincount(other[1], minlength=800).topk(10).indices.tolist())
+    assert len(top_a & top_b) >= 7
+
+
+def test_adjacency_index_construction():
+    from laplace_amd.interactions import Interactions
+    ei = t.tensor([[0, 0, 2], [1, 3, 0]])
+    inter = Interactions(ei, num_users=3, num_items=4)
+    ref = inter.adjacency("reference")
+    r, c, v = ref.coo()
+    assert ref.sparse_sizes() == (7, 7) and not ref.is_symmetric and v is None
+    assert r.tolist() == [0, 0, 2] and c.tolist() == [1, 3, 0]  # item ids, NOT offset by U
+    bi = inter.adjacency("bipartite")
+    r, c, _ = bi.coo()
+    assert bi.is_symmetric
+    assert sorted(zip(r.tolist(), c.tolist())) == sorted([(0, 4), (0, 6), (2, 3), (4, 0), (6, 0), (3, 2)])
+    with pytest.raises(ValueError):
+        inter.adjacency("nope")
+
+
+def test_lightgcn_module_surface_on_cpu():
+    """Constructor, attributes, parameter list and init statistics need no GPU."""
+    from laplace_amd.model.lightgcn import LightGCN
+    t.manual_seed(0)
+    m = LightGCN(num_users=300, num_items=200, embedding_dim=32, num_iterations=3)
+    names = [n for n, _ in m.named_parameters()]
+    assert names == ["users_emb.weight", "items_emb.weight"]
+    assert m.users_emb.weight.shape == (300, 32) and m.items_emb.weight.shape == (200, 32)
+    tab = m.table()
+    assert tab.shape == (500, 32)
+    assert tab.data_ptr() == m.users_emb.weight.data_ptr()
+    assert t.equal(tab[300:], m.items_emb.weight.data)
+    assert abs(float(tab.std()) - 0.1) < 0.01 and abs(float(tab.mean())) < 0.01
+    # same draws as two independent nn.init.normal_ calls in the reference's order
+    t.manual_seed(0)
+    a = t.empty(300, 32); t.nn.init.normal_(a, std=0.1)
+    b = t.empty(200, 32); t.nn.init.normal_(b, std=0.1)
+    assert t.equal(a, m.users_emb.weight.data) and t.equal(b, m.items_emb.weight.data)
+    # dtype casts keep the two tables adjacent
+    m.double()
+    assert m.table().dtype == t.float64 and m.table().shape == (500, 32)
+    with pytest.raises(TypeError):
+        m.float().forward(t.zeros(2, 3))
+    with pytest.raises(ValueError):
+        LightGCN(3, 4, embedding_dim=30, num_iterations=1)

@@ -1,0 +1,167 @@
+"""Pins the oracle against the reference's own outputs (tests/golden/, produced by
+tests/make_golden.py importing the reference) and against dense float64 known answers."""
+import os
+
+import numpy as np
+import pytest
+import torch as t
+
+from oracle import lightgcn_ref as R
+from oracle.philox import philox4x32
+
+
+def _load(golden_dir, name):
+    return t.load(os.path.join(golden_dir, name), weights_only=False)
+
+
+def test_philox_known_answers():
+    # Random123 kat_vectors for philox4x32-10
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0),
+            (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for ctr, key, want in kat:
+        got = tuple(int(x) for x in philox4x32(*ctr, *key))
+        assert got == want
+
+
+def test_bpr_loss_matches_reference(golden_dir):
+    for case in _load(golden_dir, "bpr_loss.pt"):
+        ins = [x.clone().requires_grad_(True) for x in case["inputs"]]
+        loss = R.bpr_loss(*ins, case["lambda"])
+        assert t.equal(loss.detach(), case["loss"])
+        grads = t.autograd.grad(loss, ins)
+        for g, w in zip(grads, case["grads"]):
+            assert t.equal(g, w)
+
+
+def test_make_predictions_matches_reference(golden_dir):
+    g = _load(golden_dir, "topk_metrics.pt")
+    ue, ie, excl = g["users_emb"], g["items_emb"], g["excl"]
+    for k, per_user in g["preds"].items():
+        for u, want in per_user.items():
+            got = R.make_predictions_for_user(ue, ie, u, excl, k)
+            assert t.equal(got, want)
+
+
+def test_exact_topk_definition_agrees_with_reference_on_separated_scores(golden_dir):
+    """The (fma-chain score, desc score / asc id) definition the HIP top-K implements picks the
+    same items in the same order as the reference's topk + setdiff on this fixture."""
+    g = _load(golden_dir, "topk_metrics.pt")
+    ue, ie, excl = g["users_emb"], g["items_emb"], g["excl"]
+    U = ue.shape[0]
+    scores = R.scores_fma(ue, ie)
+    ex = [excl.get(u, t.empty(0, dtype=t.int64)) for u in range(U)]
+    for k, per_user in g["preds"].items():
+        got = R.topk_excl_exact(scores, ex, k)
+        for u in range(U):
+            assert t.equal(got[u], per_user[u]), (k, u)
+
+
+def _small_graph(seed=0, U=5, I=7, E=18):
+    g = t.Generator().manual_seed(seed)
+    u = t.randint(0, U, (E,), generator=g)
+    i = t.randint(0, I, (E,), generator=g)
+    return u, i, U, I
+
+
+@pytest.mark.parametrize("K", [0, 1, 2, 3])
+def test_lightgcn_forward_vs_dense_float64_reference_adjacency(K):
+    """compat='reference' adjacency (rows=user, cols=item id) vs dense fp64."""
+    u, i, U, I = _small_graph()
+    g = t.Generator().manual_seed(1)
+    uw, iw = t.randn(U, 8, generator=g) * 0.1, t.randn(I, 8, generator=g) * 0.1
+    uf, u0, itf, i0 = R.lightgcn_forward(uw, iw, u, i, K)
+    du, di = R.lightgcn_forward_dense64(uw, iw, u, i, K)
+    assert t.allclose(uf.double(), du, atol=1e-6)
+    assert t.allclose(itf.double(), di, atol=1e-6)
+    assert u0 is uw and i0 is iw
+    # F7: item rows are never a destination => items_final == items_0 / (K+1)
+    assert t.allclose(itf, iw / (K + 1), atol=1e-7)
+    # C restatement of spmm_cpu agrees with torch's CSR kernel
+    ufc, _, itfc, _ = R.lightgcn_forward(uw, iw, u, i, K, use_c=True)
+    assert t.allclose(ufc, uf, atol=1e-6) and t.allclose(itfc, itf, atol=1e-6)
+
+
+@pytest.mark.parametrize("K", [1, 3])
+def test_lightgcn_forward_vs_dense_float64_bipartite(K):
+    u, i, U, I = _small_graph(seed=3, U=9, I=6, E=30)
+    r, c = R.bipartite_edges(u, i, U)
+    g = t.Generator().manual_seed(2)
+    uw, iw = t.randn(U, 16, generator=g) * 0.1, t.randn(I, 16, generator=g) * 0.1
+    uf, _, itf, _ = R.lightgcn_forward(uw, iw, r, c, K)
+    du, di = R.lightgcn_forward_dense64(uw, iw, r, c, K)
+    assert t.allclose(uf.double(), du, atol=1e-6) and t.allclose(itf.double(), di, atol=1e-6)
+
+
+def test_gcn_norm_known_answer():
+    # 3 nodes: 0->{1,2}, 1->{0}, 2->{} ; deg = [2,1,0]; dis=[2^-.5, 1, 0]
+    row, col = t.tensor([0, 0, 1]), t.tensor([1, 2, 0])
+    rowptr, col_s, _ = R.sparse_tensor_csr(row, col, 3, 3)
+    assert rowptr.tolist() == [0, 2, 3, 3] and col_s.tolist() == [1, 2, 0]
+    val = R.gcn_norm_csr(rowptr, col_s)
+    s = 2 ** -0.5
+    assert t.allclose(val, t.tensor([s * 1.0, 0.0, 1.0 * s]))
+
+
+def test_sparse_tensor_keeps_duplicates_sorted():
+    row, col = t.tensor([2, 0, 2, 0, 2]), t.tensor([1, 3, 1, 0, 0])
+    rowptr, col_s, perm = R.sparse_tensor_csr(row, col, 4, 4)
+    assert rowptr.tolist() == [0, 2, 2, 5, 5]
+    assert col_s.tolist() == [0, 3, 0, 1, 1]
+    assert sorted(perm.tolist()) == list(range(5))
+
+
+def test_c_spmm_matches_torch_and_f64(tmp_path):
+    g = t.Generator().manual_seed(5)
+    n, d, nnz = 300, 64, 4000
+    row, col = t.randint(0, n, (nnz,), generator=g), t.randint(0, n, (nnz,), generator=g)
+    rowptr, col_s, _ = R.sparse_tensor_csr(row, col, n, n)
+    val = t.rand(nnz, generator=g)
+    X = t.randn(n, d, generator=g)
+    yc = R.spmm_c(rowptr, col_s, val, X)
+    yt = R.spmm_torch(rowptr, col_s, val, X)
+    y64 = R.spmm_torch(rowptr, col_s, val.double(), X.double())
+    assert t.allclose(yc, yt, atol=1e-4, rtol=1e-5)
+    assert t.allclose(yc.double(), y64, atol=1e-4, rtol=1e-5)
+
+
+def test_rank_metrics_restated_match_reference(golden_dir):
+    from laplace_amd.utils.metrics import RecallPrecision_ATk, NDCGatK_r
+    g = _load(golden_dir, "rank_metrics.pt")
+    rp = RecallPrecision_ATk(g["groundTruth"], g["r"], g["k"])
+    nd = NDCGatK_r(g["groundTruth"], g["r"], g["k"])
+    assert rp == pytest.approx(g["recall_precision"], abs=1e-7)
+    assert nd == pytest.approx(g["ndcg"], abs=1e-7)
+
+
+def test_tensor_utils_match_reference(golden_dir):
+    from laplace_amd.utils.tensor import padded_stack, difference_1d
+    g = _load(golden_dir, "tensor_utils.pt")
+    assert t.equal(padded_stack(g["tensors"], value=-(1 << 50)), g["right"])
+    assert t.equal(padded_stack(g["tensors"], side="left", value=0.5), g["left"])
+    assert t.equal(difference_1d(g["a"], g["b"], assume_unique=True), g["diff"])
+
+
+def test_sampler_oracle_is_structured_negative_sampling_in_distribution():
+    """The Philox restatement (what the device runs) and the PyG-semantics restatement agree in law:
+    negatives are uniform over the user's non-neighbours within [0, neg_range)."""
+    U, I = 6, 12
+    u = t.tensor([0, 0, 0, 1, 2, 2, 3, 4, 4, 4, 4, 5])
+    i = t.tensor([0, 3, 5, 1, 2, 7, 9, 0, 1, 2, 3, 10])
+    rowptr, col_s, _ = R.sparse_tensor_csr(u, i, U, I)
+    neg_range = int(i.max())  # reference: num_nodes = max(col)
+    counts = np.zeros((U, neg_range))
+    for step in range(300):
+        us, ps, ns = R.sample_bpr_batch_philox(rowptr, col_s, 64, neg_range, seed=9, step=step)
+        for a, b, c in zip(us.tolist(), ps.tolist(), ns.tolist()):
+            assert b in col_s[rowptr[a]:rowptr[a + 1]].tolist()
+            assert c not in col_s[rowptr[a]:rowptr[a + 1]].tolist() and 0 <= c < neg_range
+            counts[a, c] += 1
+    for a in range(U):
+        allowed = [c for c in range(neg_range) if c not in col_s[rowptr[a]:rowptr[a + 1]].tolist()]
+        freq = counts[a, allowed] / counts[a].sum()
+        assert np.abs(freq - 1.0 / len(allowed)).max() < 0.06  # ~3 sigma at 300 effective draws
+    # user frequency follows edge counts (edges are drawn uniformly with replacement)
+    deg = np.diff(rowptr.numpy())
+    assert np.abs(counts.sum(1) / counts.sum() - deg / deg.sum()).max() < 0.02
