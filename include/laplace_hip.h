@@ -189,14 +189,15 @@ int    mi_bpr_fwd_bwd_f32(int64_t batch, int64_t d, int64_t n_users,
  * replaces: optimizer.step() at run_pipeline_lightgcn.py:159.
  *   g   = grad[i] + (reg_w ? reg_w[row(i)] * p[i] : 0)
  *   m   = b1*m + (1-b1)*g ; v = b2*v + (1-b2)*g*g
- *   p  -= step_size * m / (sqrt(v)/sqrt(bc2) + eps)
- * step_size = lr / (1 - b1^t), bc2_sqrt = sqrt(1 - b2^t) are computed by the host in
- * double.  n_rows x d row-major, ld in floats.
+ *   p  -= (lr / (1 - b1^step)) * m / (sqrt(v)/sqrt(1 - b2^step) + eps)
+ * Hyper-parameters arrive as doubles and the derived scalars are formed in double on the
+ * host before one rounding to fp32, as torch does; `step` counts from 1.
+ * n_rows x d row-major, ld in floats; m, v dense [n_rows, d].
  * ---------------------------------------------------------------------------------- */
 int mi_adam_dense_f32(int64_t n_rows, int64_t d,
                       float* p, int64_t ldp, const float* grad, int64_t ldgr,
                       float* m, float* v, const float* reg_w,
-                      float beta1, float beta2, float step_size, float bc2_sqrt, float eps,
+                      double lr, double beta1, double beta2, double eps, int64_t step,
                       mi_stream_t stream);
 
 #ifdef __cplusplus

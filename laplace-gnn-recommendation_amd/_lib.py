@@ -3,7 +3,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import POINTER, Structure, c_char_p, c_float, c_int32, c_int64, c_size_t, c_uint64, c_void_p
+from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int32, c_int64, c_size_t, c_uint64, c_void_p
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG_DIR, "liblaplace_hip.so")
@@ -46,7 +46,7 @@ _PROTOTYPES = {
     "mi_bpr_fwd_bwd_f32": (c_int32, [c_int64, c_int64, c_int64, P, P, P, P, c_int64, P, c_int64,
                                      c_float, c_float, c_float, P, P, c_int64, P, P, c_size_t, P]),
     "mi_adam_dense_f32": (c_int32, [c_int64, c_int64, P, c_int64, P, c_int64, P, P, P,
-                                    c_float, c_float, c_float, c_float, c_float, P]),
+                                    c_double, c_double, c_double, c_double, c_int64, P]),
 }
 
 _LIB = None

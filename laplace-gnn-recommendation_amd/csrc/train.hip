@@ -3,6 +3,7 @@
 //   a7/8 mi_bpr_fwd_bwd_f32    run_pipeline_lightgcn.py:133-155, utils/metrics_lightgcn.py:9-45
 //   a9   mi_adam_dense_f32     run_pipeline_lightgcn.py:157-159 (torch.optim.Adam)
 #include "common.hpp"
+#include <cmath>
 
 namespace {
 
@@ -155,9 +156,9 @@ __global__ __launch_bounds__(kBlock) void adam_kernel(int64_t n_rows, int d4, fl
                                                       int64_t ldg4, float4* __restrict__ m,
                                                       float4* __restrict__ v,
                                                       const float* __restrict__ reg_w, float b1, float b2,
-                                                      float step_size, float bc2_sqrt, float eps) {
+                                                      float omb1, float omb2, float step_size,
+                                                      float bc2_sqrt, float eps) {
     const int64_t total = n_rows * d4;
-    const float omb1 = 1.f - b1, omb2 = 1.f - b2;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t r = i / d4;
@@ -230,21 +231,27 @@ int mi_bpr_fwd_bwd_f32(int64_t batch, int64_t d, int64_t n_users, const int64_t*
 }
 
 int mi_adam_dense_f32(int64_t n_rows, int64_t d, float* p, int64_t ldp, const float* grad,
-                      int64_t ldgr, float* m, float* v, const float* reg_w, float beta1, float beta2,
-                      float step_size, float bc2_sqrt, float eps, mi_stream_t stream) {
-    MI_CHECK_ARG(n_rows >= 0 && d > 0);
+                      int64_t ldgr, float* m, float* v, const float* reg_w, double lr, double beta1,
+                      double beta2, double eps, int64_t step, mi_stream_t stream) {
+    MI_CHECK_ARG(n_rows >= 0 && d > 0 && step >= 1);
     if (n_rows == 0) return 0;
     MI_CHECK_ARG(p && grad && m && v);
     if (d % 4 != 0) return MI_ERR_UNSUPPORTED;
     MI_CHECK_ARG(ldp % 4 == 0 && ldgr % 4 == 0 && ldp >= d && ldgr >= d);
     MI_CHECK_ARG(mi_aligned16(p) && mi_aligned16(grad) && mi_aligned16(m) && mi_aligned16(v));
+    // scalar constants in double, as torch.optim.Adam derives them, then rounded once to fp32
+    const double bc1 = 1.0 - pow(beta1, (double)step);
+    const double bc2 = 1.0 - pow(beta2, (double)step);
+    const float step_size = (float)(lr / bc1);
+    const float bc2_sqrt = (float)sqrt(bc2);
     const int64_t total = n_rows * (d / 4);
     int64_t blocks = mi_ceil_div(total, kBlock);
     if (blocks > 256 * 16) blocks = 256 * 16;
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, n_rows,
                        (int)(d / 4), reinterpret_cast<float4*>(p), ldp / 4,
                        reinterpret_cast<const float4*>(grad), ldgr / 4, reinterpret_cast<float4*>(m),
-                       reinterpret_cast<float4*>(v), reg_w, beta1, beta2, step_size, bc2_sqrt, eps);
+                       reinterpret_cast<float4*>(v), reg_w, (float)beta1, (float)beta2,
+                       (float)(1.0 - beta1), (float)(1.0 - beta2), step_size, bc2_sqrt, (float)eps);
     return mi_launch_status();
 }
 

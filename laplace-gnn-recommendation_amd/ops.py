@@ -268,8 +268,6 @@ def adam_step(p: Tensor, grad: Tensor, m: Tensor, v: Tensor, *, step: int, lr: f
     _need(v, t.float32, "v")
     if m.shape != p.shape or v.shape != p.shape or grad.shape != p.shape:
         raise ValueError("p, grad, m, v must have equal shapes")
-    bc1 = 1.0 - beta1 ** step
-    bc2 = 1.0 - beta2 ** step
     check(_lib.lib().mi_adam_dense_f32(p.shape[0], p.shape[1], p.data_ptr(), ldp, grad.data_ptr(), ldg,
-                                       m.data_ptr(), v.data_ptr(), _ptr(reg_w), beta1, beta2, lr / bc1,
-                                       math.sqrt(bc2), eps, _stream()), "mi_adam_dense_f32")
+                                       m.data_ptr(), v.data_ptr(), _ptr(reg_w), float(lr), float(beta1),
+                                       float(beta2), float(eps), int(step), _stream()), "mi_adam_dense_f32")
