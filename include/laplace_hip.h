@@ -82,6 +82,15 @@ int mi_gcn_norm_csr_f32(int64_t n, int64_t nnz, const int32_t* rowptr, const int
                         const float* val_in, float* val_out, float* dis_out,
                         mi_stream_t stream);
 
+/* Edge re-weighting: val_out[p] = (val_in[p] * row_scale[row(p)]) * col_scale[col[p]], any null
+ * input meaning all ones.  gcn_norm is this with row_scale = col_scale = deg^-1/2; the
+ * user-sharded multi-GPU path calls it directly because an item's degree is the sum over all
+ * shards (one RCCL all-reduce of the degree vector at set-up), and SAGEConv's mean aggregation
+ * (model/layers.py:11-24, aggr="mean") is row_scale = 1/in-degree. */
+int mi_scale_csr_f32(int64_t n_rows, int64_t nnz, const int32_t* rowptr, const int32_t* col,
+                     const float* val_in, const float* row_scale, const float* col_scale,
+                     float* val_out, mi_stream_t stream);
+
 /* ------------------------------------------------------------------------------------
  * K1/K2  CSR SpMM with fused epilogue — the LightGCN propagate.
  * replaces: torch_sparse.matmul(adj_t, x) at model/lightgcn.py:87 (called K times per

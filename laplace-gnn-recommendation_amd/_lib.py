@@ -33,6 +33,7 @@ _PROTOTYPES = {
     "mi_csr_transpose_i32": (c_int32, [c_int64, c_int64, c_int64, P, P, P, P, P, P, c_size_t, P]),
     "mi_gather_f32": (c_int32, [c_int64, P, P, P, P]),
     "mi_gcn_norm_csr_f32": (c_int32, [c_int64, c_int64, P, P, P, P, P, P]),
+    "mi_scale_csr_f32": (c_int32, [c_int64, c_int64, P, P, P, P, P, P, P]),
     "mi_spmm_plan_bounds": (c_int32, [c_int64, c_int64, c_int32, POINTER(c_int64), POINTER(c_int64)]),
     "mi_spmm_plan_workspace_bytes": (c_size_t, [c_int64]),
     "mi_spmm_plan_build": (c_int32, [c_int64, P, c_int32, POINTER(SpmmPlanStruct), P, c_size_t, P]),

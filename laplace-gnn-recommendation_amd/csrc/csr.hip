@@ -100,14 +100,17 @@ __global__ void gcn_dis_kernel(int64_t n, const int32_t* __restrict__ rowptr,
     if (lane == 0) dis[r] = (deg > 0.f) ? (1.0f / sqrtf(deg)) : 0.f;
 }
 
+// val_out[p] = (val_in[p] * row_scale[row(p)]) * col_scale[col[p]]   (null pointer = all ones)
 __global__ void gcn_scale_kernel(int64_t n, int64_t nnz, const int32_t* __restrict__ rowptr,
                                  const int32_t* __restrict__ col, const float* __restrict__ val_in,
-                                 const float* __restrict__ dis, float* __restrict__ val_out) {
+                                 const float* __restrict__ row_scale,
+                                 const float* __restrict__ col_scale, float* __restrict__ val_out) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nnz) return;
-    int32_t r = row_of(rowptr, n, (int32_t)i);
     float v = val_in ? val_in[i] : 1.0f;
-    val_out[i] = (v * dis[r]) * dis[col[i]];
+    if (row_scale) v = v * row_scale[row_of(rowptr, n, (int32_t)i)];
+    if (col_scale) v = v * col_scale[col[i]];
+    val_out[i] = v;
 }
 
 inline unsigned bits_for(int64_t n) {  // bits needed to represent values in [0, n)
@@ -230,8 +233,19 @@ int mi_gcn_norm_csr_f32(int64_t n, int64_t nnz, const int32_t* rowptr, const int
     hipLaunchKernelGGL(gcn_dis_kernel, grid_for(n * MI_WAVE), dim3(kBlock), 0, s, n, rowptr, val_in, dis_out);
     if (nnz > 0) {
         MI_CHECK_ARG(col && val_out);
-        hipLaunchKernelGGL(gcn_scale_kernel, grid_for(nnz), dim3(kBlock), 0, s, n, nnz, rowptr, col, val_in, dis_out, val_out);
+        hipLaunchKernelGGL(gcn_scale_kernel, grid_for(nnz), dim3(kBlock), 0, s, n, nnz, rowptr, col, val_in, dis_out, dis_out, val_out);
     }
+    return mi_launch_status();
+}
+
+int mi_scale_csr_f32(int64_t n_rows, int64_t nnz, const int32_t* rowptr, const int32_t* col,
+                     const float* val_in, const float* row_scale, const float* col_scale,
+                     float* val_out, mi_stream_t stream) {
+    MI_CHECK_ARG(n_rows >= 0 && nnz >= 0);
+    if (nnz == 0) return 0;
+    MI_CHECK_ARG(rowptr && col && val_out);
+    hipLaunchKernelGGL(gcn_scale_kernel, grid_for(nnz), dim3(kBlock), 0, (hipStream_t)stream, n_rows, nnz,
+                       rowptr, col, val_in, row_scale, col_scale, val_out);
     return mi_launch_status();
 }
 

@@ -1,0 +1,167 @@
+"""User-sharded multi-GPU LightGCN training — one process per GPU, torch.distributed
+(backend "nccl" = RCCL over xGMI on ROCm; "gloo" in the CPU tests).
+
+Partition: rank p owns a contiguous block of users, every edge incident to them (both directions
+of the bipartite CSR), their embedding rows and Adam state.  The item table (I x D, 51 MB at
+I=100K, D=128) is replicated.  The reference has no distributed code at all; this
+is new design, not a port.
+
+Per propagate layer, on rank p (local node space: U_p user rows, then I item rows):
+    1. item rows:  partial[i] = sum_{u in U_p} a(i,u) x[u]      local SpMM over rows [U_p, U_p+I)
+    2. all-reduce(sum, fp32) of the I x D partials                 the ONE exchange of the layer
+    3. user rows:  y[u] = sum_i a(u,i) x[i]  (+ epilogue)          local SpMM, overlaps with 2
+Backward mirrors it (the normalised bipartite adjacency is symmetric).  The BPR gradient of the
+item rows and the L2 weights are all-reduced once per step; every rank then applies the same Adam
+update to its item replica, so replicas stay bitwise identical.  User rows never leave their rank.
+
+Edge weights a(u,i) = (deg(u) * deg(i))^-1/2 need the GLOBAL item degree: one all-reduce of the
+int degree vector at set-up.
+
+xGMI is point-to-point, 7 links per GPU: the payload per collective is small (I*D*4 bytes), so
+what matters is that the collective runs beside the user-row SpMM of the same layer (independent
+work) rather than peak bus bandwidth; RCCL picks the algorithm.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch as t
+import torch.distributed as dist
+from torch import Tensor
+
+from . import ops as hip_ops
+from .interactions import Interactions
+from .model.lightgcn import LightGCN
+
+
+class ShardedLightGCNTrainer:
+    def __init__(self, model: LightGCN, train: Interactions, *, lr: float, Lambda: float, batch_size: int,
+                 betas: Tuple[float, float] = (0.9, 0.999), eps: float = 1e-8, seed: int = 0,
+                 neg_range: Optional[int] = None, group=None, ops_impl=None):
+        """model: LightGCN(num_users = this rank's users, num_items = all items).  `train` holds this
+        rank's edges with LOCAL user ids.  ops_impl: the kernel provider (default: the HIP ops;
+        the CPU gloo tests inject an oracle-backed one — the product never does)."""
+        self.ops = ops_impl if ops_impl is not None else hip_ops
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.model, self.train = model, train
+        self.table = model.table()
+        self.U, self.I = model.num_users, model.num_items
+        self.K = model.num_iterations
+        self.lr, self.Lambda, self.batch_size = float(lr), float(Lambda), int(batch_size)
+        self.betas, self.eps, self.seed = betas, float(eps), int(seed)
+        self.neg_range = int(neg_range) if neg_range is not None else self.I
+        n, d = self.table.shape
+        dev = self.table.device
+        U, I = self.U, self.I
+
+        # item replicas start identical: rank 0's rows win
+        self._bcast(self.table[U:])
+
+        # local symmetric bipartite CSR, globally-normalised edge weights
+        u, i = train.edge_index[0], train.edge_index[1]
+        iu = i + U
+        raw = self.ops.coo_to_csr(t.cat([u, iu]).contiguous(), t.cat([iu, u]).contiguous(), n, n, want_perm=False)
+        deg = (raw.rowptr[1:] - raw.rowptr[:-1]).to(t.int64)
+        item_deg = deg[U:].clone()
+        self._allreduce(item_deg)
+        deg = t.cat([deg[:U], item_deg]).to(t.float32)
+        dis = deg.pow(-0.5)
+        dis.masked_fill_(dis == float("inf"), 0.0)
+        raw.val = self.ops.scale_csr(raw, None, dis, dis)
+        self.adj_fwd = raw  # kept whole for bookkeeping (bench reads nnz / n_rows)
+        self.a_users = self.ops.row_slice(raw, 0, U)
+        self.a_items = self.ops.row_slice(raw, U, n)
+        self.a_users.plan = self.ops.build_spmm_plan(self.a_users)
+        self.a_items.plan = self.ops.build_spmm_plan(self.a_items)
+
+        self.final = t.empty(n, d, device=dev)
+        self.bufs = (t.empty(n, d, device=dev), t.empty(n, d, device=dev))
+        self.gc = t.zeros(n, d, device=dev)
+        self.reg_w = t.zeros(n, device=dev)
+        self.m = t.zeros(n, d, device=dev)
+        self.v = t.zeros(n, d, device=dev)
+        self.loss = t.zeros(1, device=dev)
+        self.batch_idx = tuple(t.empty(self.batch_size, dtype=t.int64, device=dev) for _ in range(3))
+        self.step_count = 0
+        self._r = train.csr() if ops_impl is None else self.ops.coo_to_csr(u.contiguous(), i.contiguous(), U, I,
+                                                                             want_perm=False)
+        self._row_of_edge = self.ops.expand_rows(self._r)
+
+    # -- collectives ---------------------------------------------------------------------------
+    def _allreduce(self, x: Tensor, async_op: bool = False):
+        if self.world == 1:
+            return None
+        return dist.all_reduce(x, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
+
+    def _bcast(self, x: Tensor) -> None:
+        if self.world > 1:
+            dist.broadcast(x, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0,
+                           group=self.group)
+
+    # -- one propagate layer: out = A @ x, the item rows all-reduced -------------------------------
+    def _layer(self, x: Tensor, out: Optional[Tensor], *, addend_users: Optional[Tensor], s_users: Optional[Tensor],
+               scale: float, items_out: Tensor) -> None:
+        """items_out[I, D] <- all-reduced item rows of A @ x; user rows go to out[:U] (if out) and to
+        s_users = scale * (addend_users + acc) (if s_users)."""
+        U = self.U
+        self.ops.spmm(self.a_items, x, Y=items_out)
+        work = self._allreduce(items_out, async_op=True)
+        self.ops.spmm(self.a_users, x, Y=None if out is None else out[:U], addend=addend_users, S=s_users,
+                      scale=scale)
+        if work is not None:
+            work.wait()
+
+    def forward(self) -> Tensor:
+        """final = mean_k(A^k E0) on the local node space (model/lightgcn.py:46-80, sharded)."""
+        U, K = self.U, self.K
+        S, tab = self.final, self.table
+        if K == 0:
+            S.copy_(tab)
+            return S
+        c = 1.0 / (K + 1)
+        x = tab
+        for k in range(1, K + 1):
+            last = k == K
+            out = self.bufs[k % 2]
+            self._layer(x, None if last else out, addend_users=(tab[:U] if k == 1 else S[:U]), s_users=S[:U],
+                        scale=c if last else 1.0, items_out=out[U:])
+            if k == 1:
+                t.add(tab[U:], out[U:], out=S[U:])
+            else:
+                S[U:].add_(out[U:])
+            if last:
+                S[U:].mul_(c)
+            x = out
+        return S
+
+    def sample(self):
+        return self.ops.sample_bpr_batch(self._r, self._row_of_edge, self.batch_size, self.neg_range, self.seed,
+                                         self.step_count, out=self.batch_idx)
+
+    def step(self, batch=None) -> Tensor:
+        """One training iteration over the GLOBAL batch (world * batch_size positive edges); returns this
+        rank's local loss term as a 1-element tensor."""
+        U, K, P = self.U, self.K, self.world
+        self.forward()
+        users, pos, neg = batch if batch is not None else self.sample()
+        self.gc.zero_()
+        self.reg_w.zero_()
+        # global loss = mean over P*B slots => each rank's share of the softplus term carries 1/P
+        self.ops.bpr_fwd_bwd(users, pos, neg, self.final, self.table, U, self.Lambda, g_final=self.gc,
+                             reg_w=self.reg_w, g_scale=1.0 / ((K + 1) * P), loss_out=self.loss)
+        self._allreduce(self.gc[U:])
+        self._allreduce(self.reg_w[U:])
+        g = self.gc
+        for i in range(K):
+            nxt = self.bufs[i % 2]
+            self._layer(g, None, addend_users=self.gc[:U], s_users=nxt[:U], scale=1.0, items_out=nxt[U:])
+            nxt[U:].add_(self.gc[U:])
+            g = nxt
+        self.step_count += 1
+        self.ops.adam_step(self.table, g, self.m, self.v, step=self.step_count, lr=self.lr, beta1=self.betas[0],
+                           beta2=self.betas[1], eps=self.eps, reg_w=self.reg_w)
+        return self.loss
+
+    def decay_lr(self, gamma: float = 0.95) -> None:
+        self.lr *= gamma

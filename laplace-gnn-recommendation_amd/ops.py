@@ -150,6 +150,27 @@ def gcn_norm(a: DeviceCSR, val_in: Optional[Tensor] = None) -> Tuple[Tensor, Ten
     return val, dis
 
 
+def scale_csr(a: DeviceCSR, val_in: Optional[Tensor] = None, row_scale: Optional[Tensor] = None,
+              col_scale: Optional[Tensor] = None) -> Tensor:
+    """val[p] = (val_in[p] * row_scale[row]) * col_scale[col]; None = ones."""
+    for n, x in (("val_in", val_in), ("row_scale", row_scale), ("col_scale", col_scale)):
+        if x is not None:
+            _need(x, t.float32, n)
+    if row_scale is not None and row_scale.numel() != a.n_rows:
+        raise ValueError("row_scale must have one entry per row")
+    if col_scale is not None and col_scale.numel() != a.n_cols:
+        raise ValueError("col_scale must have one entry per column")
+    out = t.empty(a.nnz, dtype=t.float32, device=a.device)
+    check(_lib.lib().mi_scale_csr_f32(a.n_rows, a.nnz, _ptr(a.rowptr), _ptr(a.col), _ptr(val_in), _ptr(row_scale),
+                                      _ptr(col_scale), _ptr(out), _stream()), "mi_scale_csr_f32")
+    return out
+
+
+def row_slice(a: DeviceCSR, r0: int, r1: int) -> DeviceCSR:
+    """Rows [r0, r1) of `a` as a CSR that shares col/val storage (rowptr keeps absolute offsets)."""
+    return DeviceCSR(r1 - r0, a.n_cols, a.rowptr[r0:r1 + 1], a.col, a.val, None)
+
+
 def build_spmm_plan(a: DeviceCSR, chunk: int = DEFAULT_CHUNK) -> SpmmPlan:
     L = _lib.lib()
     ml, mi = ctypes.c_int64(0), ctypes.c_int64(0)

@@ -404,3 +404,25 @@ def test_trainer_on_device_sampling_trains():
     assert np.isfinite(losses).all()
     assert np.mean(losses[-10:]) < np.mean(losses[:10]) - 0.05
     assert tr.step_count == 60
+
+
+# ---------------------------------------------------------------------------- §8e sharded path, HIP ops
+def test_sharded_trainer_hip_ops_single_rank_equals_plain_trainer():
+    """The row-sliced (user rows / item rows) launches of the sharded step give the plain step's result."""
+    from laplace_amd.dist import ShardedLightGCNTrainer
+    from laplace_amd.trainer import LightGCNTrainer
+    U, I, E, D, K, B = 700, 300, 9000, 64, 3, 256
+    model_a, inter, adj, ei = _model_and_graph(U, I, E, D, K, seed=31, compat="bipartite")
+    model_b, _, _, _ = _model_and_graph(U, I, E, D, K, seed=31, compat="bipartite")
+    model_a.to(DEV)
+    model_b.to(DEV)
+    inter = inter.to(DEV)
+    plain = LightGCNTrainer(model_a, adj.to(DEV), inter, lr=1e-3, Lambda=1e-5, batch_size=B, seed=2)
+    shard = ShardedLightGCNTrainer(model_b, inter, lr=1e-3, Lambda=1e-5, batch_size=B, seed=2)
+    assert t.allclose(shard.adj_fwd.val, plain.adj_fwd.val, rtol=1e-6, atol=0)
+    for _ in range(5):
+        la, lb = plain.step(), shard.step()
+        assert abs(float(la) - float(lb)) < 1e-6
+    assert t.equal(plain.batch_idx[0], shard.batch_idx[0]) and t.equal(plain.batch_idx[2], shard.batch_idx[2])
+    assert t.allclose(plain.table, shard.table, atol=1e-6)
+    assert t.allclose(plain.forward(), shard.forward(), atol=1e-6)
