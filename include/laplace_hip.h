@@ -154,6 +154,8 @@ int mi_spmm_csr_f32(int64_t n_rows, int64_t d,
  * also rejects negative 0 for user u if user u-1 has an edge to item `neg_range`
  * (the reference's row*num_nodes+col key collision).
  * row_of_edge int32[nnz] is the expanded row index (mi_csr_expand_rows).
+ * edges_in_order != 0: slot b takes edge b of the CSR instead of a random one (batch <= nnz) —
+ * one negative per edge of a split, as evaluation() does (run_pipeline_lightgcn.py:40-44).
  * Outputs int64[B] each (the reference's index dtype).
  * ---------------------------------------------------------------------------------- */
 int mi_csr_expand_rows(int64_t n_rows, const int32_t* rowptr, int32_t* row_of_edge,
@@ -161,7 +163,7 @@ int mi_csr_expand_rows(int64_t n_rows, const int32_t* rowptr, int32_t* row_of_ed
 int mi_sample_bpr_batch(int64_t batch, int64_t nnz,
                         const int32_t* rowptr, const int32_t* col,
                         const int32_t* row_of_edge,
-                        int64_t neg_range, int32_t quirk_user_rows,
+                        int64_t neg_range, int32_t quirk_user_rows, int32_t edges_in_order,
                         uint64_t seed, uint64_t step,
                         int64_t* users, int64_t* pos, int64_t* neg,
                         mi_stream_t stream);
@@ -208,6 +210,38 @@ int mi_adam_dense_f32(int64_t n_rows, int64_t d,
                       float* m, float* v, const float* reg_w,
                       double lr, double beta1, double beta2, double eps, int64_t step,
                       mi_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * K6  dense fp32 GEMM on the f32 MFMA (exact fp32, k-ordered fma chain):
+ *   C[m,n] = act( sum_k A[m,k] * B(k,n) + bias[n] + (accumulate ? C[m,n] : 0) )
+ * replaces: torch.nn.Linear inside SAGEConv (lin_l, lin_r) and the decoder MLP
+ *           (model/layers.py:35-56, model/encoder_decoder.py:55-72) and their backward.
+ * trans_a: A is stored [k,m] (lda = m-stride);  trans_b: B is stored [n,k] (the
+ * nn.Linear weight layout).  act: 0 = none, 1 = relu.
+ * ---------------------------------------------------------------------------------- */
+int mi_gemm_f32(int32_t trans_a, int32_t trans_b, int64_t m, int64_t n, int64_t k,
+                const float* A, int64_t lda, const float* B, int64_t ldb,
+                const float* bias, float* C, int64_t ldc,
+                int32_t accumulate, int32_t act, mi_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * K10  batched exact top-K with per-user exclusion.
+ * replaces: make_predictions_for_user at utils/metrics_lightgcn.py:125-142
+ *           (scores = e_u @ E_i^T; topk(k+|ignore|); order-preserving setdiff; [:k]).
+ * scores[u, i] = fmaf-chain over d ascending of user_emb[uid[u], :] . item_emb[i, :]
+ * (bitwise equal to oracle/score_ref.c); excluded items (excl_ptr/excl_idx: CSR by
+ * position in uid, item ids sorted or not) never appear; output int64[n_q, k] item ids
+ * by descending score, ties by ascending item id; -1 pads when fewer than k remain.
+ * k <= 1024.  Workspace holds the [n_q, n_items] fp32 score block: callers chunk n_q.
+ * ---------------------------------------------------------------------------------- */
+size_t mi_topk_workspace_bytes(int64_t n_q, int64_t n_items, int64_t k);
+int    mi_topk_excl_f32(int64_t n_q, int64_t n_items, int64_t d, int64_t k,
+                        const int64_t* uid,
+                        const float* user_emb, int64_t ldu,
+                        const float* item_emb, int64_t ldi,
+                        const int32_t* excl_ptr, const int32_t* excl_idx,
+                        int64_t* out_idx, float* out_score /* nullable */,
+                        void* ws, size_t ws_bytes, mi_stream_t stream);
 
 #ifdef __cplusplus
 }

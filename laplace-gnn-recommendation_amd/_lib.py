@@ -41,11 +41,16 @@ _PROTOTYPES = {
     "mi_spmm_csr_f32": (c_int32, [c_int64, c_int64, P, P, P, P, c_int64, P, c_int64, P, c_int64, P, c_int64,
                                   c_float, POINTER(SpmmPlanStruct), P, c_size_t, P]),
     "mi_csr_expand_rows": (c_int32, [c_int64, P, P, c_int64, P]),
-    "mi_sample_bpr_batch": (c_int32, [c_int64, c_int64, P, P, P, c_int64, c_int32, c_uint64, c_uint64,
+    "mi_sample_bpr_batch": (c_int32, [c_int64, c_int64, P, P, P, c_int64, c_int32, c_int32, c_uint64, c_uint64,
                                       P, P, P, P]),
     "mi_bpr_workspace_bytes": (c_size_t, [c_int64]),
     "mi_bpr_fwd_bwd_f32": (c_int32, [c_int64, c_int64, c_int64, P, P, P, P, c_int64, P, c_int64,
                                      c_float, c_float, c_float, P, P, c_int64, P, P, c_size_t, P]),
+    "mi_gemm_f32": (c_int32, [c_int32, c_int32, c_int64, c_int64, c_int64, P, c_int64, P, c_int64, P, P, c_int64,
+                              c_int32, c_int32, P]),
+    "mi_topk_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int64]),
+    "mi_topk_excl_f32": (c_int32, [c_int64, c_int64, c_int64, c_int64, P, P, c_int64, P, c_int64, P, P, P, P, P,
+                                   c_size_t, P]),
     "mi_adam_dense_f32": (c_int32, [c_int64, c_int64, P, c_int64, P, c_int64, P, P, P,
                                     c_double, c_double, c_double, c_double, c_int64, P]),
 }

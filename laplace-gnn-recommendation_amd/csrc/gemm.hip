@@ -1,0 +1,117 @@
+// K6: dense fp32 GEMM on the gfx950 f32-input MFMA (v_mfma_f32_32x32x2_f32).
+//
+//   C[m,n] = act( sum_k A(m,k) * B(k,n)  + bias[n]  + (accumulate ? C[m,n] : 0) )
+//
+// replaces torch.nn.Linear in SAGEConv's lin_l / lin_r and in the decoder MLP
+// (model/layers.py:11-56, model/encoder_decoder.py:55-72) with their backward products, and
+// computes the score matrix of the top-K path (utils/metrics_lightgcn.py:137).
+//
+// Why the f32 MFMA: the reference is fp32 end to end and parity is 1e-4, so bf16 is out; gfx950 has
+// no xf32.  v_mfma_f32_32x32x2_f32 is exact fp32 and — per the CDNA4 guide — bit for bit a
+// k-ordered fma chain, D = fma(a_k1, b_k1, fma(a_k0, b_k0, C)).  Walking K in ascending order with
+// one accumulator therefore gives every output element the sequential chain
+//   acc = 0; for k in 0..K-1: acc = fmaf(A[m,k], B[k,n], acc)
+// which oracle/spmm_ref.c restates, so GEMM results (and the top-K ordering built on them) are
+// checked bitwise, not within a tolerance.
+//
+// Tiling: 256 threads = 4 wavefronts, block tile 64x64, each wavefront one 32x32 accumulator
+// (16 VGPRs), K walked in steps of 32 through LDS.  The f32 MFMA issues once per 64 cycles per
+// SIMD, so two ds_read_b32 per MFMA keep it fed; tiles are padded to 33 floats per row so both the
+// row-major and the transposed store patterns are bank-conflict free.
+#include "gemm.hpp"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 64, BN = 64, BK = 32, PAD = 33;
+
+__global__ __launch_bounds__(256) void gemm_f32_kernel(MiGemmArgs g) {
+    __shared__ float As[BM][PAD];
+    __shared__ float Bs[BN][PAD];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int64_t m0 = (int64_t)blockIdx.y * BM, n0 = (int64_t)blockIdx.x * BN;
+    const bool a_kfast = (g.sa_k == 1), b_kfast = (g.sb_k == 1);
+
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+
+    for (int64_t k0 = 0; k0 < g.K; k0 += BK) {
+#pragma unroll
+        for (int j = 0; j < (BM * BK) / 256; ++j) {
+            const int idx = tid + 256 * j;
+            const int m = a_kfast ? idx / BK : idx % BM;
+            const int k = a_kfast ? idx % BK : idx / BM;
+            const int64_t gm = m0 + m, gk = k0 + k;
+            float v = 0.f;
+            if (gm < g.M && gk < g.K) {
+                const int64_t r = g.a_rows ? g.a_rows[gm] : gm;
+                v = g.A[r * g.sa_m + gk * g.sa_k];
+            }
+            As[m][k] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < (BN * BK) / 256; ++j) {
+            const int idx = tid + 256 * j;
+            const int n = b_kfast ? idx / BK : idx % BN;
+            const int k = b_kfast ? idx % BK : idx / BN;
+            const int64_t gn = n0 + n, gk = k0 + k;
+            Bs[n][k] = (gn < g.N && gk < g.K) ? g.B[gn * g.sb_n + gk * g.sb_k] : 0.f;
+        }
+        __syncthreads();
+        const float* ap = &As[wm * 32 + (lane & 31)][lane >> 5];
+        const float* bp = &Bs[wn * 32 + (lane & 31)][lane >> 5];
+#pragma unroll
+        for (int s = 0; s < BK / 2; ++s)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * s], bp[2 * s], acc, 0, 0, 0);
+        __syncthreads();
+    }
+
+    // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    const int64_t gn = n0 + wn * 32 + (lane & 31);
+    if (gn >= g.N) return;
+    const float bv = g.bias ? g.bias[gn] : 0.f;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const int64_t gm = m0 + wm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+        if (gm >= g.M) continue;
+        float v = acc[reg];
+        if (g.bias) v += bv;
+        float* c = g.C + gm * g.ldc + gn;
+        if (g.accumulate) v += *c;
+        if (g.act == 1) v = v > 0.f ? v : 0.f;
+        *c = v;
+    }
+}
+
+}  // namespace
+
+int mi_gemm_launch(const MiGemmArgs& g, hipStream_t stream) {
+    if (g.M == 0 || g.N == 0) return 0;
+    dim3 grid((unsigned)mi_ceil_div(g.N, BN), (unsigned)mi_ceil_div(g.M, BM));
+    if (grid.y > 65535u) return MI_ERR_TOO_LARGE;  // HIP grid.y limit: M <= 4.19M rows per launch
+    hipLaunchKernelGGL(gemm_f32_kernel, grid, dim3(256), 0, stream, g);
+    return mi_launch_status();
+}
+
+extern "C" int mi_gemm_f32(int32_t trans_a, int32_t trans_b, int64_t m, int64_t n, int64_t k,
+                           const float* A, int64_t lda, const float* B, int64_t ldb, const float* bias,
+                           float* C, int64_t ldc, int32_t accumulate, int32_t act, mi_stream_t stream) {
+    MI_CHECK_ARG(m >= 0 && n >= 0 && k >= 0);
+    if (m == 0 || n == 0) return 0;
+    MI_CHECK_ARG(C && ldc >= n && (k == 0 || (A && B)));
+    MI_CHECK_ARG(act == 0 || act == 1);
+    MiGemmArgs g;
+    g.M = m; g.N = n; g.K = k;
+    g.A = A; g.a_rows = nullptr;
+    if (trans_a) { g.sa_m = 1; g.sa_k = lda; MI_CHECK_ARG(k == 0 || lda >= m); }   // A stored [k, m]
+    else         { g.sa_m = lda; g.sa_k = 1; MI_CHECK_ARG(k == 0 || lda >= k); }   // A stored [m, k]
+    g.B = B;
+    if (trans_b) { g.sb_n = ldb; g.sb_k = 1; MI_CHECK_ARG(k == 0 || ldb >= k); }   // B stored [n, k] (Linear.weight)
+    else         { g.sb_n = 1; g.sb_k = ldb; MI_CHECK_ARG(k == 0 || ldb >= n); }   // B stored [k, n]
+    g.bias = bias; g.C = C; g.ldc = ldc; g.accumulate = accumulate; g.act = act;
+    return mi_gemm_launch(g, (hipStream_t)stream);
+}

@@ -30,7 +30,7 @@ __device__ __forceinline__ bool csr_contains(const int32_t* __restrict__ rowptr,
 __global__ void sample_bpr_kernel(int64_t batch, int64_t nnz, const int32_t* __restrict__ rowptr,
                                   const int32_t* __restrict__ col,
                                   const int32_t* __restrict__ row_of_edge, int64_t neg_range,
-                                  int32_t quirk, uint64_t seed, uint64_t step,
+                                  int32_t quirk, int32_t edges_in_order, uint64_t seed, uint64_t step,
                                   int64_t* __restrict__ users, int64_t* __restrict__ pos,
                                   int64_t* __restrict__ neg) {
     const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -38,7 +38,7 @@ __global__ void sample_bpr_kernel(int64_t batch, int64_t nnz, const int32_t* __r
     const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
     const uint32_t s0 = (uint32_t)step, s1 = (uint32_t)(step >> 32);
     MiPhilox r = mi_philox4x32((uint32_t)b, (uint32_t)((uint64_t)b >> 32), s0, s1 ^ kTagEdge, k0, k1);
-    const uint64_t e = (((uint64_t)r.c[0] << 32) | r.c[1]) % (uint64_t)nnz;
+    const uint64_t e = edges_in_order ? (uint64_t)b : (((uint64_t)r.c[0] << 32) | r.c[1]) % (uint64_t)nnz;
     const int64_t u = row_of_edge[e];
     const int32_t p = col[e];
     int32_t cand = 0;
@@ -192,15 +192,15 @@ extern "C" {
 
 int mi_sample_bpr_batch(int64_t batch, int64_t nnz, const int32_t* rowptr, const int32_t* col,
                         const int32_t* row_of_edge, int64_t neg_range, int32_t quirk_user_rows,
-                        uint64_t seed, uint64_t step, int64_t* users, int64_t* pos, int64_t* neg,
-                        mi_stream_t stream) {
-    MI_CHECK_ARG(batch >= 0);
+                        int32_t edges_in_order, uint64_t seed, uint64_t step, int64_t* users, int64_t* pos,
+                        int64_t* neg, mi_stream_t stream) {
+    MI_CHECK_ARG(batch >= 0 && (!edges_in_order || batch <= nnz));
     if (batch == 0) return 0;
     MI_CHECK_ARG(nnz > 0 && neg_range > 0 && rowptr && col && row_of_edge && users && pos && neg);
     if (nnz >= INT32_MAX || neg_range >= INT32_MAX) return MI_ERR_TOO_LARGE;
     dim3 g((unsigned)mi_ceil_div(batch, kBlock));
     hipLaunchKernelGGL(sample_bpr_kernel, g, dim3(kBlock), 0, (hipStream_t)stream, batch, nnz, rowptr, col,
-                       row_of_edge, neg_range, quirk_user_rows, seed, step, users, pos, neg);
+                       row_of_edge, neg_range, quirk_user_rows, edges_in_order, seed, step, users, pos, neg);
     return mi_launch_status();
 }
 

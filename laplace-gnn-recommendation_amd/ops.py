@@ -237,8 +237,8 @@ def expand_rows(a: DeviceCSR) -> Tensor:
 
 
 def sample_bpr_batch(r: DeviceCSR, row_of_edge: Tensor, batch: int, neg_range: int, seed: int, step: int,
-                     quirk: bool = False, out: Optional[Tuple[Tensor, Tensor, Tensor]] = None
-                     ) -> Tuple[Tensor, Tensor, Tensor]:
+                     quirk: bool = False, out: Optional[Tuple[Tensor, Tensor, Tensor]] = None,
+                     edges_in_order: bool = False) -> Tuple[Tensor, Tensor, Tensor]:
     """K9 — replaces sample_mini_batch (data/lightgcn_loader.py:95-112) on device."""
     if r.nnz == 0:
         raise ValueError("cannot sample from an empty edge set")
@@ -249,7 +249,8 @@ def sample_bpr_batch(r: DeviceCSR, row_of_edge: Tensor, batch: int, neg_range: i
         out = tuple(t.empty(batch, dtype=t.int64, device=dev) for _ in range(3))
     users, pos, neg = out
     check(_lib.lib().mi_sample_bpr_batch(batch, r.nnz, _ptr(r.rowptr), _ptr(r.col), _ptr(row_of_edge),
-                                         int(neg_range), 1 if quirk else 0, int(seed) & (2**64 - 1),
+                                         int(neg_range), 1 if quirk else 0, 1 if edges_in_order else 0,
+                                         int(seed) & (2**64 - 1),
                                          int(step) & (2**64 - 1), _ptr(users), _ptr(pos), _ptr(neg),
                                          _stream()), "mi_sample_bpr_batch")
     return users, pos, neg
@@ -292,3 +293,62 @@ def adam_step(p: Tensor, grad: Tensor, m: Tensor, v: Tensor, *, step: int, lr: f
     check(_lib.lib().mi_adam_dense_f32(p.shape[0], p.shape[1], p.data_ptr(), ldp, grad.data_ptr(), ldg,
                                        m.data_ptr(), v.data_ptr(), _ptr(reg_w), float(lr), float(beta1),
                                        float(beta2), float(eps), int(step), _stream()), "mi_adam_dense_f32")
+
+
+def gemm(A: Tensor, B: Tensor, *, trans_a: bool = False, trans_b: bool = True, bias: Optional[Tensor] = None,
+         out: Optional[Tensor] = None, accumulate: bool = False, relu: bool = False) -> Tensor:
+    """K6 — C = act(op(A) @ op(B) + bias (+ C)) on the f32 MFMA.  Defaults give nn.Linear: A [m, k],
+    B = weight [n, k] (trans_b).  trans_a: A is stored [k, m];  trans_b=False: B is stored [k, n]."""
+    lda = _rows_ok(A, "A")
+    ldb = _rows_ok(B, "B")
+    m, k = (A.shape[1], A.shape[0]) if trans_a else (A.shape[0], A.shape[1])
+    n, kb = (B.shape[0], B.shape[1]) if trans_b else (B.shape[1], B.shape[0])
+    if k != kb:
+        raise ValueError(f"inner dimensions differ: {k} vs {kb}")
+    if bias is not None:
+        _need(bias, t.float32, "bias")
+        if bias.numel() != n:
+            raise ValueError("bias must have n entries")
+    if out is None:
+        if accumulate:
+            raise ValueError("accumulate needs an output tensor")
+        out = t.empty(m, n, dtype=t.float32, device=A.device)
+    ldc = _rows_ok(out, "out")
+    if out.shape != (m, n):
+        raise ValueError(f"out must be [{m}, {n}]")
+    check(_lib.lib().mi_gemm_f32(1 if trans_a else 0, 1 if trans_b else 0, m, n, k, _ptr(A), lda, _ptr(B), ldb,
+                                 _ptr(bias), out.data_ptr(), ldc, 1 if accumulate else 0, 1 if relu else 0,
+                                 _stream()), "mi_gemm_f32")
+    return out
+
+
+TOPK_WS_BYTES = 1 << 30  # score block per launch; queries are processed in chunks of this size
+
+
+def topk_excl(uid: Tensor, user_emb: Tensor, item_emb: Tensor, k: int, excl: Optional[DeviceCSR] = None,
+              want_scores: bool = False):
+    """K10 — for each query user uid[q]: the k best item ids by (score desc, id asc) among items not in
+    excl row q (a CSR with one row per query position).  Returns ids [n_q, k] (-1 pads) and optionally scores."""
+    _need(uid, t.int64, "uid")
+    ldu = _rows_ok(user_emb, "user_emb")
+    ldi = _rows_ok(item_emb, "item_emb")
+    n_q, n_items, d = uid.numel(), item_emb.shape[0], item_emb.shape[1]
+    if user_emb.shape[1] != d:
+        raise ValueError("user and item embeddings differ in width")
+    if excl is not None and excl.n_rows != n_q:
+        raise ValueError("exclusion CSR needs one row per query")
+    dev = item_emb.device
+    out_idx = t.empty(n_q, k, dtype=t.int64, device=dev)
+    out_sc = t.empty(n_q, k, dtype=t.float32, device=dev) if want_scores else None
+    L = _lib.lib()
+    chunk = max(1, min(n_q, TOPK_WS_BYTES // max(4 * n_items, 1)))
+    ws = _ws(L.mi_topk_workspace_bytes(chunk, n_items, k), dev)
+    for q0 in range(0, n_q, chunk):
+        q1 = min(n_q, q0 + chunk)
+        ep = excl.rowptr[q0:q1 + 1] if excl is not None else None
+        check(L.mi_topk_excl_f32(q1 - q0, n_items, d, k, uid[q0:q1].data_ptr(), user_emb.data_ptr(), ldu,
+                                 item_emb.data_ptr(), ldi, _ptr(ep),
+                                 (excl.col.data_ptr() if excl is not None and excl.nnz else (ep.data_ptr() if ep is not None else None)),
+                                 out_idx[q0:q1].data_ptr(), out_sc[q0:q1].data_ptr() if want_scores else None,
+                                 ws.data_ptr(), ws.numel(), _stream()), "mi_topk_excl_f32")
+    return (out_idx, out_sc) if want_scores else out_idx

@@ -35,6 +35,7 @@ def clib() -> ctypes.CDLL:
         L.ref_spmm_csr_f64acc.argtypes = [i64, i64, p, p, p, p, i64, p, i64]
         L.ref_scores_fma_f32.argtypes = [i64, i64, i64, p, i64, p, i64, p, i64]
         L.ref_adam_f32.argtypes = [i64, p, p, p, p, f, f, f, f, f]
+        L.ref_gemm_fma_f32.argtypes = [i64, i64, i64, p, i64, i64, p, i64, i64, p, p, i64, ctypes.c_int, ctypes.c_int]
         _CLIB = L
     return _CLIB
 
@@ -192,6 +193,23 @@ def scores_fma(user_rows: Tensor, item_emb: Tensor) -> Tensor:
     return out
 
 
+def gemm_fma(A: Tensor, B: Tensor, *, trans_a=False, trans_b=True, bias=None, out=None, accumulate=False,
+             relu=False) -> Tensor:
+    """C = act(op(A) @ op(B) + bias (+C)) as a k-ordered fp32 fma chain (oracle/spmm_ref.c) — bitwise the
+    arithmetic of csrc/gemm.hip.  Same argument meaning as laplace_amd.ops.gemm."""
+    A, B = A.contiguous(), B.contiguous()
+    m, k = (A.shape[1], A.shape[0]) if trans_a else A.shape
+    n = B.shape[0] if trans_b else B.shape[1]
+    sa = (1, A.shape[1]) if trans_a else (A.shape[1], 1)
+    sb = (B.shape[1], 1) if trans_b else (1, B.shape[1])
+    C = out if out is not None else t.zeros(m, n, dtype=t.float32)
+    b = bias.contiguous() if bias is not None else None
+    clib().ref_gemm_fma_f32(m, n, k, A.data_ptr(), sa[0], sa[1], B.data_ptr(), sb[0], sb[1],
+                            b.data_ptr() if b is not None else None, C.data_ptr(), C.stride(0),
+                            1 if accumulate else 0, 1 if relu else 0)
+    return C
+
+
 def topk_excl_exact(scores: Tensor, excl: List[Tensor], k: int) -> Tensor:
     """Top-k item ids per row by (score desc, id asc) among non-excluded ids; -1 pads."""
     n_q, n_items = scores.shape
@@ -246,7 +264,7 @@ _MAX_NEG_ATTEMPTS = 4096
 
 
 def sample_bpr_batch_philox(rowptr: Tensor, col: Tensor, batch: int, neg_range: int, seed: int, step: int,
-                            quirk: bool = False):
+                            quirk: bool = False, edges_in_order: bool = False):
     """Bit-exact restatement of csrc/train.hip:sample_bpr_kernel (integer work => exact parity).
     rowptr/col: the users x items interaction CSR with sorted columns."""
     rp, c = rowptr.numpy().astype(np.int64), col.numpy().astype(np.int64)
@@ -258,7 +276,7 @@ def sample_bpr_batch_philox(rowptr: Tensor, col: Tensor, batch: int, neg_range: 
     b = np.arange(batch, dtype=np.uint64)
     r = philox4x32(b & np.uint64(0xFFFFFFFF), b >> np.uint64(32), s0, s1 ^ _TAG_EDGE, k0, k1)
     e = ((r[0] << np.uint64(32)) | r[1]) % np.uint64(nnz)
-    e = e.astype(np.int64)
+    e = np.arange(batch, dtype=np.int64) if edges_in_order else e.astype(np.int64)
     users = row_of_edge[e]
     pos = c[e]
     neg = np.zeros(batch, dtype=np.int64)

@@ -88,3 +88,23 @@ void ref_adam_f32(int64_t n, float* p, const float* g, float* m, float* v, float
         v[i] = vv;
     }
 }
+
+/* General GEMM with the MFMA's arithmetic: per output element a k-ascending fmaf chain from 0,
+ * then + bias, + C (accumulate), relu.  Element (m,k) of A at A[m*sa_m + k*sa_k]; (k,n) of B at
+ * B[n*sb_n + k*sb_k].  Restates torch.nn.Linear / its backward products (model/layers.py:35-56)
+ * in the summation order csrc/gemm.hip uses, so the comparison is bitwise. */
+void ref_gemm_fma_f32(int64_t M, int64_t N, int64_t K, const float* A, int64_t sa_m, int64_t sa_k,
+                      const float* B, int64_t sb_n, int64_t sb_k, const float* bias, float* C,
+                      int64_t ldc, int accumulate, int act) {
+#pragma omp parallel for schedule(static)
+    for (int64_t m = 0; m < M; ++m) {
+        for (int64_t n = 0; n < N; ++n) {
+            float acc = 0.0f;
+            for (int64_t k = 0; k < K; ++k) acc = fmaf(A[m * sa_m + k * sa_k], B[n * sb_n + k * sb_k], acc);
+            if (bias) acc += bias[n];
+            if (accumulate) acc += C[m * ldc + n];
+            if (act == 1) acc = acc > 0.0f ? acc : 0.0f;
+            C[m * ldc + n] = acc;
+        }
+    }
+}

@@ -52,8 +52,10 @@ def expand_rows(a: DeviceCSR) -> Tensor:
     return t.repeat_interleave(t.arange(a.n_rows), (a.rowptr[1:] - a.rowptr[:-1]).long()).to(t.int32)
 
 
-def sample_bpr_batch(r: DeviceCSR, row_of_edge, batch, neg_range, seed, step, quirk=False, out=None):
-    u, p, n = R.sample_bpr_batch_philox(r.rowptr.long(), r.col.long(), batch, neg_range, seed, step, quirk)
+def sample_bpr_batch(r: DeviceCSR, row_of_edge, batch, neg_range, seed, step, quirk=False, out=None,
+                     edges_in_order=False):
+    u, p, n = R.sample_bpr_batch_philox(r.rowptr.long(), r.col.long(), batch, neg_range, seed, step, quirk,
+                                        edges_in_order)
     if out is not None:
         for dst, src in zip(out, (u, p, n)):
             dst.copy_(src)
