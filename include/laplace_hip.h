@@ -243,6 +243,38 @@ int    mi_topk_excl_f32(int64_t n_q, int64_t n_items, int64_t d, int64_t k,
                         int64_t* out_idx, float* out_score /* nullable */,
                         void* ws, size_t ws_bytes, mi_stream_t stream);
 
+/* ------------------------------------------------------------------------------------
+ * K5  SAGEConv message passing.
+ * replaces: SAGEConv.propagate -> torch_scatter.scatter(x_j, index, reduce=aggr) reached from
+ *           model/layers.py:11-24 via model/encoder_decoder.py:32,44.
+ * The CSR is by DESTINATION node (rowptr over dst, col = source ids, sorted).
+ *   aggr="add":  mi_spmm_csr_f32 with val = 1          (no [E, C] message tensor, no atomics)
+ *   aggr="mean": mi_spmm_csr_f32 with val = 1/in-degree (mi_scale_csr_f32); empty segment -> 0
+ *   aggr="max":  mi_segment_max_f32 below; empty segment -> 0; `arg` int32[n_dst, d] (nullable)
+ *                receives the winning source id (-1 for empty) for the backward:
+ *                dX[arg[r,c], c] += dY[r,c]   (dX pre-zeroed; float atomics).
+ * ---------------------------------------------------------------------------------- */
+int mi_segment_max_f32(int64_t n_dst, int64_t d, const int32_t* rowptr, const int32_t* col,
+                       const float* X, int64_t ldx, float* Y, int64_t ldy, int32_t* arg,
+                       mi_stream_t stream);
+int mi_segment_max_bwd_f32(int64_t n_dst, int64_t d, const int32_t* arg,
+                           const float* dY, int64_t ldy, float* dX, int64_t ldx,
+                           mi_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * K7  multi-column categorical embedding lookup + concat, with max_norm renorm.
+ * replaces: Encoder_Decoder_Model.__embedding at model/encoder_decoder.py:116-125
+ *           (Embedding(num_cat+1, size, max_norm=1)(x[:, i]) per column, cat on dim 1).
+ * x int64[n, n_cols] (device).  tables / table_rows / dims are HOST arrays of n_cols (<= 16)
+ * entries: device pointer to float[rows_c, dim_c], rows_c, dim_c.  out float[n, sum(dim_c)].
+ * A looked-up row whose L2 norm exceeds max_norm is scaled by max_norm / (norm + 1e-7) on the
+ * fly — the value torch's in-place embedding_renorm_ would leave in the table — so the stored
+ * (frozen) table is never written.  max_norm <= 0 disables it.
+ * ---------------------------------------------------------------------------------- */
+int mi_embed_concat_f32(int64_t n, int32_t n_cols, const int64_t* x,
+                        const float* const* tables, const int64_t* table_rows, const int32_t* dims,
+                        float max_norm, float* out, int64_t ldo, mi_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,133 @@
+// Ranker-side kernels that are not the SpMM or the GEMM:
+//   K5 (max)  mi_segment_max_f32 / mi_segment_max_bwd_f32 — SAGEConv(aggr="max") message passing
+//             (model/layers.py:11-24 -> torch_scatter.scatter(..., reduce="max")); aggr="add"/"mean"
+//             run on mi_spmm_csr_f32 with unit / 1/in-degree weights (mi_scale_csr_f32).
+//   K7        mi_embed_concat_f32 — Encoder_Decoder_Model.__embedding (model/encoder_decoder.py:116-125):
+//             per integer column an Embedding(max_norm=1) lookup, concatenated along dim 1.
+#include "common.hpp"
+
+namespace {
+
+constexpr int kBlock = 256;
+
+// One wavefront per destination row; lanes stride over the feature columns.
+__global__ __launch_bounds__(kBlock) void segment_max_kernel(int64_t n_dst, int d,
+                                                             const int32_t* __restrict__ rowptr,
+                                                             const int32_t* __restrict__ col,
+                                                             const float* __restrict__ X, int64_t ldx,
+                                                             float* __restrict__ Y, int64_t ldy,
+                                                             int32_t* __restrict__ arg) {
+    const int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / MI_WAVE;
+    if (r >= n_dst) return;
+    const int lane = mi_lane();
+    const int32_t b = rowptr[r], e = rowptr[r + 1];
+    for (int c = lane; c < d; c += MI_WAVE) {
+        float best = 0.f;  // empty segment -> 0 (torch_scatter fills untouched outputs with 0)
+        int32_t who = -1;
+        for (int32_t p = b; p < e; ++p) {
+            const int32_t s = col[p];
+            const float v = X[(int64_t)s * ldx + c];
+            if (who < 0 || v > best) {  // first maximum wins, in CSR (sorted source id) order
+                best = v;
+                who = s;
+            }
+        }
+        Y[r * ldy + c] = best;
+        if (arg) arg[r * (int64_t)d + c] = who;
+    }
+}
+
+__global__ void segment_max_bwd_kernel(int64_t total, int d, const int32_t* __restrict__ arg,
+                                       const float* __restrict__ dY, int64_t ldy, float* __restrict__ dX,
+                                       int64_t ldx) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int64_t r = i / d;
+    const int c = (int)(i - r * d);
+    const int32_t s = arg[i];
+    if (s >= 0) atomicAdd(dX + (int64_t)s * ldx + c, dY[r * ldy + c]);
+}
+
+struct EmbedCols {
+    const float* table[16];
+    int32_t dim[16];
+    int32_t off[16];
+    int64_t rows[16];
+};
+
+// One wavefront per (node, column): lanes cover the column's embedding width; the row's L2 norm is
+// reduced across the wave and the max_norm scale applied on the fly.
+__global__ __launch_bounds__(kBlock) void embed_concat_kernel(int64_t n, int n_cols,
+                                                              const int64_t* __restrict__ x, EmbedCols ec,
+                                                              float max_norm, float* __restrict__ out,
+                                                              int64_t ldo) {
+    const int64_t w = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / MI_WAVE;
+    if (w >= n * n_cols) return;
+    const int64_t node = w / n_cols;
+    const int c = (int)(w - node * n_cols);
+    const int lane = mi_lane();
+    int64_t id = x[node * n_cols + c];
+    if (id < 0) id = 0;
+    if (id >= ec.rows[c]) id = ec.rows[c] - 1;
+    const float* src = ec.table[c] + id * ec.dim[c];
+    float ss = 0.f;
+    for (int k = lane; k < ec.dim[c]; k += MI_WAVE) ss = fmaf(src[k], src[k], ss);
+    ss = mi_wave_sum(ss);
+    const float norm = sqrtf(ss);
+    const float scale = (max_norm > 0.f && norm > max_norm) ? max_norm / (norm + 1e-7f) : 1.0f;
+    float* dst = out + node * ldo + ec.off[c];
+    for (int k = lane; k < ec.dim[c]; k += MI_WAVE) dst[k] = src[k] * scale;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mi_segment_max_f32(int64_t n_dst, int64_t d, const int32_t* rowptr, const int32_t* col,
+                       const float* X, int64_t ldx, float* Y, int64_t ldy, int32_t* arg,
+                       mi_stream_t stream) {
+    MI_CHECK_ARG(n_dst >= 0 && d > 0);
+    if (n_dst == 0) return 0;
+    MI_CHECK_ARG(rowptr && Y && ldy >= d && (X == nullptr || ldx >= d));
+    dim3 g((unsigned)mi_ceil_div(n_dst * MI_WAVE, kBlock));
+    hipLaunchKernelGGL(segment_max_kernel, g, dim3(kBlock), 0, (hipStream_t)stream, n_dst, (int)d, rowptr, col, X, ldx,
+                       Y, ldy, arg);
+    return mi_launch_status();
+}
+
+int mi_segment_max_bwd_f32(int64_t n_dst, int64_t d, const int32_t* arg, const float* dY, int64_t ldy,
+                           float* dX, int64_t ldx, mi_stream_t stream) {
+    MI_CHECK_ARG(n_dst >= 0 && d > 0);
+    if (n_dst == 0) return 0;
+    MI_CHECK_ARG(arg && dY && dX && ldy >= d && ldx >= d);
+    const int64_t total = n_dst * d;
+    hipLaunchKernelGGL(segment_max_bwd_kernel, dim3((unsigned)mi_ceil_div(total, kBlock)), dim3(kBlock), 0,
+                       (hipStream_t)stream, total, (int)d, arg, dY, ldy, dX, ldx);
+    return mi_launch_status();
+}
+
+int mi_embed_concat_f32(int64_t n, int32_t n_cols, const int64_t* x, const float* const* tables,
+                        const int64_t* table_rows, const int32_t* dims, float max_norm, float* out,
+                        int64_t ldo, mi_stream_t stream) {
+    MI_CHECK_ARG(n >= 0 && n_cols >= 0);
+    if (n == 0 || n_cols == 0) return 0;
+    if (n_cols > 16) return MI_ERR_UNSUPPORTED;
+    MI_CHECK_ARG(x && tables && table_rows && dims && out);
+    EmbedCols ec;
+    int32_t off = 0;
+    for (int c = 0; c < n_cols; ++c) {  // tables/table_rows/dims are HOST arrays (a handful of entries)
+        MI_CHECK_ARG(tables[c] && dims[c] > 0 && table_rows[c] > 0);
+        ec.table[c] = tables[c];
+        ec.dim[c] = dims[c];
+        ec.rows[c] = table_rows[c];
+        ec.off[c] = off;
+        off += dims[c];
+    }
+    MI_CHECK_ARG(ldo >= off);
+    dim3 g((unsigned)mi_ceil_div(n * n_cols * MI_WAVE, kBlock));
+    hipLaunchKernelGGL(embed_concat_kernel, g, dim3(kBlock), 0, (hipStream_t)stream, n, (int)n_cols, x, ec, max_norm,
+                       out, ldo);
+    return mi_launch_status();
+}
+
+}  // extern "C"

@@ -1,0 +1,176 @@
+"""Encoder-decoder ranker — same class, constructor and methods as the reference's
+model/encoder_decoder.py:17-164, on the HIP kernels.
+
+    forward = embeddings (K7) -> hetero SAGEConv encoder (K5 + K6) -> per-type BatchNorm1d
+              -> MLP edge decoder over cat(z_user[row], z_item[col]) (K6)
+
+`to_hetero(GNNEncoder, metadata, aggr)` (model/encoder_decoder.py:93-95) is restated as
+`HeteroGNNEncoder`: every layer is duplicated per edge type with fresh parameters, the conv of
+relation (s, r, d) sees (x_s, x_d), and the outputs arriving at one destination type are combined
+with `aggr` (text spec: temporary_hetero.py:171-228,337-360).
+
+Faithful quirks: the categorical embedding tables live in a plain dict (not parameters, not in the
+state_dict, frozen) — here they are at least moved by .to(device); BatchNorm, dropout,
+relu on small [n, 64..128] tensors stay torch ops.
+"""
+from __future__ import annotations
+
+from copy import deepcopy
+from typing import Dict, List, Optional, Tuple
+
+import torch as t
+import torch.nn.functional as F
+from torch import Tensor, nn
+from torch.nn import BatchNorm1d, ModuleDict, ModuleList
+
+from .. import ops
+from ..utils.constants import Constants
+from ..utils.tensor import padded_stack
+from .layers import BipartiteGraph
+
+
+def _key(edge_type: Tuple[str, str, str]) -> str:
+    return "__".join(edge_type)
+
+
+def _combine(outs: List[Tensor], aggr: str) -> Tensor:
+    if len(outs) == 1:
+        return outs[0]
+    stack = t.stack(outs, dim=0)
+    if aggr == "sum":
+        return stack.sum(0)
+    if aggr == "mean":
+        return stack.mean(0)
+    if aggr == "min":
+        return stack.min(0)[0]
+    if aggr == "max":
+        return stack.max(0)[0]
+    if aggr == "mul":
+        return stack.prod(0)
+    raise ValueError(f"unknown heterogeneous aggregation {aggr!r}")
+
+
+class HeteroGNNEncoder(nn.Module):
+    """GNNEncoder.forward (model/encoder_decoder.py:29-46) applied per edge type."""
+
+    def __init__(self, layers: ModuleList, metadata, aggr: str, p_dropout_edges: Optional[float],
+                 p_dropout_features: Optional[float]):
+        super().__init__()
+        self.node_types, self.edge_types = list(metadata[0]), [tuple(e) for e in metadata[1]]
+        self.aggr = aggr
+        self.p_dropout_edges, self.p_dropout_features = p_dropout_edges, p_dropout_features
+        per_layer = []
+        for layer in layers:
+            convs = {}
+            for et in self.edge_types:
+                conv = deepcopy(layer)
+                conv.reset_parameters()
+                convs[_key(et)] = conv
+            per_layer.append(ModuleDict(convs))
+        self.layers = ModuleList(per_layer)
+
+    def forward(self, x_dict: Dict[str, Tensor], edge_index_dict: Dict[Tuple[str, str, str], Tensor]):
+        graphs = {}
+        for et, ei in edge_index_dict.items():
+            et = tuple(et)
+            if _key(et) in self.layers[0]:
+                graphs[et] = ei if isinstance(ei, BipartiteGraph) else BipartiteGraph(
+                    ei, x_dict[et[0]].shape[0], x_dict[et[2]].shape[0])
+        n_layers = len(self.layers)
+        for index, convs in enumerate(self.layers):
+            last = index == n_layers - 1
+            if not last and self.p_dropout_features is not None:
+                x_dict = {k: F.dropout(v, p=self.p_dropout_features, training=self.training) for k, v in x_dict.items()}
+            by_dst: Dict[str, List[Tensor]] = {}
+            for et, graph in graphs.items():
+                out = convs[_key(et)]((x_dict[et[0]], x_dict[et[2]]), graph)
+                by_dst.setdefault(et[2], []).append(out)
+            x_dict = {dst: _combine(outs, self.aggr) for dst, outs in by_dst.items()}
+            if not last:
+                x_dict = {k: v.relu() for k, v in x_dict.items()}
+        return x_dict
+
+
+class EdgeDecoder(nn.Module):
+    def __init__(self, layers: ModuleList, p_dropout_features: Optional[float]):
+        super().__init__()
+        self.layers = layers
+        self.p_dropout_features = p_dropout_features
+
+    def forward(self, z_dict: dict, edge_label_index) -> Tensor:
+        customer_index, article_index = edge_label_index
+        z = t.cat([z_dict[Constants.node_user][customer_index], z_dict[Constants.node_item][article_index]], dim=-1)
+        n_layers = len(self.layers)
+        for index, layer in enumerate(self.layers):
+            if index == n_layers - 1:
+                z = layer(z)
+            else:
+                if self.p_dropout_features is not None:
+                    z = F.dropout(z, p=self.p_dropout_features, training=self.training)
+                z = layer(z, relu=True)  # relu fused into the GEMM epilogue
+        return z.view(-1)
+
+
+class Encoder_Decoder_Model(nn.Module):
+    def __init__(self, encoder_layers: ModuleList, decoder_layers: ModuleList, feature_info: dict, metadata,
+                 embedding: bool, heterogeneous_prop_agg_type: str, batch_normalize: bool,
+                 p_dropout_edges: Optional[float], p_dropout_features: Optional[float]):
+        super().__init__()
+        self.embedding = embedding
+        self.batch_normalize = batch_normalize
+        self.encoder = HeteroGNNEncoder(encoder_layers, metadata, heterogeneous_prop_agg_type, p_dropout_edges,
+                                        p_dropout_features)
+        self.decoder = EdgeDecoder(decoder_layers, p_dropout_features)
+        self.encoder_layer_norm_customer = BatchNorm1d(encoder_layers[-1].out_channels)
+        self.encoder_layer_norm_article = BatchNorm1d(encoder_layers[-1].out_channels)
+
+        # plain dict on purpose (model/encoder_decoder.py:101): frozen tables, outside parameters()/state_dict
+        self.embedding_layers: Dict[str, List[Tensor]] = dict()
+        if self.embedding:
+            for key, item in feature_info.items():
+                tables = []
+                for i in range(item.num_feat):
+                    # nn.Embedding draws N(0, 1): create it exactly like the reference so a seeded build matches
+                    emb = nn.Embedding(num_embeddings=int(item.num_cat[i] + 1), embedding_dim=int(item.embedding_size[i]))
+                    tables.append(emb.weight.detach().clone())
+                self.embedding_layers[key] = tables
+
+    def _apply(self, fn, *args, **kwargs):
+        super()._apply(fn, *args, **kwargs)
+        self.embedding_layers = {k: [fn(tb) for tb in v] for k, v in self.embedding_layers.items()}
+        return self
+
+    def _embed(self, x_dict: dict) -> dict:
+        """Encoder_Decoder_Model.__embedding: per column Embedding(max_norm=1) lookup, concatenated."""
+        for key, tables in self.embedding_layers.items():
+            x_dict[key] = ops.embed_concat(x_dict[key].contiguous(), tables, max_norm=1.0)
+        return x_dict
+
+    def initialize_encoder_input_size(self, data) -> None:
+        x_dict, edge_index_dict = data.x_dict, data.edge_index_dict
+        if self.embedding:
+            x_dict = self._embed(x_dict)
+        with t.no_grad():
+            self.encoder(x_dict, edge_index_dict)
+
+    def forward(self, x_dict, edge_index_dict: dict, edge_label_index: Tensor) -> Tensor:
+        if self.embedding:
+            x_dict = self._embed(x_dict)
+        z_dict = self.encoder(x_dict, edge_index_dict)
+        if self.batch_normalize:
+            z_dict[Constants.node_user] = self.encoder_layer_norm_customer(z_dict[Constants.node_user])
+            z_dict[Constants.node_item] = self.encoder_layer_norm_article(z_dict[Constants.node_item])
+        return self.decoder(z_dict, edge_label_index)
+
+    def infer(self, x_dict, edge_index_dict: dict, edge_label_index: Tensor) -> Tensor:
+        self.eval()
+        out = self.forward(x_dict, edge_index_dict, edge_label_index).detach()
+        # re-batch by user: one row of candidate scores per sorted-unique user, padded on the right
+        users, inverse = edge_label_index[0].unique(sorted=True, return_inverse=True)
+        counts = t.bincount(inverse, minlength=users.numel())
+        order = t.argsort(inverse, stable=True)
+        start = t.cumsum(counts, 0) - counts
+        pos = t.arange(out.numel(), device=out.device) - start[inverse[order]]
+        res = t.full((users.numel(), int(counts.max())), float(-(1 << 50)), dtype=out.dtype, device=out.device)
+        res[inverse[order], pos] = out[order]
+        return res

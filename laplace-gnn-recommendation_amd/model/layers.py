@@ -1,0 +1,207 @@
+"""Ranker layers — factories with the reference's names and return types (model/layers.py:6-56):
+`get_SAGEConv_layers` -> ModuleList of SAGEConv, `get_linear_layers` -> ModuleList of Linear.
+
+SAGEConv follows PyG 2.0.4 (`SAGEConv((-1,-1,-1), C, aggr, normalize=False, bias=True)`):
+    out = lin_l( AGG_{j -> i} x_src[j] ) + lin_r( x_dst[i] )          lin_l has the bias, lin_r none
+with lazily sized weights.  Aggregation runs on the HIP SpMM (add / mean) or segment-max kernel
+over a CSR sorted by destination — no [E, C] message tensor, no atomics in the forward; the two
+Linear products run on the f32-MFMA GEMM.  Both are torch.autograd.Functions whose backward calls
+the same kernels (transposed CSR; dX = dY W, dW = dY^T X).
+"""
+from __future__ import annotations
+
+import math
+from copy import deepcopy
+from typing import Optional, Tuple, Union
+
+import torch as t
+import torch.nn.functional as F
+from torch import Tensor, nn
+
+from .. import ops
+
+
+# ------------------------------------------------------------------------------------------------
+# Linear on mi_gemm_f32
+# ------------------------------------------------------------------------------------------------
+class _LinearFn(t.autograd.Function):
+    @staticmethod
+    def forward(ctx, x: Tensor, weight: Tensor, bias: Optional[Tensor], relu: bool):
+        x2 = x if x.stride(-1) == 1 else x.contiguous()
+        y = ops.gemm(x2, weight, trans_b=True, bias=bias, relu=relu)
+        ctx.save_for_backward(x2, weight, y if relu else None)
+        ctx.has_bias, ctx.relu = bias is not None, relu
+        return y
+
+    @staticmethod
+    def backward(ctx, dy: Tensor):
+        x, weight, y = ctx.saved_tensors
+        dy = dy.contiguous()
+        if ctx.relu:
+            dy = dy * (y > 0)
+        dx = ops.gemm(dy, weight, trans_b=False) if ctx.needs_input_grad[0] else None   # [m,n] @ [n,k]
+        dw = ops.gemm(dy, x, trans_a=True, trans_b=False) if ctx.needs_input_grad[1] else None  # dy^T @ x
+        db = dy.sum(dim=0) if ctx.has_bias else None
+        return dx, dw, db, None
+
+
+class Linear(nn.Module):
+    """torch.nn.Linear semantics and state_dict keys (weight [out, in], bias [out]); in_features = -1
+    sizes the weight on the first forward (PyG lazy Linear)."""
+
+    def __init__(self, in_features: int, out_features: int, bias: bool = True):
+        super().__init__()
+        self.in_features, self.out_features, self.use_bias = int(in_features), int(out_features), bias
+        if self.in_features > 0:
+            self._materialize(self.in_features, None)
+        else:
+            self.register_parameter("weight", None)
+            self.register_parameter("bias", None)
+
+    def _materialize(self, in_features: int, device) -> None:
+        self.in_features = in_features
+        self.weight = nn.Parameter(t.empty(self.out_features, in_features, device=device))
+        self.bias = nn.Parameter(t.empty(self.out_features, device=device)) if self.use_bias else None
+        self.reset_parameters()
+
+    def reset_parameters(self) -> None:
+        if self.weight is None:
+            return
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))  # = U(-1/sqrt(in), 1/sqrt(in)), as nn.Linear / PyG
+        if self.bias is not None:
+            bound = 1 / math.sqrt(self.in_features) if self.in_features > 0 else 0
+            nn.init.uniform_(self.bias, -bound, bound)
+
+    def forward(self, x: Tensor, relu: bool = False) -> Tensor:
+        if self.weight is None:
+            self._materialize(int(x.shape[-1]), x.device)
+        return _LinearFn.apply(x, self.weight, self.bias, relu)
+
+    def extra_repr(self) -> str:
+        return f"in_features={self.in_features}, out_features={self.out_features}, bias={self.use_bias}"
+
+
+# ------------------------------------------------------------------------------------------------
+# message passing on a destination-sorted CSR
+# ------------------------------------------------------------------------------------------------
+class BipartiteGraph:
+    """One relation of a batch: edges src -> dst as two sorted CSRs (by dst for the forward aggregate,
+    by src for its backward), built once per batch on device and shared by all layers."""
+
+    def __init__(self, edge_index: Tensor, n_src: int, n_dst: int):
+        src, dst = edge_index[0].contiguous(), edge_index[1].contiguous()
+        self.n_src, self.n_dst = int(n_src), int(n_dst)
+        self.by_dst = ops.coo_to_csr(dst, src, self.n_dst, self.n_src, want_perm=False)
+        self.by_src = ops.coo_to_csr(src, dst, self.n_src, self.n_dst, want_perm=False)
+        self._vals = {}
+
+    def weights(self, aggr: str) -> Tuple[Tensor, Tensor]:
+        """(values for by_dst, values for by_src) realising `aggr` as a weighted sum."""
+        if aggr not in self._vals:
+            if aggr == "add":
+                ones = t.ones(self.by_dst.nnz, device=self.by_dst.device)
+                self._vals[aggr] = (ones, ones)
+            elif aggr == "mean":
+                deg = (self.by_dst.rowptr[1:] - self.by_dst.rowptr[:-1]).to(t.float32)
+                inv = t.where(deg > 0, 1.0 / deg, t.zeros_like(deg))
+                self._vals[aggr] = (ops.scale_csr(self.by_dst, None, inv, None), ops.scale_csr(self.by_src, None, None, inv))
+            else:
+                raise ValueError(aggr)
+        return self._vals[aggr]
+
+
+def _pad4(x: Tensor) -> Tensor:
+    pad = (-x.shape[1]) % 4
+    x = x if x.stride(-1) == 1 else x.contiguous()
+    return F.pad(x, (0, pad)) if pad else x
+
+
+class _AggregateFn(t.autograd.Function):
+    @staticmethod
+    def forward(ctx, x_src: Tensor, graph: BipartiteGraph, aggr: str):
+        d = x_src.shape[1]
+        ctx.graph, ctx.aggr, ctx.d = graph, aggr, d
+        if aggr == "max":
+            y, arg = ops.segment_max(graph.by_dst, x_src if x_src.stride(-1) == 1 else x_src.contiguous())
+            ctx.save_for_backward(arg)
+            return y
+        xp = _pad4(x_src)
+        v_dst, _ = graph.weights(aggr)
+        a = ops.DeviceCSR(graph.by_dst.n_rows, graph.by_dst.n_cols, graph.by_dst.rowptr, graph.by_dst.col, v_dst, None,
+                          graph.by_dst.plan)
+        y = t.empty(graph.n_dst, xp.shape[1], device=x_src.device)
+        ops.spmm(a, xp, Y=y)
+        graph.by_dst.plan = a.plan
+        return y[:, :d] if xp.shape[1] != d else y
+
+    @staticmethod
+    def backward(ctx, dy: Tensor):
+        graph, aggr, d = ctx.graph, ctx.aggr, ctx.d
+        if aggr == "max":
+            (arg,) = ctx.saved_tensors
+            return ops.segment_max_bwd(arg, dy.contiguous(), graph.n_src), None, None
+        dyp = _pad4(dy)
+        _, v_src = graph.weights(aggr)
+        a = ops.DeviceCSR(graph.by_src.n_rows, graph.by_src.n_cols, graph.by_src.rowptr, graph.by_src.col, v_src, None,
+                          graph.by_src.plan)
+        dx = t.empty(graph.n_src, dyp.shape[1], device=dy.device)
+        ops.spmm(a, dyp, Y=dx)
+        graph.by_src.plan = a.plan
+        return (dx[:, :d] if dyp.shape[1] != d else dx), None, None
+
+
+class SAGEConv(nn.Module):
+    def __init__(self, in_channels: Union[int, Tuple[int, ...]], out_channels: int, aggr: str = "mean",
+                 normalize: bool = False, root_weight: bool = True, bias: bool = True):
+        super().__init__()
+        if aggr not in ("add", "sum", "mean", "max"):
+            raise ValueError(f"aggr={aggr!r} is not supported by the HIP path (add, mean, max)")
+        if isinstance(in_channels, int):
+            in_channels = (in_channels, in_channels)
+        self.in_channels, self.out_channels = tuple(in_channels), int(out_channels)
+        self.aggr = "add" if aggr == "sum" else aggr
+        self.normalize, self.root_weight = normalize, root_weight
+        self.lin_l = Linear(self.in_channels[0], out_channels, bias=bias)
+        if root_weight:
+            self.lin_r = Linear(self.in_channels[1], out_channels, bias=False)
+
+    def reset_parameters(self) -> None:
+        self.lin_l.reset_parameters()
+        if self.root_weight:
+            self.lin_r.reset_parameters()
+
+    def forward(self, x, edge_index, relu: bool = False) -> Tensor:
+        """x: Tensor or (x_src, x_dst).  edge_index: int64 [2, E] (row 0 = source, row 1 = destination)
+        or a prebuilt BipartiteGraph."""
+        x_src, x_dst = (x, x) if isinstance(x, Tensor) else x
+        graph = edge_index if isinstance(edge_index, BipartiteGraph) else BipartiteGraph(
+            edge_index, x_src.shape[0], x_dst.shape[0])
+        agg = _AggregateFn.apply(x_src, graph, self.aggr)
+        out = self.lin_l(agg)
+        if self.root_weight and x_dst is not None:
+            out = out + self.lin_r(x_dst)
+        if self.normalize:
+            out = F.normalize(out, p=2.0, dim=-1)
+        return out.relu() if relu else out
+
+
+def get_SAGEConv_layers(num_layers: int, hidden_channels: int, out_channels: int, agg_type: str) -> nn.ModuleList:
+    """[(num_layers-1) x SAGEConv(-1 -> hidden)] + [SAGEConv(-1 -> out)]  (model/layers.py:6-32)."""
+    single = SAGEConv((-1, -1, -1), hidden_channels, aggr=agg_type, normalize=False, bias=True)
+    last = SAGEConv((-1, -1, -1), out_channels, aggr=agg_type, normalize=False, bias=True)
+    if num_layers == 1:
+        return nn.ModuleList([last])
+    return nn.ModuleList([deepcopy(single) for _ in range(num_layers - 1)] + [last])
+
+
+def get_linear_layers(num_layers: int, in_channels: int, hidden_channels: int, out_channels: int) -> nn.ModuleList:
+    """Decoder stack (model/layers.py:35-56).  Modules are created in the reference's order so that a
+    seeded build draws the same initial weights (tests/golden/linear_layers.pt)."""
+    first = Linear(in_channels, hidden_channels)
+    middle = Linear(hidden_channels, hidden_channels)
+    last = Linear(hidden_channels, out_channels)
+    if num_layers == 1:
+        return nn.ModuleList([Linear(in_channels, out_channels)])
+    if num_layers == 2:
+        return nn.ModuleList([Linear(in_channels, hidden_channels), Linear(hidden_channels, out_channels)])
+    return nn.ModuleList([first] + [deepcopy(middle) for _ in range(num_layers - 2)] + [last])

@@ -22,6 +22,11 @@ DEFAULT_CHUNK = 256  # nnz per work item of a split (hub) row
 # recorded on the stream the kernels are launched on.  None = no timing overhead.
 SPMM_EVENTS = None
 
+# Adjacencies smaller than this run without a split-row plan (one wavefront per row whatever its
+# length): building a plan reads two counters back to the host, which per-batch subgraphs of the
+# ranker cannot afford and do not need.
+PLAN_MIN_NNZ = 1 << 20
+
 
 def _stream() -> int:
     return t.cuda.current_stream().cuda_stream
@@ -206,12 +211,12 @@ def spmm(a: DeviceCSR, X: Tensor, *, Y: Optional[Tensor] = None, addend: Optiona
     ldy = _rows_ok(Y, "Y") if Y is not None else 0
     lda = _rows_ok(addend, "addend") if addend is not None else 0
     lds = _rows_ok(S, "S") if S is not None else 0
-    if a.plan is None:
+    if a.plan is None and a.nnz >= PLAN_MIN_NNZ:
         a.plan = build_spmm_plan(a)
     plan = a.plan
     L = _lib.lib()
     ws_ptr, ws_bytes = None, 0
-    if plan.n_items > 0:
+    if plan is not None and plan.n_items > 0:
         if d not in plan.partial:
             plan.partial[d] = _ws(L.mi_spmm_workspace_bytes(ctypes.byref(plan.struct), d), a.device)
         ws_ptr, ws_bytes = plan.partial[d].data_ptr(), plan.partial[d].numel()
@@ -223,7 +228,8 @@ def spmm(a: DeviceCSR, X: Tensor, *, Y: Optional[Tensor] = None, addend: Optiona
         ev[0].record()
     check(L.mi_spmm_csr_f32(a.n_rows, d, _ptr(a.rowptr), col_ptr, val_ptr, X.data_ptr(), ldx,
                             _ptr(Y), ldy, _ptr(addend), lda, _ptr(S), lds, float(scale),
-                            ctypes.byref(plan.struct), ws_ptr, ws_bytes, _stream()), "mi_spmm_csr_f32")
+                            ctypes.byref(plan.struct) if plan is not None else None, ws_ptr, ws_bytes,
+                            _stream()), "mi_spmm_csr_f32")
     if ev is not None:
         ev[1].record()
         SPMM_EVENTS.append(ev)
@@ -352,3 +358,46 @@ def topk_excl(uid: Tensor, user_emb: Tensor, item_emb: Tensor, k: int, excl: Opt
                                  out_idx[q0:q1].data_ptr(), out_sc[q0:q1].data_ptr() if want_scores else None,
                                  ws.data_ptr(), ws.numel(), _stream()), "mi_topk_excl_f32")
     return (out_idx, out_sc) if want_scores else out_idx
+
+
+def segment_max(a: DeviceCSR, X: Tensor, want_arg: bool = True):
+    """K5 (aggr="max") — Y[r] = max over the sources of destination r (0 for none); arg = winning source ids."""
+    ldx = _rows_ok(X, "X")
+    d = X.shape[1]
+    Y = t.empty(a.n_rows, d, dtype=t.float32, device=X.device)
+    arg = t.empty(a.n_rows, d, dtype=t.int32, device=X.device) if want_arg else None
+    colp = _ptr(a.col) if a.nnz else a.rowptr.data_ptr()
+    check(_lib.lib().mi_segment_max_f32(a.n_rows, d, _ptr(a.rowptr), colp, X.data_ptr(), ldx, Y.data_ptr(), d,
+                                        _ptr(arg), _stream()), "mi_segment_max_f32")
+    return Y, arg
+
+
+def segment_max_bwd(arg: Tensor, dY: Tensor, n_src: int) -> Tensor:
+    _need(arg, t.int32, "arg")
+    ldy = _rows_ok(dY, "dY")
+    d = dY.shape[1]
+    dX = t.zeros(n_src, d, dtype=t.float32, device=dY.device)
+    if n_src and dY.shape[0]:
+        check(_lib.lib().mi_segment_max_bwd_f32(dY.shape[0], d, arg.data_ptr(), dY.data_ptr(), ldy, dX.data_ptr(), d,
+                                                _stream()), "mi_segment_max_bwd_f32")
+    return dX
+
+
+def embed_concat(x: Tensor, tables, max_norm: float = 1.0) -> Tensor:
+    """K7 — cat_i Embedding_i(max_norm)(x[:, i]).  tables: list of [rows_i, dim_i] fp32 GPU tensors."""
+    _need(x, t.int64, "x")
+    if x.dim() != 2 or x.shape[1] != len(tables):
+        raise ValueError("x must be [n, n_cols] with one table per column")
+    for i, tb in enumerate(tables):
+        _need(tb, t.float32, f"tables[{i}]")
+    n, nc = x.shape
+    width = sum(int(tb.shape[1]) for tb in tables)
+    out = t.empty(n, width, dtype=t.float32, device=x.device)
+    if n == 0 or nc == 0:
+        return out
+    ptrs = (ctypes.c_void_p * nc)(*[tb.data_ptr() for tb in tables])
+    rows = (ctypes.c_int64 * nc)(*[int(tb.shape[0]) for tb in tables])
+    dims = (ctypes.c_int32 * nc)(*[int(tb.shape[1]) for tb in tables])
+    check(_lib.lib().mi_embed_concat_f32(n, nc, x.data_ptr(), ptrs, rows, dims, float(max_norm), out.data_ptr(), width,
+                                         _stream()), "mi_embed_concat_f32")
+    return out

@@ -90,3 +90,29 @@ def generate(spec: SyntheticSpec) -> t.Tensor:
         keys = keys[keep]
     keys = keys[rng.permutation(keys.size)]  # edge order carries no structure (a raw transaction log)
     return t.from_numpy(np.stack([keys // I, keys % I]))
+
+
+# H&M-shaped heterogeneous graph: integer categorical node features, customer -buys-> article
+HM_CUSTOMER_CARDS = (352_899, 2, 84, 4, 5, 2)   # postal_code, FN, age, club_member_status, fashion_news_frequency, Active
+HM_ARTICLE_CARDS = (47_224, 132, 30, 50)        # product_code, product_type_no, graphical_appearance_no, colour_group_code
+C3 = SyntheticSpec(1_371_980, 105_542, 31_800_000, seed=2, deg_max=2000, zipf_s=1.0)
+
+
+def generate_hetero(spec: SyntheticSpec, customer_cards=HM_CUSTOMER_CARDS, article_cards=HM_ARTICLE_CARDS):
+    """Returns (graph, users_adj, articles_adj) in the shapes the reference's preprocessing writes
+    (train_graph.pt / edges_train.pt / rev_edges_train.pt; run_preprocessing.py:176-195): a HeteroData with
+    int64 categorical `x` per node type and the `buys` edge_index, plus the two adjacency lists (as CSR
+    AdjList objects — a dict of Python lists does not scale to 31.8 M edges)."""
+    from .data.dataset import AdjList
+    from .hetero import HeteroData
+    from .utils.constants import Constants
+    ei = generate(spec)
+    rng = np.random.default_rng(spec.seed + 7919)
+    cx = np.stack([rng.integers(0, min(c, spec.num_users) if c > 1000 else c, size=spec.num_users) for c in customer_cards], 1)
+    ax = np.stack([rng.integers(0, min(c, spec.num_items) if c > 1000 else c, size=spec.num_items) for c in article_cards], 1)
+    g = HeteroData()
+    g[Constants.node_user].x = t.from_numpy(cx.astype(np.int64))
+    g[Constants.node_item].x = t.from_numpy(ax.astype(np.int64))
+    g[Constants.edge_key].edge_index = ei
+    u, a = ei[0].numpy(), ei[1].numpy()
+    return g, AdjList.from_edges(u, a, spec.num_users), AdjList.from_edges(a, u, spec.num_items)

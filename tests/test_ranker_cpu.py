@@ -1,0 +1,205 @@
+"""CPU tests of the ranker's host logic and of its oracle: the sampler against the reference's
+tests/test_dataset.py fixture and against the literal restatement, collate, feature info,
+scatter known answers, golden-pinned helpers."""
+import os
+import random
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch as t
+
+from oracle import dataset_ref as DR
+from oracle import ranker_ref as RR
+
+
+def _cfg(**kw):
+    base = dict(k=12, num_neighbors=64, n_hop_neighbors=2, positive_edges_ratio=0.5, negative_edges_ratio=1.0)
+    base.update(kw)
+    return SimpleNamespace(**base)
+
+
+def _fixture_graph():
+    """tests/data_generator.py:129-146 of the reference ("random" = this fixed graph)."""
+    from laplace_amd.hetero import HeteroData
+    from laplace_amd.utils.constants import Constants
+    ux = t.tensor([[0.0, 0.1], [1.0, 1.1], [2.0, 2.1]])
+    ax = t.tensor([[i + j / 10 for j in range(5)] for i in range(6)])
+    ei = t.tensor([[0, 0, 0, 1, 1, 2, 2], [0, 2, 4, 1, 5, 3, 0]])
+    g = HeteroData()
+    g[Constants.node_user].x, g[Constants.node_item].x, g[Constants.edge_key].edge_index = ux, ax, ei
+    users = {0: [0, 2, 4], 1: [1, 5], 2: [3, 0]}
+    articles = {0: [0, 2], 1: [1], 2: [0], 3: [2], 4: [0], 5: [1]}
+    return g, users, articles, ux, ax, ei
+
+
+def test_sampler_reference_fixture():
+    """Expected values derived by hand from the fixture (SURVEY §8c iii): user 0, positives [0, 4]
+    (argmin/argmax), negative [5] (= id_max: 7 edges / 2 < 100 -> exact branch), labels [1, 1, 0],
+    message-passing edges = all edges of users {0, 2}, nodes relabelled by sorted-unique buckets."""
+    from laplace_amd.data.dataset import GraphDataset
+    from laplace_amd.utils.constants import Constants
+    g, users, articles, ux, ax, ei = _fixture_graph()
+    ds = GraphDataset(_cfg(), g, users, articles, train=True, randomization=False)
+    assert len(ds) == 3
+    item = ds[0]
+    user_buckets, article_buckets = t.tensor([0, 2]), t.tensor([0, 2, 3, 4, 5])
+    assert t.equal(item[Constants.node_user].x, ux[user_buckets])
+    assert t.equal(item[Constants.node_item].x, ax[article_buckets])
+    store = item[Constants.edge_key]
+    want_edges = sorted([(0, 0), (0, 1), (0, 3), (1, 2), (1, 0)])  # (0,0)(0,2)(0,4)(2,3)(2,0) relabelled
+    assert sorted(zip(store.edge_index[0].tolist(), store.edge_index[1].tolist())) == want_edges
+    assert store.edge_label_index.tolist() == [[0, 0, 0], [0, 3, 4]]  # articles 0, 4, 5
+    assert store.edge_label.tolist() == [1, 1, 0] and store.edge_label.dtype == t.long
+    rev = item[Constants.rev_edge_key]
+    assert t.equal(rev.edge_index, store.edge_index.flip(0)) and t.equal(rev.edge_label_index, store.edge_label_index.flip(0))
+    assert t.equal(rev.edge_label, store.edge_label)
+    # the literal restatement of the reference agrees
+    ref = DR.get_item(0, {"user_x": ux, "article_x": ax, "edge_index": ei}, users, articles, _cfg(), True, None, False)
+    assert t.equal(ref["user_x"], item[Constants.node_user].x) and t.equal(ref["article_x"], item[Constants.node_item].x)
+    assert sorted(zip(*ref["edge_index"].tolist())) == want_edges
+    assert t.equal(ref["edge_label_index"], store.edge_label_index) and t.equal(ref["edge_label"], store.edge_label)
+
+
+def _random_graph(seed, U=40, A=30, E=260):
+    from laplace_amd.hetero import HeteroData
+    from laplace_amd.utils.constants import Constants
+    g = t.Generator().manual_seed(seed)
+    keys = t.randperm(U * A, generator=g)[:E]
+    ei = t.stack([keys // A, keys % A])
+    for u in range(U):  # every user needs at least one edge (the reference indexes users[idx])
+        if not (ei[0] == u).any():
+            ei = t.cat([ei, t.tensor([[u], [int(t.randint(0, A, (1,), generator=g))]])], dim=1)
+    users = {u: ei[1][ei[0] == u].tolist() for u in range(U)}
+    articles = {a: ei[0][ei[1] == a].tolist() for a in range(A) if (ei[1] == a).any()}
+    for a in range(A):
+        articles.setdefault(a, [])
+    hd = HeteroData()
+    hd[Constants.node_user].x = t.randint(0, 50, (U, 3), generator=g)
+    hd[Constants.node_item].x = t.randint(0, 9, (A, 2), generator=g)
+    hd[Constants.edge_key].edge_index = ei
+    return hd, users, articles, ei
+
+
+@pytest.mark.parametrize("hops,fan", [(1, 64), (2, 64), (3, 1000), (4, 1000)])  # caps that bite are random even upstream
+def test_sampler_equals_literal_restatement_deterministic_mode(hops, fan):
+    from laplace_amd.data.dataset import GraphDataset
+    from laplace_amd.utils.constants import Constants
+    hd, users, articles, ei = _random_graph(seed=hops)
+    cfg = _cfg(n_hop_neighbors=hops, num_neighbors=fan)
+    ds = GraphDataset(cfg, hd, users, articles, train=True, randomization=False)
+    graph = {"user_x": hd[Constants.node_user].x, "article_x": hd[Constants.node_item].x, "edge_index": ei}
+    for idx in range(len(ds)):
+        got, ref = ds[idx], DR.get_item(idx, graph, users, articles, cfg, True, None, False)
+        s = got[Constants.edge_key]
+        assert t.equal(got[Constants.node_user].x, ref["user_x"]) and t.equal(got[Constants.node_item].x, ref["article_x"])
+        assert sorted(zip(*s.edge_index.tolist())) == sorted(zip(*ref["edge_index"].tolist()))
+        assert t.equal(s.edge_label_index, ref["edge_label_index"]) and t.equal(s.edge_label, ref["edge_label"])
+
+
+def test_sampler_random_mode_structure_and_eval_negatives():
+    from laplace_amd.data.dataset import GraphDataset
+    from laplace_amd.utils.constants import Constants
+    hd, users, articles, ei = _random_graph(seed=9, U=60, A=50, E=700)
+    cfg = _cfg(n_hop_neighbors=2, num_neighbors=5, positive_edges_ratio=0.5, negative_edges_ratio=3.0)
+    ds = GraphDataset(cfg, hd, users, articles, train=True, randomization=True, seed=1)
+    pairs = set(zip(ei[0].tolist(), ei[1].tolist()))
+    for idx in range(0, 60, 7):
+        item = ds[idx]
+        s = item[Constants.edge_key]
+        ub = t.unique(t.cat([s.edge_index[0], s.edge_label_index[0]]))
+        assert item[Constants.node_user].x.shape[0] == ub.numel()  # every feature row is a touched node
+        n_pos = int(s.edge_label.sum())
+        assert n_pos == max(1, len(users[idx]) // 2)
+        n_neg = s.edge_label.numel() - n_pos
+        assert n_neg == (cfg.k - 1 if n_pos <= 1 else int(3.0 * n_pos))
+        # fan-out cap: <= 5 articles expanded, <= 5 new users, all their edges are real edges
+        x_u = item[Constants.node_user].x
+        assert x_u.shape[0] <= 1 + 5
+    # eval: negatives = ids seen exactly once in cat(unique candidates, positives) — as written upstream
+    class M:
+        def get_matches(self, u):
+            return t.tensor([1, 2, 3, 3, 7])
+    dse = GraphDataset(cfg, hd, users, articles, train=False, matchers=[M()], randomization=True, seed=2)
+    item = dse[3]
+    s = item[Constants.edge_key]
+    pos = users[3]
+    ids, cnt = np.unique(np.concatenate([np.array([1, 2, 3, 7]), np.array(pos)]), return_counts=True)
+    want_neg = ids[cnt == 1]
+    ab = np.unique(np.concatenate([ei[1][np.isin(ei[0], np.unique(s.edge_index[0]))].numpy(), want_neg]))
+    assert int((s.edge_label == 0).sum()) == len(want_neg)
+
+
+def test_collate_offsets_and_loader():
+    from laplace_amd.data.dataset import GraphDataset
+    from laplace_amd.hetero import DataLoader, collate
+    from laplace_amd.utils.constants import Constants
+    hd, users, articles, ei = _random_graph(seed=4)
+    ds = GraphDataset(_cfg(), hd, users, articles, train=True, randomization=False)
+    a, b = ds[0], ds[1]
+    batch = collate([a, b])
+    nu, na = a[Constants.node_user].x.shape[0], a[Constants.node_item].x.shape[0]
+    assert t.equal(batch[Constants.node_user].x, t.cat([a[Constants.node_user].x, b[Constants.node_user].x]))
+    eb = batch[Constants.edge_key]
+    ea, eb2 = a[Constants.edge_key], b[Constants.edge_key]
+    assert t.equal(eb.edge_index[:, :ea.edge_index.shape[1]], ea.edge_index)
+    assert t.equal(eb.edge_index[:, ea.edge_index.shape[1]:], eb2.edge_index + t.tensor([[nu], [na]]))
+    assert t.equal(eb.edge_label_index[:, ea.edge_label_index.shape[1]:], eb2.edge_label_index + t.tensor([[nu], [na]]))
+    rb = batch[Constants.rev_edge_key]
+    assert t.equal(rb.edge_index, eb.edge_index.flip(0))  # rev store offsets swap with its node types
+    assert t.equal(eb.edge_label, t.cat([ea.edge_label, eb2.edge_label]))
+    assert batch.metadata() == ([Constants.node_user, Constants.node_item], [Constants.edge_key, Constants.rev_edge_key])
+    loader = DataLoader(ds, batch_size=16, shuffle=True, generator=t.Generator().manual_seed(0))
+    sizes = [bt[Constants.node_user].x.shape[0] for bt in loader]
+    assert len(loader) == 3 and len(sizes) == 3
+
+
+def test_feature_info_and_embedding_widths():
+    from laplace_amd.utils.get_info import embedding_size_for, get_feature_info, select_properties
+    assert [embedding_size_for(m) for m in (1, 2, 3, 10, 11, 1000, 9999, 10_000, 99_999, 1_000_000, 2_000_000)] == \
+        [2, 2, 4, 4, 12, 12, 20, 20, 40, 60, 20]  # > 1M falls back to the "10000" width (Appendix A.9)
+    hd, users, articles, ei = _random_graph(seed=5)
+    info = get_feature_info(hd)
+    assert info["customer"].num_feat == 3 and info["article"].num_feat == 2
+    assert info["customer"].num_cat == hd["customer"].x.max(0)[0].tolist()
+
+
+def test_scatter_known_answers():
+    """SAGEConv aggregation on a 3 x 4 bipartite graph by explicit loops (sum / mean / max; empty dst -> 0)."""
+    x = t.tensor([[1.0, -2.0], [3.0, 5.0], [-4.0, 0.5]])
+    src, dst = t.tensor([0, 1, 2, 0, 1]), t.tensor([0, 0, 0, 2, 2])
+    want = {"add": [[0.0, 3.5], [0, 0], [4.0, 3.0], [0, 0]], "mean": [[0.0, 3.5 / 3], [0, 0], [2.0, 1.5], [0, 0]],
+            "max": [[3.0, 5.0], [0, 0], [3.0, 5.0], [0, 0]]}
+    for aggr, w in want.items():
+        got = RR.scatter_aggr(x[src], dst, 4, aggr)
+        assert t.allclose(got, t.tensor(w)), aggr
+
+
+def test_linear_layers_match_reference_seeded(golden_dir):
+    """Same module structure AND the same seeded initial weights as the reference's get_linear_layers."""
+    from laplace_amd.model.layers import get_linear_layers
+    g = t.load(os.path.join(golden_dir, "linear_layers.pt"), weights_only=False)
+    for (n, i, h, o), want in g.items():
+        t.manual_seed(23)
+        ml = get_linear_layers(n, i, h, o)
+        assert [(m.in_features, m.out_features, m.bias is not None) for m in ml] == want["shapes"]
+        for m, st in zip(ml, want["state"]):
+            assert t.equal(m.weight.detach(), st["weight"]) and t.equal(m.bias.detach(), st["bias"])
+
+
+def test_metrics_universal_matches_reference(golden_dir):
+    from laplace_amd.utils.metrics_encoder_decoder import get_metrics_universal
+    g = t.load(os.path.join(golden_dir, "metrics_universal.pt"), weights_only=False)
+    got = get_metrics_universal(g["model_output"].clone(), g["edge_index"], g["edge_label_index"], [], k=g["k"])
+    assert got == pytest.approx(g["metrics"], abs=1e-7)
+
+
+def test_sage_layers_factory_surface():
+    from laplace_amd.model.layers import SAGEConv, get_SAGEConv_layers
+    ml = get_SAGEConv_layers(3, 128, 64, "add")
+    assert len(ml) == 3 and all(isinstance(m, SAGEConv) for m in ml)
+    assert [m.out_channels for m in ml] == [128, 128, 64] and ml[-1].aggr == "add"
+    assert ml[0].lin_l.weight is None  # lazily sized like SAGEConv((-1, -1, -1), ...)
+    assert len(get_SAGEConv_layers(1, 128, 64, "mean")) == 1
+    with pytest.raises(ValueError):
+        get_SAGEConv_layers(2, 8, 8, "lstm")
