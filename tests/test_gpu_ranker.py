@@ -90,7 +90,12 @@ def _hetero_setup(seed=0, aggr="add", embedding=True, p_drop=0.0):
 
 @pytest.mark.parametrize("aggr,embedding", [("add", True), ("mean", True), ("max", False)])
 def test_encoder_decoder_logits_gradients_and_training_parity(aggr, embedding):
-    """Same weights, same batches: logits <= 1e-4, gradients close, and after 5 Adam steps still <= 1e-4."""
+    """Five training iterations of training.py:19-34.  At every iteration both models hold identical
+    weights and see the same batch: logits within 1e-4 (north_star), loss and every parameter gradient
+    close, BatchNorm running statistics tracked identically.  The oracle's Adam then advances the
+    weights and the product is re-synchronised: comparing free-running parameters after several Adam
+    steps is ill-conditioned in the reference itself (a gradient entry at rounding-noise level moves
+    its weight by +-lr whichever sign the noise takes), so the chain is cut at each step."""
     from laplace_amd.utils.get_info import select_properties
     model, loader, first = _hetero_setup(seed=1, aggr=aggr, embedding=embedding)
     ref = RR.ref_from_product(model, first.x_dict)
@@ -98,7 +103,6 @@ def test_encoder_decoder_logits_gradients_and_training_parity(aggr, embedding):
     assert names == [n for n, _ in ref.named_parameters()]
     # categorical tables are NOT parameters
     assert not any("embedding" in n for n in names) and len(model.state_dict()) == len(ref.state_dict())
-    opt = t.optim.Adam(model.parameters(), lr=0.01)
     opt_ref = t.optim.Adam(ref.parameters(), lr=0.01)
     crit = t.nn.BCEWithLogitsLoss()
     model.train(); ref.train()
@@ -107,21 +111,22 @@ def test_encoder_decoder_logits_gradients_and_training_parity(aggr, embedding):
             break
         x, ei, eli, y = select_properties(batch)
         out_ref = ref({k: v.clone() for k, v in x.items()}, ei, eli)
-        bg = batch.to(DEV)
-        xg, eig, elig, yg = select_properties(bg)
+        xg, eig, elig, yg = select_properties(batch.to(DEV))
         out = model(xg, eig, elig)
         assert out.shape == out_ref.shape
         assert (out.detach().cpu() - out_ref.detach()).abs().max() <= 1e-4, step
         loss, loss_ref = crit(out, yg), crit(out_ref, y)
-        opt.zero_grad(); opt_ref.zero_grad()
+        assert abs(float(loss) - float(loss_ref)) <= 1e-5
+        model.zero_grad(); opt_ref.zero_grad()
         loss.backward(); loss_ref.backward()
-        if step == 0:
-            for (n, p), (_, pr) in zip(model.named_parameters(), ref.named_parameters()):
-                scale = float(pr.grad.abs().max()) + 1e-8
-                assert float((p.grad.cpu() - pr.grad).abs().max()) <= 2e-4 * scale + 1e-7, n
-        opt.step(); opt_ref.step()
-    # running BatchNorm statistics tracked identically
-    assert t.allclose(model.encoder_layer_norm_customer.running_mean.cpu(), ref.encoder_layer_norm_customer.running_mean, atol=1e-5)
+        for (n, p), (_, pr) in zip(model.named_parameters(), ref.named_parameters()):
+            scale = float(pr.grad.abs().max()) + 1e-8
+            assert float((p.grad.cpu() - pr.grad).abs().max()) <= 2e-4 * scale + 1e-6, (step, n)  # biases before BatchNorm have an exactly-zero true gradient: both sides hold rounding noise ~1e-7
+        for bn in ("encoder_layer_norm_customer", "encoder_layer_norm_article"):
+            assert t.allclose(getattr(model, bn).running_mean.cpu(), getattr(ref, bn).running_mean, atol=1e-5)
+            assert t.allclose(getattr(model, bn).running_var.cpu(), getattr(ref, bn).running_var, atol=1e-5, rtol=1e-5)
+        opt_ref.step()
+        model.load_state_dict({k: v.to(DEV) for k, v in ref.state_dict().items()})
     # infer: eval-mode scores regrouped per user, padded with -(1<<50)
     batch = next(iter(loader))
     x, ei, eli, _ = select_properties(batch)
