@@ -89,11 +89,19 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N>1")
     if not t.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
+    # LAPLACE_BENCH_BACKEND=gloo + LAPLACE_BENCH_ONE_GPU=1 rehearse the N>1 path on a 1-GPU box
+    # (ranks share the card, collectives staged through the host); never used for a reported number.
+    backend = os.environ.get("LAPLACE_BENCH_BACKEND", "nccl")
+    if os.environ.get("LAPLACE_BENCH_ONE_GPU") == "1":
+        local_rank = 0
     t.cuda.set_device(local_rank)
     dev = t.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from laplace_amd import ops, synthetic as S
     from laplace_amd.interactions import Interactions
@@ -175,7 +183,7 @@ def main():
                          "kernel": "mi_spmm_csr_f32 (spmm_items_kernel + spmm_rows_kernel + spmm_fixup_kernel)",
                          "algorithmic_bytes_per_launch": algo, "avg_launch_ms": avg_ms,
                          "launches_timed": len(spmm_ms)},
-            "loss": loss_val, "graph_gen_s": round(t_gen, 1),
+            "loss": loss_val, "graph_gen_s": round(t_gen, 1), "backend": backend if world > 1 else None,
         }
         if table0 is not None:
             out["cpu_baseline"] = cpu_baseline(ei, spec, args, table0)

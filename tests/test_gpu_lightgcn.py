@@ -426,3 +426,76 @@ def test_sharded_trainer_hip_ops_single_rank_equals_plain_trainer():
     assert t.equal(plain.batch_idx[0], shard.batch_idx[0]) and t.equal(plain.batch_idx[2], shard.batch_idx[2])
     assert t.allclose(plain.table, shard.table, atol=1e-6)
     assert t.allclose(plain.forward(), shard.forward(), atol=1e-6)
+
+
+# ---------------------------------------------------------------------------- full size (C2) properties
+@pytest.fixture(scope="module")
+def c2_graph():
+    """BASELINE.json configs[1] / SURVEY C2: 1M users x 100K items, 10M edges, symmetric nnz = 20M."""
+    from laplace_amd import synthetic as S
+    from laplace_amd.interactions import Interactions
+    ei = S.generate(S.C2)
+    inter = Interactions(ei.to(DEV), S.C2.num_users, S.C2.num_items)
+    adj, _ = inter.adjacency("bipartite").gcn_normalized(False)
+    return ei, inter, adj
+
+
+def test_full_size_propagate_properties(c2_graph):
+    """Size-independent properties at the benchmark's full size, D=128:
+    linearity, the D^1/2 eigenvector of the normalised adjacency, run-to-run bit stability, and a
+    sample of rows (hubs included) against the oracle."""
+    ops = _ops()
+    ei, inter, adj = c2_graph
+    n, d = adj.n_rows, 128
+    assert adj.nnz == 20_000_000 and n == 1_100_000
+    assert adj.plan.n_long_rows > 1000 and adj.plan.n_items > 20_000  # the split-row path carries real weight
+    g = t.Generator(device=DEV).manual_seed(0)
+    X = t.randn(n, d, device=DEV, generator=g) * 0.1
+    Z = t.randn(n, d, device=DEV, generator=g) * 0.1
+    yx, yz, yl = t.empty(n, d, device=DEV), t.empty(n, d, device=DEV), t.empty(n, d, device=DEV)
+    ops.spmm(adj, X, Y=yx)
+    ops.spmm(adj, Z, Y=yz)
+    ops.spmm(adj, 2.0 * X - 0.5 * Z, Y=yl)
+    assert (yl - (2.0 * yx - 0.5 * yz)).abs().max() <= 2e-5
+    y2 = t.empty(n, d, device=DEV)
+    ops.spmm(adj, X, Y=y2)
+    assert t.equal(y2, yx)  # bitwise reproducible (no float atomics anywhere in the propagate)
+    # A~ (D^1/2 1) = D^-1/2 A 1 = D^1/2 1 on rows with deg > 0
+    deg = (adj.rowptr[1:] - adj.rowptr[:-1]).float()
+    v = deg.sqrt()[:, None].expand(n, 4).contiguous()
+    out = t.empty(n, 4, device=DEV)
+    ops.spmm(adj, v, Y=out)
+    assert ((out - v).abs() / v.clamp(min=1.0)).max() <= 1e-4
+    # sampled rows vs the oracle's sequential fp32 sum (float64 for the hubs' error budget)
+    rows = t.cat([t.randint(0, n, (2000,)), (deg.cpu().topk(20).indices)])
+    rp, col, val, Xc = adj.rowptr.cpu().long(), adj.col.cpu().long(), adj.val.cpu(), X.cpu()
+    for r in rows.tolist():
+        b, e = int(rp[r]), int(rp[r + 1])
+        want = (val[b:e, None].double() * Xc[col[b:e]].double()).sum(0)
+        assert (yx[r].cpu().double() - want).abs().max() <= 1e-5 + 1e-6 * (e - b) ** 0.5, r
+
+
+def test_full_size_sampler_and_step(c2_graph):
+    """On-device sampler at full size: every sampled positive is an edge, no negative is; one fused
+    train step leaves rows without gradient untouched and moves the sampled ones."""
+    ops = _ops()
+    from laplace_amd.model.lightgcn import LightGCN
+    from laplace_amd.trainer import LightGCNTrainer
+    from laplace_amd import synthetic as S
+    ei, inter, adj = c2_graph
+    U, I = S.C2.num_users, S.C2.num_items
+    us, ps, ns = ops.sample_bpr_batch(inter.csr(), inter.row_of_edge(), 16384, I, seed=3, step=11)
+    keys = t.sort(ei[0].to(DEV) * I + ei[1].to(DEV))[0]
+    def member(k):
+        pos = t.searchsorted(keys, k).clamp(max=keys.numel() - 1)
+        return keys[pos] == k
+    assert bool(member(us * I + ps).all()) and not bool(member(us * I + ns).any())
+    t.manual_seed(0)
+    model = LightGCN(U, I, 128, 3).to(DEV)
+    before = model.table().clone()
+    tr = LightGCNTrainer(model, inter.adjacency("bipartite"), inter, lr=1e-3, Lambda=1e-6, batch_size=16384, seed=3)
+    loss = float(tr.step())
+    assert abs(loss + 0.6931) < 0.01  # -softplus(0) at initialisation
+    moved = (model.table() - before).abs().amax(dim=1) > 0
+    assert 0.5 < float(moved.float().mean()) <= 1.0  # 3-hop receptive field of a 16K batch covers most nodes
+    assert float((model.table() - before).abs().max()) <= 1.001e-3  # |Adam step| <= lr
