@@ -154,12 +154,15 @@ def main():
 
     if rank == 0:
         spmm_ms = [s.elapsed_time(e) for s, e in events]
-        avg_ms = sum(spmm_ms) / max(len(spmm_ms), 1)
+        # one propagate layer = one mi_spmm_csr_f32 launch at N=1, two (item rows + user rows) when sharded
+        n_layers_timed = args.steps * 2 * K
+        avg_ms = sum(spmm_ms) / max(n_layers_timed, 1)
         algo = spmm_bytes(nnz, n_rows, D)
         achieved = algo / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         traffic = None
         tf = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tf):
+        default_workload = (args.users, args.items, args.edges, D) == (1_000_000, 100_000, 10_000_000, 128)
+        if os.path.exists(tf) and default_workload:  # PMC bytes were collected on exactly this workload
             try:
                 traffic = json.load(open(tf)).get("spmm_hbm_bytes_per_launch")
             except Exception:
@@ -182,7 +185,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "mi_spmm_csr_f32 (spmm_items_kernel + spmm_rows_kernel + spmm_fixup_kernel)",
                          "algorithmic_bytes_per_launch": algo, "avg_launch_ms": avg_ms,
-                         "launches_timed": len(spmm_ms)},
+                         "launches_timed": len(spmm_ms), "layers_timed": n_layers_timed},
             "loss": loss_val, "graph_gen_s": round(t_gen, 1), "backend": backend if world > 1 else None,
         }
         if table0 is not None:

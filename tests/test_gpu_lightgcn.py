@@ -495,7 +495,8 @@ def test_full_size_sampler_and_step(c2_graph):
     before = model.table().clone()
     tr = LightGCNTrainer(model, inter.adjacency("bipartite"), inter, lr=1e-3, Lambda=1e-6, batch_size=16384, seed=3)
     loss = float(tr.step())
-    assert abs(loss + 0.6931) < 0.01  # -softplus(0) at initialisation
+    # -softplus(~0) + lambda * 3 * B * D * 0.1^2 at initialisation
+    assert abs(loss - (-0.6931 + 1e-6 * 3 * 16384 * 128 * 0.01)) < 0.01
     moved = (model.table() - before).abs().amax(dim=1) > 0
     assert 0.5 < float(moved.float().mean()) <= 1.0  # 3-hop receptive field of a 16K batch covers most nodes
     assert float((model.table() - before).abs().max()) <= 1.001e-3  # |Adam step| <= lr
