@@ -218,11 +218,16 @@ int mi_adam_dense_f32(int64_t n_rows, int64_t d,
  *           (model/layers.py:35-56, model/encoder_decoder.py:55-72) and their backward.
  * trans_a: A is stored [k,m] (lda = m-stride);  trans_b: B is stored [n,k] (the
  * nn.Linear weight layout).  act: 0 = none, 1 = relu.
+ * Per output element the sum is one k-ascending fma chain (bitwise = oracle/spmm_ref.c), except
+ * when the output grid is too small to fill the chip and k >= 2048 (weight gradients
+ * dW = dY^T X): then, if the caller passes the workspace mi_gemm_workspace_bytes asks for, K is
+ * cut into slices whose chains are added in slice order (still deterministic).  ws may be null.
  * ---------------------------------------------------------------------------------- */
-int mi_gemm_f32(int32_t trans_a, int32_t trans_b, int64_t m, int64_t n, int64_t k,
-                const float* A, int64_t lda, const float* B, int64_t ldb,
-                const float* bias, float* C, int64_t ldc,
-                int32_t accumulate, int32_t act, mi_stream_t stream);
+size_t mi_gemm_workspace_bytes(int64_t m, int64_t n, int64_t k);
+int    mi_gemm_f32(int32_t trans_a, int32_t trans_b, int64_t m, int64_t n, int64_t k,
+                   const float* A, int64_t lda, const float* B, int64_t ldb,
+                   const float* bias, float* C, int64_t ldc,
+                   int32_t accumulate, int32_t act, void* ws, size_t ws_bytes, mi_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * K10  batched exact top-K with per-user exclusion.

@@ -46,8 +46,9 @@ _PROTOTYPES = {
     "mi_bpr_workspace_bytes": (c_size_t, [c_int64]),
     "mi_bpr_fwd_bwd_f32": (c_int32, [c_int64, c_int64, c_int64, P, P, P, P, c_int64, P, c_int64,
                                      c_float, c_float, c_float, P, P, c_int64, P, P, c_size_t, P]),
+    "mi_gemm_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int64]),
     "mi_gemm_f32": (c_int32, [c_int32, c_int32, c_int64, c_int64, c_int64, P, c_int64, P, c_int64, P, P, c_int64,
-                              c_int32, c_int32, P]),
+                              c_int32, c_int32, P, c_size_t, P]),
     "mi_topk_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int64]),
     "mi_topk_excl_f32": (c_int32, [c_int64, c_int64, c_int64, c_int64, P, P, c_int64, P, c_int64, P, P, P, P, P,
                                    c_size_t, P]),

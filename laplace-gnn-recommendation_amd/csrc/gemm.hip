@@ -34,12 +34,14 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(MiGemmArgs g) {
     const int wm = wave & 1, wn = wave >> 1;
     const int64_t m0 = (int64_t)blockIdx.y * BM, n0 = (int64_t)blockIdx.x * BN;
     const bool a_kfast = (g.sa_k == 1), b_kfast = (g.sb_k == 1);
+    const int64_t k_lo = (int64_t)blockIdx.z * g.k_per_split;
+    const int64_t k_hi = min(g.K, k_lo + g.k_per_split);
 
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 
-    for (int64_t k0 = 0; k0 < g.K; k0 += BK) {
+    for (int64_t k0 = k_lo; k0 < k_hi; k0 += BK) {
 #pragma unroll
         for (int j = 0; j < (BM * BK) / 256; ++j) {
             const int idx = tid + 256 * j;
@@ -47,7 +49,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(MiGemmArgs g) {
             const int k = a_kfast ? idx % BK : idx / BM;
             const int64_t gm = m0 + m, gk = k0 + k;
             float v = 0.f;
-            if (gm < g.M && gk < g.K) {
+            if (gm < g.M && gk < k_hi) {
                 const int64_t r = g.a_rows ? g.a_rows[gm] : gm;
                 v = g.A[r * g.sa_m + gk * g.sa_k];
             }
@@ -59,7 +61,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(MiGemmArgs g) {
             const int n = b_kfast ? idx / BK : idx % BN;
             const int k = b_kfast ? idx % BK : idx / BN;
             const int64_t gn = n0 + n, gk = k0 + k;
-            Bs[n][k] = (gn < g.N && gk < g.K) ? g.B[gn * g.sb_n + gk * g.sb_k] : 0.f;
+            Bs[n][k] = (gn < g.N && gk < k_hi) ? g.B[gn * g.sb_n + gk * g.sb_k] : 0.f;
         }
         __syncthreads();
         const float* ap = &As[wm * 32 + (lane & 31)][lane >> 5];
@@ -73,6 +75,15 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(MiGemmArgs g) {
     // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
     const int64_t gn = n0 + wn * 32 + (lane & 31);
     if (gn >= g.N) return;
+    if (g.splits > 1) {  // raw slice accumulator; bias / accumulate / act happen in the reduce
+        float* slab = g.partial + (int64_t)blockIdx.z * g.M * g.N;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int64_t gm = m0 + wm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+            if (gm < g.M) slab[gm * g.N + gn] = acc[reg];
+        }
+        return;
+    }
     const float bv = g.bias ? g.bias[gn] : 0.f;
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
@@ -87,19 +98,67 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(MiGemmArgs g) {
     }
 }
 
+// Sums the K-slice slabs in slice order (fixed order: bitwise reproducible), then the epilogue.
+__global__ void gemm_splitk_reduce_kernel(MiGemmArgs g) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t total = g.M * g.N;
+    if (i >= total) return;
+    const int64_t m = i / g.N, n = i - m * g.N;
+    float v = 0.f;
+    for (int z = 0; z < g.splits; ++z) v += g.partial[(int64_t)z * total + i];
+    if (g.bias) v += g.bias[n];
+    float* c = g.C + m * g.ldc + n;
+    if (g.accumulate) v += *c;
+    if (g.act == 1) v = v > 0.f ? v : 0.f;
+    *c = v;
+}
+
 }  // namespace
 
-int mi_gemm_launch(const MiGemmArgs& g, hipStream_t stream) {
+// Split K only when the output tile grid cannot fill the chip and K is long (the weight-gradient
+// products dW = dY^T X of the ranker: a 128 x 84 output over K = tens of thousands of nodes).
+int mi_gemm_splits(int64_t M, int64_t N, int64_t K) {
+    const int64_t blocks = mi_ceil_div(M, BM) * mi_ceil_div(N, BN);
+    if (blocks >= 128 || K < 2048) return 1;
+    int64_t s = mi_ceil_div(512, blocks);
+    const int64_t max_s = K / 256;  // at least 256 of K per slice
+    if (s > max_s) s = max_s;
+    return s < 2 ? 1 : (int)s;
+}
+
+int mi_gemm_launch(MiGemmArgs g, void* ws, size_t ws_bytes, hipStream_t stream) {
     if (g.M == 0 || g.N == 0) return 0;
-    dim3 grid((unsigned)mi_ceil_div(g.N, BN), (unsigned)mi_ceil_div(g.M, BM));
+    dim3 grid((unsigned)mi_ceil_div(g.N, BN), (unsigned)mi_ceil_div(g.M, BM), 1);
     if (grid.y > 65535u) return MI_ERR_TOO_LARGE;  // HIP grid.y limit: M <= 4.19M rows per launch
+    int splits = mi_gemm_splits(g.M, g.N, g.K);
+    if (splits > 1 && (ws == nullptr || ws_bytes < (size_t)splits * g.M * g.N * sizeof(float))) splits = 1;
+    g.splits = splits;
+    g.k_per_split = g.K;
+    g.partial = nullptr;
+    if (splits > 1) {
+        g.k_per_split = mi_ceil_div(mi_ceil_div(g.K, splits), BK) * BK;
+        g.splits = (int)mi_ceil_div(g.K, g.k_per_split);
+        g.partial = static_cast<float*>(ws);
+        grid.z = (unsigned)g.splits;
+    }
     hipLaunchKernelGGL(gemm_f32_kernel, grid, dim3(256), 0, stream, g);
+    if (g.splits > 1) {
+        const int64_t total = g.M * g.N;
+        hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((unsigned)mi_ceil_div(total, 256)), dim3(256), 0, stream, g);
+    }
     return mi_launch_status();
+}
+
+extern "C" size_t mi_gemm_workspace_bytes(int64_t m, int64_t n, int64_t k) {
+    if (m <= 0 || n <= 0 || k <= 0) return 0;
+    const int s = mi_gemm_splits(m, n, k);
+    return s > 1 ? mi_align_up((size_t)s * (size_t)m * (size_t)n * sizeof(float), 256) : 0;
 }
 
 extern "C" int mi_gemm_f32(int32_t trans_a, int32_t trans_b, int64_t m, int64_t n, int64_t k,
                            const float* A, int64_t lda, const float* B, int64_t ldb, const float* bias,
-                           float* C, int64_t ldc, int32_t accumulate, int32_t act, mi_stream_t stream) {
+                           float* C, int64_t ldc, int32_t accumulate, int32_t act, void* ws,
+                           size_t ws_bytes, mi_stream_t stream) {
     MI_CHECK_ARG(m >= 0 && n >= 0 && k >= 0);
     if (m == 0 || n == 0) return 0;
     MI_CHECK_ARG(C && ldc >= n && (k == 0 || (A && B)));
@@ -113,5 +172,5 @@ extern "C" int mi_gemm_f32(int32_t trans_a, int32_t trans_b, int64_t m, int64_t 
     if (trans_b) { g.sb_n = ldb; g.sb_k = 1; MI_CHECK_ARG(k == 0 || ldb >= k); }   // B stored [n, k] (Linear.weight)
     else         { g.sb_n = 1; g.sb_k = ldb; MI_CHECK_ARG(k == 0 || ldb >= n); }   // B stored [k, n]
     g.bias = bias; g.C = C; g.ldc = ldc; g.accumulate = accumulate; g.act = act;
-    return mi_gemm_launch(g, (hipStream_t)stream);
+    return mi_gemm_launch(g, ws, ws_bytes, (hipStream_t)stream);
 }

@@ -14,6 +14,13 @@ struct MiGemmArgs {
     int64_t ldc;
     int accumulate;       // C += ...
     int act;              // 0 none, 1 relu
+    // split-K (set by the launcher): this launch covers K in `splits` slices of `k_per_split`;
+    // slice z writes its raw accumulator to partial[z, M, N] and a second kernel reduces in slice order
+    int splits;
+    int64_t k_per_split;
+    float* partial;
 };
 
-int mi_gemm_launch(const MiGemmArgs& g, hipStream_t stream);
+// Number of K slices the launcher will use for this shape (1 = no split) and the workspace it needs.
+int mi_gemm_splits(int64_t M, int64_t N, int64_t K);
+int mi_gemm_launch(MiGemmArgs g, void* ws, size_t ws_bytes, hipStream_t stream);

@@ -199,7 +199,7 @@ int mi_topk_excl_f32(int64_t n_q, int64_t n_items, int64_t d, int64_t k, const i
     g.A = user_emb; g.sa_m = ldu; g.sa_k = 1; g.a_rows = uid;
     g.B = item_emb; g.sb_n = ldi; g.sb_k = 1;
     g.bias = nullptr; g.C = scores; g.ldc = n_items; g.accumulate = 0; g.act = 0;
-    int rc = mi_gemm_launch(g, s);
+    int rc = mi_gemm_launch(g, nullptr, 0, s);  // M x N = queries x items fills the chip: never split
     if (rc) return rc;
     if (excl_ptr)
         hipLaunchKernelGGL(exclude_kernel, dim3((unsigned)n_q), dim3(kBlock), 0, s, n_q, n_items, excl_ptr, excl_idx, scores);

@@ -322,9 +322,12 @@ def gemm(A: Tensor, B: Tensor, *, trans_a: bool = False, trans_b: bool = True, b
     ldc = _rows_ok(out, "out")
     if out.shape != (m, n):
         raise ValueError(f"out must be [{m}, {n}]")
-    check(_lib.lib().mi_gemm_f32(1 if trans_a else 0, 1 if trans_b else 0, m, n, k, _ptr(A), lda, _ptr(B), ldb,
-                                 _ptr(bias), out.data_ptr(), ldc, 1 if accumulate else 0, 1 if relu else 0,
-                                 _stream()), "mi_gemm_f32")
+    L = _lib.lib()
+    ws_bytes = L.mi_gemm_workspace_bytes(m, n, k)
+    ws = _ws(ws_bytes, A.device) if ws_bytes else None
+    check(L.mi_gemm_f32(1 if trans_a else 0, 1 if trans_b else 0, m, n, k, _ptr(A), lda, _ptr(B), ldb,
+                        _ptr(bias), out.data_ptr(), ldc, 1 if accumulate else 0, 1 if relu else 0,
+                        ws.data_ptr() if ws is not None else None, ws_bytes, _stream()), "mi_gemm_f32")
     return out
 
 

@@ -122,3 +122,24 @@ def test_pipeline_end_to_end_small():
         assert np.isfinite([stats.loss, stats.recall_val, stats.recall_test, stats.precision_val, stats.precision_test]).all()
         assert stats.loss < -0.70  # BPR-as-written goes down from -log(2)
         assert 0.0 <= stats.recall_test <= 1.0 and 0.0 <= stats.precision_test <= 1.0
+
+
+def test_gemm_split_k_weight_gradient_shape():
+    """dW = dY^T X with a 128 x 84 output over K = 30K rows: K is cut into slices (the output grid alone
+    is 4 workgroups).  Result = slice chains added in slice order: bitwise reproducible and bitwise
+    equal to the oracle evaluated the same way."""
+    from laplace_amd import ops
+    g = t.Generator().manual_seed(0)
+    K, M, N = 30_000, 128, 84
+    dY, X = t.randn(K, M, generator=g), t.randn(K, N, generator=g)
+    got = ops.gemm(dY.to(DEV), X.to(DEV), trans_a=True, trans_b=False)
+    again = ops.gemm(dY.to(DEV), X.to(DEV), trans_a=True, trans_b=False)
+    assert t.equal(got, again)
+    blocks = ((M + 63) // 64) * ((N + 63) // 64)
+    s = min(-(-512 // blocks), K // 256)
+    kps = -(-(-(-K // s)) // 32) * 32
+    want = t.zeros(M, N)
+    for k0 in range(0, K, kps):
+        want = want + R.gemm_fma(dY[k0:k0 + kps], X[k0:k0 + kps], trans_a=True, trans_b=False)
+    assert t.equal(got.cpu(), want)
+    assert t.allclose(got.cpu().double(), dY.double().T @ X.double(), atol=2e-3, rtol=1e-5)

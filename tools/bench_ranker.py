@@ -1,0 +1,112 @@
+#!/usr/bin/env python3
+"""Measures the ranker train step on an H&M-shaped synthetic graph:
+host sampler + collate, H2D, forward (embeddings, 2-layer hetero SAGEConv, BatchNorm, MLP decoder),
+BCE, backward, Adam.  Not the contract bench (bench.py is): this is the profiling harness for the
+ranker kernels.  Prints one JSON line."""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--users", type=int, default=200_000)
+    ap.add_argument("--items", type=int, default=50_000)
+    ap.add_argument("--edges", type=int, default=4_000_000)
+    ap.add_argument("--batch", type=int, default=24)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--hops", type=int, default=2)
+    ap.add_argument("--fanout", type=int, default=64)
+    ap.add_argument("--cpu", action="store_true", help="also time the torch-only oracle twin on the host cores")
+    args = ap.parse_args()
+    import numpy as np
+    import torch as t
+    from types import SimpleNamespace
+    from laplace_amd import synthetic as S
+    from laplace_amd.data.dataset import GraphDataset
+    from laplace_amd.hetero import DataLoader
+    from laplace_amd.model.encoder_decoder import Encoder_Decoder_Model
+    from laplace_amd.model.layers import get_SAGEConv_layers, get_linear_layers
+    from laplace_amd.utils.get_info import get_feature_info, select_properties
+
+    dev = "cuda"
+    spec = S.SyntheticSpec(args.users, args.items, args.edges, seed=2, zipf_s=1.0)
+    graph, users, articles = S.generate_hetero(spec)
+    cfg = SimpleNamespace(k=12, num_neighbors=args.fanout, n_hop_neighbors=args.hops, positive_edges_ratio=0.5,
+                          negative_edges_ratio=3.0, batch_size=args.batch)
+    ds = GraphDataset(cfg, graph, users, articles, train=True, randomization=True, seed=0)
+    loader = DataLoader(ds, batch_size=args.batch, shuffle=True, generator=t.Generator().manual_seed(0))
+    t.manual_seed(0)
+    it = iter(loader)
+    first = next(it)
+    model = Encoder_Decoder_Model(get_SAGEConv_layers(2, 128, 64, "add"), get_linear_layers(2, 128, 128, 1),
+                                  get_feature_info(graph), first.metadata(), True, "sum", True, 0.2, 0.3).to(dev)
+    model.initialize_encoder_input_size(first.to(dev))
+    opt = t.optim.Adam(model.parameters(), lr=0.01)
+    crit = t.nn.BCEWithLogitsLoss()
+    model.train()
+
+    def step(batch):
+        x, ei, eli, y = select_properties(batch)
+        opt.zero_grad()
+        loss = crit(model(x, ei, eli).view(-1), y)
+        loss.backward()
+        opt.step()
+        return loss
+
+    t_sample = t_dev = 0.0
+    pos_edges = n_nodes = n_edges = 0
+    for i in range(args.warmup + args.steps):
+        if i == args.warmup:
+            t.cuda.synchronize()
+            t_sample = t_dev = 0.0
+            pos_edges = n_nodes = n_edges = 0
+        t0 = time.perf_counter()
+        batch = next(it)
+        t1 = time.perf_counter()
+        bg = batch.to(dev)
+        loss = step(bg)
+        t.cuda.synchronize()
+        t2 = time.perf_counter()
+        t_sample += t1 - t0
+        t_dev += t2 - t1
+        store = batch[("customer", "buys", "article")]
+        pos_edges += int(store.edge_label.sum())
+        n_edges += store.edge_index.shape[1]
+        n_nodes += batch["customer"].x.shape[0] + batch["article"].x.shape[0]
+    out = {"workload": f"ranker train step, H&M-shaped synthetic {args.users}x{args.items}, {args.edges} edges, batch "
+                       f"{args.batch} users, {args.hops} hops, fan-out {args.fanout}",
+           "steps": args.steps, "ms_per_step_device": 1e3 * t_dev / args.steps,
+           "ms_per_step_host_sampler": 1e3 * t_sample / args.steps,
+           "positive_edges_per_s_device_only": pos_edges / t_dev,
+           "positive_edges_per_s_with_host_sampler": pos_edges / (t_dev + t_sample),
+           "avg_nodes_per_batch": n_nodes / args.steps, "avg_mp_edges_per_batch": n_edges / args.steps,
+           "avg_positive_label_edges_per_batch": pos_edges / args.steps, "loss": float(loss)}
+    if args.cpu:
+        from oracle import ranker_ref as RR
+        ref = RR.ref_from_product(model, first.x_dict)
+        ref.train()
+        opt_r = t.optim.Adam(ref.parameters(), lr=0.01)
+        batches = [next(it) for _ in range(6)]
+        t0 = None
+        for j, b in enumerate(batches):
+            if j == 1:
+                t0 = time.perf_counter()
+            x, ei, eli, y = select_properties(b)
+            opt_r.zero_grad()
+            l = crit(ref({k: v.clone() for k, v in x.items()}, ei, eli), y)
+            l.backward()
+            opt_r.step()
+        out["cpu_ms_per_step_model_only"] = 1e3 * (time.perf_counter() - t0) / (len(batches) - 1)
+        out["cpu_threads"] = t.get_num_threads()
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
