@@ -86,6 +86,7 @@ class GraphDataset:
         self._num_edges = int(all_edges.shape[1])
         self._id_max = int(all_edges[1].max())
         self._rng = np.random.default_rng(seed)
+        self._mark = np.zeros(n_users, dtype=bool)
 
     def __len__(self) -> int:
         return self._n_items
@@ -113,21 +114,30 @@ class GraphDataset:
         """fetch_n_hop_neighbourhood (data/dataset.py:258-286): edges of hops >= 1 only."""
         cfg = self.config
         us, arts = [], []
-        explored = np.zeros(len(self.users), dtype=bool)
+        mark = self._mark            # scratch bitmap over users, all False between calls
+        explored: List[np.ndarray] = []
         queue = np.array([user_id], dtype=np.int64)
         for hop in range(cfg.n_hop_neighbors):
             if queue.size == 0:
                 break
             new_articles, cnt = self.users.gather(queue)
-            explored[queue] = True
+            explored.append(queue)
             if hop != 0:
                 us.append(np.repeat(queue, cnt))
                 arts.append(new_articles)
+            if hop == cfg.n_hop_neighbors - 1:
+                break  # the next frontier would never be expanded
             article_queue = self._cut(new_articles, cfg.num_neighbors)
-            cand_users, _ = self.articles.gather(article_queue)
-            cand_users = np.unique(cand_users)
-            cand_users = cand_users[~explored[cand_users]]
-            queue = np.unique(self._cut(cand_users, cfg.num_neighbors))
+            # distinct unexplored users of those articles: mark / unmark instead of sort-unique — hub
+            # articles carry 10^5..10^6 users each
+            ptr, idx = self.articles.ptr, self.articles.idx
+            for a in article_queue.tolist():
+                mark[idx[ptr[a]:ptr[a + 1]]] = True
+            for q in explored:
+                mark[q] = False
+            cand_users = np.flatnonzero(mark)
+            mark[cand_users] = False
+            queue = np.sort(self._cut(cand_users, cfg.num_neighbors))
         if not us:
             return np.empty(0, dtype=np.int64), np.empty(0, dtype=np.int64)
         return np.concatenate(us), np.concatenate(arts)
