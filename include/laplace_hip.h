@@ -117,6 +117,8 @@ typedef struct mi_spmm_plan {
     int32_t* long_rows;    /* device int32[n_long_rows]                              */
     int32_t* item_ptr;     /* device int32[n_long_rows+1]: items of long row i       */
     int32_t* items;        /* device int32[4*n_items]: row, begin, end, slot         */
+    int32_t* long_index;   /* device int32[n_rows]: index into long_rows, -1 for
+                              short rows; nullable (needed only by row_list launches)  */
 } mi_spmm_plan;
 
 /* Upper bounds for the plan arrays, so the caller can allocate before building. */
@@ -139,6 +141,54 @@ int mi_spmm_csr_f32(int64_t n_rows, int64_t d,
                     float* S, int64_t lds, float scale,
                     const mi_spmm_plan* plan, void* ws, size_t ws_bytes,
                     mi_stream_t stream);
+
+/* Sparse-operand form of the same product — same arithmetic, fewer bytes.  Used by the fused
+ * train step, where the operands around the K propagates are known to be mostly zero rows
+ * (the BPR gradient touches <= 3*batch rows) or only a few output rows are consumed (the last
+ * forward layer feeds only the batch rows of the loss).  Every field is nullable:
+ *   x_map      int32[n_cols]: X is COMPACT; column c reads X[x_map[c]], and x_map[c] < 0
+ *              declares row c of the logical X to be all zeros (its entries are skipped —
+ *              adding exact zeros changes no sum).
+ *   addend_map int32[n_rows]: addend is COMPACT; row r adds addend[addend_map[r]], < 0 = none.
+ *   row_list   int32[n_list]: only these rows are computed; Y, S and addend are COMPACT,
+ *              indexed by position in the list (addend_map must be null).  n_list is the launch
+ *              bound; n_list_dev (device int32[1], nullable) the actual count, so that a
+ *              device-built list needs no host read-back.  Needs plan->long_index when the plan
+ *              has split rows.
+ * Results equal the dense call on the corresponding dense operands bit for bit (up to the
+ * sign of zero). */
+typedef struct mi_spmm_ex {
+    const int32_t* x_map;
+    const int32_t* addend_map;
+    const int32_t* row_list;
+    const int32_t* n_list_dev;
+    int64_t        n_list;
+} mi_spmm_ex;
+
+int mi_spmm_csr_ex_f32(int64_t n_rows, int64_t d,
+                       const int32_t* rowptr, const int32_t* col, const float* val,
+                       const float* X, int64_t ldx,
+                       float* Y, int64_t ldy,
+                       const float* addend, int64_t lda,
+                       float* S, int64_t lds, float scale,
+                       const mi_spmm_plan* plan, const mi_spmm_ex* ex,
+                       void* ws, size_t ws_bytes, mi_stream_t stream);
+
+/* dst[i,:] = (accumulate ? dst[i,:] : 0) + src[rows[i],:]  for i < min(n_max, *n_dev).
+ * The running layer sum of the batch rows in the fused step (model/lightgcn.py:67-68 restricted
+ * to the rows the loss reads). */
+int mi_gather_rows_f32(int64_t n_max, const int32_t* n_dev, int64_t d, const int32_t* rows,
+                       const float* src, int64_t ld_src, float* dst, int64_t ld_dst,
+                       int32_t accumulate, mi_stream_t stream);
+
+/* Unique node set of a BPR batch: gmap int32[n_nodes] = compact slot of node r (slots ordered by
+ * node id) or -1; nodes int32[>= 3*batch] = slot -> node; count = device int32[1].
+ * Users are nodes [0, n_users), item i is node n_users + i. */
+size_t mi_batch_nodes_workspace_bytes(int64_t n_nodes);
+int    mi_batch_nodes_i32(int64_t batch, int64_t n_users, int64_t n_nodes,
+                          const int64_t* users, const int64_t* pos, const int64_t* neg,
+                          int32_t* gmap, int32_t* nodes, int32_t* count,
+                          void* ws, size_t ws_bytes, mi_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * K9  mini-batch sampler: B positive edges with replacement + one structured negative
@@ -181,6 +231,8 @@ int mi_sample_bpr_batch(int64_t batch, int64_t nnz,
  * and reg_w (float[n], zeroed by the caller; nullable) receives, per occurrence of a
  * node in the batch, reg_w[row] += 2*lambda*reg_scale, so that the L2 term's gradient is
  * reg_w[row] * e0[row,:] (applied by mi_adam_dense_f32 or by the caller).
+ * node_map (nullable, from mi_batch_nodes_i32): final_emb and g_final are then COMPACT
+ * [count, d] tables addressed by node_map[node]; e0 and reg_w stay addressed by node id.
  * Repeated users/items in a batch are combined with float atomics (order-dependent in
  * the last bits); everything else is deterministic.
  * ---------------------------------------------------------------------------------- */
@@ -193,6 +245,7 @@ int    mi_bpr_fwd_bwd_f32(int64_t batch, int64_t d, int64_t n_users,
                           float* loss_out,
                           float* g_final, int64_t ldg,
                           float* reg_w,
+                          const int32_t* node_map,
                           void* ws, size_t ws_bytes, mi_stream_t stream);
 
 /* ------------------------------------------------------------------------------------

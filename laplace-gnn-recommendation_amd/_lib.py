@@ -18,8 +18,13 @@ class MiError(RuntimeError):
 class SpmmPlanStruct(Structure):
     _fields_ = [
         ("chunk", c_int32), ("n_long_rows", c_int32), ("n_items", c_int32), ("reserved", c_int32),
-        ("long_rows", c_void_p), ("item_ptr", c_void_p), ("items", c_void_p),
+        ("long_rows", c_void_p), ("item_ptr", c_void_p), ("items", c_void_p), ("long_index", c_void_p),
     ]
+
+
+class SpmmExStruct(Structure):
+    _fields_ = [("x_map", c_void_p), ("addend_map", c_void_p), ("row_list", c_void_p), ("n_list_dev", c_void_p),
+                ("n_list", c_int64)]
 
 
 P = c_void_p
@@ -40,12 +45,17 @@ _PROTOTYPES = {
     "mi_spmm_workspace_bytes": (c_size_t, [POINTER(SpmmPlanStruct), c_int64]),
     "mi_spmm_csr_f32": (c_int32, [c_int64, c_int64, P, P, P, P, c_int64, P, c_int64, P, c_int64, P, c_int64,
                                   c_float, POINTER(SpmmPlanStruct), P, c_size_t, P]),
+    "mi_spmm_csr_ex_f32": (c_int32, [c_int64, c_int64, P, P, P, P, c_int64, P, c_int64, P, c_int64, P, c_int64,
+                                     c_float, POINTER(SpmmPlanStruct), POINTER(SpmmExStruct), P, c_size_t, P]),
+    "mi_gather_rows_f32": (c_int32, [c_int64, P, c_int64, P, P, c_int64, P, c_int64, c_int32, P]),
+    "mi_batch_nodes_workspace_bytes": (c_size_t, [c_int64]),
+    "mi_batch_nodes_i32": (c_int32, [c_int64, c_int64, c_int64, P, P, P, P, P, P, P, c_size_t, P]),
     "mi_csr_expand_rows": (c_int32, [c_int64, P, P, c_int64, P]),
     "mi_sample_bpr_batch": (c_int32, [c_int64, c_int64, P, P, P, c_int64, c_int32, c_int32, c_uint64, c_uint64,
                                       P, P, P, P]),
     "mi_bpr_workspace_bytes": (c_size_t, [c_int64]),
     "mi_bpr_fwd_bwd_f32": (c_int32, [c_int64, c_int64, c_int64, P, P, P, P, c_int64, P, c_int64,
-                                     c_float, c_float, c_float, P, P, c_int64, P, P, c_size_t, P]),
+                                     c_float, c_float, c_float, P, P, c_int64, P, P, P, c_size_t, P]),
     "mi_gemm_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int64]),
     "mi_gemm_f32": (c_int32, [c_int32, c_int32, c_int64, c_int64, c_int64, P, c_int64, P, c_int64, P, P, c_int64,
                               c_int32, c_int32, P, c_size_t, P]),

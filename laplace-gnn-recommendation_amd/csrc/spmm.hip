@@ -30,13 +30,23 @@ struct Epilogue {
     float scale;
 };
 
+// Sparse-operand extensions (mi_spmm_csr_ex_f32); all pointers nullable, branches are wave-uniform.
+struct Ex {
+    const int32_t* x_map;       // [n_cols]: X is compact, neighbour c reads X[x_map[c]]; < 0 = an all-zero row, skipped
+    const int32_t* addend_map;  // [n_rows]: addend is compact, row r adds addend[addend_map[r]]; < 0 = nothing
+    const int32_t* row_list;    // [n_list]: compute only these rows; Y / S / addend are compact, indexed by list position
+    const int32_t* n_list_dev;  // device count of valid row_list entries (<= the launch bound), or null
+    const int32_t* long_index;  // [n_rows]: index into the plan's long rows, -1 for short rows (row_list mode)
+};
+
 // Accumulates entries [beg, end) of one row into acc (valid in lanes of sub-group 0 after
 // the final cross-sub-group reduce).
 template <int LPR, int VPL, int UNROLL>
 __device__ __forceinline__ void wave_accumulate(const int32_t* __restrict__ col,
                                                 const float* __restrict__ val,
                                                 const float4* __restrict__ X4, int64_t ldx4, int d4,
-                                                int32_t beg, int32_t end, float4 (&acc)[VPL]) {
+                                                int32_t beg, int32_t end, float4 (&acc)[VPL],
+                                                const int32_t* __restrict__ x_map = nullptr) {
     constexpr int NB = MI_WAVE / LPR;
     const int lane = mi_lane();
     const int g = lane / LPR;
@@ -51,7 +61,9 @@ __device__ __forceinline__ void wave_accumulate(const int32_t* __restrict__ col,
         if (lane < n) {
             my_c = col[base + lane];
             my_v = val[base + lane];
+            if (x_map) my_c = x_map[my_c];  // compact row of X, or < 0 for a row that is all zeros
         }
+        if (x_map && __ballot(my_c >= 0 && lane < n) == 0ull) continue;  // nothing to gather in this 64-entry group
         for (int j = 0; j < n; j += NB * UNROLL) {
             float w[UNROLL];
             float4 x[UNROLL][VPL];
@@ -60,7 +72,7 @@ __device__ __forceinline__ void wave_accumulate(const int32_t* __restrict__ col,
                 const int idx = j + u * NB + g;
                 const int32_t c = __shfl(my_c, idx & (MI_WAVE - 1), MI_WAVE);
                 w[u] = __shfl(my_v, idx & (MI_WAVE - 1), MI_WAVE);
-                const bool ok = idx < n;
+                const bool ok = idx < n && c >= 0;
                 const float4* src = X4 + (int64_t)c * ldx4;
 #pragma unroll
                 for (int v = 0; v < VPL; ++v) {
@@ -81,6 +93,7 @@ __device__ __forceinline__ void wave_accumulate(const int32_t* __restrict__ col,
         for (int v = 0; v < VPL; ++v) acc[v] = mi_f4_add(acc[v], mi_f4_shfl_xor(acc[v], m));
 }
 
+// r = output row index (compact position in row_list mode)
 template <int LPR, int VPL>
 __device__ __forceinline__ void apply_epilogue(const Epilogue& ep, int64_t r, int d4,
                                                const float4 (&acc)[VPL], const float4 (&a)[VPL]) {
@@ -102,13 +115,14 @@ __device__ __forceinline__ void apply_epilogue(const Epilogue& ep, int64_t r, in
     }
 }
 
+// ar = addend row index, < 0 for "no addend row"
 template <int LPR, int VPL>
-__device__ __forceinline__ void load_addend(const Epilogue& ep, int64_t r, int d4, float4 (&a)[VPL]) {
+__device__ __forceinline__ void load_addend(const Epilogue& ep, int64_t ar, int d4, float4 (&a)[VPL]) {
     const int lane = mi_lane();
 #pragma unroll
     for (int v = 0; v < VPL; ++v) {
         const int e = lane + v * LPR;
-        a[v] = (ep.S && ep.addend && lane < LPR && e < d4) ? ep.addend[r * ep.lda4 + e] : mi_f4_zero();
+        a[v] = (ep.S && ep.addend && ar >= 0 && lane < LPR && e < d4) ? ep.addend[ar * ep.lda4 + e] : mi_f4_zero();
     }
 }
 
@@ -119,15 +133,18 @@ __global__ __launch_bounds__(kBlock) void spmm_rows_kernel(int64_t n_rows, int d
                                                            const int32_t* __restrict__ col,
                                                            const float* __restrict__ val,
                                                            const float4* __restrict__ X4, int64_t ldx4,
-                                                           Epilogue ep, int32_t chunk) {
-    const int64_t r = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x / MI_WAVE);
-    if (r >= n_rows) return;
+                                                           Epilogue ep, int32_t chunk, Ex ex) {
+    const int64_t i = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x / MI_WAVE);
+    if (i >= n_rows) return;
+    if (ex.n_list_dev && i >= *ex.n_list_dev) return;
+    const int64_t r = ex.row_list ? ex.row_list[i] : i;
     const int32_t beg = rowptr[r], end = rowptr[r + 1];
     if (end - beg > chunk) return;
     float4 a[VPL], acc[VPL];
-    load_addend<LPR, VPL>(ep, r, d4, a);
-    wave_accumulate<LPR, VPL, UNROLL>(col, val, X4, ldx4, d4, beg, end, acc);
-    apply_epilogue<LPR, VPL>(ep, r, d4, acc, a);
+    const int64_t ar = ex.row_list ? i : (ex.addend_map ? (int64_t)ex.addend_map[r] : r);
+    load_addend<LPR, VPL>(ep, ar, d4, a);
+    wave_accumulate<LPR, VPL, UNROLL>(col, val, X4, ldx4, d4, beg, end, acc, ex.x_map);
+    apply_epilogue<LPR, VPL>(ep, ex.row_list ? i : r, d4, acc, a);
 }
 
 // Split rows: one wavefront per work item (row, begin, end, slot) -> partial[slot, :].
@@ -137,12 +154,13 @@ __global__ __launch_bounds__(kBlock) void spmm_items_kernel(int32_t n_items, int
                                                             const int32_t* __restrict__ col,
                                                             const float* __restrict__ val,
                                                             const float4* __restrict__ X4, int64_t ldx4,
-                                                            float4* __restrict__ partial) {
+                                                            float4* __restrict__ partial,
+                                                            const int32_t* __restrict__ x_map) {
     const int32_t it = blockIdx.x * kWavesPerBlock + (threadIdx.x / MI_WAVE);
     if (it >= n_items) return;
     const int32_t beg = items[4 * it + 1], end = items[4 * it + 2], slot = items[4 * it + 3];
     float4 acc[VPL];
-    wave_accumulate<LPR, VPL, UNROLL>(col, val, X4, ldx4, d4, beg, end, acc);
+    wave_accumulate<LPR, VPL, UNROLL>(col, val, X4, ldx4, d4, beg, end, acc, x_map);
     const int lane = mi_lane();
     if (lane < LPR) {
 #pragma unroll
@@ -161,13 +179,25 @@ __global__ __launch_bounds__(kBlock) void spmm_fixup_kernel(int32_t n_long, int 
                                                             const int32_t* __restrict__ long_rows,
                                                             const int32_t* __restrict__ item_ptr,
                                                             const float4* __restrict__ partial,
-                                                            Epilogue ep) {
+                                                            Epilogue ep, Ex ex) {
     constexpr int NB = MI_WAVE / LPR;
     constexpr int NSG = NB * kWavesPerBlock;  // sub-groups per block
     __shared__ float4 red[kWavesPerBlock][VPL][LPR];
-    const int32_t i = blockIdx.x;
-    if (i >= n_long) return;
-    const int64_t r = long_rows[i];
+    // all exits below depend on blockIdx only: the whole block leaves together, before any barrier
+    int32_t i = blockIdx.x;
+    int64_t r, out_row, ar;
+    if (ex.row_list) {  // n_long = launch bound on the list length
+        if (i >= n_long || (ex.n_list_dev && i >= *ex.n_list_dev)) return;
+        r = ex.row_list[i];
+        out_row = ar = i;
+        i = ex.long_index[r];
+        if (i < 0) return;  // a short row: done by spmm_rows_kernel
+    } else {
+        if (i >= n_long) return;
+        r = long_rows[i];
+        out_row = r;
+        ar = ex.addend_map ? (int64_t)ex.addend_map[r] : r;
+    }
     const int32_t sb = item_ptr[i], se = item_ptr[i + 1];
     const int lane = mi_lane();
     const int wave = threadIdx.x / MI_WAVE;
@@ -202,7 +232,7 @@ __global__ __launch_bounds__(kBlock) void spmm_fixup_kernel(int32_t n_long, int 
     __syncthreads();
     if (wave != 0) return;
     float4 a[VPL];
-    load_addend<LPR, VPL>(ep, r, d4, a);
+    load_addend<LPR, VPL>(ep, ar, d4, a);
     if (lane < LPR) {
 #pragma unroll
         for (int v = 0; v < VPL; ++v) {
@@ -212,7 +242,7 @@ __global__ __launch_bounds__(kBlock) void spmm_fixup_kernel(int32_t n_long, int 
             acc[v] = t;
         }
     }
-    apply_epilogue<LPR, VPL>(ep, r, d4, acc, a);
+    apply_epilogue<LPR, VPL>(ep, out_row, d4, acc, a);
 }
 
 // ---- plan construction --------------------------------------------------------------------
@@ -229,7 +259,7 @@ __global__ void plan_flags_kernel(int64_t n_rows, const int32_t* __restrict__ ro
 __global__ void plan_fill_kernel(int64_t n_rows, const int32_t* __restrict__ rowptr, int32_t chunk,
                                  const int32_t* __restrict__ long_off, const int32_t* __restrict__ item_off,
                                  int32_t* __restrict__ long_rows, int32_t* __restrict__ item_ptr,
-                                 int32_t* __restrict__ items) {
+                                 int32_t* __restrict__ items, int32_t* __restrict__ long_index) {
     int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r > n_rows) return;
     if (r == n_rows) {  // sentinel: item_ptr[n_long] = n_items
@@ -237,8 +267,12 @@ __global__ void plan_fill_kernel(int64_t n_rows, const int32_t* __restrict__ row
         return;
     }
     const int32_t b = rowptr[r], e = rowptr[r + 1];
-    if (e - b <= chunk) return;
+    if (e - b <= chunk) {
+        if (long_index) long_index[r] = -1;
+        return;
+    }
     const int32_t li = long_off[r], io = item_off[r];
+    if (long_index) long_index[r] = li;
     long_rows[li] = (int32_t)r;
     item_ptr[li] = io;
     int32_t k = 0;
@@ -253,21 +287,25 @@ __global__ void plan_fill_kernel(int64_t n_rows, const int32_t* __restrict__ row
 template <int LPR, int VPL>
 int launch_spmm(int64_t n_rows, int d4, const int32_t* rowptr, const int32_t* col, const float* val,
                 const float4* X4, int64_t ldx4, const Epilogue& ep, const mi_spmm_plan* plan,
-                float4* partial, hipStream_t s) {
+                float4* partial, const Ex& ex, int64_t n_list, hipStream_t s) {
     constexpr int UNROLL = (VPL == 1) ? 4 : 2;
     const int32_t chunk = plan ? plan->chunk : INT32_MAX;
-    if (plan && plan->n_items > 0) {
+    if (plan && plan->n_items > 0) {  // row_list mode still reduces every split row: hubs are few and almost always wanted
         dim3 gi((unsigned)mi_ceil_div(plan->n_items, kWavesPerBlock));
         hipLaunchKernelGGL((spmm_items_kernel<LPR, VPL, UNROLL>), gi, dim3(kBlock), 0, s, plan->n_items, d4,
-                           plan->items, col, val, X4, ldx4, partial);
+                           plan->items, col, val, X4, ldx4, partial, ex.x_map);
     }
-    dim3 gr((unsigned)mi_ceil_div(n_rows, kWavesPerBlock));
-    hipLaunchKernelGGL((spmm_rows_kernel<LPR, VPL, UNROLL>), gr, dim3(kBlock), 0, s, n_rows, d4, rowptr, col,
-                       val, X4, ldx4, ep, chunk);
+    const int64_t n_out = ex.row_list ? n_list : n_rows;
+    if (n_out > 0) {
+        dim3 gr((unsigned)mi_ceil_div(n_out, kWavesPerBlock));
+        hipLaunchKernelGGL((spmm_rows_kernel<LPR, VPL, UNROLL>), gr, dim3(kBlock), 0, s, n_out, d4, rowptr, col,
+                           val, X4, ldx4, ep, chunk, ex);
+    }
     if (plan && plan->n_long_rows > 0) {
-        dim3 gf((unsigned)plan->n_long_rows);
-        hipLaunchKernelGGL((spmm_fixup_kernel<LPR, VPL>), gf, dim3(kBlock), 0, s, plan->n_long_rows, d4,
-                           plan->long_rows, plan->item_ptr, partial, ep);
+        const int64_t nf = ex.row_list ? n_list : (int64_t)plan->n_long_rows;
+        if (nf > 0)
+            hipLaunchKernelGGL((spmm_fixup_kernel<LPR, VPL>), dim3((unsigned)nf), dim3(kBlock), 0, s, (int32_t)nf, d4,
+                               plan->long_rows, plan->item_ptr, partial, ep, ex);
     }
     return mi_launch_status();
 }
@@ -327,8 +365,11 @@ int mi_spmm_plan_build(int64_t n_rows, const int32_t* rowptr, int32_t chunk, mi_
     if (totals[0] > 0) {
         MI_CHECK_ARG(plan->long_rows && plan->item_ptr && plan->items);
         hipLaunchKernelGGL(plan_fill_kernel, g, dim3(256), 0, s, n_rows, rowptr, chunk, long_off, item_off,
-                           plan->long_rows, plan->item_ptr, plan->items);
+                           plan->long_rows, plan->item_ptr, plan->items, plan->long_index);
         MI_HIP(hipStreamSynchronize(s));  // ws may be released by the caller on return
+    } else if (plan->long_index) {
+        MI_HIP(hipMemsetAsync(plan->long_index, 0xFF, (size_t)n_rows * sizeof(int32_t), s));
+        MI_HIP(hipStreamSynchronize(s));
     }
     return mi_launch_status();
 }
@@ -338,10 +379,11 @@ size_t mi_spmm_workspace_bytes(const mi_spmm_plan* plan, int64_t d) {
     return mi_align_up((size_t)plan->n_items * (size_t)d * sizeof(float), 256);
 }
 
-int mi_spmm_csr_f32(int64_t n_rows, int64_t d, const int32_t* rowptr, const int32_t* col,
-                    const float* val, const float* X, int64_t ldx, float* Y, int64_t ldy,
-                    const float* addend, int64_t lda, float* S, int64_t lds, float scale,
-                    const mi_spmm_plan* plan, void* ws, size_t ws_bytes, mi_stream_t stream) {
+int mi_spmm_csr_ex_f32(int64_t n_rows, int64_t d, const int32_t* rowptr, const int32_t* col,
+                       const float* val, const float* X, int64_t ldx, float* Y, int64_t ldy,
+                       const float* addend, int64_t lda, float* S, int64_t lds, float scale,
+                       const mi_spmm_plan* plan, const mi_spmm_ex* exh, void* ws, size_t ws_bytes,
+                       mi_stream_t stream) {
     MI_CHECK_ARG(n_rows >= 0 && d > 0 && rowptr);
     if (n_rows == 0) return 0;
     if (d % 4 != 0 || d > 512) return MI_ERR_UNSUPPORTED;
@@ -351,6 +393,23 @@ int mi_spmm_csr_f32(int64_t n_rows, int64_t d, const int32_t* rowptr, const int3
     MI_CHECK_ARG(!Y || (ldy % 4 == 0 && ldy >= d && mi_aligned16(Y) && Y != X));
     MI_CHECK_ARG(!S || (lds % 4 == 0 && lds >= d && mi_aligned16(S) && S != X));
     MI_CHECK_ARG(!addend || (lda % 4 == 0 && lda >= d && mi_aligned16(addend)));
+    Ex ex = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    int64_t n_list = 0;
+    if (exh) {
+        ex.x_map = exh->x_map;
+        ex.addend_map = exh->addend_map;
+        ex.row_list = exh->row_list;
+        ex.n_list_dev = exh->n_list_dev;
+        n_list = exh->n_list;
+        if (ex.row_list) {
+            MI_CHECK_ARG(n_list >= 0 && !ex.addend_map);
+            if (n_list == 0) return 0;
+            if (plan && plan->n_long_rows > 0) {
+                MI_CHECK_ARG(plan->long_index);
+                ex.long_index = plan->long_index;
+            }
+        }
+    }
     float4* partial = nullptr;
     if (plan && plan->n_items > 0) {
         if (!ws || ws_bytes < mi_spmm_workspace_bytes(plan, d)) return MI_ERR_WORKSPACE;
@@ -365,11 +424,19 @@ int mi_spmm_csr_f32(int64_t n_rows, int64_t d, const int32_t* rowptr, const int3
     const float4* X4 = reinterpret_cast<const float4*>(X);
     const int d4 = (int)(d / 4);
     hipStream_t s = (hipStream_t)stream;
-    if (d4 <= 8)   return launch_spmm<8, 1>(n_rows, d4, rowptr, col, val, X4, ldx / 4, ep, plan, partial, s);
-    if (d4 <= 16)  return launch_spmm<16, 1>(n_rows, d4, rowptr, col, val, X4, ldx / 4, ep, plan, partial, s);
-    if (d4 <= 32)  return launch_spmm<32, 1>(n_rows, d4, rowptr, col, val, X4, ldx / 4, ep, plan, partial, s);
-    if (d4 <= 64)  return launch_spmm<64, 1>(n_rows, d4, rowptr, col, val, X4, ldx / 4, ep, plan, partial, s);
-    return launch_spmm<64, 2>(n_rows, d4, rowptr, col, val, X4, ldx / 4, ep, plan, partial, s);
+    if (d4 <= 8)   return launch_spmm<8, 1>(n_rows, d4, rowptr, col, val, X4, ldx / 4, ep, plan, partial, ex, n_list, s);
+    if (d4 <= 16)  return launch_spmm<16, 1>(n_rows, d4, rowptr, col, val, X4, ldx / 4, ep, plan, partial, ex, n_list, s);
+    if (d4 <= 32)  return launch_spmm<32, 1>(n_rows, d4, rowptr, col, val, X4, ldx / 4, ep, plan, partial, ex, n_list, s);
+    if (d4 <= 64)  return launch_spmm<64, 1>(n_rows, d4, rowptr, col, val, X4, ldx / 4, ep, plan, partial, ex, n_list, s);
+    return launch_spmm<64, 2>(n_rows, d4, rowptr, col, val, X4, ldx / 4, ep, plan, partial, ex, n_list, s);
+}
+
+int mi_spmm_csr_f32(int64_t n_rows, int64_t d, const int32_t* rowptr, const int32_t* col,
+                    const float* val, const float* X, int64_t ldx, float* Y, int64_t ldy,
+                    const float* addend, int64_t lda, float* S, int64_t lds, float scale,
+                    const mi_spmm_plan* plan, void* ws, size_t ws_bytes, mi_stream_t stream) {
+    return mi_spmm_csr_ex_f32(n_rows, d, rowptr, col, val, X, ldx, Y, ldy, addend, lda, S, lds, scale, plan,
+                              nullptr, ws, ws_bytes, stream);
 }
 
 }  // extern "C"

@@ -4,6 +4,7 @@
 //   a9   mi_adam_dense_f32     run_pipeline_lightgcn.py:157-159 (torch.optim.Adam)
 #include "common.hpp"
 #include <cmath>
+#include <rocprim/rocprim.hpp>
 
 namespace {
 
@@ -72,14 +73,17 @@ __global__ __launch_bounds__(kBlock) void bpr_slot_kernel(
     const float* __restrict__ fin, int64_t ldf, const float* __restrict__ e0, int64_t lde,
     float inv_batch, float g_scale, float reg_coef /* = lambda*reg_scale */,
     float* __restrict__ softplus_out, float* __restrict__ reg_out,
-    float* __restrict__ g_final, int64_t ldg, float* __restrict__ reg_w) {
+    float* __restrict__ g_final, int64_t ldg, float* __restrict__ reg_w,
+    const int32_t* __restrict__ node_map) {
     const int64_t b = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / MI_WAVE;
     if (b >= batch) return;
     const int lane = mi_lane();
     const int64_t u = users[b], p = n_users + pos[b], n = n_users + neg[b];
-    const float* uf = fin + u * ldf;
-    const float* pf = fin + p * ldf;
-    const float* nf = fin + n * ldf;
+    // rows of final / g_final: node ids, or compact slots when the batch-node map is given
+    const int64_t fu = node_map ? node_map[u] : u, fp = node_map ? node_map[p] : p, fn = node_map ? node_map[n] : n;
+    const float* uf = fin + fu * ldf;
+    const float* pf = fin + fp * ldf;
+    const float* nf = fin + fn * ldf;
     const float* u0 = e0 + u * lde;
     const float* p0 = e0 + p * lde;
     const float* n0 = e0 + n * lde;
@@ -104,9 +108,9 @@ __global__ __launch_bounds__(kBlock) void bpr_slot_kernel(
     if (g_final) {
         // loss = -mean softplus(x)  =>  dL/dx = -sigmoid'(x)/B
         const float coef = -softplus_grad_ref(x) * inv_batch * g_scale;
-        float* gu = g_final + u * ldg;
-        float* gp = g_final + p * ldg;
-        float* gn = g_final + n * ldg;
+        float* gu = g_final + fu * ldg;
+        float* gp = g_final + fp * ldg;
+        float* gn = g_final + fn * ldg;
         for (int k = lane; k < d; k += MI_WAVE) {
             float a = uf[k], pk = pf[k], nk = nf[k];
             atomicAdd(gu + k, coef * (pk - nk));
@@ -148,6 +152,49 @@ __global__ __launch_bounds__(1024) void bpr_finish_kernel(int64_t batch,
         __syncthreads();
     }
     if (t == 0) loss_out[0] = -sh_a[0] * inv_batch + lambda * sh_b[0];
+}
+
+// ------------------------------------------------------------------ batch node set ------
+__global__ void mark_batch_nodes_kernel(int64_t batch, int64_t n_users, const int64_t* __restrict__ users,
+                                        const int64_t* __restrict__ pos, const int64_t* __restrict__ neg,
+                                        int32_t* __restrict__ flag) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= batch) return;
+    flag[users[b]] = 1;  // same value from every writer: order does not matter
+    flag[n_users + pos[b]] = 1;
+    flag[n_users + neg[b]] = 1;
+}
+
+__global__ void finish_batch_nodes_kernel(int64_t n_nodes, const int32_t* __restrict__ flag,
+                                          const int32_t* __restrict__ slot, int32_t* __restrict__ gmap,
+                                          int32_t* __restrict__ nodes, int32_t* __restrict__ count) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r > n_nodes) return;
+    if (r == n_nodes) {
+        count[0] = slot[r];
+        return;
+    }
+    if (flag[r]) {
+        gmap[r] = slot[r];
+        nodes[slot[r]] = (int32_t)r;
+    } else {
+        gmap[r] = -1;
+    }
+}
+
+// dst[i,:] (+)= src[rows[i],:], one wavefront per row, float4 lanes
+__global__ __launch_bounds__(kBlock) void gather_rows_kernel(int64_t n_max, const int32_t* __restrict__ n_dev,
+                                                             int d4, const int32_t* __restrict__ rows,
+                                                             const float4* __restrict__ src, int64_t lds4,
+                                                             float4* __restrict__ dst, int64_t ldd4, int accumulate) {
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / MI_WAVE;
+    if (i >= n_max || (n_dev && i >= *n_dev)) return;
+    const int64_t r = rows[i];
+    for (int e = mi_lane(); e < d4; e += MI_WAVE) {
+        float4 v = src[r * lds4 + e];
+        if (accumulate) v = mi_f4_add(dst[i * ldd4 + e], v);
+        dst[i * ldd4 + e] = v;
+    }
 }
 
 // ------------------------------------------------------------------ Adam ---------------
@@ -204,6 +251,49 @@ int mi_sample_bpr_batch(int64_t batch, int64_t nnz, const int32_t* rowptr, const
     return mi_launch_status();
 }
 
+size_t mi_batch_nodes_workspace_bytes(int64_t n_nodes) {
+    const size_t n1 = (size_t)(n_nodes > 0 ? n_nodes : 0) + 1;
+    return 2 * mi_align_up(n1 * sizeof(int32_t), 256) + ((size_t)16 << 20);
+}
+
+int mi_batch_nodes_i32(int64_t batch, int64_t n_users, int64_t n_nodes, const int64_t* users,
+                       const int64_t* pos, const int64_t* neg, int32_t* gmap, int32_t* nodes,
+                       int32_t* count, void* ws, size_t ws_bytes, mi_stream_t stream) {
+    MI_CHECK_ARG(batch > 0 && n_users >= 0 && n_nodes >= n_users && n_nodes > 0);
+    MI_CHECK_ARG(users && pos && neg && gmap && nodes && count && ws);
+    if (n_nodes >= INT32_MAX) return MI_ERR_TOO_LARGE;
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t n1 = n_nodes + 1;
+    MiArena arena(ws, ws_bytes);
+    int32_t* flag = arena.take<int32_t>(n1);
+    int32_t* slot = arena.take<int32_t>(n1);
+    if (!flag || !slot) return MI_ERR_WORKSPACE;
+    MI_HIP(hipMemsetAsync(flag, 0, (size_t)n1 * sizeof(int32_t), s));
+    hipLaunchKernelGGL(mark_batch_nodes_kernel, dim3((unsigned)mi_ceil_div(batch, kBlock)), dim3(kBlock), 0, s, batch,
+                       n_users, users, pos, neg, flag);
+    size_t tmp_bytes = 0;
+    MI_HIP(rocprim::exclusive_scan(nullptr, tmp_bytes, flag, slot, 0, (size_t)n1, rocprim::plus<int32_t>(), s));
+    char* tmp = arena.take<char>(tmp_bytes ? tmp_bytes : 1);
+    if (!tmp) return MI_ERR_WORKSPACE;
+    MI_HIP(rocprim::exclusive_scan(tmp, tmp_bytes, flag, slot, 0, (size_t)n1, rocprim::plus<int32_t>(), s));
+    hipLaunchKernelGGL(finish_batch_nodes_kernel, dim3((unsigned)mi_ceil_div(n1, kBlock)), dim3(kBlock), 0, s, n_nodes,
+                       flag, slot, gmap, nodes, count);
+    return mi_launch_status();
+}
+
+int mi_gather_rows_f32(int64_t n_max, const int32_t* n_dev, int64_t d, const int32_t* rows, const float* src,
+                       int64_t ld_src, float* dst, int64_t ld_dst, int32_t accumulate, mi_stream_t stream) {
+    MI_CHECK_ARG(n_max >= 0 && d > 0);
+    if (n_max == 0) return 0;
+    if (d % 4 != 0) return MI_ERR_UNSUPPORTED;
+    MI_CHECK_ARG(rows && src && dst && ld_src % 4 == 0 && ld_dst % 4 == 0 && ld_src >= d && ld_dst >= d);
+    MI_CHECK_ARG(mi_aligned16(src) && mi_aligned16(dst));
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)mi_ceil_div(n_max * MI_WAVE, kBlock)), dim3(kBlock), 0,
+                       (hipStream_t)stream, n_max, n_dev, (int)(d / 4), rows, reinterpret_cast<const float4*>(src),
+                       ld_src / 4, reinterpret_cast<float4*>(dst), ld_dst / 4, accumulate);
+    return mi_launch_status();
+}
+
 size_t mi_bpr_workspace_bytes(int64_t batch) {
     return 2 * mi_align_up((size_t)(batch > 0 ? batch : 1) * sizeof(float), 256);
 }
@@ -211,8 +301,8 @@ size_t mi_bpr_workspace_bytes(int64_t batch) {
 int mi_bpr_fwd_bwd_f32(int64_t batch, int64_t d, int64_t n_users, const int64_t* users,
                        const int64_t* pos, const int64_t* neg, const float* final_emb, int64_t ldf,
                        const float* e0, int64_t lde, float lambda, float g_scale, float reg_scale,
-                       float* loss_out, float* g_final, int64_t ldg, float* reg_w, void* ws,
-                       size_t ws_bytes, mi_stream_t stream) {
+                       float* loss_out, float* g_final, int64_t ldg, float* reg_w,
+                       const int32_t* node_map, void* ws, size_t ws_bytes, mi_stream_t stream) {
     MI_CHECK_ARG(batch > 0 && d > 0 && n_users >= 0);
     MI_CHECK_ARG(users && pos && neg && final_emb && e0 && loss_out && ws);
     MI_CHECK_ARG(ldf >= d && lde >= d && (!g_final || ldg >= d));
@@ -225,7 +315,7 @@ int mi_bpr_fwd_bwd_f32(int64_t batch, int64_t d, int64_t n_users, const int64_t*
     dim3 g((unsigned)mi_ceil_div(batch * MI_WAVE, kBlock));
     hipLaunchKernelGGL(bpr_slot_kernel, g, dim3(kBlock), 0, s, batch, (int)d, n_users, users, pos, neg,
                        final_emb, ldf, e0, lde, inv_b, g_scale, reg_scale * lambda, spv, rgv, g_final, ldg,
-                       reg_w);
+                       reg_w, node_map);
     hipLaunchKernelGGL(bpr_finish_kernel, dim3(1), dim3(1024), 0, s, batch, spv, rgv, inv_b, lambda, loss_out);
     return mi_launch_status();
 }

@@ -14,7 +14,7 @@ import torch as t
 from torch import Tensor
 
 from . import _lib
-from ._lib import SpmmPlanStruct, check
+from ._lib import SpmmExStruct, SpmmPlanStruct, check
 
 DEFAULT_CHUNK = 256  # nnz per work item of a split (hub) row
 
@@ -70,6 +70,7 @@ class SpmmPlan:
     long_rows: Optional[Tensor]
     item_ptr: Optional[Tensor]
     items: Optional[Tensor]
+    long_index: Optional[Tensor] = None
     partial: dict = field(default_factory=dict)  # d -> workspace tensor
 
     @property
@@ -184,34 +185,56 @@ def build_spmm_plan(a: DeviceCSR, chunk: int = DEFAULT_CHUNK) -> SpmmPlan:
     long_rows = t.empty(max(ml.value, 1), dtype=t.int32, device=dev)
     item_ptr = t.empty(max(ml.value, 1) + 1, dtype=t.int32, device=dev)
     items = t.empty(4 * max(mi.value, 1), dtype=t.int32, device=dev)
+    long_index = t.empty(max(a.n_rows, 1), dtype=t.int32, device=dev)
     st = SpmmPlanStruct()
     st.long_rows, st.item_ptr, st.items = long_rows.data_ptr(), item_ptr.data_ptr(), items.data_ptr()
+    st.long_index = long_index.data_ptr()
     ws = _ws(L.mi_spmm_plan_workspace_bytes(a.n_rows), dev)
     check(L.mi_spmm_plan_build(a.n_rows, _ptr(a.rowptr), chunk, ctypes.byref(st), ws.data_ptr(), ws.numel(),
                                _stream()), "mi_spmm_plan_build")
     # shrink to what is used (keeps the pointers valid: slices share storage)
     nl, ni = int(st.n_long_rows), int(st.n_items)
-    return SpmmPlan(st, long_rows[:max(nl, 1)], item_ptr[:max(nl, 1) + 1], items[:4 * max(ni, 1)])
+    return SpmmPlan(st, long_rows[:max(nl, 1)], item_ptr[:max(nl, 1) + 1], items[:4 * max(ni, 1)], long_index)
 
 
 def spmm(a: DeviceCSR, X: Tensor, *, Y: Optional[Tensor] = None, addend: Optional[Tensor] = None,
-         S: Optional[Tensor] = None, scale: float = 1.0) -> None:
-    """K1/K2 — acc = A @ X; Y = acc (optional); S = scale * (addend + acc) (optional)."""
+         S: Optional[Tensor] = None, scale: float = 1.0, x_map: Optional[Tensor] = None,
+         addend_map: Optional[Tensor] = None, row_list: Optional[Tensor] = None,
+         n_list_dev: Optional[Tensor] = None) -> None:
+    """K1/K2 — acc = A @ X; Y = acc (optional); S = scale * (addend + acc) (optional).
+
+    Sparse-operand forms (mi_spmm_csr_ex_f32): x_map int32[n_cols] — X is compact, column c reads
+    X[x_map[c]], negative = an all-zero row; addend_map int32[n_rows] — addend is compact; row_list
+    int32[n] (+ n_list_dev, device int32[1]) — compute only these rows, Y/S/addend compact by list position."""
     if a.val is None:
         raise ValueError("spmm needs edge values (run gcn_norm or set val)")
     d = X.shape[1]
     ldx = _rows_ok(X, "X")
-    if X.shape[0] != a.n_cols:
+    for nm, mp, ln in (("x_map", x_map, a.n_cols), ("addend_map", addend_map, a.n_rows)):
+        if mp is not None:
+            _need(mp, t.int32, nm)
+            if mp.numel() != ln:
+                raise ValueError(f"{nm} must have {ln} entries")
+    if row_list is not None:
+        _need(row_list, t.int32, "row_list")
+        if addend_map is not None:
+            raise ValueError("row_list and addend_map are exclusive (addend is indexed by list position)")
+    if n_list_dev is not None:
+        _need(n_list_dev, t.int32, "n_list_dev")
+    if x_map is None and X.shape[0] != a.n_cols:
         raise ValueError(f"X has {X.shape[0]} rows, adjacency has {a.n_cols} columns")
-    for name, m in (("Y", Y), ("addend", addend), ("S", S)):
-        if m is not None and (m.shape[0] != a.n_rows or m.shape[1] != d):
-            raise ValueError(f"{name} must be [{a.n_rows}, {d}], got {tuple(m.shape)}")
+    n_out = row_list.numel() if row_list is not None else a.n_rows
+    for name, m in (("Y", Y), ("S", S)) + ((("addend", addend),) if addend_map is None else ()):
+        if m is not None and (m.shape[0] != n_out or m.shape[1] != d):
+            raise ValueError(f"{name} must be [{n_out}, {d}], got {tuple(m.shape)}")
+    if addend is not None and addend.shape[1] != d:
+        raise ValueError("addend width differs from X")
     if Y is None and S is None:
         raise ValueError("spmm needs an output (Y and/or S)")
     ldy = _rows_ok(Y, "Y") if Y is not None else 0
     lda = _rows_ok(addend, "addend") if addend is not None else 0
     lds = _rows_ok(S, "S") if S is not None else 0
-    if a.plan is None and a.nnz >= PLAN_MIN_NNZ:
+    if a.plan is None and (a.nnz >= PLAN_MIN_NNZ or row_list is not None):
         a.plan = build_spmm_plan(a)
     plan = a.plan
     L = _lib.lib()
@@ -226,10 +249,15 @@ def spmm(a: DeviceCSR, X: Tensor, *, Y: Optional[Tensor] = None, addend: Optiona
     if SPMM_EVENTS is not None:
         ev = (t.cuda.Event(enable_timing=True), t.cuda.Event(enable_timing=True))
         ev[0].record()
-    check(L.mi_spmm_csr_f32(a.n_rows, d, _ptr(a.rowptr), col_ptr, val_ptr, X.data_ptr(), ldx,
-                            _ptr(Y), ldy, _ptr(addend), lda, _ptr(S), lds, float(scale),
-                            ctypes.byref(plan.struct) if plan is not None else None, ws_ptr, ws_bytes,
-                            _stream()), "mi_spmm_csr_f32")
+    exs = None
+    if x_map is not None or addend_map is not None or row_list is not None:
+        exs = SpmmExStruct(_ptr(x_map), _ptr(addend_map), _ptr(row_list), _ptr(n_list_dev),
+                           row_list.numel() if row_list is not None else 0)
+    check(L.mi_spmm_csr_ex_f32(a.n_rows, d, _ptr(a.rowptr), col_ptr, val_ptr, X.data_ptr(), ldx,
+                               _ptr(Y), ldy, _ptr(addend), lda, _ptr(S), lds, float(scale),
+                               ctypes.byref(plan.struct) if plan is not None else None,
+                               ctypes.byref(exs) if exs is not None else None, ws_ptr, ws_bytes,
+                               _stream()), "mi_spmm_csr_ex_f32")
     if ev is not None:
         ev[1].record()
         SPMM_EVENTS.append(ev)
@@ -264,7 +292,8 @@ def sample_bpr_batch(r: DeviceCSR, row_of_edge: Tensor, batch: int, neg_range: i
 
 def bpr_fwd_bwd(users: Tensor, pos: Tensor, neg: Tensor, final_emb: Tensor, e0: Tensor, n_users: int,
                 lambda_val: float, *, g_final: Optional[Tensor] = None, reg_w: Optional[Tensor] = None,
-                g_scale: float = 1.0, reg_scale: float = 1.0, loss_out: Optional[Tensor] = None) -> Tensor:
+                g_scale: float = 1.0, reg_scale: float = 1.0, loss_out: Optional[Tensor] = None,
+                node_map: Optional[Tensor] = None) -> Tensor:
     """a7+a8 — batch gather + bpr_loss (utils/metrics_lightgcn.py:9-45) forward and backward."""
     for n, x in (("users", users), ("pos", pos), ("neg", neg)):
         _need(x, t.int64, n)
@@ -282,7 +311,7 @@ def bpr_fwd_bwd(users: Tensor, pos: Tensor, neg: Tensor, final_emb: Tensor, e0: 
     ws = _ws(L.mi_bpr_workspace_bytes(batch), dev)
     check(L.mi_bpr_fwd_bwd_f32(batch, d, n_users, _ptr(users), _ptr(pos), _ptr(neg), final_emb.data_ptr(), ldf,
                                e0.data_ptr(), lde, float(lambda_val), float(g_scale), float(reg_scale),
-                               loss_out.data_ptr(), _ptr(g_final), ldg, _ptr(reg_w), ws.data_ptr(),
+                               loss_out.data_ptr(), _ptr(g_final), ldg, _ptr(reg_w), _ptr(node_map), ws.data_ptr(),
                                ws.numel(), _stream()), "mi_bpr_fwd_bwd_f32")
     return loss_out
 
@@ -404,3 +433,29 @@ def embed_concat(x: Tensor, tables, max_norm: float = 1.0) -> Tensor:
     check(_lib.lib().mi_embed_concat_f32(n, nc, x.data_ptr(), ptrs, rows, dims, float(max_norm), out.data_ptr(), width,
                                          _stream()), "mi_embed_concat_f32")
     return out
+
+
+def batch_nodes(users: Tensor, pos: Tensor, neg: Tensor, n_users: int, n_nodes: int, *, gmap: Optional[Tensor] = None,
+                nodes: Optional[Tensor] = None, count: Optional[Tensor] = None, ws: Optional[Tensor] = None):
+    """Unique node set of a BPR batch: (gmap int32[n_nodes], nodes int32[3B], count int32[1] on device)."""
+    for n, x in (("users", users), ("pos", pos), ("neg", neg)):
+        _need(x, t.int64, n)
+    B, dev = users.numel(), users.device
+    gmap = gmap if gmap is not None else t.empty(n_nodes, dtype=t.int32, device=dev)
+    nodes = nodes if nodes is not None else t.empty(3 * B, dtype=t.int32, device=dev)
+    count = count if count is not None else t.empty(1, dtype=t.int32, device=dev)
+    L = _lib.lib()
+    ws = ws if ws is not None else _ws(L.mi_batch_nodes_workspace_bytes(n_nodes), dev)
+    check(L.mi_batch_nodes_i32(B, n_users, n_nodes, _ptr(users), _ptr(pos), _ptr(neg), _ptr(gmap), _ptr(nodes),
+                               _ptr(count), ws.data_ptr(), ws.numel(), _stream()), "mi_batch_nodes_i32")
+    return gmap, nodes, count
+
+
+def gather_rows(dst: Tensor, src: Tensor, rows: Tensor, n_dev: Optional[Tensor] = None, accumulate: bool = False) -> None:
+    """dst[i] (+)= src[rows[i]] for i < min(len(rows), *n_dev)."""
+    _need(rows, t.int32, "rows")
+    lds_, ldd = _rows_ok(src, "src"), _rows_ok(dst, "dst")
+    if dst.shape[0] < rows.numel() or dst.shape[1] != src.shape[1]:
+        raise ValueError("dst must be [len(rows), d]")
+    check(_lib.lib().mi_gather_rows_f32(rows.numel(), _ptr(n_dev), src.shape[1], _ptr(rows), src.data_ptr(), lds_,
+                                        dst.data_ptr(), ldd, 1 if accumulate else 0, _stream()), "mi_gather_rows_f32")

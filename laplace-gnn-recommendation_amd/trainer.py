@@ -12,6 +12,21 @@ removed is memory traffic: no cat, no [N,K+1,D] stack, no saved activations (the
 linear), no materialised per-batch gathers, gradient and L2 term consumed in the Adam pass.
 
 HBM-resident state (fp32, N = U+I rows of D): table, final, two ping-pong buffers, Gc, m, v.
+
+`sparse_batch=True` (default) additionally uses what is known about the operands of one step — the
+loss reads `final` only at the <= 3B batch rows, and its gradient is non-zero only there — to move
+fewer bytes for the SAME result (bit for bit up to the sign of zero and the order of the BPR atomics):
+  * the batch is drawn first (it does not depend on the embeddings); its unique node set and the
+    node -> slot map are built on device (mi_batch_nodes_i32), no host read-back;
+  * forward: layers 1..K-1 are plain products; the running layer sum is kept only at the batch rows
+    (mi_gather_rows_f32); layer K is computed only at the batch rows (row_list) — hub rows still go
+    through the split path;
+  * the BPR kernel reads / writes compact [<= 3B, D] tables through the node map, so the dense Gc
+    buffer, its zero-fill and its K reads as an addend disappear;
+  * backward layer 1 gathers only the non-zero rows of its input (x_map); all layers take the compact
+    gradient as addend (addend_map).
+`sparse_batch=False` is the straightforward form (full `final`, dense Gc) kept for A/B and for callers
+that want the full forward output of the step.
 """
 from __future__ import annotations
 
@@ -26,10 +41,16 @@ from .model.lightgcn import LightGCN, propagate_mean, propagate_mean_backward
 from .sparse import SparseTensor
 
 
+def _lib_bytes_batch_nodes(n_nodes: int) -> int:
+    from . import _lib
+    return int(_lib.lib().mi_batch_nodes_workspace_bytes(n_nodes))
+
+
 class LightGCNTrainer:
     def __init__(self, model: LightGCN, adj: SparseTensor, train: Interactions, *, lr: float, Lambda: float,
                  batch_size: int, betas: Tuple[float, float] = (0.9, 0.999), eps: float = 1e-8, seed: int = 0,
-                 neg_range: Optional[int] = None, reference_sampler_quirks: bool = False):
+                 neg_range: Optional[int] = None, reference_sampler_quirks: bool = False,
+                 sparse_batch: bool = True):
         self.model = model
         self.table = model.table()
         if not self.table.is_cuda:
@@ -44,10 +65,22 @@ class LightGCNTrainer:
         self.quirk = bool(reference_sampler_quirks)
         n, d = self.table.shape
         dev = self.table.device
+        self.sparse_batch = bool(sparse_batch)
         self.final = t.empty(n, d, device=dev)
         self.buf_a = t.empty(n, d, device=dev)
         self.buf_b = t.empty(n, d, device=dev)
-        self.gc = t.zeros(n, d, device=dev)
+        nb = 3 * self.batch_size
+        if self.sparse_batch:  # compact per-batch tables instead of the dense gradient buffer
+            self.gc = None
+            self.gmap = t.empty(n, dtype=t.int32, device=dev)
+            self.nodes = t.zeros(nb, dtype=t.int32, device=dev)
+            self.n_nodes = t.zeros(1, dtype=t.int32, device=dev)
+            self.sum_c = t.empty(nb, d, device=dev)
+            self.final_c = t.empty(nb, d, device=dev)
+            self.gc_c = t.zeros(nb, d, device=dev)
+            self._nodes_ws = t.empty(_lib_bytes_batch_nodes(n), dtype=t.uint8, device=dev)
+        else:
+            self.gc = t.zeros(n, d, device=dev)
         self.reg_w = t.zeros(n, device=dev)
         self.m = t.zeros(n, d, device=dev)
         self.v = t.zeros(n, d, device=dev)
@@ -67,6 +100,8 @@ class LightGCNTrainer:
 
     def step(self, batch: Optional[Tuple[Tensor, Tensor, Tensor]] = None) -> Tensor:
         """One training iteration; returns the loss as a 1-element device tensor (no sync)."""
+        if self.sparse_batch:
+            return self._step_sparse(batch)
         K = self.K
         self.forward()
         users, pos, neg = batch if batch is not None else self.sample()
@@ -77,6 +112,53 @@ class LightGCNTrainer:
         g0 = propagate_mean_backward(self.adj_bwd, self.gc, K, scratch=(self.buf_a, self.buf_b), pre_scaled=True)
         self.step_count += 1
         ops.adam_step(self.table, g0, self.m, self.v, step=self.step_count, lr=self.lr, beta1=self.betas[0],
+                      beta2=self.betas[1], eps=self.eps, reg_w=self.reg_w)
+        return self.loss
+
+    def _step_sparse(self, batch: Optional[Tuple[Tensor, Tensor, Tensor]]) -> Tensor:
+        K, tab, adj, adj_t = self.K, self.table, self.adj_fwd, self.adj_bwd
+        users, pos, neg = batch if batch is not None else self.sample()
+        if users.numel() != self.batch_size:
+            raise ValueError("batch size differs from the trainer's")
+        gmap, nodes, cnt = ops.batch_nodes(users, pos, neg, self.model.num_users, tab.shape[0], gmap=self.gmap,
+                                           nodes=self.nodes, count=self.n_nodes, ws=self._nodes_ws)
+        # ---- forward: final only at the batch rows
+        c = 1.0 / (K + 1)
+        ops.gather_rows(self.sum_c, tab, nodes, cnt)                      # S_c = E0[batch rows]
+        x = tab
+        bufs = (self.buf_a, self.buf_b)
+        for k in range(1, K):                                             # layers 1..K-1: plain products
+            y = bufs[(k - 1) % 2]
+            ops.spmm(adj, x, Y=y)
+            ops.gather_rows(self.sum_c, y, nodes, cnt, accumulate=True)   # S_c += X_k[batch rows]
+            x = y
+        if K >= 1:                                                        # layer K at the batch rows only
+            ops.spmm(adj, x, addend=self.sum_c, S=self.final_c, scale=c, row_list=nodes, n_list_dev=cnt)
+            final_c = self.final_c
+        else:
+            final_c = self.sum_c
+        # ---- loss + its gradient on the compact tables
+        self.gc_c.zero_()
+        self.reg_w.zero_()
+        ops.bpr_fwd_bwd(users, pos, neg, final_c, tab, self.model.num_users, self.Lambda, g_final=self.gc_c,
+                        reg_w=self.reg_w, g_scale=c, loss_out=self.loss, node_map=gmap)
+        # ---- backward: g_K = Gc (compact); g_k = Gc + A^T g_{k+1}
+        if K == 0:
+            g0 = self.buf_a
+            g0.zero_()
+            g0.index_add_(0, nodes[: int(cnt)].long(), self.gc_c[: int(cnt)])  # K = 0 is not a hot path
+        else:
+            cur = None
+            for i in range(K):
+                nxt = bufs[i % 2]
+                if i == 0:   # input = the compact gradient itself: skip its all-zero rows
+                    ops.spmm(adj_t, self.gc_c, addend=self.gc_c, S=nxt, x_map=gmap, addend_map=gmap)
+                else:
+                    ops.spmm(adj_t, cur, addend=self.gc_c, S=nxt, addend_map=gmap)
+                cur = nxt
+            g0 = cur
+        self.step_count += 1
+        ops.adam_step(tab, g0, self.m, self.v, step=self.step_count, lr=self.lr, beta1=self.betas[0],
                       beta2=self.betas[1], eps=self.eps, reg_w=self.reg_w)
         return self.loss
 

@@ -500,3 +500,81 @@ def test_full_size_sampler_and_step(c2_graph):
     moved = (model.table() - before).abs().amax(dim=1) > 0
     assert 0.5 < float(moved.float().mean()) <= 1.0  # 3-hop receptive field of a 16K batch covers most nodes
     assert float((model.table() - before).abs().max()) <= 1.001e-3  # |Adam step| <= lr
+
+
+# ---------------------------------------------------------------------------- sparse-operand SpMM forms
+def test_spmm_sparse_operand_forms_equal_dense_bitwise():
+    """x_map (compact X, zero rows skipped), addend_map (compact addend) and row_list (row subset, compact
+    outputs, hub rows through the split path) give exactly the dense call's numbers."""
+    ops = _ops()
+    n, d = 4000, 128
+    g = t.Generator().manual_seed(3)
+    hub = t.stack([t.full((30_000,), 11), t.randint(0, n, (30_000,), generator=g)])
+    rest = t.stack(_rand_graph(n, n, 40_000, seed=4))
+    ei = t.cat([hub, rest], dim=1)
+    a = _csr_with_vals(ei[0], ei[1], n, n, seed=5)
+    a.plan = ops.build_spmm_plan(a, chunk=256)
+    assert a.plan.n_long_rows >= 1
+    # a sparse-row operand: 300 non-zero rows, incl. row 11 (the hub) and some of its neighbours
+    nz = t.unique(t.cat([t.tensor([11]), t.randint(0, n, (299,), generator=g)]))
+    m = nz.numel()
+    gmap = t.full((n,), -1, dtype=t.int32)
+    gmap[nz] = t.arange(m, dtype=t.int32)
+    Xc = t.randn(m, d, generator=g)
+    Xd = t.zeros(n, d)
+    Xd[nz] = Xc
+    Xc_g, Xd_g, gmap_g = Xc.to(DEV), Xd.to(DEV), gmap.to(DEV)
+    dense, sparse = t.empty(n, d, device=DEV), t.empty(n, d, device=DEV)
+    ops.spmm(a, Xd_g, addend=Xd_g, S=dense, scale=0.5)
+    ops.spmm(a, Xc_g, addend=Xc_g, S=sparse, scale=0.5, x_map=gmap_g, addend_map=gmap_g)
+    assert t.equal(dense, sparse)
+    # row subset: every row of nz, compact outputs, actual count given on device, launch bound larger
+    full = t.empty(n, d, device=DEV)
+    W = t.randn(n, d, generator=g).to(DEV)
+    ops.spmm(a, W, addend=W, S=full, scale=0.25)
+    rows = t.zeros(m + 50, dtype=t.int32)
+    rows[:m] = nz.to(t.int32)
+    cnt = t.tensor([m], dtype=t.int32, device=DEV)
+    sub = t.full((m + 50, d), float("nan"), device=DEV)
+    ops.spmm(a, W, addend=W[nz.to(DEV)].contiguous().new_zeros(m + 50, d).index_copy_(0, t.arange(m, device=DEV), W[nz.to(DEV)]),
+             S=sub, scale=0.25, row_list=rows.to(DEV), n_list_dev=cnt)
+    assert t.equal(sub[:m], full[nz.to(DEV)])
+    assert bool(t.isnan(sub[m:]).all())  # rows beyond the device count are not touched
+
+
+def test_batch_nodes_and_gather_rows():
+    ops = _ops()
+    U, I, B = 50, 40, 64
+    g = t.Generator().manual_seed(1)
+    u, p, n_ = t.randint(0, U, (B,), generator=g), t.randint(0, I, (B,), generator=g), t.randint(0, I, (B,), generator=g)
+    gmap, nodes, cnt = ops.batch_nodes(u.to(DEV), p.to(DEV), n_.to(DEV), U, U + I)
+    want = t.unique(t.cat([u, U + p, U + n_]))
+    c = int(cnt)
+    assert c == want.numel() and t.equal(nodes[:c].cpu().long(), want)
+    gm = gmap.cpu().long()
+    assert t.equal(gm[want], t.arange(c)) and int((gm >= 0).sum()) == c
+    src = t.randn(U + I, 32, generator=g).to(DEV)
+    dst = t.zeros(3 * B, 32, device=DEV)
+    ops.gather_rows(dst, src, nodes, cnt)
+    ops.gather_rows(dst, src, nodes, cnt, accumulate=True)
+    assert t.equal(dst[:c], 2 * src[want.to(DEV)]) and float(dst[c:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("K", [0, 1, 2, 3, 4])
+def test_sparse_batch_step_equals_plain_step(K):
+    """The byte-saving step and the straightforward step are the same computation."""
+    from laplace_amd.trainer import LightGCNTrainer
+    U, I, E, D, B = 900, 500, 15000, 64, 512
+    ma, inter, adj, ei = _model_and_graph(U, I, E, D, K, seed=41, compat="bipartite")
+    mb, _, _, _ = _model_and_graph(U, I, E, D, K, seed=41, compat="bipartite")
+    ma.to(DEV); mb.to(DEV)
+    inter = inter.to(DEV)
+    adj = adj.to(DEV)
+    plain = LightGCNTrainer(ma, adj, inter, lr=1e-3, Lambda=1e-4, batch_size=B, seed=9, sparse_batch=False)
+    fast = LightGCNTrainer(mb, adj, inter, lr=1e-3, Lambda=1e-4, batch_size=B, seed=9, sparse_batch=True)
+    for it in range(6):
+        la, lb = float(plain.step()), float(fast.step())
+        assert abs(la - lb) <= 1e-6, it
+        assert t.equal(plain.batch_idx[0], fast.batch_idx[0]) and t.equal(plain.batch_idx[2], fast.batch_idx[2])
+    # identical up to the order of the float atomics that combine repeated batch nodes
+    assert (plain.table - fast.table).abs().max() <= 2e-6
