@@ -41,7 +41,7 @@ struct Ex {
 
 // Accumulates entries [beg, end) of one row into acc (valid in lanes of sub-group 0 after
 // the final cross-sub-group reduce).
-template <int LPR, int VPL, int UNROLL>
+template <int LPR, int VPL, int UNROLL, bool SPARSE>
 __device__ __forceinline__ void wave_accumulate(const int32_t* __restrict__ col,
                                                 const float* __restrict__ val,
                                                 const float4* __restrict__ X4, int64_t ldx4, int d4,
@@ -61,9 +61,9 @@ __device__ __forceinline__ void wave_accumulate(const int32_t* __restrict__ col,
         if (lane < n) {
             my_c = col[base + lane];
             my_v = val[base + lane];
-            if (x_map) my_c = x_map[my_c];  // compact row of X, or < 0 for a row that is all zeros
+            if (SPARSE && x_map) my_c = x_map[my_c];  // compact row of X, or < 0 for a row that is all zeros
         }
-        if (x_map && __ballot(my_c >= 0 && lane < n) == 0ull) continue;  // nothing to gather in this 64-entry group
+        if (SPARSE && x_map && __ballot(my_c >= 0 && lane < n) == 0ull) continue;  // nothing to gather in this 64-entry group
         for (int j = 0; j < n; j += NB * UNROLL) {
             float w[UNROLL];
             float4 x[UNROLL][VPL];
@@ -127,7 +127,10 @@ __device__ __forceinline__ void load_addend(const Epilogue& ep, int64_t ar, int 
 }
 
 // One wavefront per row; rows with more than `chunk` entries are left to the split path.
-template <int LPR, int VPL, int UNROLL>
+// SPARSE = false: the dense product (every entry gathered; addend_map allowed) — the kernel the
+// roofline is quoted on.  SPARSE = true: x_map / row_list launches of the fused train step, kept as a
+// separate instantiation so that profiles list them apart.
+template <int LPR, int VPL, int UNROLL, bool SPARSE>
 __global__ __launch_bounds__(kBlock) void spmm_rows_kernel(int64_t n_rows, int d4,
                                                            const int32_t* __restrict__ rowptr,
                                                            const int32_t* __restrict__ col,
@@ -136,19 +139,20 @@ __global__ __launch_bounds__(kBlock) void spmm_rows_kernel(int64_t n_rows, int d
                                                            Epilogue ep, int32_t chunk, Ex ex) {
     const int64_t i = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x / MI_WAVE);
     if (i >= n_rows) return;
-    if (ex.n_list_dev && i >= *ex.n_list_dev) return;
-    const int64_t r = ex.row_list ? ex.row_list[i] : i;
+    const bool listed = SPARSE && ex.row_list != nullptr;
+    if (listed && ex.n_list_dev && i >= *ex.n_list_dev) return;
+    const int64_t r = listed ? ex.row_list[i] : i;
     const int32_t beg = rowptr[r], end = rowptr[r + 1];
     if (end - beg > chunk) return;
     float4 a[VPL], acc[VPL];
-    const int64_t ar = ex.row_list ? i : (ex.addend_map ? (int64_t)ex.addend_map[r] : r);
+    const int64_t ar = listed ? i : (ex.addend_map ? (int64_t)ex.addend_map[r] : r);
     load_addend<LPR, VPL>(ep, ar, d4, a);
-    wave_accumulate<LPR, VPL, UNROLL>(col, val, X4, ldx4, d4, beg, end, acc, ex.x_map);
-    apply_epilogue<LPR, VPL>(ep, ex.row_list ? i : r, d4, acc, a);
+    wave_accumulate<LPR, VPL, UNROLL, SPARSE>(col, val, X4, ldx4, d4, beg, end, acc, ex.x_map);
+    apply_epilogue<LPR, VPL>(ep, listed ? i : r, d4, acc, a);
 }
 
 // Split rows: one wavefront per work item (row, begin, end, slot) -> partial[slot, :].
-template <int LPR, int VPL, int UNROLL>
+template <int LPR, int VPL, int UNROLL, bool SPARSE>
 __global__ __launch_bounds__(kBlock) void spmm_items_kernel(int32_t n_items, int d4,
                                                             const int32_t* __restrict__ items,
                                                             const int32_t* __restrict__ col,
@@ -160,7 +164,7 @@ __global__ __launch_bounds__(kBlock) void spmm_items_kernel(int32_t n_items, int
     if (it >= n_items) return;
     const int32_t beg = items[4 * it + 1], end = items[4 * it + 2], slot = items[4 * it + 3];
     float4 acc[VPL];
-    wave_accumulate<LPR, VPL, UNROLL>(col, val, X4, ldx4, d4, beg, end, acc, x_map);
+    wave_accumulate<LPR, VPL, UNROLL, SPARSE>(col, val, X4, ldx4, d4, beg, end, acc, x_map);
     const int lane = mi_lane();
     if (lane < LPR) {
 #pragma unroll
@@ -174,7 +178,7 @@ __global__ __launch_bounds__(kBlock) void spmm_items_kernel(int32_t n_items, int
 // One 256-thread block per split row.  Its 4 wavefronts x NB sub-groups stride over the row's
 // partial sums (several loads in flight each), then combine through LDS in a fixed order, so the
 // result does not depend on scheduling.  Wave 0 applies the epilogue.
-template <int LPR, int VPL>
+template <int LPR, int VPL, bool SPARSE>
 __global__ __launch_bounds__(kBlock) void spmm_fixup_kernel(int32_t n_long, int d4,
                                                             const int32_t* __restrict__ long_rows,
                                                             const int32_t* __restrict__ item_ptr,
@@ -186,7 +190,7 @@ __global__ __launch_bounds__(kBlock) void spmm_fixup_kernel(int32_t n_long, int 
     // all exits below depend on blockIdx only: the whole block leaves together, before any barrier
     int32_t i = blockIdx.x;
     int64_t r, out_row, ar;
-    if (ex.row_list) {  // n_long = launch bound on the list length
+    if (SPARSE && ex.row_list) {  // n_long = launch bound on the list length
         if (i >= n_long || (ex.n_list_dev && i >= *ex.n_list_dev)) return;
         r = ex.row_list[i];
         out_row = ar = i;
@@ -284,30 +288,40 @@ __global__ void plan_fill_kernel(int64_t n_rows, const int32_t* __restrict__ row
     }
 }
 
+template <int LPR, int VPL, bool SPARSE>
+int launch_spmm_mode(int64_t n_rows, int d4, const int32_t* rowptr, const int32_t* col, const float* val,
+                     const float4* X4, int64_t ldx4, const Epilogue& ep, const mi_spmm_plan* plan,
+                     float4* partial, const Ex& ex, int64_t n_list, hipStream_t s) {
+    constexpr int UNROLL = (VPL == 1) ? 4 : 2;
+    const int32_t chunk = plan ? plan->chunk : INT32_MAX;
+    const bool listed = SPARSE && ex.row_list != nullptr;
+    if (plan && plan->n_items > 0) {  // row_list mode still reduces every split row: hubs are few and almost always wanted
+        dim3 gi((unsigned)mi_ceil_div(plan->n_items, kWavesPerBlock));
+        hipLaunchKernelGGL((spmm_items_kernel<LPR, VPL, UNROLL, SPARSE>), gi, dim3(kBlock), 0, s, plan->n_items, d4,
+                           plan->items, col, val, X4, ldx4, partial, ex.x_map);
+    }
+    const int64_t n_out = listed ? n_list : n_rows;
+    if (n_out > 0) {
+        dim3 gr((unsigned)mi_ceil_div(n_out, kWavesPerBlock));
+        hipLaunchKernelGGL((spmm_rows_kernel<LPR, VPL, UNROLL, SPARSE>), gr, dim3(kBlock), 0, s, n_out, d4, rowptr,
+                           col, val, X4, ldx4, ep, chunk, ex);
+    }
+    if (plan && plan->n_long_rows > 0) {
+        const int64_t nf = listed ? n_list : (int64_t)plan->n_long_rows;
+        if (nf > 0)
+            hipLaunchKernelGGL((spmm_fixup_kernel<LPR, VPL, SPARSE>), dim3((unsigned)nf), dim3(kBlock), 0, s,
+                               (int32_t)nf, d4, plan->long_rows, plan->item_ptr, partial, ep, ex);
+    }
+    return mi_launch_status();
+}
+
 template <int LPR, int VPL>
 int launch_spmm(int64_t n_rows, int d4, const int32_t* rowptr, const int32_t* col, const float* val,
                 const float4* X4, int64_t ldx4, const Epilogue& ep, const mi_spmm_plan* plan,
                 float4* partial, const Ex& ex, int64_t n_list, hipStream_t s) {
-    constexpr int UNROLL = (VPL == 1) ? 4 : 2;
-    const int32_t chunk = plan ? plan->chunk : INT32_MAX;
-    if (plan && plan->n_items > 0) {  // row_list mode still reduces every split row: hubs are few and almost always wanted
-        dim3 gi((unsigned)mi_ceil_div(plan->n_items, kWavesPerBlock));
-        hipLaunchKernelGGL((spmm_items_kernel<LPR, VPL, UNROLL>), gi, dim3(kBlock), 0, s, plan->n_items, d4,
-                           plan->items, col, val, X4, ldx4, partial, ex.x_map);
-    }
-    const int64_t n_out = ex.row_list ? n_list : n_rows;
-    if (n_out > 0) {
-        dim3 gr((unsigned)mi_ceil_div(n_out, kWavesPerBlock));
-        hipLaunchKernelGGL((spmm_rows_kernel<LPR, VPL, UNROLL>), gr, dim3(kBlock), 0, s, n_out, d4, rowptr, col,
-                           val, X4, ldx4, ep, chunk, ex);
-    }
-    if (plan && plan->n_long_rows > 0) {
-        const int64_t nf = ex.row_list ? n_list : (int64_t)plan->n_long_rows;
-        if (nf > 0)
-            hipLaunchKernelGGL((spmm_fixup_kernel<LPR, VPL>), dim3((unsigned)nf), dim3(kBlock), 0, s, (int32_t)nf, d4,
-                               plan->long_rows, plan->item_ptr, partial, ep, ex);
-    }
-    return mi_launch_status();
+    if (ex.x_map || ex.row_list)
+        return launch_spmm_mode<LPR, VPL, true>(n_rows, d4, rowptr, col, val, X4, ldx4, ep, plan, partial, ex, n_list, s);
+    return launch_spmm_mode<LPR, VPL, false>(n_rows, d4, rowptr, col, val, X4, ldx4, ep, plan, partial, ex, n_list, s);
 }
 
 }  // namespace

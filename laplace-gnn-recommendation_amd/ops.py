@@ -18,7 +18,7 @@ from ._lib import SpmmExStruct, SpmmPlanStruct, check
 
 DEFAULT_CHUNK = 256  # nnz per work item of a split (hub) row
 
-# bench.py sets this to a list to collect (start, end) HIP events around every propagate launch,
+# bench.py sets this to a list to collect (start, end, kind) HIP events around every propagate launch,
 # recorded on the stream the kernels are launched on.  None = no timing overhead.
 SPMM_EVENTS = None
 
@@ -260,7 +260,7 @@ def spmm(a: DeviceCSR, X: Tensor, *, Y: Optional[Tensor] = None, addend: Optiona
                                _stream()), "mi_spmm_csr_ex_f32")
     if ev is not None:
         ev[1].record()
-        SPMM_EVENTS.append(ev)
+        SPMM_EVENTS.append((ev[0], ev[1], "sparse" if (x_map is not None or row_list is not None) else "dense"))
 
 
 def expand_rows(a: DeviceCSR) -> Tensor:

@@ -60,10 +60,11 @@ def main():
             b = (2 * f + w) * 1024
             traffic[k] = b
             lines.append(f"| `{k}` | {f:.0f} | {w:.0f} | {b/1e9:.3f} GB |")
-    spmm = sum(v for k, v in traffic.items() if k.startswith("spmm_"))
-    spmm_us = sum(v for k, v in per_kernel.items() if k.startswith("spmm_"))
+    dense = lambda k: k.startswith("spmm_") and not k.rstrip(">").endswith("true")  # SPARSE=false instantiations
+    spmm = sum(v for k, v in traffic.items() if dense(k))
+    spmm_us = sum(v for k, v in per_kernel.items() if dense(k))
     if spmm:
-        lines.append(f"\nOne propagate launch (items + rows + fixup kernels): {spmm/1e9:.3f} GB of L2-miss traffic"
+        lines.append(f"\nOne DENSE propagate launch (items + rows + fixup kernels, SPARSE=false): {spmm/1e9:.3f} GB of L2-miss traffic"
                      + (f", {spmm_us:.1f} us summed kernel time => {spmm/spmm_us/1e6:.2f} TB/s" if spmm_us else ""))
     with open(out + ".md", "w") as fh:
         fh.write(f"# {os.path.basename(out)}\n\n" + "\n".join(lines) + "\n")
