@@ -198,6 +198,8 @@ __global__ __launch_bounds__(kBlock) void gather_rows_kernel(int64_t n_max, cons
 }
 
 // ------------------------------------------------------------------ Adam ---------------
+// One wavefront per group of rows: lane -> (row within group, float4 column), so the row index (needed
+// for the L2 weight) costs no integer division, and every lane keeps 4 independent 16-byte loads in flight.
 __global__ __launch_bounds__(kBlock) void adam_kernel(int64_t n_rows, int d4, float4* __restrict__ p,
                                                       int64_t ldp4, const float4* __restrict__ g,
                                                       int64_t ldg4, float4* __restrict__ m,
@@ -205,31 +207,35 @@ __global__ __launch_bounds__(kBlock) void adam_kernel(int64_t n_rows, int d4, fl
                                                       const float* __restrict__ reg_w, float b1, float b2,
                                                       float omb1, float omb2, float step_size,
                                                       float bc2_sqrt, float eps) {
-    const int64_t total = n_rows * d4;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-         i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t r = i / d4;
-        const int c = (int)(i - r * d4);
-        float4 pp = p[r * ldp4 + c];
-        float4 gg = g[r * ldg4 + c];
-        float4 mm = m[i];
-        float4 vv = v[i];
-        if (reg_w) {
-            const float w = reg_w[r];
-            gg.x = fmaf(w, pp.x, gg.x);
-            gg.y = fmaf(w, pp.y, gg.y);
-            gg.z = fmaf(w, pp.z, gg.z);
-            gg.w = fmaf(w, pp.w, gg.w);
-        }
+    // rows per pass of one block: blockDim.x / lanes-per-row, lanes-per-row = smallest power of two >= d4 (<= 256)
+    int lpr = 1;
+    while (lpr < d4 && lpr < (int)blockDim.x) lpr <<= 1;
+    const int rows_per_block = blockDim.x / lpr;
+    const int sub = threadIdx.x / lpr, e0 = threadIdx.x % lpr;
+    for (int64_t r = (int64_t)blockIdx.x * rows_per_block + sub; r < n_rows; r += (int64_t)gridDim.x * rows_per_block) {
+        const float w = reg_w ? reg_w[r] : 0.f;
+        for (int c = e0; c < d4; c += lpr) {
+            const int64_t i = r * d4 + c;
+            float4 pp = p[r * ldp4 + c];
+            float4 gg = g[r * ldg4 + c];
+            float4 mm = m[i];
+            float4 vv = v[i];
+            if (reg_w) {
+                gg.x = fmaf(w, pp.x, gg.x);
+                gg.y = fmaf(w, pp.y, gg.y);
+                gg.z = fmaf(w, pp.z, gg.z);
+                gg.w = fmaf(w, pp.w, gg.w);
+            }
 #define MI_ADAM_1(f)                                              \
-        mm.f = b1 * mm.f + omb1 * gg.f;                           \
-        vv.f = b2 * vv.f + omb2 * gg.f * gg.f;                    \
-        pp.f = pp.f - step_size * (mm.f / (sqrtf(vv.f) / bc2_sqrt + eps));
-        MI_ADAM_1(x) MI_ADAM_1(y) MI_ADAM_1(z) MI_ADAM_1(w)
+            mm.f = b1 * mm.f + omb1 * gg.f;                           \
+            vv.f = b2 * vv.f + omb2 * gg.f * gg.f;                    \
+            pp.f = pp.f - step_size * (mm.f / (sqrtf(vv.f) / bc2_sqrt + eps));
+            MI_ADAM_1(x) MI_ADAM_1(y) MI_ADAM_1(z) MI_ADAM_1(w)
 #undef MI_ADAM_1
-        p[r * ldp4 + c] = pp;
-        m[i] = mm;
-        v[i] = vv;
+            p[r * ldp4 + c] = pp;
+            m[i] = mm;
+            v[i] = vv;
+        }
     }
 }
 
@@ -336,7 +342,7 @@ int mi_adam_dense_f32(int64_t n_rows, int64_t d, float* p, int64_t ldp, const fl
     const float bc2_sqrt = (float)sqrt(bc2);
     const int64_t total = n_rows * (d / 4);
     int64_t blocks = mi_ceil_div(total, kBlock);
-    if (blocks > 256 * 16) blocks = 256 * 16;
+    if (blocks > 256 * 32) blocks = 256 * 32;
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, n_rows,
                        (int)(d / 4), reinterpret_cast<float4*>(p), ldp / 4,
                        reinterpret_cast<const float4*>(grad), ldgr / 4, reinterpret_cast<float4*>(m),
