@@ -333,6 +333,44 @@ int mi_embed_concat_f32(int64_t n, int32_t n_cols, const int64_t* x,
                         const float* const* tables, const int64_t* table_rows, const int32_t* dims,
                         float max_norm, float* out, int64_t ldo, mi_stream_t stream);
 
+/* ------------------------------------------------------------------------------------
+ * N1  on-device N-hop subgraph sampler for the ranker.
+ * replaces: GraphDataset.__getitem__ + helpers (data/dataset.py:39-309, train mode) for a whole
+ *           batch of seed users, and the PyG collate of the resulting HeteroData items
+ *           (data/data_loader.py:48): sampled positive label edges (with
+ *           replacement), negatives (fast path / exact path), the seed user's own edges, the
+ *           N-hop neighbourhood with the fan-out cap on both frontiers, sorted-unique relabelling.
+ * users_ptr/users_idx: CSR user -> article ids IN LIST ORDER (edges_*.pt); articles_ptr/idx:
+ * CSR article -> user ids (rev_edges_*.pt); all int32, device.  id_max = max article id of the
+ * graph, num_edges its edge count (the fast-path test E / n_neg > 100).  max_pos / max_neg:
+ * capacity per sample of the label lists, >= max(2, floor(max_degree*ratio)) and
+ * >= max(k-1, int(neg_ratio*max_pos)).
+ * Two calls per batch because the output sizes are data dependent:
+ *   mi_sampler_count  runs the walk, SYNCHRONISES, returns totals_host[4] = {user nodes,
+ *                     article nodes, message-passing edges, label edges} of the collated batch;
+ *   mi_sampler_emit   writes user_ids int64[tot0], article_ids int64[tot1] (global ids, sorted
+ *                     within each sample), edge_index int64[2, tot2], edge_label_index
+ *                     int64[2, tot3] (batch-local ids), edge_label int64[tot3],
+ *                     user_ptr / article_ptr int64[batch+1] (node offsets per sample).
+ * Randomness: Philox4x32-10 keyed on (seed, step); bit-exact mirror in oracle/sampler_ref.py.
+ * ---------------------------------------------------------------------------------- */
+typedef struct mi_sampler_desc {
+    int32_t batch, n_hops, num_neighbors, k;
+    int32_t randomization, max_pos, max_neg, reserved;
+    int64_t num_users, num_articles, num_edges, id_max;
+    const int32_t* users_ptr;    const int32_t* users_idx;
+    const int32_t* articles_ptr; const int32_t* articles_idx;
+    double positive_edges_ratio, negative_edges_ratio;
+} mi_sampler_desc;
+
+size_t mi_sampler_workspace_bytes(const mi_sampler_desc* d);
+int    mi_sampler_count(const mi_sampler_desc* d, const int64_t* seed_users, uint64_t seed, uint64_t step,
+                        void* ws, size_t ws_bytes, int64_t* totals_host, mi_stream_t stream);
+int    mi_sampler_emit(const mi_sampler_desc* d, const int64_t* seed_users, void* ws, size_t ws_bytes,
+                       const int64_t* totals_host, int64_t* user_ids, int64_t* article_ids,
+                       int64_t* edge_index, int64_t* edge_label_index, int64_t* edge_label,
+                       int64_t* user_ptr, int64_t* article_ptr, mi_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -27,6 +27,14 @@ class SpmmExStruct(Structure):
                 ("n_list", c_int64)]
 
 
+class SamplerDesc(Structure):
+    _fields_ = [("batch", c_int32), ("n_hops", c_int32), ("num_neighbors", c_int32), ("k", c_int32),
+                ("randomization", c_int32), ("max_pos", c_int32), ("max_neg", c_int32), ("reserved", c_int32),
+                ("num_users", c_int64), ("num_articles", c_int64), ("num_edges", c_int64), ("id_max", c_int64),
+                ("users_ptr", c_void_p), ("users_idx", c_void_p), ("articles_ptr", c_void_p), ("articles_idx", c_void_p),
+                ("positive_edges_ratio", c_double), ("negative_edges_ratio", c_double)]
+
+
 P = c_void_p
 _PROTOTYPES = {
     # name: (restype, [argtypes])
@@ -66,6 +74,9 @@ _PROTOTYPES = {
     "mi_segment_max_bwd_f32": (c_int32, [c_int64, c_int64, P, P, c_int64, P, c_int64, P]),
     "mi_embed_concat_f32": (c_int32, [c_int64, c_int32, P, POINTER(c_void_p), POINTER(c_int64), POINTER(c_int32),
                                       c_float, P, c_int64, P]),
+    "mi_sampler_workspace_bytes": (c_size_t, [POINTER(SamplerDesc)]),
+    "mi_sampler_count": (c_int32, [POINTER(SamplerDesc), P, c_uint64, c_uint64, P, c_size_t, POINTER(c_int64), P]),
+    "mi_sampler_emit": (c_int32, [POINTER(SamplerDesc), P, P, c_size_t, POINTER(c_int64), P, P, P, P, P, P, P, P]),
     "mi_adam_dense_f32": (c_int32, [c_int64, c_int64, P, c_int64, P, c_int64, P, P, P,
                                     c_double, c_double, c_double, c_double, c_int64, P]),
 }

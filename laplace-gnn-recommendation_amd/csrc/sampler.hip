@@ -1,0 +1,516 @@
+// N1: on-device N-hop subgraph sampler for the ranker — the algorithm of the reference's live sampler
+// `GraphDataset.__getitem__` (data/dataset.py:39-309, train mode) for a whole batch of seed users at
+// once, with no host round trip except one read-back of four totals to size the outputs.
+//
+// Per seed user (one workgroup per sample in most phases):
+//   seed     positives with replacement, negatives (fast path: uniform in [0, id_max); exact path for
+//            tiny graphs), hop-0 article cut                                   data/dataset.py:42-106,189-230
+//   expand   per hop: mark the users of the <= n queued articles in a per-sample bitmap (atomicOr),
+//            drop the explored ones, popcount-scan, draw a uniform n-subset of the set bits (Floyd on
+//            ranks, rank -> id by select), cut the next article queue          data/dataset.py:258-293
+//   relabel  article bitmap + popcount prefix = sorted-unique buckets; users ranked directly
+//            (bucketize, data/dataset.py:134-150,233-241)
+//   emit     collated batch (disjoint union of the samples, PyG collate semantics): global node ids,
+//            edge_index, edge_label_index, edge_label, per-sample node offsets
+//
+// Every random choice is a counter-based Philox4x32-10 draw keyed on (seed, step) and counted by
+// (purpose, seed user, i, j): oracle/sampler_ref.py mirrors it bit for bit (integer work => exact parity).
+#include "common.hpp"
+
+namespace {
+
+enum { P_POS = 1, P_NEG = 2, P_ART_CUT = 3, P_USER_CUT = 4, P_NEG_EXACT = 5 };
+constexpr int kMaxFan = 1024;       // num_neighbors cap of this implementation
+constexpr int kSelThreads = 1024;
+
+struct Smp {
+    int32_t B, H, n;
+    int64_t U, A, E, id_max;
+    const int32_t* uptr; const int32_t* uidx;
+    const int32_t* aptr; const int32_t* aidx;
+    const int64_t* seeds;
+    double pos_ratio, neg_ratio;
+    int32_t k, randomization;
+    uint64_t seed, step;
+    int32_t max_pos, max_neg;
+    uint32_t* bm_users; int32_t WU;
+    uint32_t* bm_art;   int32_t WA;
+    int32_t* pre_a;
+    int32_t* uq; int32_t* uq_n; int32_t* uq_local; int32_t* uq_estart;
+    int32_t* aq; int32_t* aq_n;
+    int32_t* pos_items; int32_t* neg_items; int32_t* n_pos; int32_t* n_neg;
+    int32_t* cnt;   // [B][4]
+    int32_t* off;   // [4][B+1]
+};
+
+__device__ __forceinline__ uint64_t rand_below(uint64_t m, uint32_t purpose, uint32_t seed_user, uint32_t i,
+                                               uint32_t j, uint64_t seed, uint64_t step) {
+    const uint32_t c3 = (purpose & 0xFFu) | ((uint32_t)(step & 0xFFFFFFu) << 8);
+    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)((seed >> 32) ^ (step >> 24));
+    MiPhilox r = mi_philox4x32(i, j, seed_user, c3, k0, k1);
+    return (((uint64_t)r.c[0] << 32) | r.c[1]) % m;
+}
+
+// Floyd: n distinct positions of [0, L), ascending, into out[] (all of [0, L) when L <= n). One thread.
+__device__ int floyd_subset(int64_t L, int n, uint32_t purpose, uint32_t seed_user, uint32_t i, uint64_t seed,
+                            uint64_t step, int32_t* out) {
+    if (L <= n) {
+        for (int t = 0; t < (int)L; ++t) out[t] = t;
+        return (int)L;
+    }
+    int c = 0;
+    for (int64_t j = L - n; j < L; ++j) {
+        int32_t t = (int32_t)rand_below((uint64_t)(j + 1), purpose, seed_user, i, (uint32_t)j, seed, step);
+        bool seen = false;
+        for (int q = 0; q < c; ++q) seen |= (out[q] == t);
+        out[c++] = seen ? (int32_t)j : t;
+    }
+    for (int a = 1; a < c; ++a) {  // insertion sort, ascending
+        int32_t v = out[a];
+        int b = a - 1;
+        while (b >= 0 && out[b] > v) { out[b + 1] = out[b]; --b; }
+        out[b + 1] = v;
+    }
+    return c;
+}
+
+// positions (ascending) of the concatenated article lists of `users[0..nu)` -> article ids
+__device__ void cut_articles(const Smp& p, const int32_t* users, int nu, uint32_t seed_user, int hop, int32_t* sel,
+                             int32_t* aq_out, int32_t* aq_n_out) {
+    int64_t L = 0;
+    for (int t = 0; t < nu; ++t) L += p.uptr[users[t] + 1] - p.uptr[users[t]];
+    const int c = floyd_subset(L, p.n, P_ART_CUT, seed_user, (uint32_t)hop, p.seed, p.step, sel);
+    int t = 0;
+    int64_t base = 0;
+    for (int q = 0; q < c; ++q) {
+        while (t < nu && sel[q] >= base + (p.uptr[users[t] + 1] - p.uptr[users[t]])) {
+            base += p.uptr[users[t] + 1] - p.uptr[users[t]];
+            ++t;
+        }
+        aq_out[q] = p.uidx[p.uptr[users[t]] + (sel[q] - base)];
+    }
+    *aq_n_out = c;
+}
+
+// ---- phase 1: label edges + hop-0 article cut -------------------------------------------------
+__global__ __launch_bounds__(256) void smp_seed_kernel(Smp p) {
+    __shared__ int32_t sel[kMaxFan];
+    __shared__ int32_t sh_npos, sh_nneg, sh_fast;
+    const int s = blockIdx.x, tid = threadIdx.x;
+    const int32_t u = (int32_t)p.seeds[s];
+    const int32_t beg = p.uptr[u], deg = p.uptr[u + 1] - beg;
+    int32_t* pos_items = p.pos_items + (int64_t)s * p.max_pos;
+    int32_t* neg_items = p.neg_items + (int64_t)s * p.max_neg;
+    if (tid == 0) {
+        int npos = 0, nneg = 0, fast = 1;
+        if (deg > 0) {
+            if (p.randomization) {
+                const int64_t cut = (int64_t)floor((double)deg * p.pos_ratio);
+                npos = (int)(cut < 1 ? 1 : cut);
+                const double ratio = npos <= 1 ? (double)(p.k - 1) : p.neg_ratio;
+                nneg = (int)(ratio * (double)npos);
+                fast = (nneg == 0) || ((double)p.E / (double)nneg > 100.0);
+            } else {
+                npos = 2;
+                nneg = 1;
+            }
+        }
+        if (npos > p.max_pos) npos = p.max_pos;  // capacities are sized from the max degree: cannot trigger
+        if (nneg > p.max_neg) nneg = p.max_neg;
+        sh_npos = npos; sh_nneg = nneg; sh_fast = fast;
+        p.n_pos[s] = npos;
+        p.uq[((int64_t)s * p.H) * p.n] = u;
+        p.uq_n[(int64_t)s * p.H] = 1;
+        for (int h = 1; h < p.H; ++h) p.uq_n[(int64_t)s * p.H + h] = 0;
+        p.aq_n[s] = 0;
+    }
+    __syncthreads();
+    const int npos = sh_npos, nneg = sh_nneg;
+    if (p.randomization) {
+        for (int i = tid; i < npos; i += blockDim.x)
+            pos_items[i] = p.uidx[beg + (int32_t)rand_below((uint64_t)deg, P_POS, (uint32_t)u, (uint32_t)i, 0, p.seed, p.step)];
+        if (sh_fast) {
+            for (int i = tid; i < nneg; i += blockDim.x)
+                neg_items[i] = (int32_t)rand_below((uint64_t)p.id_max, P_NEG, (uint32_t)u, (uint32_t)i, 0, p.seed, p.step);
+        }
+    } else if (tid == 0 && deg > 0) {  // argmin / argmax (first occurrence), negative = id_max
+        int amin = 0, amax = 0;
+        for (int i = 1; i < deg; ++i) {
+            if (p.uidx[beg + i] < p.uidx[beg + amin]) amin = i;
+            if (p.uidx[beg + i] > p.uidx[beg + amax]) amax = i;
+        }
+        pos_items[0] = p.uidx[beg + amin];
+        pos_items[1] = p.uidx[beg + amax];
+        neg_items[0] = (int32_t)p.id_max;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int nn = nneg;
+        if (p.randomization && !sh_fast) {
+            // exact path (tiny graphs): uniform subset of {0..id_max} minus the distinct sampled positives.
+            // banned = sorted distinct sampled positives, kept in neg_items' tail as scratch.
+            int32_t* banned = neg_items + (p.max_neg - npos > 0 ? p.max_neg - npos : 0);
+            int nb = 0;
+            for (int i = 0; i < npos; ++i) {
+                const int32_t v = pos_items[i];
+                if (v > p.id_max) continue;
+                int q = 0;
+                while (q < nb && banned[q] < v) ++q;
+                if (q < nb && banned[q] == v) continue;
+                for (int r = nb; r > q; --r) banned[r] = banned[r - 1];
+                banned[q] = v;
+                ++nb;
+            }
+            const int64_t M = p.id_max + 1 - nb;
+            const int want = nneg < kMaxFan ? nneg : kMaxFan;
+            nn = floyd_subset(M, want, P_NEG_EXACT, (uint32_t)u, 0, p.seed, p.step, sel);
+            for (int q = 0; q < nn; ++q) {
+                int32_t id = sel[q];
+                for (int b = 0; b < nb; ++b)
+                    if (banned[b] <= id) ++id;
+                sel[q] = id;
+            }
+            for (int q = 0; q < nn; ++q) neg_items[q] = sel[q];
+        }
+        p.n_neg[s] = nn;
+        if (p.H >= 2 && deg > 0) cut_articles(p, &u, 1, (uint32_t)u, 0, sel, p.aq + (int64_t)s * p.n, p.aq_n + s);
+    }
+}
+
+// ---- phase 2 (per hop): mark the users of the queued articles -------------------------------------
+__global__ __launch_bounds__(256) void smp_mark_users_kernel(Smp p) {
+    const int s = blockIdx.y, j = blockIdx.x;
+    if (j >= p.aq_n[s]) return;
+    const int32_t a = p.aq[(int64_t)s * p.n + j];
+    uint32_t* bm = p.bm_users + (int64_t)s * p.WU;
+    for (int32_t q = p.aptr[a] + threadIdx.x; q < p.aptr[a + 1]; q += blockDim.x) {
+        const int32_t v = p.aidx[q];
+        atomicOr(bm + (v >> 5), 1u << (v & 31));
+    }
+}
+
+// ---- phase 3 (per hop): distinct unexplored candidates -> uniform n-subset -> next queue -----------
+__global__ __launch_bounds__(kSelThreads) void smp_select_users_kernel(Smp p, int hop) {
+    __shared__ int32_t scan[kSelThreads + 1];
+    __shared__ int32_t sel[kMaxFan];
+    __shared__ int32_t sh_nsel;
+    const int s = blockIdx.x, tid = threadIdx.x;
+    uint32_t* bm = p.bm_users + (int64_t)s * p.WU;
+    const int32_t u = (int32_t)p.seeds[s];
+    int32_t* uq = p.uq + (int64_t)s * p.H * p.n;
+    int32_t* uq_n = p.uq_n + (int64_t)s * p.H;
+    // explored users are not candidates
+    for (int h = 0; h <= hop; ++h)
+        for (int q = tid; q < uq_n[h]; q += blockDim.x) {
+            const int32_t v = uq[h * p.n + q];
+            atomicAnd(bm + (v >> 5), ~(1u << (v & 31)));
+        }
+    __syncthreads();
+    const int per = (p.WU + kSelThreads - 1) / kSelThreads;
+    const int w0 = min(tid * per, p.WU), w1 = min(w0 + per, p.WU);
+    int c = 0;
+    for (int w = w0; w < w1; ++w) c += __popc(bm[w]);
+    scan[tid + 1] = c;
+    if (tid == 0) scan[0] = 0;
+    __syncthreads();
+    for (int off = 1; off < kSelThreads; off <<= 1) {  // inclusive scan of scan[1..]
+        int v = (tid + 1 > off) ? scan[tid + 1 - off] : 0;
+        __syncthreads();
+        scan[tid + 1] += (tid + 1 > off) ? v : 0;
+        __syncthreads();
+    }
+    if (tid == 0) sh_nsel = floyd_subset(scan[kSelThreads], p.n, P_USER_CUT, (uint32_t)u, (uint32_t)hop, p.seed, p.step, sel);
+    __syncthreads();
+    const int nsel = sh_nsel;
+    for (int q = tid; q < nsel; q += blockDim.x) {  // rank -> id
+        const int32_t r = sel[q];
+        int lo = 0, hi = kSelThreads;  // last t with scan[t] <= r
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (scan[mid] <= r) lo = mid; else hi = mid;
+        }
+        int32_t rem = r - scan[lo];
+        int32_t id = -1;
+        for (int w = min(lo * per, p.WU); w < min(lo * per + per, p.WU); ++w) {
+            uint32_t word = bm[w];
+            const int pc = __popc(word);
+            if (rem < pc) {
+                for (int b = 0; b < rem; ++b) word &= word - 1;  // drop the `rem` lowest set bits
+                id = w * 32 + (__ffs(word) - 1);
+                break;
+            }
+            rem -= pc;
+        }
+        uq[(hop + 1) * p.n + q] = id;
+    }
+    __syncthreads();
+    for (int w = w0; w < w1; ++w) bm[w] = 0u;  // ready for the next hop / batch
+    if (tid == 0) {
+        uq_n[hop + 1] = nsel;
+        p.aq_n[s] = 0;
+        if (hop + 1 <= p.H - 2 && nsel > 0)  // these users will be expanded too: cut their article lists
+            cut_articles(p, uq + (hop + 1) * p.n, nsel, (uint32_t)u, hop + 1, sel, p.aq + (int64_t)s * p.n, p.aq_n + s);
+    }
+}
+
+// ---- phase 4: touched articles -> bitmap ---------------------------------------------------------
+__global__ __launch_bounds__(256) void smp_mark_articles_kernel(Smp p) {
+    const int s = blockIdx.y, j = blockIdx.x;
+    uint32_t* bm = p.bm_art + (int64_t)s * p.WA;
+    if (j == 0) {  // label items
+        const int32_t* pi = p.pos_items + (int64_t)s * p.max_pos;
+        const int32_t* ni = p.neg_items + (int64_t)s * p.max_neg;
+        for (int q = threadIdx.x; q < p.n_pos[s]; q += blockDim.x) atomicOr(bm + (pi[q] >> 5), 1u << (pi[q] & 31));
+        for (int q = threadIdx.x; q < p.n_neg[s]; q += blockDim.x) atomicOr(bm + (ni[q] >> 5), 1u << (ni[q] & 31));
+        return;
+    }
+    const int e = j - 1, h = e / p.n, q = e % p.n;  // user slot (h, q); h = 0 is the seed
+    if (h >= p.H || q >= p.uq_n[(int64_t)s * p.H + h]) return;
+    const int32_t usr = p.uq[((int64_t)s * p.H + h) * p.n + q];
+    for (int32_t x = p.uptr[usr] + threadIdx.x; x < p.uptr[usr + 1]; x += blockDim.x) {
+        const int32_t a = p.uidx[x];
+        atomicOr(bm + (a >> 5), 1u << (a & 31));
+    }
+}
+
+// ---- phase 5: per-sample counts, article rank prefix, user ranks, edge starts ----------------------
+__global__ __launch_bounds__(kSelThreads) void smp_count_kernel(Smp p) {
+    __shared__ int32_t scan[kSelThreads + 1];
+    const int s = blockIdx.x, tid = threadIdx.x;
+    const uint32_t* bm = p.bm_art + (int64_t)s * p.WA;
+    int32_t* pre = p.pre_a + (int64_t)s * p.WA;
+    const int per = (p.WA + kSelThreads - 1) / kSelThreads;
+    const int w0 = min(tid * per, p.WA), w1 = min(w0 + per, p.WA);
+    int c = 0;
+    for (int w = w0; w < w1; ++w) c += __popc(bm[w]);
+    scan[tid + 1] = c;
+    if (tid == 0) scan[0] = 0;
+    __syncthreads();
+    for (int off = 1; off < kSelThreads; off <<= 1) {
+        int v = (tid + 1 > off) ? scan[tid + 1 - off] : 0;
+        __syncthreads();
+        scan[tid + 1] += (tid + 1 > off) ? v : 0;
+        __syncthreads();
+    }
+    int run = scan[tid];
+    for (int w = w0; w < w1; ++w) {
+        pre[w] = run;
+        run += __popc(bm[w]);
+    }
+    const int32_t* uq = p.uq + (int64_t)s * p.H * p.n;
+    const int32_t* uq_n = p.uq_n + (int64_t)s * p.H;
+    int32_t* ul = p.uq_local + (int64_t)s * p.H * p.n;
+    // local id of a user = number of smaller user ids in the sample (all entries are distinct)
+    for (int e = tid; e < p.H * p.n; e += blockDim.x) {
+        const int h = e / p.n, q = e % p.n;
+        if (q >= uq_n[h]) continue;
+        const int32_t v = uq[e];
+        int r = 0;
+        for (int h2 = 0; h2 < p.H; ++h2)
+            for (int q2 = 0; q2 < uq_n[h2]; ++q2) r += (uq[h2 * p.n + q2] < v);
+        ul[e] = r;
+    }
+    if (tid == 0) {
+        int32_t* es = p.uq_estart + (int64_t)s * p.H * p.n;
+        int nu = 0, ne = 0;
+        for (int h = 0; h < p.H; ++h)
+            for (int q = 0; q < uq_n[h]; ++q) {
+                const int32_t v = uq[h * p.n + q];
+                es[h * p.n + q] = ne;
+                ne += p.uptr[v + 1] - p.uptr[v];
+                ++nu;
+            }
+        int32_t* cnt = p.cnt + (int64_t)s * 4;
+        cnt[0] = nu;
+        cnt[1] = scan[kSelThreads];
+        cnt[2] = ne;
+        cnt[3] = p.n_pos[s] + p.n_neg[s];
+    }
+}
+
+__global__ void smp_offsets_kernel(Smp p) {  // B is small: one thread per counter
+    const int c = threadIdx.x;
+    if (c >= 4) return;
+    int32_t run = 0;
+    for (int s = 0; s < p.B; ++s) {
+        p.off[c * (p.B + 1) + s] = run;
+        run += p.cnt[(int64_t)s * 4 + c];
+    }
+    p.off[c * (p.B + 1) + p.B] = run;
+}
+
+struct SmpOut {
+    int64_t* user_ids; int64_t* article_ids;
+    int64_t* edge_index; int64_t n_edges;        // [2, n_edges]
+    int64_t* label_index; int64_t n_labels;      // [2, n_labels]
+    int64_t* labels;                             // [n_labels]
+    int64_t* user_ptr; int64_t* article_ptr;     // [B+1]
+};
+
+__device__ __forceinline__ int32_t article_rank(const Smp& p, int s, int32_t a) {
+    const uint32_t word = p.bm_art[(int64_t)s * p.WA + (a >> 5)];
+    return p.pre_a[(int64_t)s * p.WA + (a >> 5)] + __popc(word & ((1u << (a & 31)) - 1u));
+}
+
+// ---- phase 6: emit ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void smp_emit_edges_kernel(Smp p, SmpOut o) {
+    const int s = blockIdx.y, j = blockIdx.x;
+    const int32_t off_u = p.off[0 * (p.B + 1) + s], off_a = p.off[1 * (p.B + 1) + s];
+    const int32_t off_e = p.off[2 * (p.B + 1) + s], off_l = p.off[3 * (p.B + 1) + s];
+    if (j == 0) {  // label edges: positives in draw order, then negatives
+        const int32_t seed_local = p.uq_local[(int64_t)s * p.H * p.n];
+        const int np_ = p.n_pos[s], nn = p.n_neg[s];
+        for (int q = threadIdx.x; q < np_ + nn; q += blockDim.x) {
+            const int32_t a = q < np_ ? p.pos_items[(int64_t)s * p.max_pos + q] : p.neg_items[(int64_t)s * p.max_neg + q - np_];
+            o.label_index[off_l + q] = off_u + seed_local;
+            o.label_index[o.n_labels + off_l + q] = off_a + article_rank(p, s, a);
+            o.labels[off_l + q] = q < np_ ? 1 : 0;
+        }
+        if (threadIdx.x == 0) {
+            o.user_ptr[s] = off_u;
+            o.article_ptr[s] = off_a;
+            if (s == p.B - 1) {
+                o.user_ptr[p.B] = p.off[0 * (p.B + 1) + p.B];
+                o.article_ptr[p.B] = p.off[1 * (p.B + 1) + p.B];
+            }
+        }
+        return;
+    }
+    const int e = j - 1, h = e / p.n, q = e % p.n;
+    if (h >= p.H || q >= p.uq_n[(int64_t)s * p.H + h]) return;
+    const int64_t slot = ((int64_t)s * p.H + h) * p.n + q;
+    const int32_t usr = p.uq[slot], ul = p.uq_local[slot], es = p.uq_estart[slot];
+    if (threadIdx.x == 0) o.user_ids[off_u + ul] = usr;
+    const int32_t beg = p.uptr[usr], deg = p.uptr[usr + 1] - beg;
+    for (int x = threadIdx.x; x < deg; x += blockDim.x) {
+        o.edge_index[off_e + es + x] = off_u + ul;
+        o.edge_index[o.n_edges + off_e + es + x] = off_a + article_rank(p, s, p.uidx[beg + x]);
+    }
+}
+
+__global__ __launch_bounds__(256) void smp_emit_articles_kernel(Smp p, SmpOut o) {
+    const int s = blockIdx.y;
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= p.WA) return;
+    uint32_t word = p.bm_art[(int64_t)s * p.WA + w];
+    int32_t r = p.off[1 * (p.B + 1) + s] + p.pre_a[(int64_t)s * p.WA + w];
+    while (word) {
+        const int b = __ffs(word) - 1;
+        o.article_ids[r++] = (int64_t)w * 32 + b;
+        word &= word - 1;
+    }
+}
+
+size_t smp_scratch_layout(const Smp& p, Smp* out, char* base) {
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        char* r = base ? base + off : nullptr;
+        off += mi_align_up(bytes, 256);
+        return r;
+    };
+    const size_t B = p.B, H = p.H, n = p.n;
+    char* a0 = take(B * p.WU * 4);
+    char* a1 = take(B * p.WA * 4);
+    char* a2 = take(B * p.WA * 4);
+    char* a3 = take(B * H * n * 4);
+    char* a4 = take(B * H * 4);
+    char* a5 = take(B * H * n * 4);
+    char* a6 = take(B * H * n * 4);
+    char* a7 = take(B * n * 4);
+    char* a8 = take(B * 4);
+    char* a9 = take(B * (size_t)p.max_pos * 4);
+    char* a10 = take(B * (size_t)p.max_neg * 4);
+    char* a11 = take(B * 4);
+    char* a12 = take(B * 4);
+    char* a13 = take(B * 4 * 4);
+    char* a14 = take(4 * (B + 1) * 4);
+    if (out) {
+        out->bm_users = (uint32_t*)a0; out->bm_art = (uint32_t*)a1; out->pre_a = (int32_t*)a2;
+        out->uq = (int32_t*)a3; out->uq_n = (int32_t*)a4; out->uq_local = (int32_t*)a5; out->uq_estart = (int32_t*)a6;
+        out->aq = (int32_t*)a7; out->aq_n = (int32_t*)a8; out->pos_items = (int32_t*)a9; out->neg_items = (int32_t*)a10;
+        out->n_pos = (int32_t*)a11; out->n_neg = (int32_t*)a12; out->cnt = (int32_t*)a13; out->off = (int32_t*)a14;
+    }
+    return off;
+}
+
+int fill_params(Smp& p, const mi_sampler_desc* d) {
+    MI_CHECK_ARG(d && d->batch > 0 && d->n_hops >= 1 && d->num_neighbors >= 1 && d->num_neighbors <= kMaxFan);
+    MI_CHECK_ARG(d->num_users > 0 && d->num_articles > 0 && d->users_ptr && d->users_idx && d->articles_ptr && d->articles_idx);
+    MI_CHECK_ARG(d->max_pos >= 2 && d->max_neg >= 1);
+    if (d->num_users >= INT32_MAX || d->num_articles >= INT32_MAX || d->num_edges >= INT32_MAX) return MI_ERR_TOO_LARGE;
+    p.B = d->batch; p.H = d->n_hops; p.n = d->num_neighbors;
+    p.U = d->num_users; p.A = d->num_articles; p.E = d->num_edges; p.id_max = d->id_max;
+    p.uptr = d->users_ptr; p.uidx = d->users_idx; p.aptr = d->articles_ptr; p.aidx = d->articles_idx;
+    p.pos_ratio = d->positive_edges_ratio; p.neg_ratio = d->negative_edges_ratio; p.k = d->k;
+    p.randomization = d->randomization;
+    p.max_pos = d->max_pos; p.max_neg = d->max_neg;
+    p.WU = (int32_t)((d->num_users + 31) / 32);
+    p.WA = (int32_t)((d->num_articles + 31) / 32);
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t mi_sampler_workspace_bytes(const mi_sampler_desc* d) {
+    Smp p;
+    if (fill_params(p, d)) return 0;
+    return smp_scratch_layout(p, nullptr, nullptr);
+}
+
+// Phase A: everything up to the per-sample counts; writes totals[4] (users, articles, edges, labels)
+// to the HOST array after synchronising the stream.
+int mi_sampler_count(const mi_sampler_desc* d, const int64_t* seed_users, uint64_t seed, uint64_t step, void* ws,
+                     size_t ws_bytes, int64_t* totals_host, mi_stream_t stream) {
+    Smp p;
+    int rc = fill_params(p, d);
+    if (rc) return rc;
+    MI_CHECK_ARG(seed_users && ws && totals_host);
+    if (ws_bytes < smp_scratch_layout(p, nullptr, nullptr)) return MI_ERR_WORKSPACE;
+    smp_scratch_layout(p, &p, static_cast<char*>(ws));
+    p.seeds = seed_users; p.seed = seed; p.step = step;
+    hipStream_t s = (hipStream_t)stream;
+    MI_HIP(hipMemsetAsync(p.bm_users, 0, (size_t)p.B * p.WU * 4, s));
+    MI_HIP(hipMemsetAsync(p.bm_art, 0, (size_t)p.B * p.WA * 4, s));
+    hipLaunchKernelGGL(smp_seed_kernel, dim3(p.B), dim3(256), 0, s, p);
+    for (int hop = 0; hop <= p.H - 2; ++hop) {
+        hipLaunchKernelGGL(smp_mark_users_kernel, dim3(p.n, p.B), dim3(256), 0, s, p);
+        hipLaunchKernelGGL(smp_select_users_kernel, dim3(p.B), dim3(kSelThreads), 0, s, p, hop);
+    }
+    hipLaunchKernelGGL(smp_mark_articles_kernel, dim3(1 + p.H * p.n, p.B), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(smp_count_kernel, dim3(p.B), dim3(kSelThreads), 0, s, p);
+    hipLaunchKernelGGL(smp_offsets_kernel, dim3(1), dim3(64), 0, s, p);
+    int32_t tot[4];
+    for (int c = 0; c < 4; ++c)
+        MI_HIP(hipMemcpyAsync(&tot[c], p.off + c * (p.B + 1) + p.B, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    MI_HIP(hipStreamSynchronize(s));
+    for (int c = 0; c < 4; ++c) totals_host[c] = tot[c];
+    return mi_launch_status();
+}
+
+// Phase B: emit into caller-allocated outputs sized from the totals of phase A (same ws, untouched between).
+int mi_sampler_emit(const mi_sampler_desc* d, const int64_t* seed_users, void* ws, size_t ws_bytes,
+                    const int64_t* totals_host, int64_t* user_ids, int64_t* article_ids, int64_t* edge_index,
+                    int64_t* edge_label_index, int64_t* edge_label, int64_t* user_ptr, int64_t* article_ptr,
+                    mi_stream_t stream) {
+    Smp p;
+    int rc = fill_params(p, d);
+    if (rc) return rc;
+    MI_CHECK_ARG(ws && totals_host && user_ids && article_ids && edge_label_index && edge_label && user_ptr && article_ptr);
+    MI_CHECK_ARG(totals_host[2] == 0 || edge_index);
+    if (ws_bytes < smp_scratch_layout(p, nullptr, nullptr)) return MI_ERR_WORKSPACE;
+    smp_scratch_layout(p, &p, static_cast<char*>(ws));
+    p.seeds = seed_users;
+    SmpOut o;
+    o.user_ids = user_ids; o.article_ids = article_ids;
+    o.edge_index = edge_index; o.n_edges = totals_host[2];
+    o.label_index = edge_label_index; o.n_labels = totals_host[3];
+    o.labels = edge_label; o.user_ptr = user_ptr; o.article_ptr = article_ptr;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(smp_emit_edges_kernel, dim3(1 + p.H * p.n, p.B), dim3(256), 0, s, p, o);
+    hipLaunchKernelGGL(smp_emit_articles_kernel, dim3((p.WA + 255) / 256, p.B), dim3(256), 0, s, p, o);
+    return mi_launch_status();
+}
+
+}  // extern "C"

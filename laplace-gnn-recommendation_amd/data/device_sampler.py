@@ -1,0 +1,103 @@
+"""On-device N-hop sampler: whole batches of the ranker's training subgraphs are
+sampled, relabelled and collated on the GPU (csrc/sampler.hip) — the mini-batch never exists on
+the host.  Same algorithm as `GraphDataset.__getitem__` (data/dataset.py of the reference) + the
+PyG collate; draws come from a counter-based Philox stream (oracle/sampler_ref.py mirrors it)."""
+from __future__ import annotations
+
+import ctypes
+import math
+from typing import Iterator, Optional
+
+import numpy as np
+import torch as t
+from torch import Tensor
+
+from .. import _lib
+from .._lib import SamplerDesc, check
+from ..hetero import HeteroData
+from ..utils.constants import Constants
+from .dataset import AdjList
+
+
+class DeviceGraphSampler:
+    def __init__(self, config, graph: HeteroData, users_adj_list, articles_adj_list, batch_size: Optional[int] = None,
+                 randomization: bool = True, device: str = "cuda", seed: int = 0):
+        self.config, self.device, self.seed = config, t.device(device), int(seed)
+        self.batch_size = int(batch_size if batch_size is not None else config.batch_size)
+        self.randomization = randomization
+        ux, ax = graph[Constants.node_user].x, graph[Constants.node_item].x
+        n_users, n_articles = ux.shape[0], ax.shape[0]
+        users, articles = AdjList(users_adj_list, n_users), AdjList(articles_adj_list, n_articles)
+        ei = graph[Constants.edge_key].edge_index
+        self.num_edges, self.id_max = int(ei.shape[1]), int(ei[1].max())
+        dev = self.device
+        to32 = lambda a: t.from_numpy(np.ascontiguousarray(a.astype(np.int32))).to(dev)
+        self.uptr, self.uidx = to32(users.ptr), to32(users.idx)
+        self.aptr, self.aidx = to32(articles.ptr), to32(articles.idx)
+        self.user_x, self.article_x = ux.to(dev), ax.to(dev)
+        self.num_users, self.num_articles = n_users, n_articles
+        max_deg = int(np.diff(users.ptr).max()) if n_users else 1
+        self.max_pos = max(2, math.floor(max_deg * config.positive_edges_ratio) if randomization else 2)
+        self.max_neg = max(1, config.k - 1, int(config.negative_edges_ratio * self.max_pos))
+        self._desc = self._make_desc(self.batch_size)
+        self._ws = t.empty(int(_lib.lib().mi_sampler_workspace_bytes(ctypes.byref(self._desc))), dtype=t.uint8, device=dev)
+        self.step = 0
+
+    def _make_desc(self, batch: int) -> SamplerDesc:
+        c = self.config
+        return SamplerDesc(batch, int(c.n_hop_neighbors), int(c.num_neighbors), int(c.k), 1 if self.randomization else 0,
+                           self.max_pos, self.max_neg, 0, self.num_users, self.num_articles, self.num_edges, self.id_max,
+                           self.uptr.data_ptr(), self.uidx.data_ptr(), self.aptr.data_ptr(), self.aidx.data_ptr(),
+                           float(c.positive_edges_ratio), float(c.negative_edges_ratio))
+
+    def __len__(self) -> int:
+        return (self.num_users + self.batch_size - 1) // self.batch_size
+
+    def sample(self, seed_users: Tensor, step: Optional[int] = None, raw: bool = False):
+        """Collated batch for `seed_users` (int64, any device). raw=True returns the flat arrays."""
+        if step is None:
+            step = self.step
+            self.step += 1
+        seeds = seed_users.to(self.device, t.int64).contiguous()
+        B = seeds.numel()
+        if B > self.batch_size:
+            raise ValueError("more seed users than the sampler's batch size")
+        desc = self._desc if B == self.batch_size else self._make_desc(B)
+        L = _lib.lib()
+        stream = t.cuda.current_stream().cuda_stream
+        totals = (ctypes.c_int64 * 4)()
+        check(L.mi_sampler_count(ctypes.byref(desc), seeds.data_ptr(), self.seed & (2**64 - 1), int(step) & (2**64 - 1),
+                                 self._ws.data_ptr(), self._ws.numel(), totals, stream), "mi_sampler_count")
+        nu, na, ne, nl = (int(x) for x in totals)
+        dev = self.device
+        user_ids = t.empty(nu, dtype=t.int64, device=dev)
+        article_ids = t.empty(na, dtype=t.int64, device=dev)
+        edge_index = t.empty(2, ne, dtype=t.int64, device=dev)
+        label_index = t.empty(2, nl, dtype=t.int64, device=dev)
+        labels = t.empty(nl, dtype=t.int64, device=dev)
+        user_ptr = t.empty(B + 1, dtype=t.int64, device=dev)
+        article_ptr = t.empty(B + 1, dtype=t.int64, device=dev)
+        check(L.mi_sampler_emit(ctypes.byref(desc), seeds.data_ptr(), self._ws.data_ptr(), self._ws.numel(), totals,
+                                user_ids.data_ptr(), article_ids.data_ptr(), edge_index.data_ptr() if ne else None,
+                                label_index.data_ptr(), labels.data_ptr(), user_ptr.data_ptr(), article_ptr.data_ptr(),
+                                stream), "mi_sampler_emit")
+        if raw:
+            return {"user_ids": user_ids, "article_ids": article_ids, "edge_index": edge_index,
+                    "edge_label_index": label_index, "edge_label": labels, "user_ptr": user_ptr, "article_ptr": article_ptr}
+        data = HeteroData()
+        data[Constants.node_user].x = self.user_x[user_ids]
+        data[Constants.node_item].x = self.article_x[article_ids]
+        data[Constants.edge_key].edge_index = edge_index
+        data[Constants.edge_key].edge_label_index = label_index
+        data[Constants.edge_key].edge_label = labels
+        data[Constants.rev_edge_key].edge_index = edge_index.flip(0)
+        data[Constants.rev_edge_key].edge_label_index = label_index.flip(0)
+        data[Constants.rev_edge_key].edge_label = labels
+        return data
+
+    def __iter__(self) -> Iterator[HeteroData]:
+        """One epoch: every user once, shuffled on device (DataLoader(shuffle=True) semantics)."""
+        g = t.Generator(device="cpu").manual_seed(self.seed + self.step)
+        order = t.randperm(self.num_users, generator=g)
+        for b in range(0, self.num_users, self.batch_size):
+            yield self.sample(order[b:b + self.batch_size])

@@ -1,0 +1,95 @@
+"""GPU: the on-device N-hop sampler (csrc/sampler.hip) against its bit-exact numpy mirror, and end to
+end into the ranker."""
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch as t
+
+from oracle import sampler_ref as SR
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _graph(seed, U, A, E, zipf=1.0):
+    from laplace_amd import synthetic as S
+    spec = S.SyntheticSpec(U, A, E, seed=seed, deg_min=1, deg_max=min(400, A), zipf_s=zipf)
+    return S.generate_hetero(spec, customer_cards=(50, 2, 84), article_cards=(40, 9))
+
+
+def _cfg(**kw):
+    base = dict(k=12, num_neighbors=8, n_hop_neighbors=2, positive_edges_ratio=0.5, negative_edges_ratio=3.0, batch_size=16)
+    base.update(kw)
+    return SimpleNamespace(**base)
+
+
+@pytest.mark.parametrize("hops,fan,E,rand", [(1, 8, 6000, True), (2, 8, 6000, True), (3, 5, 6000, True), (3, 64, 6000, True),
+                                             (2, 8, 900, True), (2, 1000, 6000, False), (4, 3, 20000, True)])
+def test_device_sampler_bit_exact_vs_mirror(hops, fan, E, rand):
+    from laplace_amd.data.device_sampler import DeviceGraphSampler
+    from laplace_amd.utils.constants import Constants
+    graph, users, articles = _graph(seed=hops * 7 + fan, U=300, A=120, E=E)
+    cfg = _cfg(n_hop_neighbors=hops, num_neighbors=fan)
+    smp = DeviceGraphSampler(cfg, graph, users, articles, batch_size=16, randomization=rand, device=DEV, seed=1234)
+    ei = graph[Constants.edge_key].edge_index
+    ucsr, acsr = SR.CsrAdj(users.ptr, users.idx), SR.CsrAdj(articles.ptr, articles.idx)
+    g = t.Generator().manual_seed(0)
+    for step in (0, 1, 77):
+        seeds = t.randperm(300, generator=g)[:16]
+        got = smp.sample(seeds, step=step, raw=True)
+        want = SR.sample_batch(seeds.tolist(), ucsr, acsr, int(ei.shape[1]), int(ei[1].max()), cfg, 1234, step, rand)
+        for key in ("user_ids", "article_ids", "edge_index", "edge_label_index", "edge_label"):
+            assert np.array_equal(got[key].cpu().numpy(), want[key]), (key, step)
+        assert np.array_equal(got["user_ptr"].cpu().numpy(), want["user_ptr"])
+        assert np.array_equal(got["article_ptr"].cpu().numpy(), want["article_ptr"])
+    # a short last batch reuses the scratch with a smaller descriptor
+    got = smp.sample(t.tensor([5, 9, 200]), step=3, raw=True)
+    want = SR.sample_batch([5, 9, 200], ucsr, acsr, int(ei.shape[1]), int(ei[1].max()), cfg, 1234, 3, rand)
+    assert np.array_equal(got["edge_index"].cpu().numpy(), want["edge_index"])
+
+
+def test_device_sampler_hub_graph_and_collated_heterodata():
+    """Hub articles (10^4+ users), default fan-out 64: bitmap marking + select; the HeteroData it returns
+    has the collate layout the model consumes."""
+    from laplace_amd.data.device_sampler import DeviceGraphSampler
+    from laplace_amd.utils.constants import Constants
+    graph, users, articles = _graph(seed=3, U=30_000, A=2_000, E=400_000, zipf=1.1)
+    cfg = _cfg(n_hop_neighbors=3, num_neighbors=64, batch_size=24)
+    smp = DeviceGraphSampler(cfg, graph, users, articles, randomization=True, device=DEV, seed=5)
+    ei = graph[Constants.edge_key].edge_index
+    ucsr, acsr = SR.CsrAdj(users.ptr, users.idx), SR.CsrAdj(articles.ptr, articles.idx)
+    seeds = t.arange(100, 124)
+    got = smp.sample(seeds, step=9, raw=True)
+    want = SR.sample_batch(seeds.tolist(), ucsr, acsr, int(ei.shape[1]), int(ei[1].max()), cfg, 5, 9, True)
+    for key in ("user_ids", "article_ids", "edge_index", "edge_label_index", "edge_label"):
+        assert np.array_equal(got[key].cpu().numpy(), want[key]), key
+    batch = smp.sample(seeds, step=9)
+    s, r = batch[Constants.edge_key], batch[Constants.rev_edge_key]
+    assert t.equal(batch[Constants.node_user].x.cpu(), graph[Constants.node_user].x[t.from_numpy(want["user_ids"])])
+    assert t.equal(batch[Constants.node_item].x.cpu(), graph[Constants.node_item].x[t.from_numpy(want["article_ids"])])
+    assert t.equal(r.edge_index, s.edge_index.flip(0)) and t.equal(r.edge_label, s.edge_label)
+    assert int(s.edge_index[0].max()) < batch[Constants.node_user].x.shape[0]
+    assert int(s.edge_index[1].max()) < batch[Constants.node_item].x.shape[0]
+    assert batch.metadata() == ([Constants.node_user, Constants.node_item], [Constants.edge_key, Constants.rev_edge_key])
+
+
+def test_ranker_trains_from_device_sampled_batches():
+    from laplace_amd.data.device_sampler import DeviceGraphSampler
+    from laplace_amd.model.encoder_decoder import Encoder_Decoder_Model
+    from laplace_amd.model.layers import get_SAGEConv_layers, get_linear_layers
+    from laplace_amd.training import train_with_dataloader
+    from laplace_amd.utils.get_info import get_feature_info
+    graph, users, articles = _graph(seed=8, U=600, A=150, E=6000)
+    cfg = _cfg(n_hop_neighbors=2, num_neighbors=8, batch_size=32)
+    smp = DeviceGraphSampler(cfg, graph, users, articles, device=DEV, seed=2)
+    t.manual_seed(0)
+    first = smp.sample(t.arange(32), step=0)
+    model = Encoder_Decoder_Model(get_SAGEConv_layers(2, 64, 32, "add"), get_linear_layers(2, 64, 64, 1),
+                                  get_feature_info(graph), first.metadata(), True, "sum", True, 0.0, 0.2).to(DEV)
+    model.initialize_encoder_input_size(first)
+    opt = t.optim.Adam(model.parameters(), lr=0.01)
+    first_epoch = train_with_dataloader(model, opt, smp, 0, DEV)
+    for ep in range(1, 4):
+        losses = train_with_dataloader(model, opt, smp, ep, DEV)
+    assert np.isfinite(losses).all() and np.mean(losses) < np.mean(first_epoch)
