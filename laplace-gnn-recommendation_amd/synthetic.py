@@ -78,8 +78,9 @@ def generate(spec: SyntheticSpec) -> t.Tensor:
         np.minimum(i, I - 1, out=i)
         keys = np.unique(np.concatenate([keys, u * I + i]))
         have = np.bincount(keys // I, minlength=U)
-    if keys.size < E:
-        raise RuntimeError(f"generator produced {keys.size} < {E} distinct edges")
+    while keys.size < E:  # dense small graphs: the Zipf head saturates; fill up with uniform pairs
+        extra = rng.integers(0, U * I, size=int((E - keys.size) * 1.5) + 16)
+        keys = np.unique(np.concatenate([keys, extra]))
     if keys.size > E:  # trim uniformly, but never a user's only edge
         u_of = keys // I
         first = np.ones(keys.size, dtype=bool)

@@ -25,7 +25,7 @@ def _cfg(**kw):
 
 
 @pytest.mark.parametrize("hops,fan,E,rand", [(1, 8, 6000, True), (2, 8, 6000, True), (3, 5, 6000, True), (3, 64, 6000, True),
-                                             (2, 8, 900, True), (2, 1000, 6000, False), (4, 3, 9000, True)])
+                                             (2, 8, 900, True), (2, 1000, 6000, False), (4, 3, 8000, True)])
 def test_device_sampler_bit_exact_vs_mirror(hops, fan, E, rand):
     from laplace_amd.data.device_sampler import DeviceGraphSampler
     from laplace_amd.utils.constants import Constants
