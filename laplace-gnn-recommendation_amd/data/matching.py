@@ -1,0 +1,78 @@
+"""Candidate matchers for evaluation (reference: data/matching/*.py, `Matcher.get_matches(user_id) ->
+LongTensor`).  Same outputs, computed over the CSR adjacency instead of dicts of lists, and lazily:
+the reference materialises every article of every co-purchasing user and then keeps the first k.
+
+  LightGCNMatcher              first k of the user's LightGCN top-N row (data/matching/lightgcn.py:5-11);
+                               fed directly by run_pipeline_lightgcn.save_predictions' [U, N] tensor
+  PopularItemsMatcher          first k most popular items (data/matching/fashion/popular_items.py)
+  UsersWithCommonItemsMatcher  first k entries of: for each article of the user (list order), for each
+                               user of that article (list order, the user itself included), all their
+                               articles (data/matching/users_with_common_purchases.py:14-26)
+"""
+from __future__ import annotations
+
+from typing import List
+
+import numpy as np
+import torch as t
+from torch import Tensor
+
+from .dataset import AdjList
+
+
+class Matcher:
+    def get_matches(self, user_id: int) -> Tensor:
+        raise NotImplementedError
+
+
+class LightGCNMatcher(Matcher):
+    def __init__(self, top_articles_per_user: Tensor, k: int):
+        self.top, self.k = top_articles_per_user.cpu(), int(k)
+
+    def get_matches(self, user_id: int) -> Tensor:
+        row = self.top[user_id][: self.k]
+        return row[row >= 0]
+
+
+class PopularItemsMatcher(Matcher):
+    def __init__(self, popular_items, k: int):
+        self.popular_items, self.k = t.as_tensor(popular_items).to(t.long), int(k)
+
+    @classmethod
+    def from_adjacency(cls, articles_adj, k: int) -> "PopularItemsMatcher":
+        adj = AdjList(articles_adj) if not isinstance(articles_adj, AdjList) else articles_adj
+        deg = np.diff(adj.ptr)
+        order = np.argsort(-deg, kind="stable")
+        return cls(order.copy(), k)
+
+    def get_matches(self, user_id: int) -> Tensor:
+        return self.popular_items[: self.k]
+
+
+class UsersWithCommonItemsMatcher(Matcher):
+    def __init__(self, users_adj, articles_adj, k: int):
+        self.users = users_adj if isinstance(users_adj, AdjList) else AdjList(users_adj)
+        self.articles = articles_adj if isinstance(articles_adj, AdjList) else AdjList(articles_adj)
+        self.k = int(k)
+
+    def get_matches(self, user_id: int) -> Tensor:
+        out: List[np.ndarray] = []
+        have = 0
+        for a in self.users[user_id]:
+            for v in self.articles[int(a)]:
+                lst = self.users[int(v)]
+                out.append(lst)
+                have += len(lst)
+                if have >= self.k:
+                    return t.from_numpy(np.concatenate(out)[: self.k].astype(np.int64))
+        return t.from_numpy(np.concatenate(out).astype(np.int64)) if out else t.empty(0, dtype=t.long)
+
+
+def get_matchers(dataset_type: str, users_adj, articles_adj, candidate_pool_size: int) -> List[Matcher]:
+    """data/matching/__init__.py:9-24."""
+    if dataset_type == "movielens":
+        return [UsersWithCommonItemsMatcher(users_adj, articles_adj, candidate_pool_size)]
+    if dataset_type == "fashion":
+        return [PopularItemsMatcher.from_adjacency(articles_adj, candidate_pool_size),
+                UsersWithCommonItemsMatcher(users_adj, articles_adj, candidate_pool_size)]
+    raise ValueError("Unknown matchers type: {}".format(dataset_type))

@@ -274,3 +274,26 @@ def test_device_sampler_mirror_random_mode_laws():
         for v in SR.floyd_subset(10, 3, SR.P_USER_CUT, 7, trial, seed=3, step=trial):
             counts[v] += 1
     assert np.abs(counts / counts.sum() - 0.1).max() < 0.01
+
+
+def test_matchers_equal_reference_semantics():
+    """UsersWithCommonItemsMatcher vs the reference's eager flatten/cat/[:k]; popular items; LightGCN rows."""
+    from laplace_amd.data.matching import (LightGCNMatcher, PopularItemsMatcher, UsersWithCommonItemsMatcher, get_matchers)
+    hd, users, articles, ei = _random_graph(seed=12, U=30, A=25, E=200)
+    m = UsersWithCommonItemsMatcher(users, articles, k=20)
+    for u in range(30):
+        same = [v for a in users[u] for v in articles[a]]                       # users_with_common_purchases.py:15-19
+        want = t.cat([t.as_tensor(users[v]) for v in same], dim=0)[:20]           # :20-26
+        assert t.equal(m.get_matches(u), want)
+    pop = PopularItemsMatcher.from_adjacency(articles, 5)
+    deg = np.array([len(articles[a]) for a in range(25)])
+    assert sorted(deg[pop.get_matches(0).numpy()].tolist(), reverse=True) == sorted(deg.tolist(), reverse=True)[:5]
+    top = t.tensor([[4, 2, 9, -1], [1, 3, 5, 7]])
+    assert LightGCNMatcher(top, 3).get_matches(0).tolist() == [4, 2, 9] and LightGCNMatcher(top, 4).get_matches(0).tolist() == [4, 2, 9]
+    assert len(get_matchers("fashion", users, articles, 20)) == 2 and len(get_matchers("movielens", users, articles, 20)) == 1
+    # eval-mode dataset with real matchers runs and labels positives 1 / candidates 0
+    from laplace_amd.data.dataset import GraphDataset
+    from laplace_amd.utils.constants import Constants
+    ds = GraphDataset(_cfg(), hd, users, articles, train=False, matchers=get_matchers("fashion", users, articles, 10))
+    item = ds[2]
+    assert int(item[Constants.edge_key].edge_label.sum()) >= 1
