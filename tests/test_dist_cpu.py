@@ -139,3 +139,46 @@ def test_single_rank_sharded_trainer_matches_plain_reference():
     us, ps, ns = tr.sample()
     keys = set((ei[0] * I + ei[1]).tolist())
     assert all(k in keys for k in (us * I + ps).tolist()) and not any(k in keys for k in (us * I + ns).tolist())
+
+
+def _ddp_worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from laplace_amd.dist_ranker import allreduce_gradients, broadcast_parameters, user_shard
+    t.manual_seed(100 + rank)  # different initial weights per rank on purpose
+    net = t.nn.Sequential(t.nn.Linear(6, 5), t.nn.BatchNorm1d(5), t.nn.ReLU(), t.nn.Linear(5, 1))
+    broadcast_parameters(net)
+    g = t.Generator().manual_seed(7)
+    X, Y = t.randn(40, 6, generator=g), t.randn(40, 1, generator=g)
+    lo, hi = user_shard(40, rank, world)
+    loss = ((net(X[lo:hi]) - Y[lo:hi]) ** 2).mean()
+    loss.backward()
+    allreduce_gradients(net.parameters())
+    ret[rank] = {"state": {k: v.clone() for k, v in net.state_dict().items()},
+                 "grads": [p.grad.clone() for p in net.parameters()], "shard": (lo, hi)}
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ranker_data_parallel_helpers_two_ranks():
+    """Replicas start identical (broadcast), shards tile the users, gradients come out as the rank mean."""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_ddp_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
+    a, b = ret[0], ret[1]
+    assert a["shard"] == (0, 20) and b["shard"] == (20, 40)
+    for ga, gb in zip(a["grads"], b["grads"]):
+        assert t.equal(ga, gb)
+    # reference: one process, mean of the two shard losses' gradients (weights = rank 0's initial weights)
+    t.manual_seed(100)
+    net = t.nn.Sequential(t.nn.Linear(6, 5), t.nn.BatchNorm1d(5), t.nn.ReLU(), t.nn.Linear(5, 1))
+    g = t.Generator().manual_seed(7)
+    X, Y = t.randn(40, 6, generator=g), t.randn(40, 1, generator=g)
+    total = 0.5 * (((net(X[:20]) - Y[:20]) ** 2).mean() + ((net(X[20:]) - Y[20:]) ** 2).mean())
+    total.backward()
+    for p, ga in zip(net.parameters(), a["grads"]):
+        assert t.allclose(p.grad, ga, atol=1e-6)
+    from laplace_amd.dist_ranker import user_shard
+    assert [user_shard(10, r, 4) for r in range(4)] == [(0, 3), (3, 6), (6, 9), (9, 10)]

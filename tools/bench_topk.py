@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Throughput of the batched exact top-K with exclusion at C2's item count:
+users/s for k = 12 (evaluation) and k = 256 (the matcher dump of run_pipeline_lightgcn.py:212-221)."""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    import torch as t
+    from laplace_amd import ops, synthetic as S
+    from laplace_amd.interactions import Interactions
+    dev = "cuda"
+    spec = S.C2 if "--full" in sys.argv else S.SyntheticSpec(200_000, 100_000, 2_000_000, seed=1)
+    ei = S.generate(spec).to(dev)
+    inter = Interactions(ei, spec.num_users, spec.num_items)
+    r = inter.csr()
+    g = t.Generator(device=dev).manual_seed(0)
+    ue = t.randn(spec.num_users, 128, device=dev, generator=g) * 0.1
+    ie = t.randn(spec.num_items, 128, device=dev, generator=g) * 0.1
+    out = {"workload": f"top-K with exclusion, {spec.num_items} items, D=128, users' own edges excluded"}
+    n_q = 16384
+    uid = t.arange(n_q, device=dev)
+    excl = ops.row_slice(r, 0, n_q)
+    for k in (12, 256):
+        ops.topk_excl(uid[:2048], ue, ie, k, ops.row_slice(r, 0, 2048))
+        t.cuda.synchronize()
+        t0 = time.perf_counter()
+        ids = ops.topk_excl(uid, ue, ie, k, excl)
+        t.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        out[f"k{k}_users_per_s"] = n_q / dt
+        out[f"k{k}_ms_per_1k_users"] = 1e3 * dt / (n_q / 1000)
+    # the reference's way, on the host: one GEMV + topk + setdiff per user (utils/metrics_lightgcn.py:125-142)
+    from oracle import lightgcn_ref as R
+    uec, iec = ue[:64].cpu(), ie.cpu()
+    rp, col = r.rowptr.cpu().long(), r.col.cpu().long()
+    pos = {u: col[rp[u]:rp[u + 1]] for u in range(64)}
+    t0 = time.perf_counter()
+    for u in range(64):
+        R.make_predictions_for_user(uec, iec, u, pos, 256)
+    out["cpu_reference_loop_users_per_s_k256"] = 64 / (time.perf_counter() - t0)
+    out["cpu_threads"] = t.get_num_threads()
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
