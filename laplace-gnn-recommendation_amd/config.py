@@ -5,7 +5,7 @@ by the hot path exactly as the reference ignores them."""
 from __future__ import annotations
 
 from dataclasses import dataclass
-from typing import Any, Optional, Tuple
+from typing import Any, Optional
 
 from .utils.constants import Constants
 

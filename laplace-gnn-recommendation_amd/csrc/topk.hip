@@ -190,7 +190,7 @@ int mi_topk_excl_f32(int64_t n_q, int64_t n_items, int64_t d, int64_t k, const i
     if (k > kMaxK) return MI_ERR_UNSUPPORTED;
     if (n_items >= INT32_MAX) return MI_ERR_TOO_LARGE;
     MI_CHECK_ARG(user_emb && item_emb && out_idx && ws && ldu >= d && ldi >= d);
-    MI_CHECK_ARG((excl_ptr == nullptr) || excl_idx != nullptr || true);
+    // excl_idx may be null when every exclusion row is empty (excl_ptr all equal)
     if (ws_bytes < mi_topk_workspace_bytes(n_q, n_items, k)) return MI_ERR_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     float* scores = static_cast<float*>(ws);

@@ -11,10 +11,9 @@ from .dataset import GraphDataset
 
 def to_undirected(graph: HeteroData) -> HeteroData:
     """T.ToUndirected() for the customer-article graph: add the rev_buys store (data/data_loader.py:52-53)."""
-    out = graph.to("cpu") if False else graph
-    if Constants.rev_edge_key not in out.edge_types:
-        out[Constants.rev_edge_key].edge_index = out[Constants.edge_key].edge_index.flip(0)
-    return out
+    if Constants.rev_edge_key not in graph.edge_types:
+        graph[Constants.rev_edge_key].edge_index = graph[Constants.edge_key].edge_index.flip(0)
+    return graph
 
 
 def create_dataloaders(config, splits: dict, matchers: Optional[dict] = None, customer_id_map: Optional[dict] = None,

@@ -17,7 +17,6 @@ from typing import Dict, List, Optional, Sequence, Union
 
 import numpy as np
 import torch as t
-from torch import Tensor
 
 from ..hetero import HeteroData
 from ..utils.constants import Constants

@@ -15,7 +15,6 @@ from torch import Tensor
 
 from .. import ops
 from ..interactions import Interactions
-from ..sparse import SparseTensor
 
 
 def split(edge_index: Tensor, seed: int = 1):

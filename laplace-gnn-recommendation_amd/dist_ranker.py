@@ -6,7 +6,7 @@ The frozen categorical tables are identical on every rank by construction (same 
 exchanged.  The reference has no distributed code."""
 from __future__ import annotations
 
-from typing import Iterable, List, Optional, Tuple
+from typing import Iterable, List, Tuple
 
 import torch as t
 import torch.distributed as dist

@@ -6,7 +6,7 @@ counts of their source / destination types, edge_label concatenated.
 """
 from __future__ import annotations
 
-from typing import Dict, Iterable, Iterator, List, Optional, Sequence, Tuple
+from typing import Dict, Iterator, List, Optional, Sequence, Tuple
 
 import torch as t
 from torch import Tensor

@@ -25,7 +25,6 @@ from torch.nn import BatchNorm1d, ModuleDict, ModuleList
 
 from .. import ops
 from ..utils.constants import Constants
-from ..utils.tensor import padded_stack
 from .layers import BipartiteGraph
 
 

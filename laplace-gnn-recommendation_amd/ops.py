@@ -6,7 +6,6 @@ function requires GPU tensors and raises otherwise — there is no CPU path in t
 from __future__ import annotations
 
 import ctypes
-import math
 from dataclasses import dataclass, field
 from typing import Optional, Tuple
 
@@ -383,10 +382,11 @@ def topk_excl(uid: Tensor, user_emb: Tensor, item_emb: Tensor, k: int, excl: Opt
     ws = _ws(L.mi_topk_workspace_bytes(chunk, n_items, k), dev)
     for q0 in range(0, n_q, chunk):
         q1 = min(n_q, q0 + chunk)
+        # rowptr keeps absolute offsets into excl.col, so a chunk is just a slice of rowptr
         ep = excl.rowptr[q0:q1 + 1] if excl is not None else None
+        ei = excl.col if (excl is not None and excl.nnz) else None
         check(L.mi_topk_excl_f32(q1 - q0, n_items, d, k, uid[q0:q1].data_ptr(), user_emb.data_ptr(), ldu,
-                                 item_emb.data_ptr(), ldi, _ptr(ep),
-                                 (excl.col.data_ptr() if excl is not None and excl.nnz else (ep.data_ptr() if ep is not None else None)),
+                                 item_emb.data_ptr(), ldi, _ptr(ep), _ptr(ei),
                                  out_idx[q0:q1].data_ptr(), out_sc[q0:q1].data_ptr() if want_scores else None,
                                  ws.data_ptr(), ws.numel(), _stream()), "mi_topk_excl_f32")
     return (out_idx, out_sc) if want_scores else out_idx

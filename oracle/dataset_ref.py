@@ -6,7 +6,7 @@ of a PyG HeteroData.  Pinned by the reference's tests/test_dataset.py fixture (g
 tests/test_ranker_cpu.py."""
 import math
 import random
-from typing import Dict, List, Optional, Tuple
+from typing import Dict, List, Optional
 
 import torch as t
 from torch import Tensor

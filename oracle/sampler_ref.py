@@ -25,7 +25,7 @@ edges: positives in draw order, then negatives in draw order.
 from __future__ import annotations
 
 import math
-from typing import Dict, List, Tuple
+from typing import Dict, List
 
 import numpy as np
 

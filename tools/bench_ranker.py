@@ -26,7 +26,6 @@ def main():
     ap.add_argument("--cpu", action="store_true", help="also time the torch-only oracle twin on the host cores")
     ap.add_argument("--device-sampler", action="store_true", help="sample batches on the GPU (N1) instead of on the host")
     args = ap.parse_args()
-    import numpy as np
     import torch as t
     from types import SimpleNamespace
     from laplace_amd import synthetic as S

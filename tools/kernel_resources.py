@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Print VGPR/SGPR/LDS/occupancy of our own kernels in one csrc/*.hip (hipcc remarks)."""
-import re, subprocess, sys, os
+import re, subprocess, sys
 src = sys.argv[1]
 pat = sys.argv[2] if len(sys.argv) > 2 else ""
 r = subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-c", src, "-o", "/dev/null",
