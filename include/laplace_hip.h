@@ -174,15 +174,26 @@ int mi_spmm_csr_ex_f32(int64_t n_rows, int64_t d,
                        const mi_spmm_plan* plan, const mi_spmm_ex* ex,
                        void* ws, size_t ws_bytes, mi_stream_t stream);
 
-/* dst[i,:] = (accumulate ? dst[i,:] : 0) + src[rows[i],:]  for i < min(n_max, *n_dev).
+/* dst[i,:] = scale * ((accumulate ? dst[i,:] : 0) + src[rows[i] - row_offset,:])
+ * for i in [begin_dev ? *begin_dev : 0, min(n_max, n_dev ? *n_dev : n_max)).
  * The running layer sum of the batch rows in the fused step (model/lightgcn.py:67-68 restricted
- * to the rows the loss reads). */
-int mi_gather_rows_f32(int64_t n_max, const int32_t* n_dev, int64_t d, const int32_t* rows,
-                       const float* src, int64_t ld_src, float* dst, int64_t ld_dst,
-                       int32_t accumulate, mi_stream_t stream);
+ * to the rows the loss reads); begin / row_offset address the item part of a batch node list
+ * against an item-only table in the sharded step. */
+int mi_gather_rows_f32(int64_t n_max, const int32_t* n_dev, const int32_t* begin_dev, int64_t d,
+                       const int32_t* rows, int64_t row_offset, const float* src, int64_t ld_src,
+                       float* dst, int64_t ld_dst, int32_t accumulate, float scale,
+                       mi_stream_t stream);
+
+/* dst[rows[i] - row_offset,:] = src[i,:] for i in [begin, min(n_max, *n_dev)); rows distinct.
+ * Expands the item part of the compact batch gradient into the dense item table that the sharded
+ * step all-reduces. */
+int mi_scatter_rows_f32(int64_t n_max, const int32_t* n_dev, const int32_t* begin_dev, int64_t d,
+                        const int32_t* rows, int64_t row_offset, const float* src, int64_t ld_src,
+                        float* dst, int64_t ld_dst, mi_stream_t stream);
 
 /* Unique node set of a BPR batch: gmap int32[n_nodes] = compact slot of node r (slots ordered by
- * node id) or -1; nodes int32[>= 3*batch] = slot -> node; count = device int32[1].
+ * node id) or -1; nodes int32[>= 3*batch] = slot -> node; count = device int32[2]:
+ * count[0] = unique nodes, count[1] = unique USER nodes (their slots come first).
  * Users are nodes [0, n_users), item i is node n_users + i. */
 size_t mi_batch_nodes_workspace_bytes(int64_t n_nodes);
 int    mi_batch_nodes_i32(int64_t batch, int64_t n_users, int64_t n_nodes,

@@ -55,7 +55,8 @@ _PROTOTYPES = {
                                   c_float, POINTER(SpmmPlanStruct), P, c_size_t, P]),
     "mi_spmm_csr_ex_f32": (c_int32, [c_int64, c_int64, P, P, P, P, c_int64, P, c_int64, P, c_int64, P, c_int64,
                                      c_float, POINTER(SpmmPlanStruct), POINTER(SpmmExStruct), P, c_size_t, P]),
-    "mi_gather_rows_f32": (c_int32, [c_int64, P, c_int64, P, P, c_int64, P, c_int64, c_int32, P]),
+    "mi_gather_rows_f32": (c_int32, [c_int64, P, P, c_int64, P, c_int64, P, c_int64, P, c_int64, c_int32, c_float, P]),
+    "mi_scatter_rows_f32": (c_int32, [c_int64, P, P, c_int64, P, c_int64, P, c_int64, P, c_int64, P]),
     "mi_batch_nodes_workspace_bytes": (c_size_t, [c_int64]),
     "mi_batch_nodes_i32": (c_int32, [c_int64, c_int64, c_int64, P, P, P, P, P, P, P, c_size_t, P]),
     "mi_csr_expand_rows": (c_int32, [c_int64, P, P, c_int64, P]),

@@ -165,11 +165,12 @@ __global__ void mark_batch_nodes_kernel(int64_t batch, int64_t n_users, const in
     flag[n_users + neg[b]] = 1;
 }
 
-__global__ void finish_batch_nodes_kernel(int64_t n_nodes, const int32_t* __restrict__ flag,
+__global__ void finish_batch_nodes_kernel(int64_t n_nodes, int64_t n_users, const int32_t* __restrict__ flag,
                                           const int32_t* __restrict__ slot, int32_t* __restrict__ gmap,
                                           int32_t* __restrict__ nodes, int32_t* __restrict__ count) {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r > n_nodes) return;
+    if (r == n_users) count[1] = slot[r];  // unique USER nodes: slots [0, count[1]) are users, the rest items
     if (r == n_nodes) {
         count[0] = slot[r];
         return;
@@ -182,19 +183,36 @@ __global__ void finish_batch_nodes_kernel(int64_t n_nodes, const int32_t* __rest
     }
 }
 
-// dst[i,:] (+)= src[rows[i],:], one wavefront per row, float4 lanes
+// dst[i,:] = scale * ((accumulate ? dst[i,:] : 0) + src[rows[i] - row_offset,:]) for i in [*begin_dev, *n_dev);
+// one wavefront per row, float4 lanes
 __global__ __launch_bounds__(kBlock) void gather_rows_kernel(int64_t n_max, const int32_t* __restrict__ n_dev,
+                                                             const int32_t* __restrict__ begin_dev,
                                                              int d4, const int32_t* __restrict__ rows,
+                                                             int64_t row_offset,
                                                              const float4* __restrict__ src, int64_t lds4,
-                                                             float4* __restrict__ dst, int64_t ldd4, int accumulate) {
+                                                             float4* __restrict__ dst, int64_t ldd4, int accumulate,
+                                                             float scale) {
     const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / MI_WAVE;
-    if (i >= n_max || (n_dev && i >= *n_dev)) return;
-    const int64_t r = rows[i];
+    if (i >= n_max || (n_dev && i >= *n_dev) || (begin_dev && i < *begin_dev)) return;
+    const int64_t r = (int64_t)rows[i] - row_offset;
     for (int e = mi_lane(); e < d4; e += MI_WAVE) {
         float4 v = src[r * lds4 + e];
         if (accumulate) v = mi_f4_add(dst[i * ldd4 + e], v);
+        if (scale != 1.0f) { v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale; }
         dst[i * ldd4 + e] = v;
     }
+}
+
+// dst[rows[i] - row_offset,:] = src[i,:] for i in [*begin_dev, *n_dev): the inverse of gather_rows (rows are distinct)
+__global__ __launch_bounds__(kBlock) void scatter_rows_kernel(int64_t n_max, const int32_t* __restrict__ n_dev,
+                                                              const int32_t* __restrict__ begin_dev, int d4,
+                                                              const int32_t* __restrict__ rows, int64_t row_offset,
+                                                              const float4* __restrict__ src, int64_t lds4,
+                                                              float4* __restrict__ dst, int64_t ldd4) {
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / MI_WAVE;
+    if (i >= n_max || (n_dev && i >= *n_dev) || (begin_dev && i < *begin_dev)) return;
+    const int64_t r = (int64_t)rows[i] - row_offset;
+    for (int e = mi_lane(); e < d4; e += MI_WAVE) dst[r * ldd4 + e] = src[i * lds4 + e];
 }
 
 // ------------------------------------------------------------------ Adam ---------------
@@ -283,20 +301,36 @@ int mi_batch_nodes_i32(int64_t batch, int64_t n_users, int64_t n_nodes, const in
     if (!tmp) return MI_ERR_WORKSPACE;
     MI_HIP(rocprim::exclusive_scan(tmp, tmp_bytes, flag, slot, 0, (size_t)n1, rocprim::plus<int32_t>(), s));
     hipLaunchKernelGGL(finish_batch_nodes_kernel, dim3((unsigned)mi_ceil_div(n1, kBlock)), dim3(kBlock), 0, s, n_nodes,
-                       flag, slot, gmap, nodes, count);
+                       n_users, flag, slot, gmap, nodes, count);
     return mi_launch_status();
 }
 
-int mi_gather_rows_f32(int64_t n_max, const int32_t* n_dev, int64_t d, const int32_t* rows, const float* src,
-                       int64_t ld_src, float* dst, int64_t ld_dst, int32_t accumulate, mi_stream_t stream) {
+int mi_gather_rows_f32(int64_t n_max, const int32_t* n_dev, const int32_t* begin_dev, int64_t d,
+                       const int32_t* rows, int64_t row_offset, const float* src, int64_t ld_src, float* dst,
+                       int64_t ld_dst, int32_t accumulate, float scale, mi_stream_t stream) {
     MI_CHECK_ARG(n_max >= 0 && d > 0);
     if (n_max == 0) return 0;
     if (d % 4 != 0) return MI_ERR_UNSUPPORTED;
     MI_CHECK_ARG(rows && src && dst && ld_src % 4 == 0 && ld_dst % 4 == 0 && ld_src >= d && ld_dst >= d);
     MI_CHECK_ARG(mi_aligned16(src) && mi_aligned16(dst));
     hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)mi_ceil_div(n_max * MI_WAVE, kBlock)), dim3(kBlock), 0,
-                       (hipStream_t)stream, n_max, n_dev, (int)(d / 4), rows, reinterpret_cast<const float4*>(src),
-                       ld_src / 4, reinterpret_cast<float4*>(dst), ld_dst / 4, accumulate);
+                       (hipStream_t)stream, n_max, n_dev, begin_dev, (int)(d / 4), rows, row_offset,
+                       reinterpret_cast<const float4*>(src), ld_src / 4, reinterpret_cast<float4*>(dst), ld_dst / 4,
+                       accumulate, scale);
+    return mi_launch_status();
+}
+
+int mi_scatter_rows_f32(int64_t n_max, const int32_t* n_dev, const int32_t* begin_dev, int64_t d,
+                        const int32_t* rows, int64_t row_offset, const float* src, int64_t ld_src, float* dst,
+                        int64_t ld_dst, mi_stream_t stream) {
+    MI_CHECK_ARG(n_max >= 0 && d > 0);
+    if (n_max == 0) return 0;
+    if (d % 4 != 0) return MI_ERR_UNSUPPORTED;
+    MI_CHECK_ARG(rows && src && dst && ld_src % 4 == 0 && ld_dst % 4 == 0 && ld_src >= d && ld_dst >= d);
+    MI_CHECK_ARG(mi_aligned16(src) && mi_aligned16(dst));
+    hipLaunchKernelGGL(scatter_rows_kernel, dim3((unsigned)mi_ceil_div(n_max * MI_WAVE, kBlock)), dim3(kBlock), 0,
+                       (hipStream_t)stream, n_max, n_dev, begin_dev, (int)(d / 4), rows, row_offset,
+                       reinterpret_cast<const float4*>(src), ld_src / 4, reinterpret_cast<float4*>(dst), ld_dst / 4);
     return mi_launch_status();
 }
 

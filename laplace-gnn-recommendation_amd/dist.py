@@ -37,7 +37,7 @@ from .model.lightgcn import LightGCN
 class ShardedLightGCNTrainer:
     def __init__(self, model: LightGCN, train: Interactions, *, lr: float, Lambda: float, batch_size: int,
                  betas: Tuple[float, float] = (0.9, 0.999), eps: float = 1e-8, seed: int = 0,
-                 neg_range: Optional[int] = None, group=None, ops_impl=None):
+                 neg_range: Optional[int] = None, group=None, ops_impl=None, sparse_batch: bool = True):
         """model: LightGCN(num_users = this rank's users, num_items = all items).  `train` holds this
         rank's edges with LOCAL user ids.  ops_impl: the kernel provider (default: the HIP ops;
         the CPU gloo tests inject an oracle-backed one — the product never does)."""
@@ -75,9 +75,23 @@ class ShardedLightGCNTrainer:
         self.a_users.plan = self.ops.build_spmm_plan(self.a_users)
         self.a_items.plan = self.ops.build_spmm_plan(self.a_items)
 
+        self.sparse_batch = bool(sparse_batch)
         self.final = t.empty(n, d, device=dev)
         self.bufs = (t.empty(n, d, device=dev), t.empty(n, d, device=dev))
-        self.gc = t.zeros(n, d, device=dev)
+        if self.sparse_batch:  # compact per-batch tables (see trainer.py) + dense item-side exchange buffers
+            nb = 3 * self.batch_size
+            self.gc = None
+            self.gmap = t.empty(n, dtype=t.int32, device=dev)
+            self.nodes = t.zeros(nb, dtype=t.int32, device=dev)
+            self.n_nodes = t.zeros(2, dtype=t.int32, device=dev)
+            self.sum_c = t.empty(nb, d, device=dev)
+            self.gc_c = t.zeros(nb, d, device=dev)
+            self.items_y = t.empty(I, d, device=dev)
+            self.items_g = t.zeros(I, d, device=dev)
+            self.imap = t.full((n,), -1, dtype=t.int32, device=dev)
+            self._item_ids = t.arange(I, dtype=t.int32, device=dev)
+        else:
+            self.gc = t.zeros(n, d, device=dev)
         self.reg_w = t.zeros(n, device=dev)
         self.m = t.zeros(n, d, device=dev)
         self.v = t.zeros(n, d, device=dev)
@@ -142,6 +156,10 @@ class ShardedLightGCNTrainer:
     def step(self, batch=None) -> Tensor:
         """One training iteration over the GLOBAL batch (world * batch_size positive edges); returns this
         rank's local loss term as a 1-element tensor."""
+        if self.sparse_batch and self.K >= 1:
+            return self._step_sparse(batch)
+        if self.gc is None:
+            self.gc = t.zeros_like(self.table)
         U, K, P = self.U, self.K, self.world
         self.forward()
         users, pos, neg = batch if batch is not None else self.sample()
@@ -161,6 +179,66 @@ class ShardedLightGCNTrainer:
         self.step_count += 1
         self.ops.adam_step(self.table, g, self.m, self.v, step=self.step_count, lr=self.lr, beta1=self.betas[0],
                            beta2=self.betas[1], eps=self.eps, reg_w=self.reg_w)
+        return self.loss
+
+    def _step_sparse(self, batch) -> Tensor:
+        """The byte-saving form of trainer.LightGCNTrainer._step_sparse, sharded.  User rows get the
+        row_list / x_map / compact-addend treatment; item rows stay dense because their partial sums
+        are exchanged: forward layer K still needs every rank's users, and the item gradient is the
+        sum of every rank's batch."""
+        U, I, K, P, ops = self.U, self.I, self.K, self.world, self.ops
+        tab, c = self.table, 1.0 / (self.K + 1)
+        users, pos, neg = batch if batch is not None else self.sample()
+        gmap, nodes, cnt2 = ops.batch_nodes(users, pos, neg, U, tab.shape[0], gmap=self.gmap, nodes=self.nodes,
+                                            count=self.n_nodes)
+        cnt, cnt_u = cnt2[0:1], cnt2[1:2]
+        # ---- forward: final only at this rank's batch rows, kept in sum_c
+        ops.gather_rows(self.sum_c, tab, nodes, cnt)
+        x = tab
+        for k in range(1, K):
+            y = self.bufs[(k - 1) % 2]
+            self._layer(x, y, addend_users=None, s_users=None, scale=1.0, items_out=y[U:])
+            ops.gather_rows(self.sum_c, y, nodes, cnt, accumulate=True)
+            x = y
+        ops.spmm(self.a_items, x, Y=self.items_y)                      # layer K, item rows: every rank contributes
+        work = self._allreduce(self.items_y, async_op=True)
+        ops.spmm(self.a_users, x, addend=self.sum_c, S=self.sum_c, scale=c, row_list=nodes, n_list_dev=cnt_u)
+        if work is not None:
+            work.wait()
+        ops.gather_rows(self.sum_c, self.items_y, nodes, cnt, accumulate=True, scale=c, begin_dev=cnt_u, row_offset=U)
+        # ---- loss on the compact tables; softplus share of the global mean carries 1/P
+        self.gc_c.zero_()
+        self.reg_w.zero_()
+        ops.bpr_fwd_bwd(users, pos, neg, self.sum_c, tab, U, self.Lambda, g_final=self.gc_c, reg_w=self.reg_w,
+                        g_scale=c / P, loss_out=self.loss, node_map=gmap)
+        # ---- global item gradient: dense [I, D], summed over ranks; which item rows are non-zero anywhere
+        self.items_g.zero_()
+        ops.scatter_rows(self.items_g, self.gc_c, nodes, cnt, begin_dev=cnt_u, row_offset=U)
+        flag = (gmap[U:] >= 0).to(t.int32)
+        self._allreduce(self.items_g)
+        self._allreduce(self.reg_w[U:])
+        if self.world > 1:
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.group)
+        self.imap[U:] = t.where(flag > 0, self._item_ids, t.full_like(self._item_ids, -1))
+        gmap_u = gmap[:U]
+        cur = None
+        for i in range(K):
+            nxt = self.bufs[i % 2]
+            if i == 0:  # input = the batch gradient: item rows gather local batch users, user rows the non-zero item rows
+                ops.spmm(self.a_items, self.gc_c, Y=nxt[U:], x_map=gmap)
+                work = self._allreduce(nxt[U:], async_op=True)
+                ops.spmm(self.a_users, self.items_g, addend=self.gc_c, S=nxt[:U], x_map=self.imap, addend_map=gmap_u)
+            else:
+                ops.spmm(self.a_items, cur, Y=nxt[U:])
+                work = self._allreduce(nxt[U:], async_op=True)
+                ops.spmm(self.a_users, cur, addend=self.gc_c, S=nxt[:U], addend_map=gmap_u)
+            if work is not None:
+                work.wait()
+            nxt[U:].add_(self.items_g)
+            cur = nxt
+        self.step_count += 1
+        ops.adam_step(tab, cur, self.m, self.v, step=self.step_count, lr=self.lr, beta1=self.betas[0],
+                      beta2=self.betas[1], eps=self.eps, reg_w=self.reg_w)
         return self.loss
 
     def decay_lr(self, gamma: float = 0.95) -> None:

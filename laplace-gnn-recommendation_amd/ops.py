@@ -437,13 +437,14 @@ def embed_concat(x: Tensor, tables, max_norm: float = 1.0) -> Tensor:
 
 def batch_nodes(users: Tensor, pos: Tensor, neg: Tensor, n_users: int, n_nodes: int, *, gmap: Optional[Tensor] = None,
                 nodes: Optional[Tensor] = None, count: Optional[Tensor] = None, ws: Optional[Tensor] = None):
-    """Unique node set of a BPR batch: (gmap int32[n_nodes], nodes int32[3B], count int32[1] on device)."""
+    """Unique node set of a BPR batch: (gmap int32[n_nodes], nodes int32[3B], count int32[2] on device:
+    count[0] = unique nodes, count[1] = unique user nodes, whose slots come first)."""
     for n, x in (("users", users), ("pos", pos), ("neg", neg)):
         _need(x, t.int64, n)
     B, dev = users.numel(), users.device
     gmap = gmap if gmap is not None else t.empty(n_nodes, dtype=t.int32, device=dev)
     nodes = nodes if nodes is not None else t.empty(3 * B, dtype=t.int32, device=dev)
-    count = count if count is not None else t.empty(1, dtype=t.int32, device=dev)
+    count = count if count is not None else t.empty(2, dtype=t.int32, device=dev)
     L = _lib.lib()
     ws = ws if ws is not None else _ws(L.mi_batch_nodes_workspace_bytes(n_nodes), dev)
     check(L.mi_batch_nodes_i32(B, n_users, n_nodes, _ptr(users), _ptr(pos), _ptr(neg), _ptr(gmap), _ptr(nodes),
@@ -451,11 +452,25 @@ def batch_nodes(users: Tensor, pos: Tensor, neg: Tensor, n_users: int, n_nodes: 
     return gmap, nodes, count
 
 
-def gather_rows(dst: Tensor, src: Tensor, rows: Tensor, n_dev: Optional[Tensor] = None, accumulate: bool = False) -> None:
-    """dst[i] (+)= src[rows[i]] for i < min(len(rows), *n_dev)."""
+def gather_rows(dst: Tensor, src: Tensor, rows: Tensor, n_dev: Optional[Tensor] = None, accumulate: bool = False,
+                scale: float = 1.0, begin_dev: Optional[Tensor] = None, row_offset: int = 0) -> None:
+    """dst[i] = scale * ((accumulate ? dst[i] : 0) + src[rows[i] - row_offset]) for i in [*begin_dev, *n_dev)."""
     _need(rows, t.int32, "rows")
     lds_, ldd = _rows_ok(src, "src"), _rows_ok(dst, "dst")
     if dst.shape[0] < rows.numel() or dst.shape[1] != src.shape[1]:
         raise ValueError("dst must be [len(rows), d]")
-    check(_lib.lib().mi_gather_rows_f32(rows.numel(), _ptr(n_dev), src.shape[1], _ptr(rows), src.data_ptr(), lds_,
-                                        dst.data_ptr(), ldd, 1 if accumulate else 0, _stream()), "mi_gather_rows_f32")
+    check(_lib.lib().mi_gather_rows_f32(rows.numel(), _ptr(n_dev), _ptr(begin_dev), src.shape[1], _ptr(rows),
+                                        int(row_offset), src.data_ptr(), lds_, dst.data_ptr(), ldd,
+                                        1 if accumulate else 0, float(scale), _stream()), "mi_gather_rows_f32")
+
+
+def scatter_rows(dst: Tensor, src: Tensor, rows: Tensor, n_dev: Optional[Tensor] = None,
+                 begin_dev: Optional[Tensor] = None, row_offset: int = 0) -> None:
+    """dst[rows[i] - row_offset] = src[i] for i in [*begin_dev, *n_dev) (rows distinct)."""
+    _need(rows, t.int32, "rows")
+    lds_, ldd = _rows_ok(src, "src"), _rows_ok(dst, "dst")
+    if src.shape[0] < rows.numel() or dst.shape[1] != src.shape[1]:
+        raise ValueError("src must be [len(rows), d]")
+    check(_lib.lib().mi_scatter_rows_f32(rows.numel(), _ptr(n_dev), _ptr(begin_dev), src.shape[1], _ptr(rows),
+                                         int(row_offset), src.data_ptr(), lds_, dst.data_ptr(), ldd, _stream()),
+          "mi_scatter_rows_f32")

@@ -74,7 +74,7 @@ class LightGCNTrainer:
             self.gc = None
             self.gmap = t.empty(n, dtype=t.int32, device=dev)
             self.nodes = t.zeros(nb, dtype=t.int32, device=dev)
-            self.n_nodes = t.zeros(1, dtype=t.int32, device=dev)
+            self.n_nodes = t.zeros(2, dtype=t.int32, device=dev)
             self.sum_c = t.empty(nb, d, device=dev)
             self.final_c = t.empty(nb, d, device=dev)
             self.gc_c = t.zeros(nb, d, device=dev)
@@ -120,8 +120,9 @@ class LightGCNTrainer:
         users, pos, neg = batch if batch is not None else self.sample()
         if users.numel() != self.batch_size:
             raise ValueError("batch size differs from the trainer's")
-        gmap, nodes, cnt = ops.batch_nodes(users, pos, neg, self.model.num_users, tab.shape[0], gmap=self.gmap,
-                                           nodes=self.nodes, count=self.n_nodes, ws=self._nodes_ws)
+        gmap, nodes, cnt2 = ops.batch_nodes(users, pos, neg, self.model.num_users, tab.shape[0], gmap=self.gmap,
+                                            nodes=self.nodes, count=self.n_nodes, ws=self._nodes_ws)
+        cnt = cnt2[:1]
         # ---- forward: final only at the batch rows
         c = 1.0 / (K + 1)
         ops.gather_rows(self.sum_c, tab, nodes, cnt)                      # S_c = E0[batch rows]

@@ -39,13 +39,67 @@ def build_spmm_plan(a, chunk=256):
     return _Plan()
 
 
-def spmm(a: DeviceCSR, X: Tensor, *, Y=None, addend=None, S=None, scale=1.0) -> None:
+def spmm(a: DeviceCSR, X: Tensor, *, Y=None, addend=None, S=None, scale=1.0, x_map=None, addend_map=None,
+         row_list=None, n_list_dev=None) -> None:
+    """Dense semantics of every sparse-operand form: expand, multiply, then select."""
+    d = X.shape[1]
+    if x_map is not None:
+        Xd = t.zeros(a.n_cols, d)
+        nz = (x_map >= 0).nonzero().view(-1)
+        Xd[nz] = X[x_map[nz].long()]
+        X = Xd
     acc = R.spmm_c(a.rowptr, a.col, a.val, X)
+    if row_list is not None:
+        n = int(n_list_dev[0]) if n_list_dev is not None else row_list.numel()
+        accs = acc[row_list[:n].long()]
+        if Y is not None:
+            Y[:n] = accs
+        if S is not None:
+            base = addend[:n].clone() if addend is not None else 0.0
+            S[:n] = scale * (base + accs)
+        return
+    base = 0.0
+    if addend is not None:
+        if addend_map is not None:
+            base = t.zeros(a.n_rows, d)
+            nz = (addend_map >= 0).nonzero().view(-1)
+            base[nz] = addend[addend_map[nz].long()]
+        else:
+            base = addend.clone()
     if Y is not None:
         Y.copy_(acc)
     if S is not None:
-        base = addend if addend is not None else 0.0
         S.copy_(scale * (base + acc))
+
+
+def batch_nodes(users, pos, neg, n_users, n_nodes, *, gmap=None, nodes=None, count=None, ws=None):
+    uniq = t.unique(t.cat([users, n_users + pos, n_users + neg]))
+    gmap = gmap if gmap is not None else t.empty(n_nodes, dtype=t.int32)
+    nodes = nodes if nodes is not None else t.zeros(3 * users.numel(), dtype=t.int32)
+    count = count if count is not None else t.zeros(2, dtype=t.int32)
+    gmap.fill_(-1)
+    gmap[uniq] = t.arange(uniq.numel(), dtype=t.int32)
+    nodes[: uniq.numel()] = uniq.to(t.int32)
+    count[0] = uniq.numel()
+    count[1] = int((uniq < n_users).sum())
+    return gmap, nodes, count
+
+
+def _span(rows, n_dev, begin_dev):
+    hi = int(n_dev[0]) if n_dev is not None else rows.numel()
+    lo = int(begin_dev[0]) if begin_dev is not None else 0
+    return lo, hi
+
+
+def gather_rows(dst, src, rows, n_dev=None, accumulate=False, scale=1.0, begin_dev=None, row_offset=0) -> None:
+    lo, hi = _span(rows, n_dev, begin_dev)
+    g = src[rows[lo:hi].long() - row_offset]
+    dst[lo:hi] = scale * ((dst[lo:hi] if accumulate else 0.0) + g)
+
+
+def scatter_rows(dst, src, rows, n_dev=None, begin_dev=None, row_offset=0) -> None:
+    lo, hi = _span(rows, n_dev, begin_dev)
+    dst[rows[lo:hi].long() - row_offset] = src[lo:hi]
 
 
 def expand_rows(a: DeviceCSR) -> Tensor:
@@ -64,15 +118,16 @@ def sample_bpr_batch(r: DeviceCSR, row_of_edge, batch, neg_range, seed, step, qu
 
 
 def bpr_fwd_bwd(users, pos, neg, final_emb, e0, n_users, lambda_val, *, g_final=None, reg_w=None, g_scale=1.0,
-                reg_scale=1.0, loss_out=None) -> Tensor:
+                reg_scale=1.0, loss_out=None, node_map=None) -> Tensor:
     U = n_users
-    rows = [final_emb[users], e0[users], final_emb[U + pos], e0[U + pos], final_emb[U + neg], e0[U + neg]]
+    f = (lambda idx: node_map[idx].long()) if node_map is not None else (lambda idx: idx)
+    rows = [final_emb[f(users)], e0[users], final_emb[f(U + pos)], e0[U + pos], final_emb[f(U + neg)], e0[U + neg]]
     rows = [x.detach().requires_grad_(True) for x in rows]
     loss = R.bpr_loss(*rows, lambda_val)
     if g_final is not None:
         grads = t.autograd.grad(loss, rows)
         for idx, gf in ((users, grads[0]), (U + pos, grads[2]), (U + neg, grads[4])):
-            g_final.index_add_(0, idx, g_scale * gf)
+            g_final.index_add_(0, f(idx), g_scale * gf)
             if reg_w is not None:
                 reg_w.index_add_(0, idx, t.full((idx.numel(),), 2.0 * lambda_val * reg_scale))
     if loss_out is None:

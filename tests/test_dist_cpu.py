@@ -37,7 +37,7 @@ def _batches(step):
     return out
 
 
-def _worker(rank, world, port, ret):
+def _worker(rank, world, port, ret, sparse_batch):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -57,7 +57,7 @@ def _worker(rank, world, port, ret):
         # rank 1 starts with garbage item rows: the constructor's broadcast must fix them
         model.items_emb.weight.copy_(ti if rank == 0 else t.zeros_like(ti))
     tr = ShardedLightGCNTrainer(model, Interactions(ei, U, I), lr=1e-2, Lambda=1e-4, batch_size=B, seed=3,
-                                ops_impl=cpu_ops)
+                                ops_impl=cpu_ops, sparse_batch=sparse_batch)
     losses = []
     for s in range(STEPS):
         losses.append(float(tr.step(_batches(s)[rank])))
@@ -73,11 +73,12 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def test_two_rank_sharded_training_equals_single_process_reference():
+@pytest.mark.parametrize("sparse_batch", [False, True])
+def test_two_rank_sharded_training_equals_single_process_reference(sparse_batch):
     from oracle import lightgcn_ref as R
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, _free_port(), ret, sparse_batch), nprocs=2, join=True)
 
     # single-process reference on the union graph: users of rank 1 follow those of rank 0
     e0, e1 = _shards()
@@ -110,7 +111,8 @@ def test_two_rank_sharded_training_equals_single_process_reference():
     assert len(ref_losses) == STEPS
 
 
-def test_single_rank_sharded_trainer_matches_plain_reference():
+@pytest.mark.parametrize("sparse_batch", [False, True])
+def test_single_rank_sharded_trainer_matches_plain_reference(sparse_batch):
     """world_size 1 (no process group): the sharded code path degenerates to the plain step."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import cpu_ops
@@ -125,7 +127,7 @@ def test_single_rank_sharded_trainer_matches_plain_reference():
         model.users_emb.weight.copy_(tu0)
         model.items_emb.weight.copy_(ti)
     tr = ShardedLightGCNTrainer(model, Interactions(ei, U0, I), lr=1e-2, Lambda=1e-4, batch_size=B, seed=3,
-                                ops_impl=cpu_ops)
+                                ops_impl=cpu_ops, sparse_batch=sparse_batch)
     uw, iw = t.nn.Parameter(tu0.clone()), t.nn.Parameter(ti.clone())
     opt = t.optim.Adam([uw, iw], lr=1e-2)
     row, col = R.bipartite_edges(ei[0], ei[1], U0)

@@ -407,7 +407,8 @@ def test_trainer_on_device_sampling_trains():
 
 
 # ---------------------------------------------------------------------------- §8e sharded path, HIP ops
-def test_sharded_trainer_hip_ops_single_rank_equals_plain_trainer():
+@pytest.mark.parametrize("sparse_batch", [False, True])
+def test_sharded_trainer_hip_ops_single_rank_equals_plain_trainer(sparse_batch):
     """The row-sliced (user rows / item rows) launches of the sharded step give the plain step's result."""
     from laplace_amd.dist import ShardedLightGCNTrainer
     from laplace_amd.trainer import LightGCNTrainer
@@ -417,8 +418,8 @@ def test_sharded_trainer_hip_ops_single_rank_equals_plain_trainer():
     model_a.to(DEV)
     model_b.to(DEV)
     inter = inter.to(DEV)
-    plain = LightGCNTrainer(model_a, adj.to(DEV), inter, lr=1e-3, Lambda=1e-5, batch_size=B, seed=2)
-    shard = ShardedLightGCNTrainer(model_b, inter, lr=1e-3, Lambda=1e-5, batch_size=B, seed=2)
+    plain = LightGCNTrainer(model_a, adj.to(DEV), inter, lr=1e-3, Lambda=1e-5, batch_size=B, seed=2, sparse_batch=False)
+    shard = ShardedLightGCNTrainer(model_b, inter, lr=1e-3, Lambda=1e-5, batch_size=B, seed=2, sparse_batch=sparse_batch)
     assert t.allclose(shard.adj_fwd.val, plain.adj_fwd.val, rtol=1e-6, atol=0)
     for _ in range(5):
         la, lb = plain.step(), shard.step()
@@ -549,15 +550,25 @@ def test_batch_nodes_and_gather_rows():
     u, p, n_ = t.randint(0, U, (B,), generator=g), t.randint(0, I, (B,), generator=g), t.randint(0, I, (B,), generator=g)
     gmap, nodes, cnt = ops.batch_nodes(u.to(DEV), p.to(DEV), n_.to(DEV), U, U + I)
     want = t.unique(t.cat([u, U + p, U + n_]))
-    c = int(cnt)
+    c = int(cnt[0])
+    assert int(cnt[1]) == int((want < U).sum())
     assert c == want.numel() and t.equal(nodes[:c].cpu().long(), want)
     gm = gmap.cpu().long()
     assert t.equal(gm[want], t.arange(c)) and int((gm >= 0).sum()) == c
     src = t.randn(U + I, 32, generator=g).to(DEV)
     dst = t.zeros(3 * B, 32, device=DEV)
-    ops.gather_rows(dst, src, nodes, cnt)
-    ops.gather_rows(dst, src, nodes, cnt, accumulate=True)
+    ops.gather_rows(dst, src, nodes, cnt[:1])
+    ops.gather_rows(dst, src, nodes, cnt[:1], accumulate=True)
     assert t.equal(dst[:c], 2 * src[want.to(DEV)]) and float(dst[c:].abs().max()) == 0.0
+    # item part only, against an item-only table, scaled; and the inverse scatter
+    items = src[U:].contiguous()
+    part = t.zeros(3 * B, 32, device=DEV)
+    ops.gather_rows(part, items, nodes, cnt[:1], scale=0.5, begin_dev=cnt[1:], row_offset=U)
+    cu = int(cnt[1])
+    assert float(part[:cu].abs().max()) == 0.0 and t.equal(part[cu:c], 0.5 * src[want[cu:].to(DEV)])
+    back = t.zeros(I, 32, device=DEV)
+    ops.scatter_rows(back, part, nodes, cnt[:1], begin_dev=cnt[1:], row_offset=U)
+    assert t.equal(back[(want[cu:] - U).to(DEV)], part[cu:c]) and int((back.abs().sum(1) > 0).sum()) <= c - cu
 
 
 @pytest.mark.parametrize("K", [0, 1, 2, 3, 4])
