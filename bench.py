@@ -129,7 +129,8 @@ def main():
                                   sparse_batch=not args.plain_step)
     else:
         from laplace_amd.dist import ShardedLightGCNTrainer
-        trainer = ShardedLightGCNTrainer(model, inter, lr=1e-3, Lambda=1e-6, batch_size=B, seed=7 + rank)
+        trainer = ShardedLightGCNTrainer(model, inter, lr=1e-3, Lambda=1e-6, batch_size=B, seed=7 + rank,
+                                         sparse_batch=not args.plain_step)
     nnz, n_rows = trainer.adj_fwd.nnz, trainer.adj_fwd.n_rows
     t.cuda.synchronize()
 
@@ -156,20 +157,23 @@ def main():
         elapsed = float(tt)
 
     if rank == 0:
-        # The roofline is quoted on the DENSE propagate (every entry of the adjacency gathered): kernels
-        # spmm_*_kernel<..., false>.  The two sparse-operand launches of the byte-saving step (last forward
-        # layer at the batch rows, first backward layer over the non-zero gradient rows) gather a
-        # data-dependent subset and are reported beside it, not mixed in.
-        dense_ms = [s.elapsed_time(e) for s, e, kind in events if kind == "dense"]
-        sparse_ms = [s.elapsed_time(e) for s, e, kind in events if kind == "sparse"]
-        spmm_ms = dense_ms
-        if world == 1:
-            n_layers_timed = len(dense_ms)
-        else:  # sharded: one layer = two dense launches (item rows + user rows)
-            n_layers_timed = len(dense_ms) // 2
-        avg_ms = sum(dense_ms) / max(n_layers_timed, 1)
-        algo = spmm_bytes(nnz, n_rows, D)
-        achieved = algo / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        # The roofline is quoted on the DENSE propagate (every entry of the adjacency slice gathered): kernels
+        # spmm_*_kernel<..., false>.  The sparse-operand launches of the byte-saving step (last forward layer at
+        # the batch rows, first backward layer over the non-zero gradient rows) gather a data-dependent subset and
+        # are reported beside it, not mixed in.  Algorithmic bytes are summed per launch from that launch's own
+        # entry and row counts (a sharded layer is two launches: item rows and user rows).
+        dense = [(s.elapsed_time(e), a) for s, e, kind, _, _, a in events if kind == "dense"]
+        sparse_ms = [s.elapsed_time(e) for s, e, kind, _, _, _ in events if kind == "sparse"]
+        nnz_of = {}
+        for _, a in dense:
+            if id(a) not in nnz_of:  # entries of a row slice = rowptr[last] - rowptr[first]
+                nnz_of[id(a)] = int(a.rowptr[-1]) - int(a.rowptr[0])
+        spmm_ms = [ms for ms, _ in dense]
+        algo_total = sum(spmm_bytes(nnz_of[id(a)], a.n_rows, D) for _, a in dense)
+        n_layers_timed = len(dense)
+        avg_ms = sum(spmm_ms) / max(len(spmm_ms), 1)
+        algo = algo_total / max(len(dense), 1)
+        achieved = algo_total / (sum(spmm_ms) * 1e-3) / 1e9 if spmm_ms else 0.0
         traffic = None
         tf = os.path.join(ROOT, "profiles", "traffic.json")
         default_workload = (args.users, args.items, args.edges, D) == (1_000_000, 100_000, 10_000_000, 128)
@@ -200,7 +204,7 @@ def main():
                          "dense_launches_per_step": len(dense_ms) / args.steps,
                          "sparse_launches_per_step": len(sparse_ms) / args.steps,
                          "sparse_launch_avg_ms": (sum(sparse_ms) / len(sparse_ms)) if sparse_ms else None},
-            "step_form": "plain" if args.plain_step or world > 1 else "sparse_batch",
+            "step_form": "plain" if args.plain_step else "sparse_batch",
             "loss": loss_val, "graph_gen_s": round(t_gen, 1), "backend": backend if world > 1 else None,
         }
         if table0 is not None:

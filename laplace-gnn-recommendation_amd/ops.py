@@ -259,7 +259,8 @@ def spmm(a: DeviceCSR, X: Tensor, *, Y: Optional[Tensor] = None, addend: Optiona
                                _stream()), "mi_spmm_csr_ex_f32")
     if ev is not None:
         ev[1].record()
-        SPMM_EVENTS.append((ev[0], ev[1], "sparse" if (x_map is not None or row_list is not None) else "dense"))
+        SPMM_EVENTS.append((ev[0], ev[1], "sparse" if (x_map is not None or row_list is not None) else "dense",
+                            None, a.n_rows, a))
 
 
 def expand_rows(a: DeviceCSR) -> Tensor:
