@@ -201,7 +201,7 @@ def main():
                          "kernel": "mi_spmm_csr_f32 dense launch (spmm_items_kernel + spmm_rows_kernel + spmm_fixup_kernel, SPARSE=false)",
                          "algorithmic_bytes_per_launch": algo, "avg_launch_ms": avg_ms,
                          "launches_timed": len(spmm_ms), "layers_timed": n_layers_timed,
-                         "dense_launches_per_step": len(dense_ms) / args.steps,
+                         "dense_launches_per_step": len(dense) / args.steps,
                          "sparse_launches_per_step": len(sparse_ms) / args.steps,
                          "sparse_launch_avg_ms": (sum(sparse_ms) / len(sparse_ms)) if sparse_ms else None},
             "step_form": "plain" if args.plain_step else "sparse_batch",
