@@ -5,7 +5,8 @@ The fixtures hold inputs and the reference's outputs — data, no reference sour
 the oracle (oracle/*.py) for the rows of SURVEY §8 whose arithmetic lives in the reference's own
 files: bpr_loss (+ its autograd gradients), make_predictions_for_user, get_metrics_lightgcn,
 RecallPrecision_ATk / NDCGatK_r, get_metrics_universal, padded_stack, difference_1d,
-get_linear_layers, Config / LightGCNConfig defaults, embedding_range_dict.
+get_linear_layers, Config / LightGCNConfig defaults, embedding_range_dict, and (N2) the chronological
+split + adjacency dicts of run_data_splitting.py / utils/preprocessing.py.
 """
 import dataclasses
 import os
@@ -115,5 +116,32 @@ def main() -> None:
         print(f"  {f}: {os.path.getsize(os.path.join(OUT, f))} bytes")
 
 
+
+
+def time_split_golden() -> None:
+    """tests/golden/time_split.pt: the reference's train_test_split_by_time (run_data_splitting.py:36-52) and
+    extract_edges / extract_reverse_edges (utils/preprocessing.py:84-89) on a seeded transaction table."""
+    sys.path.insert(0, REF)
+    import numpy as np
+    import pandas as pd
+    from run_data_splitting import train_test_split_by_time
+    from utils.preprocessing import extract_edges, extract_reverse_edges
+    rng = np.random.default_rng(0)
+    n = 400
+    df = pd.DataFrame({"customer_id": rng.integers(0, 60, n), "article_id": rng.integers(0, 45, n),
+                       "timestamp": np.sort(rng.integers(0, 10 ** 6, n))})
+    df.loc[df.customer_id == 7, "customer_id"] = 8
+    df.loc[df.index[:3], "customer_id"] = [58, 58, 59]
+    out = train_test_split_by_time(df.copy(), "customer_id")
+    if out.index.nlevels > 1:  # pandas >= 2 prepends the group key to the index; the reference's era did not
+        out = out.reset_index(level=0, drop=True).sort_index()
+    tr = out[out["train_mask"] == True]  # noqa: E712
+    t.save({"customer_id": df.customer_id.to_numpy(), "article_id": df.article_id.to_numpy(),
+            "train_mask": out.train_mask.to_numpy(), "val_mask": out.val_mask.to_numpy(),
+            "test_mask": out.test_mask.to_numpy(), "edges_train": extract_edges(tr),
+            "rev_edges_train": extract_reverse_edges(tr)}, os.path.join(OUT, "time_split.pt"))
+
+
 if __name__ == "__main__":
     main()
+    time_split_golden()

@@ -297,3 +297,28 @@ def test_matchers_equal_reference_semantics():
     ds = GraphDataset(_cfg(), hd, users, articles, train=False, matchers=get_matchers("fashion", users, articles, 10))
     item = ds[2]
     assert int(item[Constants.edge_key].edge_label.sum()) >= 1
+
+
+def test_time_split_and_graph_files_match_reference(golden_dir, tmp_path):
+    """Chronological leave-last-two-out split and the adjacency dicts equal the reference's pandas code
+    (golden); files round-trip in the reference's layout and feed create_dataloaders."""
+    from laplace_amd.data import graph_io
+    from laplace_amd.data.data_loader import create_dataloaders
+    from laplace_amd.data.matching import get_matchers
+    from laplace_amd.utils.constants import Constants
+    g = t.load(os.path.join(golden_dir, "time_split.pt"), weights_only=False)
+    tr, va, te = graph_io.train_test_split_by_time(g["customer_id"])
+    assert np.array_equal(tr, g["train_mask"]) and np.array_equal(va, g["val_mask"]) and np.array_equal(te, g["test_mask"])
+    cx = t.randint(0, 9, (60, 3))
+    ax = t.randint(0, 5, (45, 2))
+    splits = graph_io.build_splits(cx, ax, g["customer_id"], g["article_id"])
+    assert splits["train"][1] == g["edges_train"] and splits["train"][2] == g["rev_edges_train"]
+    n_tr, n_va, n_te = (splits[k][0][Constants.edge_key].edge_index.shape[1] for k in ("train", "val", "test"))
+    assert n_tr == int(tr.sum()) and n_va == n_tr + int(va.sum()) and n_te == n_va + int(te.sum())
+    graph_io.write_splits(splits, str(tmp_path), {str(i): f"c{i}" for i in range(60)}, {str(i): f"a{i}" for i in range(45)})
+    assert sorted(os.listdir(tmp_path)) == sorted(
+        [f"{s}_graph.pt" for s in ("train", "val", "test")] + [f"edges_{s}.pt" for s in ("train", "val", "test")]
+        + [f"rev_edges_{s}.pt" for s in ("train", "val", "test")] + ["customer_id_map_forward.json", "article_id_map_forward.json"])
+    back, cmap, amap = graph_io.read_splits(str(tmp_path))
+    assert back["val"][1] == splits["val"][1] and cmap["3"] == "c3" and amap["44"] == "a44"
+    assert t.equal(back["test"][0][Constants.edge_key].edge_index, splits["test"][0][Constants.edge_key].edge_index)
