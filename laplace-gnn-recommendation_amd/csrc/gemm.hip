@@ -98,6 +98,95 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(MiGemmArgs g) {
     }
 }
 
+// Fast path for the layout that dominates: A [M, K] and B [N, K] both K-contiguous (nn.Linear forward
+// x @ W^T, the top-K score block).  One global-load phase stages a 64 x KC panel of each operand
+// (KC = 128: every lane keeps 16 independent 16-byte loads in flight), one barrier, then KC/2 MFMAs
+// back to back per wavefront; the accumulator walks K in ascending order exactly as in the generic
+// kernel, so results are bitwise the same.  LDS rows are padded to 129 floats: conflict-free fragment
+// reads (bank = (row + k) mod 32).
+constexpr int KC = 128, KPAD = 129;
+
+__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(MiGemmArgs g) {
+    __shared__ float As[BM][KPAD];
+    __shared__ float Bs[BN][KPAD];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int64_t m0 = (int64_t)blockIdx.y * BM, n0 = (int64_t)blockIdx.x * BN;
+    const int64_t k_lo = (int64_t)blockIdx.z * g.k_per_split;
+    const int64_t k_hi = min(g.K, k_lo + g.k_per_split);
+
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+
+    for (int64_t kc = k_lo; kc < k_hi; kc += KC) {
+        const int kw = (int)min((int64_t)KC, k_hi - kc);  // multiple of 4
+        float4 va[(BM * KC / 4) / 256], vb[(BN * KC / 4) / 256];
+#pragma unroll
+        for (int j = 0; j < (BM * KC / 4) / 256; ++j) {
+            const int idx = tid + 256 * j, r = idx / (KC / 4), c4 = idx % (KC / 4);
+            const int64_t gm = m0 + r;
+            va[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gm < g.M && c4 * 4 < kw) {
+                const int64_t row = g.a_rows ? g.a_rows[gm] : gm;
+                va[j] = *reinterpret_cast<const float4*>(g.A + row * g.sa_m + kc + c4 * 4);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < (BN * KC / 4) / 256; ++j) {
+            const int idx = tid + 256 * j, r = idx / (KC / 4), c4 = idx % (KC / 4);
+            const int64_t gn = n0 + r;
+            vb[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gn < g.N && c4 * 4 < kw) vb[j] = *reinterpret_cast<const float4*>(g.B + gn * g.sb_n + kc + c4 * 4);
+        }
+#pragma unroll
+        for (int j = 0; j < (BM * KC / 4) / 256; ++j) {
+            const int idx = tid + 256 * j, r = idx / (KC / 4), c = (idx % (KC / 4)) * 4;
+            As[r][c] = va[j].x; As[r][c + 1] = va[j].y; As[r][c + 2] = va[j].z; As[r][c + 3] = va[j].w;
+        }
+#pragma unroll
+        for (int j = 0; j < (BN * KC / 4) / 256; ++j) {
+            const int idx = tid + 256 * j, r = idx / (KC / 4), c = (idx % (KC / 4)) * 4;
+            Bs[r][c] = vb[j].x; Bs[r][c + 1] = vb[j].y; Bs[r][c + 2] = vb[j].z; Bs[r][c + 3] = vb[j].w;
+        }
+        __syncthreads();
+        const float* ap = &As[wm * 32 + (lane & 31)][lane >> 5];
+        const float* bp = &Bs[wn * 32 + (lane & 31)][lane >> 5];
+        if (kw == KC) {
+#pragma unroll 16
+            for (int s = 0; s < KC / 2; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * s], bp[2 * s], acc, 0, 0, 0);
+        } else {
+            for (int s = 0; s < kw / 2; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * s], bp[2 * s], acc, 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    const int64_t gn = n0 + wn * 32 + (lane & 31);
+    if (gn >= g.N) return;
+    if (g.splits > 1) {
+        float* slab = g.partial + (int64_t)blockIdx.z * g.M * g.N;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int64_t gm = m0 + wm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+            if (gm < g.M) slab[gm * g.N + gn] = acc[reg];
+        }
+        return;
+    }
+    const float bv = g.bias ? g.bias[gn] : 0.f;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const int64_t gm = m0 + wm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+        if (gm >= g.M) continue;
+        float v = acc[reg];
+        if (g.bias) v += bv;
+        float* c = g.C + gm * g.ldc + gn;
+        if (g.accumulate) v += *c;
+        if (g.act == 1) v = v > 0.f ? v : 0.f;
+        *c = v;
+    }
+}
+
 // Sums the K-slice slabs in slice order (fixed order: bitwise reproducible), then the epilogue.
 __global__ void gemm_splitk_reduce_kernel(MiGemmArgs g) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -141,7 +230,12 @@ int mi_gemm_launch(MiGemmArgs g, void* ws, size_t ws_bytes, hipStream_t stream) 
         g.partial = static_cast<float*>(ws);
         grid.z = (unsigned)g.splits;
     }
-    hipLaunchKernelGGL(gemm_f32_kernel, grid, dim3(256), 0, stream, g);
+    const bool nt_fast = g.sa_k == 1 && g.sb_k == 1 && g.K % 4 == 0 && g.sa_m % 4 == 0 && g.sb_n % 4 == 0 &&
+                         mi_aligned16(g.A) && mi_aligned16(g.B) && g.k_per_split % 4 == 0;
+    if (nt_fast)
+        hipLaunchKernelGGL(gemm_nt_kernel, grid, dim3(256), 0, stream, g);
+    else
+        hipLaunchKernelGGL(gemm_f32_kernel, grid, dim3(256), 0, stream, g);
     if (g.splits > 1) {
         const int64_t total = g.M * g.N;
         hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((unsigned)mi_ceil_div(total, 256)), dim3(256), 0, stream, g);
