@@ -178,12 +178,14 @@ __global__ __launch_bounds__(256) void smp_seed_kernel(Smp p) {
 }
 
 // ---- phase 2 (per hop): mark the users of the queued articles -------------------------------------
+// grid (n, B, kMarkSplit): a hub article's user list (10^5..10^6 entries) is spread over kMarkSplit workgroups
+constexpr int kMarkSplit = 32;
 __global__ __launch_bounds__(256) void smp_mark_users_kernel(Smp p) {
     const int s = blockIdx.y, j = blockIdx.x;
     if (j >= p.aq_n[s]) return;
     const int32_t a = p.aq[(int64_t)s * p.n + j];
     uint32_t* bm = p.bm_users + (int64_t)s * p.WU;
-    for (int32_t q = p.aptr[a] + threadIdx.x; q < p.aptr[a + 1]; q += blockDim.x) {
+    for (int32_t q = p.aptr[a] + blockIdx.z * blockDim.x + threadIdx.x; q < p.aptr[a + 1]; q += kMarkSplit * blockDim.x) {
         const int32_t v = p.aidx[q];
         atomicOr(bm + (v >> 5), 1u << (v & 31));
     }
@@ -475,7 +477,7 @@ int mi_sampler_count(const mi_sampler_desc* d, const int64_t* seed_users, uint64
     MI_HIP(hipMemsetAsync(p.bm_art, 0, (size_t)p.B * p.WA * 4, s));
     hipLaunchKernelGGL(smp_seed_kernel, dim3(p.B), dim3(256), 0, s, p);
     for (int hop = 0; hop <= p.H - 2; ++hop) {
-        hipLaunchKernelGGL(smp_mark_users_kernel, dim3(p.n, p.B), dim3(256), 0, s, p);
+        hipLaunchKernelGGL(smp_mark_users_kernel, dim3(p.n, p.B, kMarkSplit), dim3(256), 0, s, p);
         hipLaunchKernelGGL(smp_select_users_kernel, dim3(p.B), dim3(kSelThreads), 0, s, p, hop);
     }
     hipLaunchKernelGGL(smp_mark_articles_kernel, dim3(1 + p.H * p.n, p.B), dim3(256), 0, s, p);
