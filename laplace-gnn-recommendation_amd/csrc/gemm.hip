@@ -98,15 +98,70 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(MiGemmArgs g) {
     }
 }
 
-// Fast path for the layout that dominates: A [M, K] and B [N, K] both K-contiguous (nn.Linear forward
-// x @ W^T, the top-K score block).  One global-load phase stages a 64 x KC panel of each operand
-// (KC = 128: every lane keeps 16 independent 16-byte loads in flight), one barrier, then KC/2 MFMAs
-// back to back per wavefront; the accumulator walks K in ascending order exactly as in the generic
-// kernel, so results are bitwise the same.  LDS rows are padded to 129 floats: conflict-free fragment
+// Fast path (operands 16-byte aligned, leading dimensions and K multiples of 4).  One global-load phase
+// stages a 64 x KC panel of each operand (KC = 128: every lane keeps 16 independent 16-byte loads in
+// flight), one barrier, then KC/2 MFMAs back to back per wavefront; the accumulator walks K in ascending
+// order exactly as in the generic kernel, so results are bitwise the same.  Either operand may be
+// K-contiguous (x @ W^T: nn.Linear forward, the top-K score block) or contiguous along its output
+// dimension (dX = dY @ W, dW = dY^T @ X): the float4 is loaded along whichever dimension is contiguous
+// and written to the same [row][k] LDS panel.  Rows are padded to 129 floats: conflict-free fragment
 // reads (bank = (row + k) mod 32).
 constexpr int KC = 128, KPAD = 129;
 
-__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(MiGemmArgs g) {
+// A 64 x KC panel of an operand whose element (row, k) sits at base[row * s_row + k * s_k]; rows >= n_rows
+// and k >= kw read as zero.  Split in two so that both operands' global loads are in flight before the
+// first LDS store: panel_issue loads into registers, panel_commit writes panel[r][k].
+constexpr int kN4 = (64 * KC / 4) / 256;  // float4 per thread and operand
+
+template <bool KFAST>
+__device__ __forceinline__ void panel_issue(float4 (&v)[kN4], const float* __restrict__ base, int64_t s_row,
+                                            int64_t s_k, const int64_t* __restrict__ row_map, int64_t row0,
+                                            int64_t n_rows, int64_t kc, int kw, int tid) {
+#pragma unroll
+    for (int j = 0; j < kN4; ++j) {
+        const int idx = tid + 256 * j;
+        v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (KFAST) {  // float4 along k
+            const int r = idx / (KC / 4), c4 = idx % (KC / 4);
+            const int64_t gr = row0 + r;
+            if (gr < n_rows && c4 * 4 < kw) {
+                const int64_t row = row_map ? row_map[gr] : gr;
+                v[j] = *reinterpret_cast<const float4*>(base + row * s_row + kc + c4 * 4);
+            }
+        } else {      // contiguous along the row index: one float4 = 4 consecutive rows at one k
+            const int k = idx / 16, r4 = (idx % 16) * 4;
+            const int64_t gr = row0 + r4;
+            if (k < kw) {
+                const float* src = base + (kc + k) * s_k + gr;
+                if (gr + 3 < n_rows) {
+                    v[j] = *reinterpret_cast<const float4*>(src);
+                } else {
+                    if (gr < n_rows) v[j].x = src[0];
+                    if (gr + 1 < n_rows) v[j].y = src[1];
+                    if (gr + 2 < n_rows) v[j].z = src[2];
+                }
+            }
+        }
+    }
+}
+
+template <bool KFAST>
+__device__ __forceinline__ void panel_commit(float (*panel)[KPAD], const float4 (&v)[kN4], int tid) {
+#pragma unroll
+    for (int j = 0; j < kN4; ++j) {
+        const int idx = tid + 256 * j;
+        if (KFAST) {
+            const int r = idx / (KC / 4), c = (idx % (KC / 4)) * 4;
+            panel[r][c] = v[j].x; panel[r][c + 1] = v[j].y; panel[r][c + 2] = v[j].z; panel[r][c + 3] = v[j].w;
+        } else {
+            const int k = idx / 16, r4 = (idx % 16) * 4;
+            panel[r4][k] = v[j].x; panel[r4 + 1][k] = v[j].y; panel[r4 + 2][k] = v[j].z; panel[r4 + 3][k] = v[j].w;
+        }
+    }
+}
+
+template <bool A_KFAST, bool B_KFAST>
+__global__ __launch_bounds__(256, 2) void gemm_fast_kernel(MiGemmArgs g) {
     __shared__ float As[BM][KPAD];
     __shared__ float Bs[BN][KPAD];
     const int tid = threadIdx.x;
@@ -122,34 +177,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(MiGemmArgs g) {
 
     for (int64_t kc = k_lo; kc < k_hi; kc += KC) {
         const int kw = (int)min((int64_t)KC, k_hi - kc);  // multiple of 4
-        float4 va[(BM * KC / 4) / 256], vb[(BN * KC / 4) / 256];
-#pragma unroll
-        for (int j = 0; j < (BM * KC / 4) / 256; ++j) {
-            const int idx = tid + 256 * j, r = idx / (KC / 4), c4 = idx % (KC / 4);
-            const int64_t gm = m0 + r;
-            va[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (gm < g.M && c4 * 4 < kw) {
-                const int64_t row = g.a_rows ? g.a_rows[gm] : gm;
-                va[j] = *reinterpret_cast<const float4*>(g.A + row * g.sa_m + kc + c4 * 4);
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < (BN * KC / 4) / 256; ++j) {
-            const int idx = tid + 256 * j, r = idx / (KC / 4), c4 = idx % (KC / 4);
-            const int64_t gn = n0 + r;
-            vb[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (gn < g.N && c4 * 4 < kw) vb[j] = *reinterpret_cast<const float4*>(g.B + gn * g.sb_n + kc + c4 * 4);
-        }
-#pragma unroll
-        for (int j = 0; j < (BM * KC / 4) / 256; ++j) {
-            const int idx = tid + 256 * j, r = idx / (KC / 4), c = (idx % (KC / 4)) * 4;
-            As[r][c] = va[j].x; As[r][c + 1] = va[j].y; As[r][c + 2] = va[j].z; As[r][c + 3] = va[j].w;
-        }
-#pragma unroll
-        for (int j = 0; j < (BN * KC / 4) / 256; ++j) {
-            const int idx = tid + 256 * j, r = idx / (KC / 4), c = (idx % (KC / 4)) * 4;
-            Bs[r][c] = vb[j].x; Bs[r][c + 1] = vb[j].y; Bs[r][c + 2] = vb[j].z; Bs[r][c + 3] = vb[j].w;
-        }
+        float4 va[kN4], vb[kN4];
+        panel_issue<A_KFAST>(va, g.A, g.sa_m, g.sa_k, g.a_rows, m0, g.M, kc, kw, tid);
+        panel_issue<B_KFAST>(vb, g.B, g.sb_n, g.sb_k, nullptr, n0, g.N, kc, kw, tid);
+        panel_commit<A_KFAST>(As, va, tid);
+        panel_commit<B_KFAST>(Bs, vb, tid);
         __syncthreads();
         const float* ap = &As[wm * 32 + (lane & 31)][lane >> 5];
         const float* bp = &Bs[wn * 32 + (lane & 31)][lane >> 5];
@@ -230,12 +262,22 @@ int mi_gemm_launch(MiGemmArgs g, void* ws, size_t ws_bytes, hipStream_t stream) 
         g.partial = static_cast<float*>(ws);
         grid.z = (unsigned)g.splits;
     }
-    const bool nt_fast = g.sa_k == 1 && g.sb_k == 1 && g.K % 4 == 0 && g.sa_m % 4 == 0 && g.sb_n % 4 == 0 &&
-                         mi_aligned16(g.A) && mi_aligned16(g.B) && g.k_per_split % 4 == 0;
-    if (nt_fast)
-        hipLaunchKernelGGL(gemm_nt_kernel, grid, dim3(256), 0, stream, g);
-    else
+    // fast path: float4-addressable operands.  K-contiguous operand: row stride % 4; output-contiguous
+    // operand (stride 1 along its rows): k stride % 4 and no row gather.
+    const bool a_kfast = g.sa_k == 1, b_kfast = g.sb_k == 1;
+    const bool a_ok = a_kfast ? (g.sa_m % 4 == 0) : (g.sa_m == 1 && g.sa_k % 4 == 0 && g.a_rows == nullptr);
+    const bool b_ok = b_kfast ? (g.sb_n % 4 == 0) : (g.sb_n == 1 && g.sb_k % 4 == 0);
+    const bool fast = a_ok && b_ok && g.K % 4 == 0 && g.k_per_split % 4 == 0 && mi_aligned16(g.A) && mi_aligned16(g.B);
+    if (!fast)
         hipLaunchKernelGGL(gemm_f32_kernel, grid, dim3(256), 0, stream, g);
+    else if (a_kfast && b_kfast)
+        hipLaunchKernelGGL((gemm_fast_kernel<true, true>), grid, dim3(256), 0, stream, g);
+    else if (a_kfast)
+        hipLaunchKernelGGL((gemm_fast_kernel<true, false>), grid, dim3(256), 0, stream, g);
+    else if (b_kfast)
+        hipLaunchKernelGGL((gemm_fast_kernel<false, true>), grid, dim3(256), 0, stream, g);
+    else
+        hipLaunchKernelGGL((gemm_fast_kernel<false, false>), grid, dim3(256), 0, stream, g);
     if (g.splits > 1) {
         const int64_t total = g.M * g.N;
         hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((unsigned)mi_ceil_div(total, 256)), dim3(256), 0, stream, g);
