@@ -363,6 +363,10 @@ int mi_embed_concat_f32(int64_t n, int32_t n_cols, const int64_t* x,
  *                     within each sample), edge_index int64[2, tot2], edge_label_index
  *                     int64[2, tot3] (batch-local ids), edge_label int64[tot3],
  *                     user_ptr / article_ptr int64[batch+1] (node offsets per sample).
+ * Frontier: when the queued articles' user lists total more than reject_min_entries, the
+ * uniform num_neighbors-subset of their distinct unexplored users is drawn by rejection (position of
+ * the concatenated lists, acceptance 1/multiplicity) instead of materialising the set — hub
+ * articles carry 10^5..10^6 users; the bound guarantees >= num_neighbors candidates exist.
  * Randomness: Philox4x32-10 keyed on (seed, step); bit-exact mirror in oracle/sampler_ref.py.
  * ---------------------------------------------------------------------------------- */
 typedef struct mi_sampler_desc {
@@ -372,6 +376,7 @@ typedef struct mi_sampler_desc {
     const int32_t* users_ptr;    const int32_t* users_idx;
     const int32_t* articles_ptr; const int32_t* articles_idx;
     double positive_edges_ratio, negative_edges_ratio;
+    int64_t reject_min_entries; /* 0 = default 4*n*(n*(hops+1)+1); must be >= n*(n*(hops+1)+1) */
 } mi_sampler_desc;
 
 size_t mi_sampler_workspace_bytes(const mi_sampler_desc* d);

@@ -32,7 +32,7 @@ class SamplerDesc(Structure):
                 ("randomization", c_int32), ("max_pos", c_int32), ("max_neg", c_int32), ("reserved", c_int32),
                 ("num_users", c_int64), ("num_articles", c_int64), ("num_edges", c_int64), ("id_max", c_int64),
                 ("users_ptr", c_void_p), ("users_idx", c_void_p), ("articles_ptr", c_void_p), ("articles_idx", c_void_p),
-                ("positive_edges_ratio", c_double), ("negative_edges_ratio", c_double)]
+                ("positive_edges_ratio", c_double), ("negative_edges_ratio", c_double), ("reject_min_entries", c_int64)]
 
 
 P = c_void_p

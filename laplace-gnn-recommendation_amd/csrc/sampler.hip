@@ -19,7 +19,8 @@
 
 namespace {
 
-enum { P_POS = 1, P_NEG = 2, P_ART_CUT = 3, P_USER_CUT = 4, P_NEG_EXACT = 5 };
+enum { P_POS = 1, P_NEG = 2, P_ART_CUT = 3, P_USER_CUT = 4, P_NEG_EXACT = 5, P_USER_REJ = 6 };
+constexpr int kRejectCap = 1 << 16;  // draws; unreachable when reject_min respects its bound (see header)
 constexpr int kMaxFan = 1024;       // num_neighbors cap of this implementation
 constexpr int kSelThreads = 1024;
 
@@ -38,6 +39,8 @@ struct Smp {
     int32_t* pre_a;
     int32_t* uq; int32_t* uq_n; int32_t* uq_local; int32_t* uq_estart;
     int32_t* aq; int32_t* aq_n;
+    int64_t* aq_L;      // [B] total length of the queued articles' user lists
+    int64_t reject_min; // above this the next frontier is drawn by rejection instead of being materialised
     int32_t* pos_items; int32_t* neg_items; int32_t* n_pos; int32_t* n_neg;
     int32_t* cnt;   // [B][4]
     int32_t* off;   // [4][B+1]
@@ -74,6 +77,8 @@ __device__ int floyd_subset(int64_t L, int n, uint32_t purpose, uint32_t seed_us
     return c;
 }
 
+__device__ __forceinline__ int s_of(const Smp& p, const int32_t* aq_n_ptr) { return (int)(aq_n_ptr - p.aq_n); }
+
 // positions (ascending) of the concatenated article lists of `users[0..nu)` -> article ids
 __device__ void cut_articles(const Smp& p, const int32_t* users, int nu, uint32_t seed_user, int hop, int32_t* sel,
                              int32_t* aq_out, int32_t* aq_n_out) {
@@ -90,6 +95,9 @@ __device__ void cut_articles(const Smp& p, const int32_t* users, int nu, uint32_
         aq_out[q] = p.uidx[p.uptr[users[t]] + (sel[q] - base)];
     }
     *aq_n_out = c;
+    int64_t tot = 0;
+    for (int q = 0; q < c; ++q) tot += p.aptr[aq_out[q] + 1] - p.aptr[aq_out[q]];
+    p.aq_L[s_of(p, aq_n_out)] = tot;
 }
 
 // ---- phase 1: label edges + hop-0 article cut -------------------------------------------------
@@ -123,6 +131,7 @@ __global__ __launch_bounds__(256) void smp_seed_kernel(Smp p) {
         p.uq_n[(int64_t)s * p.H] = 1;
         for (int h = 1; h < p.H; ++h) p.uq_n[(int64_t)s * p.H + h] = 0;
         p.aq_n[s] = 0;
+        p.aq_L[s] = 0;
     }
     __syncthreads();
     const int npos = sh_npos, nneg = sh_nneg;
@@ -182,7 +191,7 @@ __global__ __launch_bounds__(256) void smp_seed_kernel(Smp p) {
 constexpr int kMarkSplit = 32;
 __global__ __launch_bounds__(256) void smp_mark_users_kernel(Smp p) {
     const int s = blockIdx.y, j = blockIdx.x;
-    if (j >= p.aq_n[s]) return;
+    if (j >= p.aq_n[s] || p.aq_L[s] > p.reject_min) return;  // long lists: drawn by rejection, nothing to mark
     const int32_t a = p.aq[(int64_t)s * p.n + j];
     uint32_t* bm = p.bm_users + (int64_t)s * p.WU;
     for (int32_t q = p.aptr[a] + blockIdx.z * blockDim.x + threadIdx.x; q < p.aptr[a + 1]; q += kMarkSplit * blockDim.x) {
@@ -201,6 +210,81 @@ __global__ __launch_bounds__(kSelThreads) void smp_select_users_kernel(Smp p, in
     const int32_t u = (int32_t)p.seeds[s];
     int32_t* uq = p.uq + (int64_t)s * p.H * p.n;
     int32_t* uq_n = p.uq_n + (int64_t)s * p.H;
+    if (p.aq_L[s] > p.reject_min) {  // block-uniform
+        // Rejection pick (oracle/sampler_ref.py:reject_pick_users): position of the concatenated user lists ->
+        // user v with probability ~ m(v); accept with probability 1/m(v); skip explored / picked; draws are
+        // evaluated 64 at a time by wavefront 0 and committed in counter order.
+        __shared__ int64_t pre[kMaxFan + 1];
+        __shared__ int sh_np;
+        volatile int32_t* picked = sel;
+        const int32_t* aq = p.aq + (int64_t)s * p.n;
+        const int naq = p.aq_n[s];
+        if (tid == 0) {
+            int64_t run = 0;
+            for (int q = 0; q < naq; ++q) {
+                pre[q] = run;
+                run += p.aptr[aq[q] + 1] - p.aptr[aq[q]];
+            }
+            pre[naq] = run;
+            sh_np = 0;
+        }
+        __syncthreads();
+        if (tid < MI_WAVE) {
+            const int64_t L = pre[naq];
+            int np = 0;
+            for (int t0 = 0; np < p.n && t0 < kRejectCap; t0 += MI_WAVE) {
+                const uint32_t tt = (uint32_t)(t0 + tid);
+                const uint32_t c3 = (P_USER_REJ & 0xFFu) | ((uint32_t)(p.step & 0xFFFFFFu) << 8);
+                MiPhilox w = mi_philox4x32(tt, (uint32_t)hop, (uint32_t)u, c3, (uint32_t)p.seed,
+                                           (uint32_t)((p.seed >> 32) ^ (p.step >> 24)));
+                const int64_t pos = (int64_t)((((uint64_t)w.c[0] << 32) | w.c[1]) % (uint64_t)L);
+                int lo = 0, hi = naq;  // last q with pre[q] <= pos
+                while (hi - lo > 1) {
+                    const int mid = (lo + hi) >> 1;
+                    if (pre[mid] <= pos) lo = mid; else hi = mid;
+                }
+                const int32_t v = p.aidx[p.aptr[aq[lo]] + (pos - pre[lo])];
+                uint32_t m = 0;
+                for (int32_t x = p.uptr[v]; x < p.uptr[v + 1]; ++x) {
+                    const int32_t a = p.uidx[x];
+                    for (int q = 0; q < naq; ++q) m += (aq[q] == a);
+                }
+                bool ok = (m > 0) && (w.c[2] % m == 0);
+                for (int h = 0; ok && h <= hop; ++h)
+                    for (int q = 0; q < uq_n[h]; ++q) ok &= (uq[h * p.n + q] != v);
+                unsigned long long mask = __ballot(ok);
+                while (mask && np < p.n) {
+                    const int l = __ffsll((long long)mask) - 1;
+                    mask &= mask - 1;
+                    const int32_t vv = __shfl(v, l, MI_WAVE);
+                    bool dup = false;
+                    for (int q = tid; q < np; q += MI_WAVE) dup |= (picked[q] == vv);
+                    if (__ballot(dup) == 0ull) {
+                        if (tid == 0) picked[np] = vv;
+                        ++np;
+                    }
+                }
+            }
+            if (tid == 0) sh_np = np;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            const int np = sh_np;
+            for (int a = 1; a < np; ++a) {  // ascending
+                int32_t v = sel[a];
+                int b = a - 1;
+                while (b >= 0 && sel[b] > v) { sel[b + 1] = sel[b]; --b; }
+                sel[b + 1] = v;
+            }
+            for (int q = 0; q < np; ++q) uq[(hop + 1) * p.n + q] = sel[q];
+            uq_n[hop + 1] = np;
+            p.aq_n[s] = 0;
+            p.aq_L[s] = 0;
+            if (hop + 1 <= p.H - 2 && np > 0)
+                cut_articles(p, uq + (hop + 1) * p.n, np, (uint32_t)u, hop + 1, sel, p.aq + (int64_t)s * p.n, p.aq_n + s);
+        }
+        return;
+    }
     // explored users are not candidates
     for (int h = 0; h <= hop; ++h)
         for (int q = tid; q < uq_n[h]; q += blockDim.x) {
@@ -250,6 +334,7 @@ __global__ __launch_bounds__(kSelThreads) void smp_select_users_kernel(Smp p, in
     if (tid == 0) {
         uq_n[hop + 1] = nsel;
         p.aq_n[s] = 0;
+        p.aq_L[s] = 0;
         if (hop + 1 <= p.H - 2 && nsel > 0)  // these users will be expanded too: cut their article lists
             cut_articles(p, uq + (hop + 1) * p.n, nsel, (uint32_t)u, hop + 1, sel, p.aq + (int64_t)s * p.n, p.aq_n + s);
     }
@@ -420,6 +505,7 @@ size_t smp_scratch_layout(const Smp& p, Smp* out, char* base) {
     char* a6 = take(B * H * n * 4);
     char* a7 = take(B * n * 4);
     char* a8 = take(B * 4);
+    char* a8b = take(B * 8);
     char* a9 = take(B * (size_t)p.max_pos * 4);
     char* a10 = take(B * (size_t)p.max_neg * 4);
     char* a11 = take(B * 4);
@@ -429,7 +515,7 @@ size_t smp_scratch_layout(const Smp& p, Smp* out, char* base) {
     if (out) {
         out->bm_users = (uint32_t*)a0; out->bm_art = (uint32_t*)a1; out->pre_a = (int32_t*)a2;
         out->uq = (int32_t*)a3; out->uq_n = (int32_t*)a4; out->uq_local = (int32_t*)a5; out->uq_estart = (int32_t*)a6;
-        out->aq = (int32_t*)a7; out->aq_n = (int32_t*)a8; out->pos_items = (int32_t*)a9; out->neg_items = (int32_t*)a10;
+        out->aq = (int32_t*)a7; out->aq_n = (int32_t*)a8; out->aq_L = (int64_t*)a8b; out->pos_items = (int32_t*)a9; out->neg_items = (int32_t*)a10;
         out->n_pos = (int32_t*)a11; out->n_neg = (int32_t*)a12; out->cnt = (int32_t*)a13; out->off = (int32_t*)a14;
     }
     return off;
@@ -446,6 +532,10 @@ int fill_params(Smp& p, const mi_sampler_desc* d) {
     p.pos_ratio = d->positive_edges_ratio; p.neg_ratio = d->negative_edges_ratio; p.k = d->k;
     p.randomization = d->randomization;
     p.max_pos = d->max_pos; p.max_neg = d->max_neg;
+    // termination of the rejection pick needs >= n distinct unexplored users among the lists (header)
+    const int64_t rmin_floor = (int64_t)d->num_neighbors * ((int64_t)d->num_neighbors * (d->n_hops + 1) + 1);
+    p.reject_min = d->reject_min_entries > 0 ? d->reject_min_entries : 4 * rmin_floor;
+    MI_CHECK_ARG(p.reject_min >= rmin_floor);
     p.WU = (int32_t)((d->num_users + 31) / 32);
     p.WA = (int32_t)((d->num_articles + 31) / 32);
     return 0;

@@ -48,7 +48,8 @@ class DeviceGraphSampler:
         return SamplerDesc(batch, int(c.n_hop_neighbors), int(c.num_neighbors), int(c.k), 1 if self.randomization else 0,
                            self.max_pos, self.max_neg, 0, self.num_users, self.num_articles, self.num_edges, self.id_max,
                            self.uptr.data_ptr(), self.uidx.data_ptr(), self.aptr.data_ptr(), self.aidx.data_ptr(),
-                           float(c.positive_edges_ratio), float(c.negative_edges_ratio))
+                           float(c.positive_edges_ratio), float(c.negative_edges_ratio),
+                           int(getattr(c, "reject_min_entries", 0) or 0))
 
     def __len__(self) -> int:
         return (self.num_users + self.batch_size - 1) // self.batch_size

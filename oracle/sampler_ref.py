@@ -9,7 +9,9 @@ every random choice drawn from a counter-based Philox stream so that device and 
               exact path: a uniform n_neg-subset of {0..id_max} minus the sampled positives (:211-230)
   n-hop       frontier caps on both sides (:258-293): a uniform `num_neighbors`-subset of the POSITIONS
               of the concatenated article lists, then a uniform `num_neighbors`-subset of the DISTINCT
-              unexplored users of those articles; hop-0 edges are not emitted by the walk
+              unexplored users of those articles (materialised and cut with Floyd when the lists are
+              short; drawn by rejection with acceptance 1/multiplicity when they are long — hub
+              articles carry 10^5..10^6 users); hop-0 edges are not emitted by the walk
   relabel     nodes by sorted-unique buckets (:134-150); forward + reverse stores (:164-182)
 
 The reference draws with torch.randint / random.sample / randperm; the law of every draw is the same
@@ -31,7 +33,22 @@ import numpy as np
 
 from .philox import philox4x32
 
-P_POS, P_NEG, P_ART_CUT, P_USER_CUT, P_NEG_EXACT = 1, 2, 3, 4, 5
+P_POS, P_NEG, P_ART_CUT, P_USER_CUT, P_NEG_EXACT, P_USER_REJ = 1, 2, 3, 4, 5, 6
+REJECT_CAP = 1 << 16  # draws; cannot be reached when reject_min_entries respects its bound
+
+
+def reject_min_entries(n: int, hops: int) -> int:
+    """Smallest total length L of the queued articles' user lists above which the frontier is drawn by
+    rejection instead of being materialised.  A user appears at most |queue| <= n times in the lists, so
+    there are >= L/n distinct users, of which <= 1 + n*hops are explored: L >= n*(n*(hops+1)+1) leaves
+    >= n candidates (termination); 4x that keeps the acceptance rate high."""
+    return 4 * n * (n * (hops + 1) + 1)
+
+
+def philox_words(purpose: int, seed_user: int, i: int, j: int, seed: int, step: int):
+    c3 = (purpose & 0xFF) | ((step & 0xFFFFFF) << 8)
+    k0, k1 = seed & 0xFFFFFFFF, ((seed >> 32) ^ (step >> 24)) & 0xFFFFFFFF
+    return [int(x) for x in philox4x32(i & 0xFFFFFFFF, j & 0xFFFFFFFF, seed_user & 0xFFFFFFFF, c3, k0, k1)]
 
 
 def rand_below(m: int, purpose: int, seed_user: int, i: int, j: int, seed: int, step: int) -> int:
@@ -51,6 +68,30 @@ def floyd_subset(L: int, n: int, purpose: int, seed_user: int, i: int, seed: int
         t = rand_below(j + 1, purpose, seed_user, i, j, seed, step)
         picked.append(j if t in picked else t)
     return sorted(picked)
+
+
+def reject_pick_users(article_queue, users: "CsrAdj", articles: "CsrAdj", explored: set, n: int, seed_user: int,
+                      hop: int, seed: int, step: int) -> np.ndarray:
+    """Uniform n-subset of the distinct unexplored users of the queued articles WITHOUT materialising
+    them: draw a position of the concatenated user lists (user v comes up with probability proportional
+    to m(v), the number of queued articles it bought, duplicates of the queue counted), accept with
+    probability 1/m(v), skip explored / already picked users; draws are taken in counter order t = 0, 1, ..."""
+    degs = [len(articles[int(a)]) for a in article_queue]
+    pre = np.concatenate([[0], np.cumsum(degs)])
+    L = int(pre[-1])
+    aq = [int(a) for a in article_queue]
+    picked = []
+    t = 0
+    while len(picked) < n and t < REJECT_CAP:
+        w = philox_words(P_USER_REJ, seed_user, t, hop, seed, step)
+        pos = ((w[0] << 32) | w[1]) % L
+        ai = int(np.searchsorted(pre, pos, side="right") - 1)
+        v = int(articles[aq[ai]][pos - int(pre[ai])])
+        m = sum(aq.count(int(x)) for x in users[v])
+        if w[2] % m == 0 and v not in explored and v not in picked:
+            picked.append(v)
+        t += 1
+    return np.array(sorted(picked), dtype=np.int64)
 
 
 class CsrAdj:
@@ -106,10 +147,15 @@ def sample_one(u: int, users: CsrAdj, articles: CsrAdj, num_edges: int, id_max: 
         flat = np.concatenate(lists) if lists else np.empty(0, dtype=np.int64)
         cut = floyd_subset(len(flat), cfg.num_neighbors, P_ART_CUT, u, hop, seed, step)
         article_queue = flat[cut]
-        cand = np.unique(np.concatenate([articles[int(a)] for a in article_queue])) if len(article_queue) else np.empty(0, dtype=np.int64)
-        cand = np.array([c for c in cand if c not in explored], dtype=np.int64)
-        pick = floyd_subset(len(cand), cfg.num_neighbors, P_USER_CUT, u, hop, seed, step)
-        queue = cand[pick]
+        total = sum(len(articles[int(a)]) for a in article_queue)
+        rmin = getattr(cfg, "reject_min_entries", None) or reject_min_entries(cfg.num_neighbors, H)
+        if total > rmin:
+            queue = reject_pick_users(article_queue, users, articles, explored, cfg.num_neighbors, u, hop, seed, step)
+        else:
+            cand = np.unique(np.concatenate([articles[int(a)] for a in article_queue])) if len(article_queue) else np.empty(0, dtype=np.int64)
+            cand = np.array([c for c in cand if c not in explored], dtype=np.int64)
+            pick = floyd_subset(len(cand), cfg.num_neighbors, P_USER_CUT, u, hop, seed, step)
+            queue = cand[pick]
         explored |= set(queue.tolist())
 
     sub_u = [np.full(deg, u, dtype=np.int64)] + [np.repeat(q, [len(users[int(x)]) for x in q]) for q in hop_users]

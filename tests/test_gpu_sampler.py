@@ -24,13 +24,16 @@ def _cfg(**kw):
     return SimpleNamespace(**base)
 
 
-@pytest.mark.parametrize("hops,fan,E,rand", [(1, 8, 6000, True), (2, 8, 6000, True), (3, 5, 6000, True), (3, 64, 6000, True),
-                                             (2, 8, 900, True), (2, 1000, 6000, False), (4, 3, 8000, True)])
-def test_device_sampler_bit_exact_vs_mirror(hops, fan, E, rand):
+@pytest.mark.parametrize("hops,fan,E,rand,rmin", [
+    (1, 8, 6000, True, 0), (2, 8, 6000, True, 0), (3, 5, 6000, True, 0), (3, 64, 6000, True, 0), (2, 8, 900, True, 0),
+    (2, 1000, 6000, False, 0), (4, 3, 8000, True, 0),
+    # frontier drawn by rejection: thresholds at their lower bound n*(n*(hops+1)+1) so that it triggers on this graph
+    (3, 5, 6000, True, 105), (2, 8, 6000, True, 200), (4, 3, 8000, True, 48)])
+def test_device_sampler_bit_exact_vs_mirror(hops, fan, E, rand, rmin):
     from laplace_amd.data.device_sampler import DeviceGraphSampler
     from laplace_amd.utils.constants import Constants
     graph, users, articles = _graph(seed=hops * 7 + fan, U=300, A=120, E=E)
-    cfg = _cfg(n_hop_neighbors=hops, num_neighbors=fan)
+    cfg = _cfg(n_hop_neighbors=hops, num_neighbors=fan, reject_min_entries=rmin)
     smp = DeviceGraphSampler(cfg, graph, users, articles, batch_size=16, randomization=rand, device=DEV, seed=1234)
     ei = graph[Constants.edge_key].edge_index
     ucsr, acsr = SR.CsrAdj(users.ptr, users.idx), SR.CsrAdj(articles.ptr, articles.idx)
