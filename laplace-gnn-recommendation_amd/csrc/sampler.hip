@@ -215,10 +215,12 @@ __global__ __launch_bounds__(kSelThreads) void smp_select_users_kernel(Smp p, in
         // user v with probability ~ m(v); accept with probability 1/m(v); skip explored / picked; draws are
         // evaluated 64 at a time by wavefront 0 and committed in counter order.
         __shared__ int64_t pre[kMaxFan + 1];
+        __shared__ int32_t aq[kMaxFan];  // the queue is compared against every article of every drawn user: keep it in LDS
         __shared__ int sh_np;
         volatile int32_t* picked = sel;
-        const int32_t* aq = p.aq + (int64_t)s * p.n;
         const int naq = p.aq_n[s];
+        for (int q = tid; q < naq; q += blockDim.x) aq[q] = p.aq[(int64_t)s * p.n + q];
+        __syncthreads();
         if (tid == 0) {
             int64_t run = 0;
             for (int q = 0; q < naq; ++q) {
