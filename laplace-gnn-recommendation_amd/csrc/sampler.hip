@@ -215,8 +215,11 @@ __global__ __launch_bounds__(kSelThreads) void smp_select_users_kernel(Smp p, in
         // user v with probability ~ m(v); accept with probability 1/m(v); skip explored / picked; draws are
         // evaluated 64 at a time by wavefront 0 and committed in counter order.
         __shared__ int64_t pre[kMaxFan + 1];
-        __shared__ int32_t aq[kMaxFan];  // the queue is compared against every article of every drawn user: keep it in LDS
-        __shared__ int sh_np;
+        __shared__ int32_t aq[kMaxFan];      // queue order: positions of the concatenated lists refer to it
+        __shared__ int32_t aq_sorted[kMaxFan];  // ascending: multiplicity lookups by binary search
+        __shared__ int32_t cand_v[kSelThreads];
+        __shared__ int32_t cand_ok[kSelThreads];
+        __shared__ int sh_np, sh_t0;
         volatile int32_t* picked = sel;
         const int naq = p.aq_n[s];
         for (int q = tid; q < naq; q += blockDim.x) aq[q] = p.aq[(int64_t)s * p.n + q];
@@ -226,50 +229,70 @@ __global__ __launch_bounds__(kSelThreads) void smp_select_users_kernel(Smp p, in
             for (int q = 0; q < naq; ++q) {
                 pre[q] = run;
                 run += p.aptr[aq[q] + 1] - p.aptr[aq[q]];
+                int32_t v = aq[q];  // insertion into aq_sorted
+                int b2 = q - 1;
+                while (b2 >= 0 && aq_sorted[b2] > v) { aq_sorted[b2 + 1] = aq_sorted[b2]; --b2; }
+                aq_sorted[b2 + 1] = v;
             }
             pre[naq] = run;
             sh_np = 0;
+            sh_t0 = 0;
         }
         __syncthreads();
-        if (tid < MI_WAVE) {
-            const int64_t L = pre[naq];
-            int np = 0;
-            for (int t0 = 0; np < p.n && t0 < kRejectCap; t0 += MI_WAVE) {
-                const uint32_t tt = (uint32_t)(t0 + tid);
-                const uint32_t c3 = (P_USER_REJ & 0xFFu) | ((uint32_t)(p.step & 0xFFFFFFu) << 8);
-                MiPhilox w = mi_philox4x32(tt, (uint32_t)hop, (uint32_t)u, c3, (uint32_t)p.seed,
-                                           (uint32_t)((p.seed >> 32) ^ (p.step >> 24)));
-                const int64_t pos = (int64_t)((((uint64_t)w.c[0] << 32) | w.c[1]) % (uint64_t)L);
-                int lo = 0, hi = naq;  // last q with pre[q] <= pos
-                while (hi - lo > 1) {
-                    const int mid = (lo + hi) >> 1;
-                    if (pre[mid] <= pos) lo = mid; else hi = mid;
+        const int64_t L = pre[naq];
+        const uint32_t c3 = (P_USER_REJ & 0xFFu) | ((uint32_t)(p.step & 0xFFFFFFu) << 8);
+        const uint32_t k0 = (uint32_t)p.seed, k1 = (uint32_t)((p.seed >> 32) ^ (p.step >> 24));
+        while (true) {  // one round = kSelThreads draws evaluated in parallel, committed in counter order
+            const int t0 = sh_t0;
+            if (sh_np >= p.n || t0 >= kRejectCap) break;  // block-uniform (shared)
+            MiPhilox w = mi_philox4x32((uint32_t)(t0 + tid), (uint32_t)hop, (uint32_t)u, c3, k0, k1);
+            const int64_t pos = (int64_t)((((uint64_t)w.c[0] << 32) | w.c[1]) % (uint64_t)L);
+            int lo = 0, hi = naq;  // last q with pre[q] <= pos
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (pre[mid] <= pos) lo = mid; else hi = mid;
+            }
+            const int32_t v = p.aidx[p.aptr[aq[lo]] + (pos - pre[lo])];
+            uint32_t m = 0;  // number of queued articles (duplicates counted) that v bought
+            for (int32_t x = p.uptr[v]; x < p.uptr[v + 1]; ++x) {
+                const int32_t a = p.uidx[x];
+                int l2 = 0, h2 = naq;
+                while (l2 < h2) {
+                    const int mid = (l2 + h2) >> 1;
+                    if (aq_sorted[mid] < a) l2 = mid + 1; else h2 = mid;
                 }
-                const int32_t v = p.aidx[p.aptr[aq[lo]] + (pos - pre[lo])];
-                uint32_t m = 0;
-                for (int32_t x = p.uptr[v]; x < p.uptr[v + 1]; ++x) {
-                    const int32_t a = p.uidx[x];
-                    for (int q = 0; q < naq; ++q) m += (aq[q] == a);
-                }
-                bool ok = (m > 0) && (w.c[2] % m == 0);
-                for (int h = 0; ok && h <= hop; ++h)
-                    for (int q = 0; q < uq_n[h]; ++q) ok &= (uq[h * p.n + q] != v);
-                unsigned long long mask = __ballot(ok);
-                while (mask && np < p.n) {
-                    const int l = __ffsll((long long)mask) - 1;
-                    mask &= mask - 1;
-                    const int32_t vv = __shfl(v, l, MI_WAVE);
-                    bool dup = false;
-                    for (int q = tid; q < np; q += MI_WAVE) dup |= (picked[q] == vv);
-                    if (__ballot(dup) == 0ull) {
-                        if (tid == 0) picked[np] = vv;
-                        ++np;
+                while (l2 < naq && aq_sorted[l2] == a) { ++m; ++l2; }
+            }
+            bool ok = (m > 0) && (w.c[2] % m == 0);
+            for (int h = 0; ok && h <= hop; ++h)
+                for (int q = 0; q < uq_n[h]; ++q) ok &= (uq[h * p.n + q] != v);
+            cand_v[tid] = v;
+            cand_ok[tid] = ok ? 1 : 0;
+            __syncthreads();
+            if (tid < MI_WAVE) {
+                int np = sh_np;
+                for (int c = 0; c < kSelThreads / MI_WAVE && np < p.n; ++c) {
+                    const int32_t cv = cand_v[c * MI_WAVE + tid];
+                    unsigned long long mask = __ballot(cand_ok[c * MI_WAVE + tid] != 0);
+                    while (mask && np < p.n) {
+                        const int l = __ffsll((long long)mask) - 1;
+                        mask &= mask - 1;
+                        const int32_t vv = __shfl(cv, l, MI_WAVE);
+                        bool dup = false;
+                        for (int q = tid; q < np; q += MI_WAVE) dup |= (picked[q] == vv);
+                        if (__ballot(dup) == 0ull) {
+                            if (tid == 0) picked[np] = vv;
+                            ++np;
+                        }
                     }
                 }
+                if (tid == 0) {
+                    sh_np = np;
+                    sh_t0 = t0 + kSelThreads;
+                }
             }
-            if (tid == 0) sh_np = np;
+            __syncthreads();
         }
-        __syncthreads();
         if (tid == 0) {
             const int np = sh_np;
             for (int a = 1; a < np; ++a) {  // ascending
