@@ -285,7 +285,7 @@ int mi_adam_dense_f32(int64_t n_rows, int64_t d,
  * Per output element the sum is one k-ascending fma chain (bitwise = oracle/spmm_ref.c), except
  * when the output grid is too small to fill the chip and k >= 2048 (weight gradients
  * dW = dY^T X): then, if the caller passes the workspace mi_gemm_workspace_bytes asks for, K is
- * cut into slices whose chains are added in slice order (still deterministic).  ws may be null.
+ * cut into slices whose chains are added in a fixed association (still deterministic).  ws may be null.
  * ---------------------------------------------------------------------------------- */
 size_t mi_gemm_workspace_bytes(int64_t m, int64_t n, int64_t k);
 int    mi_gemm_f32(int32_t trans_a, int32_t trans_b, int64_t m, int64_t n, int64_t k,

@@ -189,7 +189,8 @@ __global__ __launch_bounds__(256, 2) void gemm_fast_kernel(MiGemmArgs g) {
 #pragma unroll 16
             for (int s = 0; s < KC / 2; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * s], bp[2 * s], acc, 0, 0, 0);
         } else {
-            for (int s = 0; s < kw / 2; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * s], bp[2 * s], acc, 0, 0, 0);
+            // the panel is zero beyond kw, so an odd tail pairs its last k with a zero
+            for (int s = 0; s < (kw + 1) / 2; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * s], bp[2 * s], acc, 0, 0, 0);
         }
         __syncthreads();
     }
@@ -219,19 +220,29 @@ __global__ __launch_bounds__(256, 2) void gemm_fast_kernel(MiGemmArgs g) {
     }
 }
 
-// Sums the K-slice slabs in slice order (fixed order: bitwise reproducible), then the epilogue.
-__global__ void gemm_splitk_reduce_kernel(MiGemmArgs g) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+// Sums the K-slice slabs, then the epilogue.  32 outputs per block, 8 lane groups each summing every
+// 8th slice in ascending order; the 8 group sums are added in group order: a fixed association, so the
+// result is bitwise reproducible (and equals summing the slices in order only up to fp32 rounding).
+__global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(MiGemmArgs g) {
+    __shared__ float part[8][32];
+    const int o = threadIdx.x & 31, grp = threadIdx.x >> 5;
     const int64_t total = g.M * g.N;
-    if (i >= total) return;
-    const int64_t m = i / g.N, n = i - m * g.N;
+    const int64_t i = (int64_t)blockIdx.x * 32 + o;
     float v = 0.f;
-    for (int z = 0; z < g.splits; ++z) v += g.partial[(int64_t)z * total + i];
-    if (g.bias) v += g.bias[n];
+    if (i < total)
+        for (int z = grp; z < g.splits; z += 8) v += g.partial[(int64_t)z * total + i];
+    part[grp][o] = v;
+    __syncthreads();
+    if (grp != 0 || i >= total) return;
+    float acc = part[0][o];
+#pragma unroll
+    for (int q = 1; q < 8; ++q) acc += part[q][o];
+    const int64_t m = i / g.N, n = i - m * g.N;
+    if (g.bias) acc += g.bias[n];
     float* c = g.C + m * g.ldc + n;
-    if (g.accumulate) v += *c;
-    if (g.act == 1) v = v > 0.f ? v : 0.f;
-    *c = v;
+    if (g.accumulate) acc += *c;
+    if (g.act == 1) acc = acc > 0.f ? acc : 0.f;
+    *c = acc;
 }
 
 }  // namespace
@@ -267,7 +278,9 @@ int mi_gemm_launch(MiGemmArgs g, void* ws, size_t ws_bytes, hipStream_t stream) 
     const bool a_kfast = g.sa_k == 1, b_kfast = g.sb_k == 1;
     const bool a_ok = a_kfast ? (g.sa_m % 4 == 0) : (g.sa_m == 1 && g.sa_k % 4 == 0 && g.a_rows == nullptr);
     const bool b_ok = b_kfast ? (g.sb_n % 4 == 0) : (g.sb_n == 1 && g.sb_k % 4 == 0);
-    const bool fast = a_ok && b_ok && g.K % 4 == 0 && g.k_per_split % 4 == 0 && mi_aligned16(g.A) && mi_aligned16(g.B);
+    // float4 along k needs K (and every slice start) to be a multiple of 4; operands read along rows do not
+    const bool k_ok = (!a_kfast && !b_kfast) || (g.K % 4 == 0 && g.k_per_split % 4 == 0);
+    const bool fast = a_ok && b_ok && k_ok && mi_aligned16(g.A) && mi_aligned16(g.B);
     if (!fast)
         hipLaunchKernelGGL(gemm_f32_kernel, grid, dim3(256), 0, stream, g);
     else if (a_kfast && b_kfast)
@@ -280,7 +293,7 @@ int mi_gemm_launch(MiGemmArgs g, void* ws, size_t ws_bytes, hipStream_t stream) 
         hipLaunchKernelGGL((gemm_fast_kernel<false, false>), grid, dim3(256), 0, stream, g);
     if (g.splits > 1) {
         const int64_t total = g.M * g.N;
-        hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((unsigned)mi_ceil_div(total, 256)), dim3(256), 0, stream, g);
+        hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((unsigned)mi_ceil_div(total, 32)), dim3(256), 0, stream, g);
     }
     return mi_launch_status();
 }

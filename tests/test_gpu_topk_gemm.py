@@ -126,11 +126,11 @@ def test_pipeline_end_to_end_small():
 
 def test_gemm_split_k_weight_gradient_shape():
     """dW = dY^T X with a 128 x 84 output over K = 30K rows: K is cut into slices (the output grid alone
-    is 4 workgroups).  Result = slice chains added in slice order: bitwise reproducible and bitwise
-    equal to the oracle evaluated the same way."""
+    is 4 workgroups).  Result = slice chains added in a fixed association: bitwise reproducible and bitwise
+    equal to the oracle evaluated the same way.  K = 30 001 also exercises the odd-K tail of the fast path."""
     from laplace_amd import ops
     g = t.Generator().manual_seed(0)
-    K, M, N = 30_000, 128, 84
+    K, M, N = 30_001, 128, 84
     dY, X = t.randn(K, M, generator=g), t.randn(K, N, generator=g)
     got = ops.gemm(dY.to(DEV), X.to(DEV), trans_a=True, trans_b=False)
     again = ops.gemm(dY.to(DEV), X.to(DEV), trans_a=True, trans_b=False)
@@ -138,8 +138,17 @@ def test_gemm_split_k_weight_gradient_shape():
     blocks = ((M + 63) // 64) * ((N + 63) // 64)
     s = min(-(-512 // blocks), K // 256)
     kps = -(-(-(-K // s)) // 32) * 32
-    want = t.zeros(M, N)
-    for k0 in range(0, K, kps):
-        want = want + R.gemm_fma(dY[k0:k0 + kps], X[k0:k0 + kps], trans_a=True, trans_b=False)
+    # slabs = one fma chain per K slice; the reduce adds every 8th slab in order per lane group, then the 8
+    # group sums in group order (csrc/gemm.hip:gemm_splitk_reduce_kernel)
+    slabs = [R.gemm_fma(dY[k0:k0 + kps], X[k0:k0 + kps], trans_a=True, trans_b=False) for k0 in range(0, K, kps)]
+    groups = []
+    for grp in range(8):
+        acc = t.zeros(M, N)
+        for z in range(grp, len(slabs), 8):
+            acc = acc + slabs[z]
+        groups.append(acc)
+    want = groups[0]
+    for q in range(1, 8):
+        want = want + groups[q]
     assert t.equal(got.cpu(), want)
     assert t.allclose(got.cpu().double(), dY.double().T @ X.double(), atol=2e-3, rtol=1e-5)
