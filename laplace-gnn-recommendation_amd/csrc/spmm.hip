@@ -20,6 +20,18 @@
 
 namespace {
 
+#ifndef MI_SPMM_NT
+#define MI_SPMM_NT 0   // 1: non-temporal loads of col/val and stores of Y/S.  Measured on C2 (tools/ab_spmm.py,
+                       // round 1): 1.226 ms vs 1.227 ms — no gain; UNROLL 8: 1.241 ms; both: 1.274 ms.  Kept off.
+#endif
+#ifndef MI_SPMM_UNROLL
+#define MI_SPMM_UNROLL 4
+#endif
+typedef float mi_f4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void mi_nt_store4(float4* p, const float4& v) {
+    mi_f4v x = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(x, reinterpret_cast<mi_f4v*>(p));
+}
 constexpr int kWavesPerBlock = 4;
 constexpr int kBlock = kWavesPerBlock * MI_WAVE;
 
@@ -59,8 +71,13 @@ __device__ __forceinline__ void wave_accumulate(const int32_t* __restrict__ col,
         int32_t my_c = 0;
         float my_v = 0.f;
         if (lane < n) {
+#if MI_SPMM_NT
+            my_c = __builtin_nontemporal_load(col + base + lane);
+            my_v = __builtin_nontemporal_load(val + base + lane);
+#else
             my_c = col[base + lane];
             my_v = val[base + lane];
+#endif
             if (SPARSE && x_map) my_c = x_map[my_c];  // compact row of X, or < 0 for a row that is all zeros
         }
         if (SPARSE && x_map && __ballot(my_c >= 0 && lane < n) == 0ull) continue;  // nothing to gather in this 64-entry group
@@ -103,14 +120,22 @@ __device__ __forceinline__ void apply_epilogue(const Epilogue& ep, int64_t r, in
     for (int v = 0; v < VPL; ++v) {
         const int e = lane + v * LPR;
         if (e >= d4) continue;
+#if MI_SPMM_NT
+        if (ep.Y) mi_nt_store4(ep.Y + r * ep.ldy4 + e, acc[v]);
+#else
         if (ep.Y) ep.Y[r * ep.ldy4 + e] = acc[v];
+#endif
         if (ep.S) {
             float4 o;
             o.x = ep.scale * (a[v].x + acc[v].x);
             o.y = ep.scale * (a[v].y + acc[v].y);
             o.z = ep.scale * (a[v].z + acc[v].z);
             o.w = ep.scale * (a[v].w + acc[v].w);
+#if MI_SPMM_NT
+            mi_nt_store4(ep.S + r * ep.lds4 + e, o);
+#else
             ep.S[r * ep.lds4 + e] = o;
+#endif
         }
     }
 }
@@ -292,7 +317,7 @@ template <int LPR, int VPL, bool SPARSE>
 int launch_spmm_mode(int64_t n_rows, int d4, const int32_t* rowptr, const int32_t* col, const float* val,
                      const float4* X4, int64_t ldx4, const Epilogue& ep, const mi_spmm_plan* plan,
                      float4* partial, const Ex& ex, int64_t n_list, hipStream_t s) {
-    constexpr int UNROLL = (VPL == 1) ? 4 : 2;
+    constexpr int UNROLL = (VPL == 1) ? MI_SPMM_UNROLL : 2;
     const int32_t chunk = plan ? plan->chunk : INT32_MAX;
     const bool listed = SPARSE && ex.row_list != nullptr;
     if (plan && plan->n_items > 0) {  // row_list mode still reduces every split row: hubs are few and almost always wanted
