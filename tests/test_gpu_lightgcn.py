@@ -589,3 +589,53 @@ def test_sparse_batch_step_equals_plain_step(K):
         assert t.equal(plain.batch_idx[0], fast.batch_idx[0]) and t.equal(plain.batch_idx[2], fast.batch_idx[2])
     # identical up to the order of the float atomics that combine repeated batch nodes
     assert (plain.table - fast.table).abs().max() <= 2e-6
+
+
+# ---------------------------------------------------------------------------- BASELINE.json configs[0]
+@pytest.mark.parametrize("compat", ["reference", "bipartite"])
+def test_c1_movielens_shaped_parity(compat):
+    """C1: U=943, I=1682, E=100 000 (80/10/10 split -> 80 000 train edges), D=64, K=2, B=128, lambda=1e-6,
+    lr=1e-3: forward within 1e-4 on all four outputs, 10 reference-loop iterations within 1e-4 on the
+    parameters, exact top-12 / top-256 lists from the trained layer-0 embeddings."""
+    from laplace_amd import synthetic as S
+    from laplace_amd.data.lightgcn_loader import split
+    from laplace_amd.interactions import Interactions
+    from laplace_amd.model.lightgcn import LightGCN
+    from laplace_amd.trainer import LightGCNTrainer
+    from laplace_amd.utils.metrics_lightgcn import topk_for_users
+    ei = S.generate(S.C1)
+    train_e, val_e, test_e, _ = split(ei)
+    assert train_e.shape[1] == 80_000 and val_e.shape[1] == 10_000 and test_e.shape[1] == 10_000
+    U, I, D, K, B = 943, 1682, 64, 2, 128
+    t.manual_seed(0)
+    model = LightGCN(U, I, D, K)
+    uw = t.nn.Parameter(model.users_emb.weight.detach().clone())
+    iw = t.nn.Parameter(model.items_emb.weight.detach().clone())
+    inter = Interactions(train_e, U, I)
+    adj = inter.adjacency(compat)
+    row, col, _ = adj.coo()
+    model.to(DEV)
+    outs = model(adj.to(DEV))
+    want = R.lightgcn_forward(uw.detach(), iw.detach(), row, col, K)
+    for got, ref in zip(outs, want):
+        assert (got.detach().cpu() - ref).abs().max() <= 1e-4
+    opt = t.optim.Adam([uw, iw], lr=1e-3)
+    tr = LightGCNTrainer(model, adj.to(DEV), inter.to(DEV), lr=1e-3, Lambda=1e-6, batch_size=B, seed=3,
+                         neg_range=int(train_e[1].max()), reference_sampler_quirks=(compat == "reference"))
+    for it in range(10):
+        batch = tr.sample()  # device sampler with the reference's negative range
+        cpu_batch = tuple(x.cpu().clone() for x in batch)
+        loss_ref = R.train_step(uw, iw, opt, row, col, K, cpu_batch, 1e-6)
+        assert abs(float(tr.step(batch)) - loss_ref) < 1e-5
+    assert (model.users_emb.weight.detach().cpu() - uw.detach()).abs().max() <= 1e-4
+    assert (model.items_emb.weight.detach().cpu() - iw.detach()).abs().max() <= 1e-4
+    # exact top-K on the SAME embeddings (the device's), as make_predictions_for_user defines it
+    ue, ie = model.users_emb.weight.detach(), model.items_emb.weight.detach()
+    users = t.arange(0, U, 7, device=DEV)
+    scores = R.scores_fma(ue[users].cpu(), ie.cpu())
+    excl_d = {}
+    tu, ti = train_e[0], train_e[1]
+    excl = [ti[tu == int(u)] for u in users.tolist()]
+    for k in (12, 256):
+        got = topk_for_users(ue, ie, users, train_e.to(DEV), k).cpu()
+        assert t.equal(got, R.topk_excl_exact(scores, excl, k))
