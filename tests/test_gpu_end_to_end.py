@@ -1,0 +1,72 @@
+"""End to end on one GPU at small scale (BASELINE.json configs[3] flow): LightGCN candidate generation ->
+top-N dump -> LightGCN matcher -> ranker trained on device-sampled batches -> evaluated on matcher candidates."""
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch as t
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def test_candidate_generation_feeds_the_ranker():
+    from laplace_amd import synthetic as S
+    from laplace_amd.config import LightGCNConfig
+    from laplace_amd.data import graph_io
+    from laplace_amd.data.dataset import GraphDataset
+    from laplace_amd.data.device_sampler import DeviceGraphSampler
+    from laplace_amd.data.matching import LightGCNMatcher, PopularItemsMatcher
+    from laplace_amd.hetero import DataLoader
+    from laplace_amd.interactions import Interactions
+    from laplace_amd.model.encoder_decoder import Encoder_Decoder_Model
+    from laplace_amd.model.layers import get_SAGEConv_layers, get_linear_layers
+    from laplace_amd.model.lightgcn import LightGCN
+    from laplace_amd.run_pipeline_lightgcn import save_predictions
+    from laplace_amd.trainer import LightGCNTrainer
+    from laplace_amd.training import test_with_dataloader, train_with_dataloader
+    from laplace_amd.utils.constants import Constants
+    from laplace_amd.utils.get_info import get_feature_info
+
+    # transactions in "time" order -> chronological train / val / test graphs (N2)
+    spec = S.SyntheticSpec(800, 300, 12_000, seed=11, deg_min=4, deg_max=120)
+    graph, _, _ = S.generate_hetero(spec, customer_cards=(200, 2, 84, 4), article_cards=(120, 30))
+    ei = graph[Constants.edge_key].edge_index
+    splits = graph_io.build_splits(graph[Constants.node_user].x, graph[Constants.node_item].x, ei[0].numpy(), ei[1].numpy())
+    train_graph, train_users, train_articles = splits["train"]
+    train_ei = train_graph[Constants.edge_key].edge_index
+
+    # 1. candidate generation: LightGCN on the train edges, fused step, on-device sampling
+    t.manual_seed(0)
+    U, I = spec.num_users, spec.num_items
+    lgcn = LightGCN(U, I, 32, 3).to(DEV)
+    inter = Interactions(train_ei.to(DEV), U, I)
+    trainer = LightGCNTrainer(lgcn, inter.adjacency("bipartite"), inter, lr=5e-3, Lambda=1e-6, batch_size=1024, seed=1)
+    losses = [float(trainer.step()) for _ in range(80)]
+    assert np.mean(losses[-10:]) < np.mean(losses[:10])
+    top = save_predictions(lgcn, train_ei.to(DEV), num_recommendations=40)   # [U, 40], seen items excluded
+    assert top.shape == (U, 40)
+    seen = set(zip(train_ei[0].tolist(), train_ei[1].tolist()))
+    assert not any((u, int(i)) in seen for u in range(0, U, 37) for i in top[u].tolist())
+
+    # 2. ranker trained from device-sampled subgraphs of the train graph
+    cfg = SimpleNamespace(k=5, num_neighbors=8, n_hop_neighbors=2, positive_edges_ratio=0.5, negative_edges_ratio=3.0,
+                          batch_size=32)
+    sampler = DeviceGraphSampler(cfg, train_graph, train_users, train_articles, device=DEV, seed=4)
+    first = sampler.sample(t.arange(32), step=0)
+    ranker = Encoder_Decoder_Model(get_SAGEConv_layers(2, 64, 32, "add"), get_linear_layers(2, 64, 64, 1),
+                                   get_feature_info(train_graph), first.metadata(), True, "sum", True, 0.0, 0.2).to(DEV)
+    ranker.initialize_encoder_input_size(first)
+    opt = t.optim.Adam(ranker.parameters(), lr=0.01)
+    first_epoch = train_with_dataloader(ranker, opt, sampler, 0, DEV)
+    for ep in range(1, 3):
+        last_epoch = train_with_dataloader(ranker, opt, sampler, ep, DEV)
+    assert np.mean(last_epoch) < np.mean(first_epoch)
+
+    # 3. evaluation on the val graph: candidates = LightGCN top-N + popular items (matchers)
+    val_graph, val_users, val_articles = splits["val"]
+    matchers = [LightGCNMatcher(top, 10), PopularItemsMatcher.from_adjacency(val_articles, 10)]
+    val_ds = GraphDataset(cfg, val_graph, val_users, val_articles, train=False, matchers=matchers, seed=5)
+    val_loader = DataLoader(val_ds, batch_size=16, shuffle=False)
+    recall, precision = test_with_dataloader("VAL", ranker, val_loader, DEV, k=cfg.k, break_at=6)
+    assert 0.0 <= recall <= 1.0 and 0.0 <= precision <= 1.0
