@@ -387,6 +387,32 @@ int    mi_sampler_emit(const mi_sampler_desc* d, const int64_t* seed_users, void
                        int64_t* edge_index, int64_t* edge_label_index, int64_t* edge_label,
                        int64_t* user_ptr, int64_t* article_ptr, mi_stream_t stream);
 
+/* ------------------------------------------------------------------------------------
+ * N5  PinSAGE samplers (reference: pinsage/sampler.py:16-106 over DGL's random_walk and
+ *     PinSAGESampler; DGL is absent and the reference's pinsage/ cannot import — SURVEY F11 — so the
+ *     semantics are restated in oracle/pinsage_ref.py, which mirrors these kernels bit for bit).
+ * iu_*: CSR item -> users; ui_*: CSR user -> items (int32, device).
+ * mi_pinsage_item_pairs: heads uniform over items; tails[b] = end of one item->user->item walk from
+ *   heads[b] (uniform neighbour per step), -1 when the walk dies; neg_tails uniform.  int64[batch] each.
+ * mi_pinsage_neighbors: per seed, num_walks walks of walk_length traversals with termination
+ *   probability restart_prob before every traversal but the first; the items reached at the end of
+ *   each traversal are counted and the num_neighbors most visited (count desc, id asc) returned:
+ *   neighbors int64[n_seeds, T] (-1 padded), weights int64[n_seeds, T] (visit counts).
+ * ---------------------------------------------------------------------------------- */
+int    mi_pinsage_item_pairs(int64_t batch, int64_t n_items,
+                             const int32_t* iu_ptr, const int32_t* iu_idx,
+                             const int32_t* ui_ptr, const int32_t* ui_idx,
+                             uint64_t seed, uint64_t step,
+                             int64_t* heads, int64_t* tails, int64_t* neg_tails, mi_stream_t stream);
+size_t mi_pinsage_neighbors_workspace_bytes(int64_t n_seeds, int32_t walk_length, int32_t num_walks);
+int    mi_pinsage_neighbors(int64_t n_seeds, const int64_t* seeds,
+                            const int32_t* iu_ptr, const int32_t* iu_idx,
+                            const int32_t* ui_ptr, const int32_t* ui_idx,
+                            int32_t walk_length, double restart_prob, int32_t num_walks,
+                            int32_t num_neighbors, int32_t layer, uint64_t seed, uint64_t step,
+                            int64_t* neighbors, int64_t* weights,
+                            void* ws, size_t ws_bytes, mi_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,99 @@
+"""PinSAGE sampling on device — the roles of ItemToItemBatchSampler, NeighborSampler and the block
+construction of the reference's pinsage/sampler.py:16-106, over csrc/pinsage.hip.
+
+A block (DGL "message flow graph") is a dict: src_ids (global item ids, destination nodes first), n_dst,
+edge_src / edge_dst (block-local ids), weights (random-walk visit counts).  Random walks and the
+top-T selection run in the HIP kernels; relabelling the few hundred nodes of a batch is torch index
+plumbing on the GPU."""
+from __future__ import annotations
+
+import ctypes
+from typing import List, Optional, Tuple
+
+import numpy as np
+import torch as t
+from torch import Tensor
+
+from .. import _lib
+from .._lib import check
+from ..data.dataset import AdjList
+
+
+class PinSAGESampler:
+    def __init__(self, users_adj_list, articles_adj_list, num_users: int, num_items: int, *, batch_size: int = 32,
+                 random_walk_length: int = 2, random_walk_restart_prob: float = 0.5, num_random_walks: int = 10,
+                 num_neighbors: int = 3, num_layers: int = 2, device: str = "cuda", seed: int = 0):
+        self.device = t.device(device)
+        users, items = AdjList(users_adj_list, num_users), AdjList(articles_adj_list, num_items)
+        to32 = lambda a: t.from_numpy(np.ascontiguousarray(a.astype(np.int32))).to(self.device)
+        self.ui_ptr, self.ui_idx = to32(users.ptr), to32(users.idx)      # user -> items
+        self.iu_ptr, self.iu_idx = to32(items.ptr), to32(items.idx)      # item -> users
+        self.num_users, self.num_items = num_users, num_items
+        self.batch_size, self.L, self.p = int(batch_size), int(random_walk_length), float(random_walk_restart_prob)
+        self.W, self.T, self.n_layers, self.seed = int(num_random_walks), int(num_neighbors), int(num_layers), int(seed)
+        self._pos = t.full((num_items,), -1, dtype=t.int64, device=self.device)  # scratch for relabelling
+        self.step = 0
+
+    def _stream(self):
+        return t.cuda.current_stream().cuda_stream
+
+    def item_pairs(self, step: int) -> Tuple[Tensor, Tensor, Tensor]:
+        """(heads, tails, neg_tails), pairs whose walk died removed (pinsage/sampler.py:26-41)."""
+        B, dev = self.batch_size, self.device
+        heads, tails, negs = (t.empty(B, dtype=t.int64, device=dev) for _ in range(3))
+        check(_lib.lib().mi_pinsage_item_pairs(B, self.num_items, self.iu_ptr.data_ptr(), self.iu_idx.data_ptr(),
+                                               self.ui_ptr.data_ptr(), self.ui_idx.data_ptr(), self.seed & (2**64 - 1),
+                                               step, heads.data_ptr(), tails.data_ptr(), negs.data_ptr(), self._stream()),
+              "mi_pinsage_item_pairs")
+        keep = tails != -1
+        return heads[keep], tails[keep], negs[keep]
+
+    def neighbors(self, seeds: Tensor, layer: int, step: int) -> Tuple[Tensor, Tensor]:
+        n, dev = seeds.numel(), self.device
+        nb = t.empty(n, self.T, dtype=t.int64, device=dev)
+        wt = t.empty(n, self.T, dtype=t.int64, device=dev)
+        L = _lib.lib()
+        ws = t.empty(int(L.mi_pinsage_neighbors_workspace_bytes(n, self.L, self.W)), dtype=t.uint8, device=dev)
+        check(L.mi_pinsage_neighbors(n, seeds.data_ptr(), self.iu_ptr.data_ptr(), self.iu_idx.data_ptr(),
+                                     self.ui_ptr.data_ptr(), self.ui_idx.data_ptr(), self.L, self.p, self.W, self.T, layer,
+                                     self.seed & (2**64 - 1), step, nb.data_ptr(), wt.data_ptr(), ws.data_ptr(), ws.numel(),
+                                     self._stream()), "mi_pinsage_neighbors")
+        return nb, wt
+
+    def sample_blocks(self, seeds: Tensor, step: int, heads: Optional[Tensor] = None, tails: Optional[Tensor] = None,
+                      neg_tails: Optional[Tensor] = None) -> List[dict]:
+        """NeighborSampler.sample_blocks (pinsage/sampler.py:73-91); input layer first."""
+        blocks: List[dict] = []
+        seeds = seeds.to(self.device, t.int64).contiguous()
+        banned = None
+        if heads is not None:
+            banned = t.unique(t.cat([heads * self.num_items + tails, heads * self.num_items + neg_tails]))
+        for layer in range(self.n_layers):
+            nb, wt = self.neighbors(seeds, layer, step)
+            n = seeds.numel()
+            dst = t.arange(n, device=self.device)[:, None].expand(n, self.T)
+            keep = nb >= 0
+            if banned is not None:  # frontier edge v -> s is removed when (v, s) is a label pair (head -> tail)
+                keep &= ~t.isin(nb * self.num_items + seeds[:, None], banned)
+            es_g, ed, ew = nb[keep], dst[keep], wt[keep].to(t.float32)
+            self._pos[seeds] = t.arange(n, device=self.device)
+            new = t.unique(es_g)
+            new = new[self._pos[new] < 0]                       # sources that are not destination nodes, ascending
+            src_ids = t.cat([seeds, new])
+            self._pos[new] = t.arange(n, n + new.numel(), device=self.device)
+            es = self._pos[es_g]
+            self._pos[src_ids] = -1                              # scratch back to all -1
+            blocks.insert(0, {"src_ids": src_ids, "n_dst": n, "edge_src": es, "edge_dst": ed, "weights": ew})
+            seeds = src_ids
+        return blocks
+
+    def sample_batch(self, step: Optional[int] = None) -> dict:
+        """One training batch: pair graphs compacted to `seeds`, blocks rooted at them (sampler.py:93-106)."""
+        if step is None:
+            step = self.step
+            self.step += 1
+        heads, tails, negs = self.item_pairs(step)
+        seeds = t.unique(t.cat([heads, tails, negs]))
+        loc = lambda x: t.searchsorted(seeds, x)
+        blocks = self.sample_blocks(seeds, step, heads, tails, negs)
+        return {"seeds": seeds, "pos": (loc(heads), loc(tails)), "neg": (loc(heads), loc(negs)), "blocks": blocks}
