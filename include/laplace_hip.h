@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MI_ABI_VERSION 1
+#define MI_ABI_VERSION 2
 
 #define MI_ERR_BAD_ARG      (-1)  /* null pointer, negative size, misaligned buffer   */
 #define MI_ERR_TOO_LARGE    (-2)  /* a size does not fit int32 indexing                */
@@ -105,31 +105,51 @@ int mi_scale_csr_f32(int64_t n_rows, int64_t nnz, const int32_t* rowptr, const i
  * 16-byte aligned with leading dimensions ld* (in floats, multiples of 4).  S may alias
  * addend (in-place running sum).  Y/S must not alias X.
  *
- * Rows longer than the plan's chunk are split over several wavefronts and reduced in a
- * fixed order (no float atomics): results are bitwise reproducible run to run.
- * The plan depends only on rowptr; build it once per adjacency.
+ * Rows longer than the plan's chunk are split into work items whose partial sums are
+ * reduced in a fixed order (no float atomics): results are bitwise reproducible run to run.
+ * A BANDED plan (band > 0; needs `col`, columns ascending within each row) also cuts the
+ * split rows at multiples of `band` columns and launches the work items band by band, the
+ * workgroups of one band on one XCD, so that the gathers the hub rows make into the same
+ * band of X meet in that XCD's L2 (choose band * d * 4 bytes ~ the 4 MB L2).  The plan
+ * depends only on the adjacency structure; build it once.
  * ---------------------------------------------------------------------------------- */
+#define MI_SPMM_GROUP 32   /* launch slots per XCD-interleave block of a banded plan */
+
 typedef struct mi_spmm_plan {
-    int32_t  chunk;        /* nnz per work item of a split row                       */
+    int32_t  chunk;        /* max nnz per work item of a split row                   */
     int32_t  n_long_rows;  /* rows with more than `chunk` entries                    */
-    int32_t  n_items;      /* work items over all long rows                          */
-    int32_t  reserved;
+    int32_t  n_items;      /* work items over all long rows = partial-sum rows       */
+    int32_t  n_launch;     /* launch slots >= n_items (banded: a multiple of 8 * MI_SPMM_GROUP) */
     int32_t* long_rows;    /* device int32[n_long_rows]                              */
-    int32_t* item_ptr;     /* device int32[n_long_rows+1]: items of long row i       */
-    int32_t* items;        /* device int32[4*n_items]: row, begin, end, slot         */
+    int32_t* item_ptr;     /* device int32[n_long_rows+1]: slots of long row i       */
+    int32_t* items;        /* device int32[4*n_launch], 16-byte aligned, in LAUNCH order:
+                              row, begin, end, slot; slot < 0 = padding              */
     int32_t* long_index;   /* device int32[n_rows]: index into long_rows, -1 for
                               short rows; nullable (needed only by row_list launches)  */
+    int32_t  band;         /* columns per band; 0 = row-major launch order           */
+    int32_t  n_bands;
 } mi_spmm_plan;
 
-/* Upper bounds for the plan arrays, so the caller can allocate before building. */
-int mi_spmm_plan_bounds(int64_t n_rows, int64_t nnz, int32_t chunk,
-                        int64_t* max_long_rows, int64_t* max_items);
-/* Fills plan->long_rows/item_ptr/items (caller-allocated to the bounds above) and the
- * counts.  SYNCHRONISES `stream` (reads two counters back); setup-time only. */
-size_t mi_spmm_plan_workspace_bytes(int64_t n_rows);
-int    mi_spmm_plan_build(int64_t n_rows, const int32_t* rowptr, int32_t chunk,
-                          mi_spmm_plan* plan, void* ws, size_t ws_bytes,
-                          mi_stream_t stream);
+/* What mi_spmm_plan_count found; the caller allocates the plan arrays from it. */
+typedef struct mi_spmm_plan_info {
+    int64_t n_long_rows, n_items, n_launch, nnz_long;
+    int32_t chunk, band, n_bands, queue_len;
+    int32_t queue_start[9];
+    int32_t keys_in_second;
+} mi_spmm_plan_info;
+
+/* Two phases, both SYNCHRONISE `stream` (counter read-backs); set-up time only.
+ *   count: analyses the adjacency into `ws` and reports the array sizes in `info`;
+ *   fill:  writes plan->long_rows[n_long_rows], item_ptr[n_long_rows+1], items[4*n_launch],
+ *          long_index[n_rows] (nullable) — caller-allocated — and the scalar fields.
+ * `ws` (mi_spmm_plan_workspace_bytes; worst case ~28 B per entry) must be the same buffer,
+ * untouched in between.  col may be null when band == 0. */
+size_t mi_spmm_plan_workspace_bytes(int64_t n_rows, int64_t nnz);
+int    mi_spmm_plan_count(int64_t n_rows, int64_t n_cols, const int32_t* rowptr, const int32_t* col,
+                          int32_t chunk, int32_t band, void* ws, size_t ws_bytes,
+                          mi_spmm_plan_info* info, mi_stream_t stream);
+int    mi_spmm_plan_fill(int64_t n_rows, const int32_t* rowptr, const mi_spmm_plan_info* info,
+                         mi_spmm_plan* plan, void* ws, size_t ws_bytes, mi_stream_t stream);
 /* Bytes of partial-sum workspace mi_spmm_csr_f32 needs for this plan and width. */
 size_t mi_spmm_workspace_bytes(const mi_spmm_plan* plan, int64_t d);
 

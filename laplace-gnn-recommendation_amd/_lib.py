@@ -8,7 +8,8 @@ from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int32, c_i
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG_DIR, "liblaplace_hip.so")
 
-MI_ABI_VERSION = 1
+MI_ABI_VERSION = 2
+MI_SPMM_GROUP = 32
 
 
 class MiError(RuntimeError):
@@ -17,9 +18,16 @@ class MiError(RuntimeError):
 
 class SpmmPlanStruct(Structure):
     _fields_ = [
-        ("chunk", c_int32), ("n_long_rows", c_int32), ("n_items", c_int32), ("reserved", c_int32),
+        ("chunk", c_int32), ("n_long_rows", c_int32), ("n_items", c_int32), ("n_launch", c_int32),
         ("long_rows", c_void_p), ("item_ptr", c_void_p), ("items", c_void_p), ("long_index", c_void_p),
+        ("band", c_int32), ("n_bands", c_int32),
     ]
+
+
+class SpmmPlanInfo(Structure):
+    _fields_ = [("n_long_rows", c_int64), ("n_items", c_int64), ("n_launch", c_int64), ("nnz_long", c_int64),
+                ("chunk", c_int32), ("band", c_int32), ("n_bands", c_int32), ("queue_len", c_int32),
+                ("queue_start", c_int32 * 9), ("keys_in_second", c_int32)]
 
 
 class SpmmExStruct(Structure):
@@ -47,9 +55,9 @@ _PROTOTYPES = {
     "mi_gather_f32": (c_int32, [c_int64, P, P, P, P]),
     "mi_gcn_norm_csr_f32": (c_int32, [c_int64, c_int64, P, P, P, P, P, P]),
     "mi_scale_csr_f32": (c_int32, [c_int64, c_int64, P, P, P, P, P, P, P]),
-    "mi_spmm_plan_bounds": (c_int32, [c_int64, c_int64, c_int32, POINTER(c_int64), POINTER(c_int64)]),
-    "mi_spmm_plan_workspace_bytes": (c_size_t, [c_int64]),
-    "mi_spmm_plan_build": (c_int32, [c_int64, P, c_int32, POINTER(SpmmPlanStruct), P, c_size_t, P]),
+    "mi_spmm_plan_workspace_bytes": (c_size_t, [c_int64, c_int64]),
+    "mi_spmm_plan_count": (c_int32, [c_int64, c_int64, P, P, c_int32, c_int32, P, c_size_t, POINTER(SpmmPlanInfo), P]),
+    "mi_spmm_plan_fill": (c_int32, [c_int64, P, POINTER(SpmmPlanInfo), POINTER(SpmmPlanStruct), P, c_size_t, P]),
     "mi_spmm_workspace_bytes": (c_size_t, [POINTER(SpmmPlanStruct), c_int64]),
     "mi_spmm_csr_f32": (c_int32, [c_int64, c_int64, P, P, P, P, c_int64, P, c_int64, P, c_int64, P, c_int64,
                                   c_float, POINTER(SpmmPlanStruct), P, c_size_t, P]),

@@ -4,36 +4,62 @@
 //   Y[r,:]   = acc                               (optional)
 //   S[r,:]   = scale * (addend[r,:] + acc)        (optional; the running layer sum / mean)
 //
-// HBM-bound gather (0.49 flop/byte at D=128): the design is about keeping many whole-row
-// 16-byte-per-lane loads in flight per wavefront, not about arithmetic.
+// HBM-bound gather (0.49 flop/byte at D=128): the design is about bytes — keeping many whole-row
+// 16-byte-per-lane loads in flight, and making the gathers of the hub rows hit L2.
 //
-// Mapping (wave64): a row of D floats is covered by LPR = D/4 lanes of float4, so one load
-// instruction fetches NB = 64/LPR neighbour rows at once (D=128: 2 rows, 1 KiB per
-// instruction).  (col,val) pairs are read 64 at a time, coalesced, one per lane, and handed to
-// the sub-groups with ds_bpermute (__shfl); UNROLL independent row loads per lane are issued
-// before the first fma.  The NB partial sums are combined with log2(NB) DPP/xor steps at the
-// end.  One wavefront owns one destination row; rows longer than plan->chunk are cut into
-// chunk-sized work items whose partial sums are reduced in item order by a fix-up kernel, so
-// there are no float atomics and results are bitwise reproducible.
+// Mapping (wave64): a row of D floats is covered by a SUB-GROUP of LPR = D/4 lanes of float4, so a
+// wavefront holds NB = 64/LPR sub-groups and one load instruction fetches NB neighbour rows (D=128:
+// 2 rows, 1 KiB).  Each sub-group owns one destination row (or one work item of a split row) and
+// accumulates its entries in list order: (col,val) pairs are read LPR at a time, coalesced, one per
+// lane, and handed round with ds_bpermute (__shfl); UNROLL independent row loads per lane are issued
+// before the first fma.  No cross-lane reduce is needed.  (Round-1 history: one wavefront per row
+// with the sub-groups splitting the row's entries was bound by the chain rowptr -> col -> gather ->
+// store over 10^6 ten-entry user rows; tools/ab_spmm.py.)
+//
+// Rows with more than plan->chunk entries are SPLIT into work items whose partial sums are reduced in
+// slot order by a fix-up kernel, so there are no float atomics and results are bitwise reproducible.
+// When the plan is banded, a split row is cut at multiples of `band` columns as well, and the work
+// items are launched band by band with workgroups of one band pinned to one XCD (the dispatcher deals
+// workgroups round-robin over the 8 XCDs, so launch blocks are interleaved 8 ways): the ~7 gathers per
+// user row that the hub items of a recommendation graph make then meet in that XCD's 4 MB L2 instead
+// of each going to HBM.  Measured on C2 (tools/ab_band.py, round 1): 1.20 -> 1.04 ms per launch with
+// one wavefront per item; see DESIGN.md for the final figures.
 #include "common.hpp"
+#include <algorithm>
 #include <rocprim/rocprim.hpp>
 
 namespace {
 
-#ifndef MI_SPMM_NT
-#define MI_SPMM_NT 0   // 1: non-temporal loads of col/val and stores of Y/S.  Measured on C2 (tools/ab_spmm.py,
-                       // round 1): 1.226 ms vs 1.227 ms — no gain; UNROLL 8: 1.241 ms; both: 1.274 ms.  Kept off.
-#endif
 #ifndef MI_SPMM_UNROLL
-#define MI_SPMM_UNROLL 4
+#define MI_SPMM_UNROLL 8   // row loads in flight per lane (VPL = 1); round-1 A/B: 4 -> 8 gains 2 % with sub-group rows
+#endif
+#ifndef MI_SPMM_ROWS_RPS
+#define MI_SPMM_ROWS_RPS 1  // rows a sub-group handles in sequence; A/B on C2: 1: 1.373 ms, 2: 1.408, 4: 1.397
+#endif
+#ifndef MI_SPMM_NT
+#define MI_SPMM_NT 0   // bit 0: non-temporal (col,val) loads; bit 1: partial-sum stores; bit 2: Y / S stores; bit 3: addend loads
 #endif
 typedef float mi_f4v __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void mi_nt_store4(float4* p, const float4& v) {
-    mi_f4v x = {v.x, v.y, v.z, v.w};
-    __builtin_nontemporal_store(x, reinterpret_cast<mi_f4v*>(p));
+template <int BIT>
+__device__ __forceinline__ void mi_store4(float4* p, const float4& v) {
+    if ((MI_SPMM_NT >> BIT) & 1) {
+        mi_f4v x = {v.x, v.y, v.z, v.w};
+        __builtin_nontemporal_store(x, reinterpret_cast<mi_f4v*>(p));
+    } else {
+        *p = v;
+    }
+}
+template <int BIT>
+__device__ __forceinline__ float4 mi_load4(const float4* p) {
+    if ((MI_SPMM_NT >> BIT) & 1) {
+        mi_f4v x = __builtin_nontemporal_load(reinterpret_cast<const mi_f4v*>(p));
+        return make_float4(x.x, x.y, x.z, x.w);
+    }
+    return *p;
 }
 constexpr int kWavesPerBlock = 4;
 constexpr int kBlock = kWavesPerBlock * MI_WAVE;
+constexpr int kPlanGroup = MI_SPMM_GROUP;  // launch slots per XCD-interleave block of a banded plan
 
 struct Epilogue {
     float4* Y;            int64_t ldy4;
@@ -42,7 +68,7 @@ struct Epilogue {
     float scale;
 };
 
-// Sparse-operand extensions (mi_spmm_csr_ex_f32); all pointers nullable, branches are wave-uniform.
+// Sparse-operand extensions (mi_spmm_csr_ex_f32); all pointers nullable.
 struct Ex {
     const int32_t* x_map;       // [n_cols]: X is compact, neighbour c reads X[x_map[c]]; < 0 = an all-zero row, skipped
     const int32_t* addend_map;  // [n_rows]: addend is compact, row r adds addend[addend_map[r]]; < 0 = nothing
@@ -51,46 +77,48 @@ struct Ex {
     const int32_t* long_index;  // [n_rows]: index into the plan's long rows, -1 for short rows (row_list mode)
 };
 
-// Accumulates entries [beg, end) of one row into acc (valid in lanes of sub-group 0 after
-// the final cross-sub-group reduce).
+// Largest n over the sub-groups of the wavefront (loop bounds must be wave-uniform around __shfl).
+template <int LPR>
+__device__ __forceinline__ int wave_max_over_subgroups(int n) {
+#pragma unroll
+    for (int m = MI_WAVE / 2; m >= LPR; m >>= 1) n = max(n, __shfl_xor(n, m, MI_WAVE));
+    return n;
+}
+
+// The calling sub-group accumulates entries [beg, beg + n) into acc, in list order.
 template <int LPR, int VPL, int UNROLL, bool SPARSE>
-__device__ __forceinline__ void wave_accumulate(const int32_t* __restrict__ col,
-                                                const float* __restrict__ val,
-                                                const float4* __restrict__ X4, int64_t ldx4, int d4,
-                                                int32_t beg, int32_t end, float4 (&acc)[VPL],
-                                                const int32_t* __restrict__ x_map = nullptr) {
-    constexpr int NB = MI_WAVE / LPR;
-    const int lane = mi_lane();
-    const int g = lane / LPR;
-    const int li = lane % LPR;
+__device__ __forceinline__ void subgroup_accumulate(const int32_t* __restrict__ col,
+                                                    const float* __restrict__ val,
+                                                    const float4* __restrict__ X4, int64_t ldx4, int d4,
+                                                    int32_t beg, int n, int nmax, int li,
+                                                    const int32_t* __restrict__ x_map, float4 (&acc)[VPL]) {
+    static_assert(LPR % UNROLL == 0, "a batch of LPR entries is consumed UNROLL at a time");
 #pragma unroll
     for (int v = 0; v < VPL; ++v) acc[v] = mi_f4_zero();
-
-    for (int32_t base = beg; base < end; base += MI_WAVE) {
-        const int n = min((int32_t)MI_WAVE, end - base);
-        int32_t my_c = 0;
+    for (int base = 0; base < nmax; base += LPR) {
+        int32_t my_c = -1;  // < 0: nothing to gather for this lane's entry
         float my_v = 0.f;
-        if (lane < n) {
-#if MI_SPMM_NT
-            my_c = __builtin_nontemporal_load(col + base + lane);
-            my_v = __builtin_nontemporal_load(val + base + lane);
-#else
-            my_c = col[base + lane];
-            my_v = val[base + lane];
-#endif
+        if (base + li < n) {
+            if (MI_SPMM_NT & 1) {
+                my_c = __builtin_nontemporal_load(col + beg + base + li);
+                my_v = __builtin_nontemporal_load(val + beg + base + li);
+            } else {
+                my_c = col[beg + base + li];
+                my_v = val[beg + base + li];
+            }
             if (SPARSE && x_map) my_c = x_map[my_c];  // compact row of X, or < 0 for a row that is all zeros
         }
-        if (SPARSE && x_map && __ballot(my_c >= 0 && lane < n) == 0ull) continue;  // nothing to gather in this 64-entry group
-        for (int j = 0; j < n; j += NB * UNROLL) {
+        if (SPARSE && __ballot(my_c >= 0) == 0ull) continue;
+        const int m = min(LPR, nmax - base);
+        for (int j = 0; j < m; j += UNROLL) {
             float w[UNROLL];
             float4 x[UNROLL][VPL];
 #pragma unroll
             for (int u = 0; u < UNROLL; ++u) {
-                const int idx = j + u * NB + g;
-                const int32_t c = __shfl(my_c, idx & (MI_WAVE - 1), MI_WAVE);
-                w[u] = __shfl(my_v, idx & (MI_WAVE - 1), MI_WAVE);
-                const bool ok = idx < n && c >= 0;
-                const float4* src = X4 + (int64_t)c * ldx4;
+                const int32_t c = __shfl(my_c, j + u, LPR);
+                w[u] = __shfl(my_v, j + u, LPR);
+                const bool ok = c >= 0;
+                const float4* src = X4 + (int64_t)(ok ? c : 0) * ldx4;
 #pragma unroll
                 for (int v = 0; v < VPL; ++v) {
                     const int e = li + v * LPR;
@@ -104,98 +132,120 @@ __device__ __forceinline__ void wave_accumulate(const int32_t* __restrict__ col,
                 for (int v = 0; v < VPL; ++v) mi_f4_fma(acc[v], w[u], x[u][v]);
         }
     }
-#pragma unroll
-    for (int m = MI_WAVE / 2; m >= LPR; m >>= 1)
-#pragma unroll
-        for (int v = 0; v < VPL; ++v) acc[v] = mi_f4_add(acc[v], mi_f4_shfl_xor(acc[v], m));
 }
 
-// r = output row index (compact position in row_list mode)
+// Y / S rows of one sub-group (li = lane within the sub-group); r = output row (compact position in row_list mode).
 template <int LPR, int VPL>
-__device__ __forceinline__ void apply_epilogue(const Epilogue& ep, int64_t r, int d4,
+__device__ __forceinline__ void store_epilogue(const Epilogue& ep, int64_t r, int d4, int li,
                                                const float4 (&acc)[VPL], const float4 (&a)[VPL]) {
-    const int lane = mi_lane();
-    if (lane >= LPR) return;
 #pragma unroll
     for (int v = 0; v < VPL; ++v) {
-        const int e = lane + v * LPR;
+        const int e = li + v * LPR;
         if (e >= d4) continue;
-#if MI_SPMM_NT
-        if (ep.Y) mi_nt_store4(ep.Y + r * ep.ldy4 + e, acc[v]);
-#else
-        if (ep.Y) ep.Y[r * ep.ldy4 + e] = acc[v];
-#endif
+        if (ep.Y) mi_store4<2>(ep.Y + r * ep.ldy4 + e, acc[v]);
         if (ep.S) {
             float4 o;
             o.x = ep.scale * (a[v].x + acc[v].x);
             o.y = ep.scale * (a[v].y + acc[v].y);
             o.z = ep.scale * (a[v].z + acc[v].z);
             o.w = ep.scale * (a[v].w + acc[v].w);
-#if MI_SPMM_NT
-            mi_nt_store4(ep.S + r * ep.lds4 + e, o);
-#else
-            ep.S[r * ep.lds4 + e] = o;
-#endif
+            mi_store4<2>(ep.S + r * ep.lds4 + e, o);
         }
     }
 }
 
 // ar = addend row index, < 0 for "no addend row"
 template <int LPR, int VPL>
-__device__ __forceinline__ void load_addend(const Epilogue& ep, int64_t ar, int d4, float4 (&a)[VPL]) {
-    const int lane = mi_lane();
+__device__ __forceinline__ void load_addend(const Epilogue& ep, int64_t ar, int d4, int li, float4 (&a)[VPL]) {
 #pragma unroll
     for (int v = 0; v < VPL; ++v) {
-        const int e = lane + v * LPR;
-        a[v] = (ep.S && ep.addend && ar >= 0 && lane < LPR && e < d4) ? ep.addend[ar * ep.lda4 + e] : mi_f4_zero();
+        const int e = li + v * LPR;
+        a[v] = (ep.S && ep.addend && ar >= 0 && e < d4) ? mi_load4<3>(ep.addend + ar * ep.lda4 + e) : mi_f4_zero();
     }
 }
 
-// One wavefront per row; rows with more than `chunk` entries are left to the split path.
+// One sub-group per row; rows with more than `chunk` entries are left to the split path.
 // SPARSE = false: the dense product (every entry gathered; addend_map allowed) — the kernel the
 // roofline is quoted on.  SPARSE = true: x_map / row_list launches of the fused train step, kept as a
 // separate instantiation so that profiles list them apart.
-template <int LPR, int VPL, int UNROLL, bool SPARSE>
-__global__ __launch_bounds__(kBlock) void spmm_rows_kernel(int64_t n_rows, int d4,
+template <int LPR, int VPL, int UNROLL, int RPS, bool SPARSE>
+__global__ __launch_bounds__(kBlock) void spmm_rows_kernel(int64_t n_out, int d4,
                                                            const int32_t* __restrict__ rowptr,
                                                            const int32_t* __restrict__ col,
                                                            const float* __restrict__ val,
                                                            const float4* __restrict__ X4, int64_t ldx4,
                                                            Epilogue ep, int32_t chunk, Ex ex) {
-    const int64_t i = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x / MI_WAVE);
-    if (i >= n_rows) return;
+    constexpr int NB = MI_WAVE / LPR, SG = NB * kWavesPerBlock;
+    const int lane = mi_lane();
+    const int li = lane % LPR;
+    const int sgi = (threadIdx.x / MI_WAVE) * NB + lane / LPR;
     const bool listed = SPARSE && ex.row_list != nullptr;
-    if (listed && ex.n_list_dev && i >= *ex.n_list_dev) return;
-    const int64_t r = listed ? ex.row_list[i] : i;
-    const int32_t beg = rowptr[r], end = rowptr[r + 1];
-    if (end - beg > chunk) return;
-    float4 a[VPL], acc[VPL];
-    const int64_t ar = listed ? i : (ex.addend_map ? (int64_t)ex.addend_map[r] : r);
-    load_addend<LPR, VPL>(ep, ar, d4, a);
-    wave_accumulate<LPR, VPL, UNROLL, SPARSE>(col, val, X4, ldx4, d4, beg, end, acc, ex.x_map);
-    apply_epilogue<LPR, VPL>(ep, listed ? i : r, d4, acc, a);
+    int64_t n_valid = n_out;
+    if (listed && ex.n_list_dev) n_valid = min(n_out, (int64_t)*ex.n_list_dev);
+    const int64_t base = (int64_t)blockIdx.x * (SG * RPS);
+#pragma unroll
+    for (int k = 0; k < RPS; ++k) {
+        const int64_t i = base + k * SG + sgi;  // output position
+        int64_t r = 0;
+        int32_t beg = 0;
+        int n = 0;
+        bool mine = i < n_valid;
+        if (mine) {
+            r = listed ? (int64_t)ex.row_list[i] : i;
+            beg = rowptr[r];
+            n = rowptr[r + 1] - beg;
+            mine = n <= chunk;  // split rows belong to the items / fix-up kernels
+        }
+        if (!mine) n = 0;
+        const int nmax = wave_max_over_subgroups<LPR>(n);
+        float4 a[VPL], acc[VPL];
+        const int64_t ar = !mine ? -1 : (listed ? i : (ex.addend_map ? (int64_t)ex.addend_map[r] : r));
+        load_addend<LPR, VPL>(ep, ar, d4, li, a);
+        subgroup_accumulate<LPR, VPL, UNROLL, SPARSE>(col, val, X4, ldx4, d4, beg, n, nmax, li, ex.x_map, acc);
+        if (mine) store_epilogue<LPR, VPL>(ep, listed ? i : r, d4, li, acc, a);
+    }
 }
 
-// Split rows: one wavefront per work item (row, begin, end, slot) -> partial[slot, :].
-template <int LPR, int VPL, int UNROLL, bool SPARSE>
-__global__ __launch_bounds__(kBlock) void spmm_items_kernel(int32_t n_items, int d4,
-                                                            const int32_t* __restrict__ items,
+// Split rows: one sub-group per work item (row, begin, end, slot) -> partial[slot, :]; slot < 0 = padding.
+// Launch slot -> workgroup: linear for a row-major plan; for a banded plan the launch array is made of
+// blocks of kPlanGroup slots dealt to 8 queues (queue = band mod 8), and workgroup w serves queue w mod 8.
+template <int LPR, int VPL, int UNROLL, int RPS, bool SPARSE>
+__global__ __launch_bounds__(kBlock) void spmm_items_kernel(int64_t n_launch, int32_t banded, int d4,
+                                                            const int4* __restrict__ items,
                                                             const int32_t* __restrict__ col,
                                                             const float* __restrict__ val,
                                                             const float4* __restrict__ X4, int64_t ldx4,
                                                             float4* __restrict__ partial,
                                                             const int32_t* __restrict__ x_map) {
-    const int32_t it = blockIdx.x * kWavesPerBlock + (threadIdx.x / MI_WAVE);
-    if (it >= n_items) return;
-    const int32_t beg = items[4 * it + 1], end = items[4 * it + 2], slot = items[4 * it + 3];
-    float4 acc[VPL];
-    wave_accumulate<LPR, VPL, UNROLL, SPARSE>(col, val, X4, ldx4, d4, beg, end, acc, x_map);
+    constexpr int NB = MI_WAVE / LPR, SG = NB * kWavesPerBlock, G = SG * RPS;
+    static_assert(kPlanGroup % G == 0, "a workgroup serves a whole fraction of a launch block");
     const int lane = mi_lane();
-    if (lane < LPR) {
+    const int li = lane % LPR;
+    const int sgi = (threadIdx.x / MI_WAVE) * NB + lane / LPR;
+    int64_t base;
+    if (banded) {
+        constexpr int per = kPlanGroup / G;
+        const int64_t x = blockIdx.x & 7, tq = blockIdx.x >> 3;
+        base = ((tq / per) * 8 + x) * kPlanGroup + (tq % per) * G;
+    } else {
+        base = (int64_t)blockIdx.x * G;
+    }
 #pragma unroll
-        for (int v = 0; v < VPL; ++v) {
-            const int e = lane + v * LPR;
-            if (e < d4) partial[(int64_t)slot * d4 + e] = acc[v];
+    for (int k = 0; k < RPS; ++k) {
+        const int64_t q = base + k * SG + sgi;
+        int4 it = make_int4(0, 0, 0, -1);
+        if (q < n_launch) it = items[q];
+        const int32_t slot = it.w;
+        const int n = slot >= 0 ? it.z - it.y : 0;
+        const int nmax = wave_max_over_subgroups<LPR>(n);
+        float4 acc[VPL];
+        subgroup_accumulate<LPR, VPL, UNROLL, SPARSE>(col, val, X4, ldx4, d4, it.y, n, nmax, li, x_map, acc);
+        if (slot >= 0) {
+#pragma unroll
+            for (int v = 0; v < VPL; ++v) {
+                const int e = li + v * LPR;
+                if (e < d4) mi_store4<1>(partial + (int64_t)slot * d4 + e, acc[v]);
+            }
         }
     }
 }
@@ -259,77 +309,217 @@ __global__ __launch_bounds__(kBlock) void spmm_fixup_kernel(int32_t n_long, int 
         for (int v = 0; v < VPL; ++v) red[wave][v][lane] = acc[v];
     }
     __syncthreads();
-    if (wave != 0) return;
+    if (wave != 0 || lane >= LPR) return;
     float4 a[VPL];
-    load_addend<LPR, VPL>(ep, ar, d4, a);
-    if (lane < LPR) {
+    load_addend<LPR, VPL>(ep, ar, d4, lane, a);
 #pragma unroll
-        for (int v = 0; v < VPL; ++v) {
-            float4 t = red[0][v][lane];
+    for (int v = 0; v < VPL; ++v) {
+        float4 t = red[0][v][lane];
 #pragma unroll
-            for (int w = 1; w < kWavesPerBlock; ++w) t = mi_f4_add(t, red[w][v][lane]);
-            acc[v] = t;
-        }
+        for (int w = 1; w < kWavesPerBlock; ++w) t = mi_f4_add(t, red[w][v][lane]);
+        acc[v] = t;
     }
-    apply_epilogue<LPR, VPL>(ep, out_row, d4, acc, a);
+    store_epilogue<LPR, VPL>(ep, out_row, d4, lane, acc, a);
 }
 
 // ---- plan construction --------------------------------------------------------------------
-__global__ void plan_flags_kernel(int64_t n_rows, const int32_t* __restrict__ rowptr, int32_t chunk,
-                                  int32_t* __restrict__ is_long, int32_t* __restrict__ n_it) {
-    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r > n_rows) return;
-    int32_t deg = (r < n_rows) ? rowptr[r + 1] - rowptr[r] : 0;
-    bool lg = deg > chunk;
-    is_long[r] = lg ? 1 : 0;
-    n_it[r] = lg ? (deg + chunk - 1) / chunk : 0;
+// Phase 1 (mi_spmm_plan_count) keeps its arrays in the caller's workspace; phase 2 (mi_spmm_plan_fill)
+// carves the same layout again from the counts in mi_spmm_plan_info.
+struct PlanWs {
+    int32_t *is_long, *ldeg, *long_off, *lnz_off;  // [n_rows + 1]
+    int32_t* qstart;                               // [16]
+    char* tmp; size_t tmp_bytes;                   // rocPRIM scratch
+    int32_t *lrows, *lprefix;                      // [n_long + 1]
+    int32_t *flags, *seg_of;                       // [nnz_long]
+    int32_t* seg_start;                            // [n_seg]
+    uint64_t *keys0, *keys1;                       // [n_seg]
+};
+
+size_t plan_tmp_bytes(int64_t n_max) { return mi_align_up((size_t)n_max * 2 + ((size_t)32 << 20), 256); }
+
+bool plan_carve(MiArena& ar, int64_t n_rows, int64_t nnz_total, int64_t n_long, int64_t nnz_long, int64_t n_seg,
+                PlanWs& w) {
+    const size_t n1 = (size_t)n_rows + 1;
+    w.is_long = ar.take<int32_t>(n1);
+    w.ldeg = ar.take<int32_t>(n1);
+    w.long_off = ar.take<int32_t>(n1);
+    w.lnz_off = ar.take<int32_t>(n1);
+    w.qstart = ar.take<int32_t>(16);
+    w.tmp_bytes = plan_tmp_bytes(nnz_total > n_rows + 1 ? nnz_total : n_rows + 1);
+    w.tmp = ar.take<char>(w.tmp_bytes);
+    if (!w.is_long || !w.ldeg || !w.long_off || !w.lnz_off || !w.qstart || !w.tmp) return false;
+    if (n_long < 0) return true;
+    w.lrows = ar.take<int32_t>((size_t)n_long + 1);
+    w.lprefix = ar.take<int32_t>((size_t)n_long + 1);
+    w.flags = ar.take<int32_t>((size_t)(nnz_long > 0 ? nnz_long : 1));
+    w.seg_of = ar.take<int32_t>((size_t)(nnz_long > 0 ? nnz_long : 1));
+    if (!w.lrows || !w.lprefix || !w.flags || !w.seg_of) return false;
+    if (n_seg < 0) return true;
+    w.seg_start = ar.take<int32_t>((size_t)(n_seg > 0 ? n_seg : 1));
+    w.keys0 = ar.take<uint64_t>((size_t)(n_seg > 0 ? n_seg : 1));
+    w.keys1 = ar.take<uint64_t>((size_t)(n_seg > 0 ? n_seg : 1));
+    return w.seg_start && w.keys0 && w.keys1;
 }
 
-__global__ void plan_fill_kernel(int64_t n_rows, const int32_t* __restrict__ rowptr, int32_t chunk,
-                                 const int32_t* __restrict__ long_off, const int32_t* __restrict__ item_off,
-                                 int32_t* __restrict__ long_rows, int32_t* __restrict__ item_ptr,
-                                 int32_t* __restrict__ items, int32_t* __restrict__ long_index) {
+__global__ void plan_flags_kernel(int64_t n_rows, const int32_t* __restrict__ rowptr, int32_t chunk,
+                                  int32_t* __restrict__ is_long, int32_t* __restrict__ ldeg) {
     int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r > n_rows) return;
-    if (r == n_rows) {  // sentinel: item_ptr[n_long] = n_items
-        item_ptr[long_off[r]] = item_off[r];
+    const int32_t deg = (r < n_rows) ? rowptr[r + 1] - rowptr[r] : 0;
+    const bool lg = deg > chunk;
+    is_long[r] = lg ? 1 : 0;
+    ldeg[r] = lg ? deg : 0;
+}
+
+__global__ void plan_long_rows_kernel(int64_t n_rows, const int32_t* __restrict__ is_long,
+                                      const int32_t* __restrict__ long_off, const int32_t* __restrict__ lnz_off,
+                                      int32_t* __restrict__ lrows, int32_t* __restrict__ lprefix) {
+    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r > n_rows) return;
+    if (r == n_rows) {
+        lprefix[long_off[r]] = lnz_off[r];  // sentinel: entries of all long rows
         return;
     }
-    const int32_t b = rowptr[r], e = rowptr[r + 1];
-    if (e - b <= chunk) {
-        if (long_index) long_index[r] = -1;
-        return;
-    }
-    const int32_t li = long_off[r], io = item_off[r];
-    if (long_index) long_index[r] = li;
-    long_rows[li] = (int32_t)r;
-    item_ptr[li] = io;
-    int32_t k = 0;
-    for (int32_t p = b; p < e; p += chunk, ++k) {
-        items[4 * (io + k) + 0] = (int32_t)r;
-        items[4 * (io + k) + 1] = p;
-        items[4 * (io + k) + 2] = min(p + chunk, e);
-        items[4 * (io + k) + 3] = io + k;
+    if (is_long[r]) {
+        lrows[long_off[r]] = (int32_t)r;
+        lprefix[long_off[r]] = lnz_off[r];
     }
 }
+
+// index i with prefix[i] <= t < prefix[i + 1]  (prefix has n + 1 ascending entries)
+__device__ __forceinline__ int32_t plan_find(const int32_t* __restrict__ prefix, int32_t n, int32_t t) {
+    int32_t lo = 0, hi = n;  // answer in [lo, hi)
+    while (hi - lo > 1) {
+        const int32_t mid = (lo + hi) >> 1;
+        if (prefix[mid] <= t) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+// flags[t] = 1 when entry t of the long rows' entry list starts a work item: the first entry of a row, the
+// first entry of a band within the row, and every chunk-th entry after either.
+__global__ void plan_seg_flags_kernel(int32_t nnz_long, int32_t n_long, const int32_t* __restrict__ lrows,
+                                      const int32_t* __restrict__ lprefix, const int32_t* __restrict__ rowptr,
+                                      const int32_t* __restrict__ col, int32_t chunk, int32_t band,
+                                      int32_t* __restrict__ flags) {
+    const int32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nnz_long) return;
+    const int32_t i = plan_find(lprefix, n_long, t);
+    const int32_t rb = rowptr[lrows[i]];
+    const int32_t p = rb + (t - lprefix[i]);
+    int32_t run = rb;  // first entry of p's band within the row
+    if (band > 0) {
+        const int32_t first_col = col[p] / band * band;
+        int32_t lo = rb, hi = p;  // smallest index in [rb, p] whose column is >= first_col (columns ascend within a row)
+        while (lo < hi) {
+            const int32_t mid = (lo + hi) >> 1;
+            if (col[mid] >= first_col) hi = mid; else lo = mid + 1;
+        }
+        run = lo;
+    }
+    flags[t] = (p == rb || (p - run) % chunk == 0) ? 1 : 0;
+}
+
+__global__ void plan_seg_starts_kernel(int32_t nnz_long, int32_t n_long, const int32_t* __restrict__ lrows,
+                                       const int32_t* __restrict__ lprefix, const int32_t* __restrict__ rowptr,
+                                       const int32_t* __restrict__ col, int32_t band,
+                                       const int32_t* __restrict__ flags, const int32_t* __restrict__ seg_of,
+                                       int32_t* __restrict__ seg_start, uint64_t* __restrict__ keys) {
+    const int32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nnz_long || !flags[t]) return;
+    const int32_t s = seg_of[t];
+    seg_start[s] = t;
+    if (band > 0) {
+        const int32_t i = plan_find(lprefix, n_long, t);
+        const int32_t p = rowptr[lrows[i]] + (t - lprefix[i]);
+        const uint64_t b = (uint64_t)(col[p] / band);
+        keys[s] = ((b & 7ull) << 60) | (b << 32) | (uint64_t)(uint32_t)s;  // (queue, band, row-major slot)
+    }
+}
+
+__global__ void plan_queue_bounds_kernel(int32_t n_seg, const uint64_t* __restrict__ keys, int32_t* __restrict__ qstart) {
+    const int x = threadIdx.x;
+    if (x > 8) return;
+    const uint64_t want = (uint64_t)x << 60;
+    int32_t lo = 0, hi = n_seg;
+    while (lo < hi) {
+        const int32_t mid = (lo + hi) >> 1;
+        if (keys[mid] >= want) hi = mid; else lo = mid + 1;
+    }
+    qstart[x] = (x == 8) ? n_seg : lo;
+}
+
+__global__ void plan_fill_rows_kernel(int64_t n_rows, const int32_t* __restrict__ is_long,
+                                      const int32_t* __restrict__ long_off, int32_t* __restrict__ long_rows,
+                                      int32_t* __restrict__ long_index) {
+    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rows) return;
+    if (is_long[r]) long_rows[long_off[r]] = (int32_t)r;
+    if (long_index) long_index[r] = is_long[r] ? long_off[r] : -1;
+}
+
+__global__ void plan_item_ptr_kernel(int32_t n_long, int32_t n_seg, const int32_t* __restrict__ lprefix,
+                                     const int32_t* __restrict__ seg_of, int32_t* __restrict__ item_ptr) {
+    const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > n_long) return;
+    item_ptr[i] = (i < n_long) ? seg_of[lprefix[i]] : n_seg;
+}
+
+__global__ void plan_pad_kernel(int64_t n_launch, int4* __restrict__ items) {
+    int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < n_launch) items[q] = make_int4(0, 0, 0, -1);
+}
+
+struct QueueStarts { int32_t q[9]; };
+
+__global__ void plan_items_kernel(int32_t n_seg, int32_t banded, const uint64_t* __restrict__ keys, QueueStarts qs,
+                                  const int32_t* __restrict__ seg_start, int32_t n_long,
+                                  const int32_t* __restrict__ lrows, const int32_t* __restrict__ lprefix,
+                                  const int32_t* __restrict__ rowptr, int4* __restrict__ items) {
+    const int32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_seg) return;
+    int32_t s = j;
+    int64_t pos = j;
+    if (banded) {
+        const uint64_t k = keys[j];
+        s = (int32_t)(uint32_t)(k & 0xFFFFFFFFull);
+        const int x = (int)(k >> 60);
+        const int64_t rank = j - qs.q[x];
+        pos = ((rank / kPlanGroup) * 8 + x) * kPlanGroup + rank % kPlanGroup;
+    }
+    const int32_t t = seg_start[s];
+    const int32_t i = plan_find(lprefix, n_long, t);
+    const int32_t r = lrows[i];
+    const int32_t p = rowptr[r] + (t - lprefix[i]);
+    const int32_t t_next = (s + 1 < n_seg) ? seg_start[s + 1] : INT32_MAX;
+    const int32_t end = (t_next < lprefix[i + 1]) ? p + (t_next - t) : rowptr[r + 1];
+    items[pos] = make_int4(r, p, end, s);
+}
+
+dim3 plan_grid(int64_t n) { return dim3((unsigned)mi_ceil_div(n > 0 ? n : 1, 256)); }
 
 template <int LPR, int VPL, bool SPARSE>
 int launch_spmm_mode(int64_t n_rows, int d4, const int32_t* rowptr, const int32_t* col, const float* val,
                      const float4* X4, int64_t ldx4, const Epilogue& ep, const mi_spmm_plan* plan,
                      float4* partial, const Ex& ex, int64_t n_list, hipStream_t s) {
-    constexpr int UNROLL = (VPL == 1) ? MI_SPMM_UNROLL : 2;
+    constexpr int UNROLL = (VPL == 1) ? MI_SPMM_UNROLL : MI_SPMM_UNROLL / 2;
+    constexpr int SG = (MI_WAVE / LPR) * kWavesPerBlock;
+    constexpr int ROWS_RPS = MI_SPMM_ROWS_RPS;
+    constexpr int ITEMS_RPS = (SG >= 16) ? 1 : 16 / SG;  // 16 launch slots per workgroup (32 when D <= 32)
     const int32_t chunk = plan ? plan->chunk : INT32_MAX;
     const bool listed = SPARSE && ex.row_list != nullptr;
     if (plan && plan->n_items > 0) {  // row_list mode still reduces every split row: hubs are few and almost always wanted
-        dim3 gi((unsigned)mi_ceil_div(plan->n_items, kWavesPerBlock));
-        hipLaunchKernelGGL((spmm_items_kernel<LPR, VPL, UNROLL, SPARSE>), gi, dim3(kBlock), 0, s, plan->n_items, d4,
-                           plan->items, col, val, X4, ldx4, partial, ex.x_map);
+        const int64_t n_launch = plan->n_launch;
+        dim3 gi((unsigned)mi_ceil_div(n_launch, SG * ITEMS_RPS));
+        hipLaunchKernelGGL((spmm_items_kernel<LPR, VPL, UNROLL, ITEMS_RPS, SPARSE>), gi, dim3(kBlock), 0, s, n_launch,
+                           plan->band > 0 ? 1 : 0, d4, reinterpret_cast<const int4*>(plan->items), col, val, X4, ldx4,
+                           partial, ex.x_map);
     }
     const int64_t n_out = listed ? n_list : n_rows;
     if (n_out > 0) {
-        dim3 gr((unsigned)mi_ceil_div(n_out, kWavesPerBlock));
-        hipLaunchKernelGGL((spmm_rows_kernel<LPR, VPL, UNROLL, SPARSE>), gr, dim3(kBlock), 0, s, n_out, d4, rowptr,
-                           col, val, X4, ldx4, ep, chunk, ex);
+        dim3 gr((unsigned)mi_ceil_div(n_out, SG * ROWS_RPS));
+        hipLaunchKernelGGL((spmm_rows_kernel<LPR, VPL, UNROLL, ROWS_RPS, SPARSE>), gr, dim3(kBlock), 0, s, n_out, d4,
+                           rowptr, col, val, X4, ldx4, ep, chunk, ex);
     }
     if (plan && plan->n_long_rows > 0) {
         const int64_t nf = listed ? n_list : (int64_t)plan->n_long_rows;
@@ -353,63 +543,126 @@ int launch_spmm(int64_t n_rows, int d4, const int32_t* rowptr, const int32_t* co
 
 extern "C" {
 
-int mi_spmm_plan_bounds(int64_t n_rows, int64_t nnz, int32_t chunk, int64_t* max_long_rows,
-                        int64_t* max_items) {
-    MI_CHECK_ARG(n_rows >= 0 && nnz >= 0 && chunk > 0 && max_long_rows && max_items);
-    int64_t ml = nnz / ((int64_t)chunk + 1);  // each long row holds > chunk entries
-    if (ml > n_rows) ml = n_rows;
-    *max_long_rows = ml;
-    *max_items = nnz / chunk + ml;  // sum ceil(deg/chunk) <= nnz/chunk + n_long
-    return 0;
+size_t mi_spmm_plan_workspace_bytes(int64_t n_rows, int64_t nnz) {
+    if (n_rows < 0 || nnz < 0) return 0;
+    const size_t n1 = (size_t)n_rows + 1, z = (size_t)(nnz > 0 ? nnz : 1);
+    // worst case: every row is split and every entry is its own work item
+    return 4 * mi_align_up(n1 * 4, 256) + 256 + plan_tmp_bytes(nnz > n_rows + 1 ? nnz : n_rows + 1) +
+           2 * mi_align_up(n1 * 4, 256) + 3 * mi_align_up(z * 4, 256) + 2 * mi_align_up(z * 8, 256);
 }
 
-size_t mi_spmm_plan_workspace_bytes(int64_t n_rows) {
-    size_t n = (size_t)n_rows + 1;
-    return 4 * mi_align_up(n * 4, 256) + ((size_t)16 << 20);
-}
-
-int mi_spmm_plan_build(int64_t n_rows, const int32_t* rowptr, int32_t chunk, mi_spmm_plan* plan,
-                       void* ws, size_t ws_bytes, mi_stream_t stream) {
-    MI_CHECK_ARG(n_rows >= 0 && rowptr && chunk > 0 && plan && ws);
-    if (n_rows >= INT32_MAX) return MI_ERR_TOO_LARGE;
+int mi_spmm_plan_count(int64_t n_rows, int64_t n_cols, const int32_t* rowptr, const int32_t* col,
+                       int32_t chunk, int32_t band, void* ws, size_t ws_bytes, mi_spmm_plan_info* info,
+                       mi_stream_t stream) {
+    MI_CHECK_ARG(n_rows >= 0 && n_cols >= 0 && rowptr && chunk > 0 && band >= 0 && ws && info);
+    MI_CHECK_ARG(band == 0 || col);
+    if (n_rows >= INT32_MAX || n_cols >= INT32_MAX) return MI_ERR_TOO_LARGE;
     hipStream_t s = (hipStream_t)stream;
-    plan->chunk = chunk;
-    plan->n_long_rows = 0;
-    plan->n_items = 0;
-    plan->reserved = 0;
-    const int64_t n1 = n_rows + 1;
-    MiArena arena(ws, ws_bytes);
-    int32_t* is_long = arena.take<int32_t>(n1);
-    int32_t* n_it = arena.take<int32_t>(n1);
-    int32_t* long_off = arena.take<int32_t>(n1);
-    int32_t* item_off = arena.take<int32_t>(n1);
-    if (!is_long || !n_it || !long_off || !item_off) return MI_ERR_WORKSPACE;
-    dim3 g((unsigned)mi_ceil_div(n1, 256));
-    hipLaunchKernelGGL(plan_flags_kernel, g, dim3(256), 0, s, n_rows, rowptr, chunk, is_long, n_it);
-    size_t tmp_bytes = 0;
-    MI_HIP(rocprim::exclusive_scan(nullptr, tmp_bytes, is_long, long_off, 0, (size_t)n1,
-                                   rocprim::plus<int32_t>(), s));
-    char* tmp = arena.take<char>(tmp_bytes ? tmp_bytes : 1);
-    if (!tmp) return MI_ERR_WORKSPACE;
-    MI_HIP(rocprim::exclusive_scan(tmp, tmp_bytes, is_long, long_off, 0, (size_t)n1,
-                                   rocprim::plus<int32_t>(), s));
-    MI_HIP(rocprim::exclusive_scan(tmp, tmp_bytes, n_it, item_off, 0, (size_t)n1,
-                                   rocprim::plus<int32_t>(), s));
-    int32_t totals[2] = {0, 0};
-    MI_HIP(hipMemcpyAsync(&totals[0], long_off + n_rows, sizeof(int32_t), hipMemcpyDeviceToHost, s));
-    MI_HIP(hipMemcpyAsync(&totals[1], item_off + n_rows, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    memset(info, 0, sizeof(*info));
+    info->chunk = chunk;
+    info->band = band;
+    info->n_bands = band > 0 ? (int32_t)mi_ceil_div(n_cols > 0 ? n_cols : 1, band) : 0;
+    int32_t nnz32 = 0;
+    MI_HIP(hipMemcpyAsync(&nnz32, rowptr + n_rows, sizeof(int32_t), hipMemcpyDeviceToHost, s));
     MI_HIP(hipStreamSynchronize(s));
-    plan->n_long_rows = totals[0];
-    plan->n_items = totals[1];
-    if (totals[0] > 0) {
-        MI_CHECK_ARG(plan->long_rows && plan->item_ptr && plan->items);
-        hipLaunchKernelGGL(plan_fill_kernel, g, dim3(256), 0, s, n_rows, rowptr, chunk, long_off, item_off,
-                           plan->long_rows, plan->item_ptr, plan->items, plan->long_index);
-        MI_HIP(hipStreamSynchronize(s));  // ws may be released by the caller on return
-    } else if (plan->long_index) {
-        MI_HIP(hipMemsetAsync(plan->long_index, 0xFF, (size_t)n_rows * sizeof(int32_t), s));
-        MI_HIP(hipStreamSynchronize(s));
+    const int64_t nnz = nnz32;
+    PlanWs w{};
+    {
+        MiArena ar(ws, ws_bytes);
+        if (!plan_carve(ar, n_rows, nnz, -1, -1, -1, w)) return MI_ERR_WORKSPACE;
     }
+    const int64_t n1 = n_rows + 1;
+    hipLaunchKernelGGL(plan_flags_kernel, plan_grid(n1), dim3(256), 0, s, n_rows, rowptr, chunk, w.is_long, w.ldeg);
+    size_t tb = w.tmp_bytes;
+    MI_HIP(rocprim::exclusive_scan(w.tmp, tb, w.is_long, w.long_off, 0, (size_t)n1, rocprim::plus<int32_t>(), s));
+    tb = w.tmp_bytes;
+    MI_HIP(rocprim::exclusive_scan(w.tmp, tb, w.ldeg, w.lnz_off, 0, (size_t)n1, rocprim::plus<int32_t>(), s));
+    int32_t totals[2] = {0, 0};
+    MI_HIP(hipMemcpyAsync(&totals[0], w.long_off + n_rows, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    MI_HIP(hipMemcpyAsync(&totals[1], w.lnz_off + n_rows, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    MI_HIP(hipStreamSynchronize(s));
+    const int32_t n_long = totals[0], nnz_long = totals[1];
+    info->n_long_rows = n_long;
+    info->nnz_long = nnz_long;
+    if (n_long == 0) return mi_launch_status();
+    {
+        MiArena ar(ws, ws_bytes);
+        if (!plan_carve(ar, n_rows, nnz, n_long, nnz_long, -1, w)) return MI_ERR_WORKSPACE;
+    }
+    hipLaunchKernelGGL(plan_long_rows_kernel, plan_grid(n1), dim3(256), 0, s, n_rows, w.is_long, w.long_off, w.lnz_off,
+                       w.lrows, w.lprefix);
+    hipLaunchKernelGGL(plan_seg_flags_kernel, plan_grid(nnz_long), dim3(256), 0, s, nnz_long, n_long, w.lrows, w.lprefix,
+                       rowptr, col, chunk, band, w.flags);
+    tb = w.tmp_bytes;
+    MI_HIP(rocprim::exclusive_scan(w.tmp, tb, w.flags, w.seg_of, 0, (size_t)nnz_long, rocprim::plus<int32_t>(), s));
+    int32_t last[2] = {0, 0};
+    MI_HIP(hipMemcpyAsync(&last[0], w.seg_of + nnz_long - 1, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    MI_HIP(hipMemcpyAsync(&last[1], w.flags + nnz_long - 1, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    MI_HIP(hipStreamSynchronize(s));
+    const int32_t n_seg = last[0] + last[1];
+    info->n_items = n_seg;
+    {
+        MiArena ar(ws, ws_bytes);
+        if (!plan_carve(ar, n_rows, nnz, n_long, nnz_long, n_seg, w)) return MI_ERR_WORKSPACE;
+    }
+    hipLaunchKernelGGL(plan_seg_starts_kernel, plan_grid(nnz_long), dim3(256), 0, s, nnz_long, n_long, w.lrows, w.lprefix,
+                       rowptr, col, band, w.flags, w.seg_of, w.seg_start, w.keys0);
+    if (band == 0) {
+        info->n_launch = n_seg;
+        return mi_launch_status();
+    }
+    rocprim::double_buffer<uint64_t> keys(w.keys0, w.keys1);
+    tb = w.tmp_bytes;
+    MI_HIP(rocprim::radix_sort_keys(w.tmp, tb, keys, (size_t)n_seg, 0, 64, s));
+    info->keys_in_second = keys.current() == w.keys1 ? 1 : 0;
+    hipLaunchKernelGGL(plan_queue_bounds_kernel, dim3(1), dim3(64), 0, s, n_seg, keys.current(), w.qstart);
+    MI_HIP(hipMemcpyAsync(info->queue_start, w.qstart, 9 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    MI_HIP(hipStreamSynchronize(s));
+    int32_t longest = 0;
+    for (int x = 0; x < 8; ++x) longest = std::max(longest, info->queue_start[x + 1] - info->queue_start[x]);
+    info->queue_len = (int32_t)(mi_ceil_div(longest, kPlanGroup) * kPlanGroup);
+    info->n_launch = 8 * (int64_t)info->queue_len;
+    return mi_launch_status();
+}
+
+int mi_spmm_plan_fill(int64_t n_rows, const int32_t* rowptr, const mi_spmm_plan_info* info, mi_spmm_plan* plan,
+                      void* ws, size_t ws_bytes, mi_stream_t stream) {
+    MI_CHECK_ARG(n_rows >= 0 && rowptr && info && plan && ws);
+    hipStream_t s = (hipStream_t)stream;
+    plan->chunk = info->chunk;
+    plan->n_long_rows = (int32_t)info->n_long_rows;
+    plan->n_items = (int32_t)info->n_items;
+    plan->n_launch = (int32_t)info->n_launch;
+    plan->band = info->band;
+    plan->n_bands = info->n_bands;
+    if (info->n_launch >= INT32_MAX) return MI_ERR_TOO_LARGE;
+    int32_t nnz32 = 0;
+    MI_HIP(hipMemcpyAsync(&nnz32, rowptr + n_rows, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    MI_HIP(hipStreamSynchronize(s));
+    PlanWs w{};
+    MiArena ar(ws, ws_bytes);
+    if (info->n_long_rows == 0) {
+        if (!plan_carve(ar, n_rows, nnz32, -1, -1, -1, w)) return MI_ERR_WORKSPACE;
+        if (plan->long_index) MI_HIP(hipMemsetAsync(plan->long_index, 0xFF, (size_t)n_rows * sizeof(int32_t), s));
+        MI_HIP(hipStreamSynchronize(s));
+        return mi_launch_status();
+    }
+    MI_CHECK_ARG(plan->long_rows && plan->item_ptr && plan->items);
+    if (!plan_carve(ar, n_rows, nnz32, info->n_long_rows, info->nnz_long, info->n_items, w)) return MI_ERR_WORKSPACE;
+    const int32_t n_long = (int32_t)info->n_long_rows, n_seg = (int32_t)info->n_items;
+    hipLaunchKernelGGL(plan_fill_rows_kernel, plan_grid(n_rows), dim3(256), 0, s, n_rows, w.is_long, w.long_off,
+                       plan->long_rows, plan->long_index);
+    hipLaunchKernelGGL(plan_item_ptr_kernel, plan_grid(n_long + 1), dim3(256), 0, s, n_long, n_seg, w.lprefix, w.seg_of,
+                       plan->item_ptr);
+    int4* items = reinterpret_cast<int4*>(plan->items);
+    if (info->band > 0)
+        hipLaunchKernelGGL(plan_pad_kernel, plan_grid(info->n_launch), dim3(256), 0, s, info->n_launch, items);
+    QueueStarts qs;
+    for (int x = 0; x < 9; ++x) qs.q[x] = info->queue_start[x];
+    hipLaunchKernelGGL(plan_items_kernel, plan_grid(n_seg), dim3(256), 0, s, n_seg, info->band > 0 ? 1 : 0,
+                       info->keys_in_second ? w.keys1 : w.keys0, qs, w.seg_start, n_long, w.lrows, w.lprefix, rowptr,
+                       items);
+    MI_HIP(hipStreamSynchronize(s));  // ws may be released by the caller on return
     return mi_launch_status();
 }
 
@@ -451,8 +704,10 @@ int mi_spmm_csr_ex_f32(int64_t n_rows, int64_t d, const int32_t* rowptr, const i
     }
     float4* partial = nullptr;
     if (plan && plan->n_items > 0) {
+        MI_CHECK_ARG(plan->items && plan->item_ptr && plan->long_rows && plan->n_launch >= plan->n_items);
+        MI_CHECK_ARG(plan->band == 0 || plan->n_launch % (8 * kPlanGroup) == 0);
         if (!ws || ws_bytes < mi_spmm_workspace_bytes(plan, d)) return MI_ERR_WORKSPACE;
-        MI_CHECK_ARG(mi_aligned16(ws));
+        MI_CHECK_ARG(mi_aligned16(ws) && mi_aligned16(plan->items));
         partial = reinterpret_cast<float4*>(ws);
     }
     Epilogue ep;

@@ -15,7 +15,9 @@ from torch import Tensor
 from . import _lib
 from ._lib import SpmmExStruct, SpmmPlanStruct, check
 
-DEFAULT_CHUNK = 256  # nnz per work item of a split (hub) row
+DEFAULT_CHUNK = 256  # max nnz per work item of a split (hub) row
+DEFAULT_BAND = 8192  # columns per band of a banded plan: 8192 rows x 128 floats = the 4 MB L2 of one XCD
+MIN_BANDS = 16       # narrower adjacencies keep the row-major plan (nothing to block for)
 
 # bench.py sets this to a list to collect (start, end, kind) HIP events around every propagate launch,
 # recorded on the stream the kernels are launched on.  None = no timing overhead.
@@ -176,24 +178,28 @@ def row_slice(a: DeviceCSR, r0: int, r1: int) -> DeviceCSR:
     return DeviceCSR(r1 - r0, a.n_cols, a.rowptr[r0:r1 + 1], a.col, a.val, None)
 
 
-def build_spmm_plan(a: DeviceCSR, chunk: int = DEFAULT_CHUNK) -> SpmmPlan:
+def build_spmm_plan(a: DeviceCSR, chunk: int = DEFAULT_CHUNK, band: Optional[int] = None) -> SpmmPlan:
+    """Split-row plan of an adjacency.  band = columns per band of a banded plan (see include/laplace_hip.h),
+    0 = row-major, None = DEFAULT_BAND when the adjacency spans at least MIN_BANDS of them."""
     L = _lib.lib()
-    ml, mi = ctypes.c_int64(0), ctypes.c_int64(0)
-    check(L.mi_spmm_plan_bounds(a.n_rows, a.nnz, chunk, ctypes.byref(ml), ctypes.byref(mi)), "mi_spmm_plan_bounds")
+    if band is None:
+        band = DEFAULT_BAND if a.n_cols >= MIN_BANDS * DEFAULT_BAND else 0
     dev = a.device
-    long_rows = t.empty(max(ml.value, 1), dtype=t.int32, device=dev)
-    item_ptr = t.empty(max(ml.value, 1) + 1, dtype=t.int32, device=dev)
-    items = t.empty(4 * max(mi.value, 1), dtype=t.int32, device=dev)
+    ws = _ws(L.mi_spmm_plan_workspace_bytes(a.n_rows, a.nnz), dev)
+    info = _lib.SpmmPlanInfo()
+    check(L.mi_spmm_plan_count(a.n_rows, a.n_cols, _ptr(a.rowptr), _ptr(a.col), chunk, band, ws.data_ptr(), ws.numel(),
+                               ctypes.byref(info), _stream()), "mi_spmm_plan_count")
+    nl, nlaunch = int(info.n_long_rows), int(info.n_launch)
+    long_rows = t.empty(max(nl, 1), dtype=t.int32, device=dev)
+    item_ptr = t.empty(max(nl, 1) + 1, dtype=t.int32, device=dev)
+    items = t.empty(4 * max(nlaunch, 1), dtype=t.int32, device=dev)
     long_index = t.empty(max(a.n_rows, 1), dtype=t.int32, device=dev)
     st = SpmmPlanStruct()
     st.long_rows, st.item_ptr, st.items = long_rows.data_ptr(), item_ptr.data_ptr(), items.data_ptr()
     st.long_index = long_index.data_ptr()
-    ws = _ws(L.mi_spmm_plan_workspace_bytes(a.n_rows), dev)
-    check(L.mi_spmm_plan_build(a.n_rows, _ptr(a.rowptr), chunk, ctypes.byref(st), ws.data_ptr(), ws.numel(),
-                               _stream()), "mi_spmm_plan_build")
-    # shrink to what is used (keeps the pointers valid: slices share storage)
-    nl, ni = int(st.n_long_rows), int(st.n_items)
-    return SpmmPlan(st, long_rows[:max(nl, 1)], item_ptr[:max(nl, 1) + 1], items[:4 * max(ni, 1)], long_index)
+    check(L.mi_spmm_plan_fill(a.n_rows, _ptr(a.rowptr), ctypes.byref(info), ctypes.byref(st), ws.data_ptr(), ws.numel(),
+                              _stream()), "mi_spmm_plan_fill")
+    return SpmmPlan(st, long_rows, item_ptr, items, long_index)
 
 
 def spmm(a: DeviceCSR, X: Tensor, *, Y: Optional[Tensor] = None, addend: Optional[Tensor] = None,

@@ -35,7 +35,7 @@ def row_slice(a: DeviceCSR, r0: int, r1: int) -> DeviceCSR:
     return DeviceCSR(r1 - r0, a.n_cols, a.rowptr[r0:r1 + 1], a.col, a.val, None)
 
 
-def build_spmm_plan(a, chunk=256):
+def build_spmm_plan(a, chunk=256, band=None):
     return _Plan()
 
 

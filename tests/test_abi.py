@@ -42,10 +42,11 @@ def test_size_queries_run_without_gpu():
     L = _lib.lib()
     assert L.mi_coo_to_csr_workspace_bytes(1000, 5000) >= 5000 * 24
     assert L.mi_bpr_workspace_bytes(128) >= 2 * 128 * 4
-    ml, mi = ctypes.c_int64(), ctypes.c_int64()
-    assert L.mi_spmm_plan_bounds(10, 1000, 256, ctypes.byref(ml), ctypes.byref(mi)) == 0
-    assert ml.value == 3 and mi.value == 1000 // 256 + 3
-    assert L.mi_spmm_plan_bounds(10, 1000, 0, ctypes.byref(ml), ctypes.byref(mi)) == -1  # MI_ERR_BAD_ARG
+    assert L.mi_spmm_plan_workspace_bytes(10, 1000) >= 6 * 11 * 4 + 1000 * 28
+    assert L.mi_spmm_plan_workspace_bytes(-1, 0) == 0
+    info = _lib.SpmmPlanInfo()
+    assert L.mi_spmm_plan_count(10, 10, None, None, 256, 0, None, 0, ctypes.byref(info), None) == -1  # MI_ERR_BAD_ARG
+    assert ctypes.sizeof(_lib.SpmmPlanStruct) == 56 and ctypes.sizeof(_lib.SpmmPlanInfo) == 88
 
 
 def test_ops_refuse_cpu_tensors():

@@ -144,6 +144,86 @@ def test_spmm_hub_rows_split_path_and_determinism():
     assert t.allclose(Y3, Y1, atol=5e-4, rtol=1e-4)
 
 
+def _hub_graph(seed, n=600, hubs=(2000, 700, 300)):
+    g = t.Generator().manual_seed(seed)
+    rows = t.cat([t.full((h,), 5 + 7 * i, dtype=t.int64) for i, h in enumerate(hubs)] + [t.randint(0, n, (1500,), generator=g)])
+    cols = t.randint(0, n, (rows.numel(),), generator=g)
+    return rows, cols
+
+
+@pytest.mark.parametrize("band,chunk", [(0, 256), (64, 256), (7, 50), (100, 1000), (1, 256)])
+def test_spmm_plan_structure(band, chunk):
+    """The work items partition the entries of every split row, slots are contiguous per row, banded items stay
+    inside one band and sit in the launch blocks of queue (band mod 8)."""
+    ops = _ops()
+    from laplace_amd._lib import MI_SPMM_GROUP as G
+    n = 600
+    rows, cols = _hub_graph(seed=5)
+    a = ops.coo_to_csr(rows.to(DEV), cols.to(DEV), n, n)
+    plan = ops.build_spmm_plan(a, chunk=chunk, band=band)
+    st = plan.struct
+    rowptr, col = a.rowptr.cpu().numpy(), a.col.cpu().numpy()
+    long_rows = np.nonzero(np.diff(rowptr) > chunk)[0]
+    assert len(long_rows) >= 1 and st.n_long_rows == len(long_rows)
+    assert np.array_equal(plan.long_rows.cpu().numpy()[: st.n_long_rows], long_rows)
+    li = plan.long_index.cpu().numpy()
+    assert np.array_equal(np.nonzero(li >= 0)[0], long_rows) and np.array_equal(li[long_rows], np.arange(len(long_rows)))
+    items = plan.items.cpu().numpy().reshape(-1, 4)
+    assert items.shape[0] == st.n_launch >= st.n_items
+    real = items[items[:, 3] >= 0]
+    assert real.shape[0] == st.n_items and np.array_equal(np.sort(real[:, 3]), np.arange(st.n_items))
+    by_slot = real[np.argsort(real[:, 3])]
+    item_ptr = plan.item_ptr.cpu().numpy()
+    for i, r in enumerate(long_rows):
+        seg = by_slot[item_ptr[i]: item_ptr[i + 1]]
+        assert (seg[:, 0] == r).all() and seg[0, 1] == rowptr[r] and seg[-1, 2] == rowptr[r + 1]
+        size = seg[:, 2] - seg[:, 1]
+        assert np.array_equal(seg[1:, 1], seg[:-1, 2]) and (size <= chunk).all() and (size > 0).all()
+        if band > 0:
+            assert (col[seg[:, 1]] // band == col[seg[:, 2] - 1] // band).all()
+    assert item_ptr[len(long_rows)] == st.n_items
+    if band > 0:
+        assert st.n_launch % (8 * G) == 0 and st.band == band
+        pos = np.nonzero(items[:, 3] >= 0)[0]
+        assert np.array_equal((pos // G) % 8, (col[items[pos, 1]] // band) % 8)
+        for x in range(8):  # within a queue: bands ascending, then slots ascending; padding only at the tail
+            q = items.reshape(-1, 8, G, 4)[:, x].reshape(-1, 4)
+            nreal = int((q[:, 3] >= 0).sum())
+            assert (q[:nreal, 3] >= 0).all()
+            key = (col[q[:nreal, 1]] // band).astype(np.int64) * (1 << 32) + q[:nreal, 3]
+            assert (np.diff(key) > 0).all()
+    else:
+        assert np.array_equal(items[:, 3], np.arange(st.n_items))
+
+
+@pytest.mark.parametrize("d", [16, 64, 128, 256, 320])
+@pytest.mark.parametrize("band", [0, 37])
+def test_spmm_banded_plan_matches_unsplit_product(band, d):
+    """Row-major and banded plans against the plan-less product (one sub-group per row whatever its length) and
+    the oracle, with the fused epilogue, for every sub-group width."""
+    ops = _ops()
+    n = 600
+    rows, cols = _hub_graph(seed=7)
+    a = _csr_with_vals(rows, cols, n, n, seed=8)
+    g = t.Generator().manual_seed(d)
+    X, A = t.randn(n, d, generator=g).to(DEV), t.randn(n, d, generator=g).to(DEV)
+    Y0, S0 = t.empty(n, d, device=DEV), t.empty(n, d, device=DEV)
+    a.plan = None
+    ops.spmm(a, X, Y=Y0, addend=A, S=S0, scale=0.5)  # nnz < PLAN_MIN_NNZ: no plan
+    assert a.plan is None
+    a.plan = ops.build_spmm_plan(a, chunk=64, band=band)
+    assert a.plan.n_long_rows >= 3
+    Y1, S1 = t.full((n, d), float("nan"), device=DEV), t.full((n, d), float("nan"), device=DEV)
+    ops.spmm(a, X, Y=Y1, addend=A, S=S1, scale=0.5)
+    Y2 = t.empty(n, d, device=DEV)
+    ops.spmm(a, X, Y=Y2)
+    assert t.equal(Y1, Y2)  # bitwise reproducible
+    want = _oracle_spmm(a, X)
+    scale = float(want.abs().max())
+    assert float((Y1.cpu() - want).abs().max()) <= 1e-5 * scale and float((Y0.cpu() - want).abs().max()) <= 1e-5 * scale
+    assert float((S1.cpu() - 0.5 * (A.cpu() + want)).abs().max()) <= 1e-5 * scale
+
+
 def test_spmm_epilogue_forms_and_strides():
     ops = _ops()
     n, d = 1500, 64
