@@ -37,7 +37,9 @@ namespace {
 #define MI_SPMM_ROWS_RPS 1  // rows a sub-group handles in sequence; A/B on C2: 1: 1.373 ms, 2: 1.408, 4: 1.397
 #endif
 #ifndef MI_SPMM_NT
-#define MI_SPMM_NT 0   // bit 0: non-temporal (col,val) loads; bit 1: partial-sum stores; bit 2: Y / S stores; bit 3: addend loads
+#define MI_SPMM_NT 0   // bit 0: non-temporal (col,val) loads; bit 1: partial-sum stores; bit 2: Y / S stores; bit 3: addend
+                       // loads.  A/B on C2, round 1 (tools/prof_spmm.py under rocprofv3): every combination within +-3 %
+                       // of off (nt keeps the line in L2 on gfx950), write-through sc1 partial stores 0.3 %.  Kept off.
 #endif
 typedef float mi_f4v __attribute__((ext_vector_type(4)));
 template <int BIT>
@@ -505,7 +507,10 @@ int launch_spmm_mode(int64_t n_rows, int d4, const int32_t* rowptr, const int32_
     constexpr int UNROLL = (VPL == 1) ? MI_SPMM_UNROLL : MI_SPMM_UNROLL / 2;
     constexpr int SG = (MI_WAVE / LPR) * kWavesPerBlock;
     constexpr int ROWS_RPS = MI_SPMM_ROWS_RPS;
-    constexpr int ITEMS_RPS = (SG >= 16) ? 1 : 16 / SG;  // 16 launch slots per workgroup (32 when D <= 32)
+#ifndef MI_SPMM_ITEMS_SLOTS
+#define MI_SPMM_ITEMS_SLOTS 8  // A/B on C2 (items kernel, band 8192): 8: 397 us, 16: 415 us, 32: 461 us — the fewer work items an
+#endif                         // XCD has in flight, the fewer bands its L2 has to hold at once
+    constexpr int ITEMS_RPS = (SG >= MI_SPMM_ITEMS_SLOTS) ? 1 : MI_SPMM_ITEMS_SLOTS / SG;  // launch slots per workgroup
     const int32_t chunk = plan ? plan->chunk : INT32_MAX;
     const bool listed = SPARSE && ex.row_list != nullptr;
     if (plan && plan->n_items > 0) {  // row_list mode still reduces every split row: hubs are few and almost always wanted
