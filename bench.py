@@ -164,6 +164,8 @@ def main():
         # entry and row counts (a sharded layer is two launches: item rows and user rows).
         dense = [(s.elapsed_time(e), a) for s, e, kind, _, _, a in events if kind == "dense"]
         sparse_ms = [s.elapsed_time(e) for s, e, kind, _, _, _ in events if kind == "sparse"]
+        # the last backward product carries the Adam update in its epilogue (+6 table streams): timed apart
+        fused_ms = [s.elapsed_time(e) for s, e, kind, _, _, _ in events if kind == "dense_adam"]
         nnz_of = {}
         for _, a in dense:
             if id(a) not in nnz_of:  # entries of a row slice = rowptr[last] - rowptr[first]
@@ -203,7 +205,9 @@ def main():
                          "launches_timed": len(spmm_ms), "layers_timed": n_layers_timed,
                          "dense_launches_per_step": len(dense) / args.steps,
                          "sparse_launches_per_step": len(sparse_ms) / args.steps,
-                         "sparse_launch_avg_ms": (sum(sparse_ms) / len(sparse_ms)) if sparse_ms else None},
+                         "sparse_launch_avg_ms": (sum(sparse_ms) / len(sparse_ms)) if sparse_ms else None,
+                         "dense_launches_with_adam_epilogue_per_step": len(fused_ms) / args.steps,
+                         "dense_with_adam_epilogue_avg_ms": (sum(fused_ms) / len(fused_ms)) if fused_ms else None},
             "step_form": "plain" if args.plain_step else "sparse_batch",
             "loss": loss_val, "graph_gen_s": round(t_gen, 1), "backend": backend if world > 1 else None,
         }

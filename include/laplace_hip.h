@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MI_ABI_VERSION 2
+#define MI_ABI_VERSION 3
 
 #define MI_ERR_BAD_ARG      (-1)  /* null pointer, negative size, misaligned buffer   */
 #define MI_ERR_TOO_LARGE    (-2)  /* a size does not fit int32 indexing                */
@@ -177,12 +177,26 @@ int mi_spmm_csr_f32(int64_t n_rows, int64_t d,
  *              has split rows.
  * Results equal the dense call on the corresponding dense operands bit for bit (up to the
  * sign of zero). */
+/* Optimizer epilogue: the product's S value g[r,:] = scale * (addend[r,:] + acc) is the gradient of
+ * parameter row r and is consumed in registers by the Adam update of mi_adam_dense_f32 (same arithmetic,
+ * bit for bit) instead of being written and read back: p / m / v rows are updated in place, reg_w as
+ * there.  S may be null (the gradient is then never stored).  p must not alias X, Y, S or addend. */
+typedef struct mi_adam_args {
+    float*       p;  int64_t ldp;   /* [n_rows, d] parameters, ld in floats */
+    float*       m;                 /* [n_rows, d] dense */
+    float*       v;                 /* [n_rows, d] dense */
+    const float* reg_w;             /* [n_rows] or null */
+    double       lr, beta1, beta2, eps;
+    int64_t      step;              /* counts from 1 */
+} mi_adam_args;
+
 typedef struct mi_spmm_ex {
     const int32_t* x_map;
     const int32_t* addend_map;
     const int32_t* row_list;
     const int32_t* n_list_dev;
     int64_t        n_list;
+    const mi_adam_args* adam;       /* nullable; not with row_list */
 } mi_spmm_ex;
 
 int mi_spmm_csr_ex_f32(int64_t n_rows, int64_t d,

@@ -8,7 +8,7 @@ from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int32, c_i
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG_DIR, "liblaplace_hip.so")
 
-MI_ABI_VERSION = 2
+MI_ABI_VERSION = 3
 MI_SPMM_GROUP = 32
 
 
@@ -30,9 +30,14 @@ class SpmmPlanInfo(Structure):
                 ("queue_start", c_int32 * 9), ("keys_in_second", c_int32)]
 
 
+class AdamArgs(Structure):
+    _fields_ = [("p", c_void_p), ("ldp", c_int64), ("m", c_void_p), ("v", c_void_p), ("reg_w", c_void_p),
+                ("lr", c_double), ("beta1", c_double), ("beta2", c_double), ("eps", c_double), ("step", c_int64)]
+
+
 class SpmmExStruct(Structure):
     _fields_ = [("x_map", c_void_p), ("addend_map", c_void_p), ("row_list", c_void_p), ("n_list_dev", c_void_p),
-                ("n_list", c_int64)]
+                ("n_list", c_int64), ("adam", POINTER(AdamArgs))]
 
 
 class SamplerDesc(Structure):

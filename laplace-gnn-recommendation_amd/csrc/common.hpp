@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <math.h>
 #include <string.h>
 #include <cstring>
 #include <stddef.h>
@@ -68,6 +69,40 @@ __device__ __forceinline__ float4 mi_f4_add(const float4& a, const float4& b) {
 __device__ __forceinline__ float4 mi_f4_shfl_xor(const float4& a, int mask) {
     return make_float4(__shfl_xor(a.x, mask, MI_WAVE), __shfl_xor(a.y, mask, MI_WAVE),
                        __shfl_xor(a.z, mask, MI_WAVE), __shfl_xor(a.w, mask, MI_WAVE));
+}
+
+// Adam update of four parameters (a9); one definition for mi_adam_dense_f32 and the SpMM optimizer epilogue,
+// so that both give the same bits.  Scalars are derived in double on the host (mi_adam_consts).
+struct MiAdamConsts {
+    float b1, b2, omb1, omb2, step_size, bc2_sqrt, eps;
+};
+__host__ inline MiAdamConsts mi_adam_consts(double lr, double beta1, double beta2, double eps, int64_t step) {
+    const double bc1 = 1.0 - pow(beta1, (double)step);
+    const double bc2 = 1.0 - pow(beta2, (double)step);
+    MiAdamConsts c;
+    c.b1 = (float)beta1; c.b2 = (float)beta2;
+    c.omb1 = (float)(1.0 - beta1); c.omb2 = (float)(1.0 - beta2);
+    c.step_size = (float)(lr / bc1);
+    c.bc2_sqrt = (float)sqrt(bc2);
+    c.eps = (float)eps;
+    return c;
+}
+__device__ __forceinline__ void mi_adam_update4(float4& pp, float4 gg, float4& mm, float4& vv, bool has_w, float w,
+                                                const MiAdamConsts& c) {
+    if (has_w) {
+        gg.x = fmaf(w, pp.x, gg.x);
+        gg.y = fmaf(w, pp.y, gg.y);
+        gg.z = fmaf(w, pp.z, gg.z);
+        gg.w = fmaf(w, pp.w, gg.w);
+    }
+    // explicit roundings (no fma contraction): the same bits wherever this is inlined
+#define MI_ADAM_1(f)                                                                                   \
+    mm.f = __fadd_rn(__fmul_rn(c.b1, mm.f), __fmul_rn(c.omb1, gg.f));                                  \
+    vv.f = __fadd_rn(__fmul_rn(c.b2, vv.f), __fmul_rn(__fmul_rn(c.omb2, gg.f), gg.f));                 \
+    pp.f = __fsub_rn(pp.f, __fmul_rn(c.step_size,                                                      \
+                                     __fdiv_rn(mm.f, __fadd_rn(__fdiv_rn(__fsqrt_rn(vv.f), c.bc2_sqrt), c.eps))));
+    MI_ADAM_1(x) MI_ADAM_1(y) MI_ADAM_1(z) MI_ADAM_1(w)
+#undef MI_ADAM_1
 }
 
 // Philox4x32-10 (Salmon et al. 2011), restated bit for bit in oracle/philox.py.

@@ -68,6 +68,12 @@ struct Epilogue {
     const float4* addend; int64_t lda4;
     float4* S;            int64_t lds4;
     float scale;
+    // optimizer epilogue (mi_adam_args): S's value is the gradient of parameter row r; null p = off
+    float4* p;            int64_t ldp4;
+    float4* m;
+    float4* v;
+    const float* reg_w;
+    MiAdamConsts adam;
 };
 
 // Sparse-operand extensions (mi_spmm_csr_ex_f32); all pointers nullable.
@@ -140,18 +146,28 @@ __device__ __forceinline__ void subgroup_accumulate(const int32_t* __restrict__ 
 template <int LPR, int VPL>
 __device__ __forceinline__ void store_epilogue(const Epilogue& ep, int64_t r, int d4, int li,
                                                const float4 (&acc)[VPL], const float4 (&a)[VPL]) {
+    const bool adam = ep.p != nullptr;
+    const float w = (adam && ep.reg_w) ? ep.reg_w[r] : 0.f;
 #pragma unroll
     for (int v = 0; v < VPL; ++v) {
         const int e = li + v * LPR;
         if (e >= d4) continue;
         if (ep.Y) mi_store4<2>(ep.Y + r * ep.ldy4 + e, acc[v]);
-        if (ep.S) {
+        if (ep.S || adam) {
             float4 o;
             o.x = ep.scale * (a[v].x + acc[v].x);
             o.y = ep.scale * (a[v].y + acc[v].y);
             o.z = ep.scale * (a[v].z + acc[v].z);
             o.w = ep.scale * (a[v].w + acc[v].w);
-            mi_store4<2>(ep.S + r * ep.lds4 + e, o);
+            if (ep.S) mi_store4<2>(ep.S + r * ep.lds4 + e, o);
+            if (adam) {
+                const int64_t i = r * d4 + e;
+                float4 pp = ep.p[r * ep.ldp4 + e], mm = ep.m[i], vv = ep.v[i];
+                mi_adam_update4(pp, o, mm, vv, ep.reg_w != nullptr, w, ep.adam);
+                ep.p[r * ep.ldp4 + e] = pp;
+                ep.m[i] = mm;
+                ep.v[i] = vv;
+            }
         }
     }
 }
@@ -162,7 +178,7 @@ __device__ __forceinline__ void load_addend(const Epilogue& ep, int64_t ar, int 
 #pragma unroll
     for (int v = 0; v < VPL; ++v) {
         const int e = li + v * LPR;
-        a[v] = (ep.S && ep.addend && ar >= 0 && e < d4) ? mi_load4<3>(ep.addend + ar * ep.lda4 + e) : mi_f4_zero();
+        a[v] = ((ep.S || ep.p) && ep.addend && ar >= 0 && e < d4) ? mi_load4<3>(ep.addend + ar * ep.lda4 + e) : mi_f4_zero();
     }
 }
 
@@ -685,7 +701,8 @@ int mi_spmm_csr_ex_f32(int64_t n_rows, int64_t d, const int32_t* rowptr, const i
     if (n_rows == 0) return 0;
     if (d % 4 != 0 || d > 512) return MI_ERR_UNSUPPORTED;
     if (n_rows >= INT32_MAX) return MI_ERR_TOO_LARGE;
-    MI_CHECK_ARG(X && (Y || S));
+    const mi_adam_args* adam = exh ? exh->adam : nullptr;
+    MI_CHECK_ARG(X && (Y || S || adam));
     MI_CHECK_ARG(ldx % 4 == 0 && ldx >= d && mi_aligned16(X));
     MI_CHECK_ARG(!Y || (ldy % 4 == 0 && ldy >= d && mi_aligned16(Y) && Y != X));
     MI_CHECK_ARG(!S || (lds % 4 == 0 && lds >= d && mi_aligned16(S) && S != X));
@@ -720,6 +737,20 @@ int mi_spmm_csr_ex_f32(int64_t n_rows, int64_t d, const int32_t* rowptr, const i
     ep.addend = reinterpret_cast<const float4*>(addend); ep.lda4 = lda / 4;
     ep.S = reinterpret_cast<float4*>(S);                 ep.lds4 = lds / 4;
     ep.scale = scale;
+    ep.p = nullptr; ep.ldp4 = 0; ep.m = nullptr; ep.v = nullptr; ep.reg_w = nullptr;
+    ep.adam = MiAdamConsts{};
+    if (adam) {
+        MI_CHECK_ARG(!ex.row_list && adam->p && adam->m && adam->v && adam->step >= 1);
+        MI_CHECK_ARG(adam->ldp % 4 == 0 && adam->ldp >= d && mi_aligned16(adam->p) && mi_aligned16(adam->m) &&
+                     mi_aligned16(adam->v));
+        MI_CHECK_ARG(adam->p != X && adam->p != Y && adam->p != S && adam->p != addend);
+        ep.p = reinterpret_cast<float4*>(adam->p);
+        ep.ldp4 = adam->ldp / 4;
+        ep.m = reinterpret_cast<float4*>(adam->m);
+        ep.v = reinterpret_cast<float4*>(adam->v);
+        ep.reg_w = adam->reg_w;
+        ep.adam = mi_adam_consts(adam->lr, adam->beta1, adam->beta2, adam->eps, adam->step);
+    }
     const float4* X4 = reinterpret_cast<const float4*>(X);
     const int d4 = (int)(d / 4);
     hipStream_t s = (hipStream_t)stream;

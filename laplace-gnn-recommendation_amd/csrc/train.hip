@@ -222,9 +222,7 @@ __global__ __launch_bounds__(kBlock) void adam_kernel(int64_t n_rows, int d4, fl
                                                       int64_t ldp4, const float4* __restrict__ g,
                                                       int64_t ldg4, float4* __restrict__ m,
                                                       float4* __restrict__ v,
-                                                      const float* __restrict__ reg_w, float b1, float b2,
-                                                      float omb1, float omb2, float step_size,
-                                                      float bc2_sqrt, float eps) {
+                                                      const float* __restrict__ reg_w, MiAdamConsts c) {
     // rows per pass of one block: blockDim.x / lanes-per-row, lanes-per-row = smallest power of two >= d4 (<= 256)
     int lpr = 1;
     while (lpr < d4 && lpr < (int)blockDim.x) lpr <<= 1;
@@ -232,25 +230,13 @@ __global__ __launch_bounds__(kBlock) void adam_kernel(int64_t n_rows, int d4, fl
     const int sub = threadIdx.x / lpr, e0 = threadIdx.x % lpr;
     for (int64_t r = (int64_t)blockIdx.x * rows_per_block + sub; r < n_rows; r += (int64_t)gridDim.x * rows_per_block) {
         const float w = reg_w ? reg_w[r] : 0.f;
-        for (int c = e0; c < d4; c += lpr) {
-            const int64_t i = r * d4 + c;
-            float4 pp = p[r * ldp4 + c];
-            float4 gg = g[r * ldg4 + c];
+        for (int e = e0; e < d4; e += lpr) {
+            const int64_t i = r * d4 + e;
+            float4 pp = p[r * ldp4 + e];
             float4 mm = m[i];
             float4 vv = v[i];
-            if (reg_w) {
-                gg.x = fmaf(w, pp.x, gg.x);
-                gg.y = fmaf(w, pp.y, gg.y);
-                gg.z = fmaf(w, pp.z, gg.z);
-                gg.w = fmaf(w, pp.w, gg.w);
-            }
-#define MI_ADAM_1(f)                                              \
-            mm.f = b1 * mm.f + omb1 * gg.f;                           \
-            vv.f = b2 * vv.f + omb2 * gg.f * gg.f;                    \
-            pp.f = pp.f - step_size * (mm.f / (sqrtf(vv.f) / bc2_sqrt + eps));
-            MI_ADAM_1(x) MI_ADAM_1(y) MI_ADAM_1(z) MI_ADAM_1(w)
-#undef MI_ADAM_1
-            p[r * ldp4 + c] = pp;
+            mi_adam_update4(pp, g[r * ldg4 + e], mm, vv, reg_w != nullptr, w, c);
+            p[r * ldp4 + e] = pp;
             m[i] = mm;
             v[i] = vv;
         }
@@ -370,18 +356,14 @@ int mi_adam_dense_f32(int64_t n_rows, int64_t d, float* p, int64_t ldp, const fl
     MI_CHECK_ARG(ldp % 4 == 0 && ldgr % 4 == 0 && ldp >= d && ldgr >= d);
     MI_CHECK_ARG(mi_aligned16(p) && mi_aligned16(grad) && mi_aligned16(m) && mi_aligned16(v));
     // scalar constants in double, as torch.optim.Adam derives them, then rounded once to fp32
-    const double bc1 = 1.0 - pow(beta1, (double)step);
-    const double bc2 = 1.0 - pow(beta2, (double)step);
-    const float step_size = (float)(lr / bc1);
-    const float bc2_sqrt = (float)sqrt(bc2);
+    const MiAdamConsts c = mi_adam_consts(lr, beta1, beta2, eps, step);
     const int64_t total = n_rows * (d / 4);
     int64_t blocks = mi_ceil_div(total, kBlock);
     if (blocks > 256 * 32) blocks = 256 * 32;
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, n_rows,
                        (int)(d / 4), reinterpret_cast<float4*>(p), ldp / 4,
                        reinterpret_cast<const float4*>(grad), ldgr / 4, reinterpret_cast<float4*>(m),
-                       reinterpret_cast<float4*>(v), reg_w, (float)beta1, (float)beta2,
-                       (float)(1.0 - beta1), (float)(1.0 - beta2), step_size, bc2_sqrt, (float)eps);
+                       reinterpret_cast<float4*>(v), reg_w, c);
     return mi_launch_status();
 }
 

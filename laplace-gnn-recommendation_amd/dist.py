@@ -222,6 +222,7 @@ class ShardedLightGCNTrainer:
         self.imap[U:] = t.where(flag > 0, self._item_ids, t.full_like(self._item_ids, -1))
         gmap_u = gmap[:U]
         cur = None
+        users_done = False
         for i in range(K):
             nxt = self.bufs[i % 2]
             if i == 0:  # input = the batch gradient: item rows gather local batch users, user rows the non-zero item rows
@@ -231,14 +232,21 @@ class ShardedLightGCNTrainer:
             else:
                 ops.spmm(self.a_items, cur, Y=nxt[U:])
                 work = self._allreduce(nxt[U:], async_op=True)
-                ops.spmm(self.a_users, cur, addend=self.gc_c, S=nxt[:U], addend_map=gmap_u)
+                if i == K - 1:  # user rows are local: their gradient goes straight into Adam (mi_adam_args)
+                    hyp = dict(step=self.step_count + 1, lr=self.lr, beta1=self.betas[0], beta2=self.betas[1], eps=self.eps)
+                    ops.spmm(self.a_users, cur, addend=self.gc_c, addend_map=gmap_u,
+                             adam=dict(p=tab[:U], m=self.m[:U], v=self.v[:U], reg_w=self.reg_w[:U], **hyp))
+                    users_done = True
+                else:
+                    ops.spmm(self.a_users, cur, addend=self.gc_c, S=nxt[:U], addend_map=gmap_u)
             if work is not None:
                 work.wait()
             nxt[U:].add_(self.items_g)
             cur = nxt
         self.step_count += 1
-        ops.adam_step(tab, cur, self.m, self.v, step=self.step_count, lr=self.lr, beta1=self.betas[0],
-                      beta2=self.betas[1], eps=self.eps, reg_w=self.reg_w)
+        lo = U if users_done else 0  # item rows (summed over ranks above), and the user rows unless already updated
+        ops.adam_step(tab[lo:], cur[lo:], self.m[lo:], self.v[lo:], step=self.step_count, lr=self.lr,
+                      beta1=self.betas[0], beta2=self.betas[1], eps=self.eps, reg_w=self.reg_w[lo:])
         return self.loss
 
     def decay_lr(self, gamma: float = 0.95) -> None:

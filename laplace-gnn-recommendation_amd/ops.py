@@ -205,8 +205,11 @@ def build_spmm_plan(a: DeviceCSR, chunk: int = DEFAULT_CHUNK, band: Optional[int
 def spmm(a: DeviceCSR, X: Tensor, *, Y: Optional[Tensor] = None, addend: Optional[Tensor] = None,
          S: Optional[Tensor] = None, scale: float = 1.0, x_map: Optional[Tensor] = None,
          addend_map: Optional[Tensor] = None, row_list: Optional[Tensor] = None,
-         n_list_dev: Optional[Tensor] = None) -> None:
+         n_list_dev: Optional[Tensor] = None, adam: Optional[dict] = None) -> None:
     """K1/K2 — acc = A @ X; Y = acc (optional); S = scale * (addend + acc) (optional).
+
+    adam = dict(p=, m=, v=, step=, lr=, beta1=, beta2=, eps=, reg_w=): S's value is the gradient of parameter
+    table p and is consumed in registers by the Adam update (adam_step's arithmetic); S itself may be None.
 
     Sparse-operand forms (mi_spmm_csr_ex_f32): x_map int32[n_cols] — X is compact, column c reads
     X[x_map[c]], negative = an all-zero row; addend_map int32[n_rows] — addend is compact; row_list
@@ -234,8 +237,24 @@ def spmm(a: DeviceCSR, X: Tensor, *, Y: Optional[Tensor] = None, addend: Optiona
             raise ValueError(f"{name} must be [{n_out}, {d}], got {tuple(m.shape)}")
     if addend is not None and addend.shape[1] != d:
         raise ValueError("addend width differs from X")
-    if Y is None and S is None:
+    if Y is None and S is None and adam is None:
         raise ValueError("spmm needs an output (Y and/or S)")
+    adam_args = None
+    if adam is not None:
+        if row_list is not None:
+            raise ValueError("the optimizer epilogue updates every parameter row: not with row_list")
+        p_, m_, v_ = adam["p"], adam["m"], adam["v"]
+        ldp = _rows_ok(p_, "adam.p")
+        _need(m_, t.float32, "adam.m")
+        _need(v_, t.float32, "adam.v")
+        if tuple(p_.shape) != (a.n_rows, d) or m_.shape != p_.shape or v_.shape != p_.shape:
+            raise ValueError(f"adam.p/m/v must be [{a.n_rows}, {d}]")
+        rw = adam.get("reg_w")
+        if rw is not None:
+            _need(rw, t.float32, "adam.reg_w")
+        adam_args = _lib.AdamArgs(p_.data_ptr(), ldp, m_.data_ptr(), v_.data_ptr(), _ptr(rw), float(adam["lr"]),
+                                  float(adam.get("beta1", 0.9)), float(adam.get("beta2", 0.999)),
+                                  float(adam.get("eps", 1e-8)), int(adam["step"]))
     ldy = _rows_ok(Y, "Y") if Y is not None else 0
     lda = _rows_ok(addend, "addend") if addend is not None else 0
     lds = _rows_ok(S, "S") if S is not None else 0
@@ -255,9 +274,10 @@ def spmm(a: DeviceCSR, X: Tensor, *, Y: Optional[Tensor] = None, addend: Optiona
         ev = (t.cuda.Event(enable_timing=True), t.cuda.Event(enable_timing=True))
         ev[0].record()
     exs = None
-    if x_map is not None or addend_map is not None or row_list is not None:
+    if x_map is not None or addend_map is not None or row_list is not None or adam_args is not None:
         exs = SpmmExStruct(_ptr(x_map), _ptr(addend_map), _ptr(row_list), _ptr(n_list_dev),
-                           row_list.numel() if row_list is not None else 0)
+                           row_list.numel() if row_list is not None else 0,
+                           ctypes.pointer(adam_args) if adam_args is not None else None)
     check(L.mi_spmm_csr_ex_f32(a.n_rows, d, _ptr(a.rowptr), col_ptr, val_ptr, X.data_ptr(), ldx,
                                _ptr(Y), ldy, _ptr(addend), lda, _ptr(S), lds, float(scale),
                                ctypes.byref(plan.struct) if plan is not None else None,
@@ -265,8 +285,8 @@ def spmm(a: DeviceCSR, X: Tensor, *, Y: Optional[Tensor] = None, addend: Optiona
                                _stream()), "mi_spmm_csr_ex_f32")
     if ev is not None:
         ev[1].record()
-        SPMM_EVENTS.append((ev[0], ev[1], "sparse" if (x_map is not None or row_list is not None) else "dense",
-                            None, a.n_rows, a))
+        kind = "sparse" if (x_map is not None or row_list is not None) else ("dense_adam" if adam is not None else "dense")
+        SPMM_EVENTS.append((ev[0], ev[1], kind, None, a.n_rows, a))
 
 
 def expand_rows(a: DeviceCSR) -> Tensor:

@@ -24,7 +24,9 @@ fewer bytes for the SAME result (bit for bit up to the sign of zero and the orde
   * the BPR kernel reads / writes compact [<= 3B, D] tables through the node map, so the dense Gc
     buffer, its zero-fill and its K reads as an addend disappear;
   * backward layer 1 gathers only the non-zero rows of its input (x_map); all layers take the compact
-    gradient as addend (addend_map).
+    gradient as addend (addend_map);
+  * the last backward product IS the parameter gradient: with fuse_adam (default) the Adam update runs in
+    that product's epilogue (mi_adam_args), so the gradient is never written or read back (-1.1 GB at C2).
 `sparse_batch=False` is the straightforward form (full `final`, dense Gc) kept for A/B and for callers
 that want the full forward output of the step.
 """
@@ -50,7 +52,7 @@ class LightGCNTrainer:
     def __init__(self, model: LightGCN, adj: SparseTensor, train: Interactions, *, lr: float, Lambda: float,
                  batch_size: int, betas: Tuple[float, float] = (0.9, 0.999), eps: float = 1e-8, seed: int = 0,
                  neg_range: Optional[int] = None, reference_sampler_quirks: bool = False,
-                 sparse_batch: bool = True):
+                 sparse_batch: bool = True, fuse_adam: bool = True):
         self.model = model
         self.table = model.table()
         if not self.table.is_cuda:
@@ -66,6 +68,7 @@ class LightGCNTrainer:
         n, d = self.table.shape
         dev = self.table.device
         self.sparse_batch = bool(sparse_batch)
+        self.fuse_adam = bool(fuse_adam)
         self.final = t.empty(n, d, device=dev)
         self.buf_a = t.empty(n, d, device=dev)
         self.buf_b = t.empty(n, d, device=dev)
@@ -152,15 +155,22 @@ class LightGCNTrainer:
             cur = None
             for i in range(K):
                 nxt = bufs[i % 2]
+                # the last product's output is the parameter gradient: Adam consumes it in the epilogue
+                opt = None
+                if i == K - 1 and self.fuse_adam:
+                    opt = dict(p=tab, m=self.m, v=self.v, step=self.step_count + 1, lr=self.lr, beta1=self.betas[0],
+                               beta2=self.betas[1], eps=self.eps, reg_w=self.reg_w)
+                out = None if opt is not None else nxt
                 if i == 0:   # input = the compact gradient itself: skip its all-zero rows
-                    ops.spmm(adj_t, self.gc_c, addend=self.gc_c, S=nxt, x_map=gmap, addend_map=gmap)
+                    ops.spmm(adj_t, self.gc_c, addend=self.gc_c, S=out, x_map=gmap, addend_map=gmap, adam=opt)
                 else:
-                    ops.spmm(adj_t, cur, addend=self.gc_c, S=nxt, addend_map=gmap)
+                    ops.spmm(adj_t, cur, addend=self.gc_c, S=out, addend_map=gmap, adam=opt)
                 cur = nxt
             g0 = cur
         self.step_count += 1
-        ops.adam_step(tab, g0, self.m, self.v, step=self.step_count, lr=self.lr, beta1=self.betas[0],
-                      beta2=self.betas[1], eps=self.eps, reg_w=self.reg_w)
+        if K == 0 or not self.fuse_adam:
+            ops.adam_step(tab, g0, self.m, self.v, step=self.step_count, lr=self.lr, beta1=self.betas[0],
+                          beta2=self.betas[1], eps=self.eps, reg_w=self.reg_w)
         return self.loss
 
     def decay_lr(self, gamma: float = 0.95) -> None:

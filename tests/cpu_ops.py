@@ -40,7 +40,7 @@ def build_spmm_plan(a, chunk=256, band=None):
 
 
 def spmm(a: DeviceCSR, X: Tensor, *, Y=None, addend=None, S=None, scale=1.0, x_map=None, addend_map=None,
-         row_list=None, n_list_dev=None) -> None:
+         row_list=None, n_list_dev=None, adam=None) -> None:
     """Dense semantics of every sparse-operand form: expand, multiply, then select."""
     d = X.shape[1]
     if x_map is not None:
@@ -70,6 +70,9 @@ def spmm(a: DeviceCSR, X: Tensor, *, Y=None, addend=None, S=None, scale=1.0, x_m
         Y.copy_(acc)
     if S is not None:
         S.copy_(scale * (base + acc))
+    if adam is not None:  # optimizer epilogue = the separate Adam pass on the S value
+        kw = {k: adam[k] for k in ("step", "lr", "beta1", "beta2", "eps", "reg_w") if k in adam}
+        adam_step(adam["p"], scale * (base + acc), adam["m"], adam["v"], **kw)
 
 
 def batch_nodes(users, pos, neg, n_users, n_nodes, *, gmap=None, nodes=None, count=None, ws=None):

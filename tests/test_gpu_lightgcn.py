@@ -224,6 +224,46 @@ def test_spmm_banded_plan_matches_unsplit_product(band, d):
     assert float((S1.cpu() - 0.5 * (A.cpu() + want)).abs().max()) <= 1e-5 * scale
 
 
+@pytest.mark.parametrize("d,band", [(128, 0), (128, 37), (64, 37), (320, 0)])
+def test_spmm_adam_epilogue_equals_spmm_then_adam(d, band):
+    """mi_adam_args: the gradient consumed in the SpMM epilogue gives the bits of spmm + mi_adam_dense_f32, for
+    short rows, split rows (fix-up kernel), rows without entries, compact addend and compact X."""
+    ops = _ops()
+    n = 600
+    rows, cols = _hub_graph(seed=11)
+    rows[rows == 17] = 18  # an empty row still gets its Adam update
+    a = _csr_with_vals(rows, cols, n, n, seed=12)
+    a.plan = ops.build_spmm_plan(a, chunk=64, band=band)
+    g = t.Generator().manual_seed(d)
+    X, A = t.randn(n, d, generator=g).to(DEV), t.randn(n, d, generator=g).to(DEV)
+    nz = t.unique(t.randint(0, n, (200,), generator=g))
+    gmap = t.full((n,), -1, dtype=t.int32)
+    gmap[nz] = t.arange(nz.numel(), dtype=t.int32)
+    gmap = gmap.to(DEV)
+    Ac = t.randn(nz.numel(), d, generator=g).to(DEV)
+    reg_w = (t.rand(n, generator=g) * 1e-3).to(DEV)
+    hyp = dict(lr=1e-2, beta1=0.9, beta2=0.999, eps=1e-8)
+    for kw in (dict(addend=A), dict(addend=Ac, addend_map=gmap), dict(x_map=gmap, addend=Ac, addend_map=gmap), dict()):
+        Xin = Ac if "x_map" in kw else X
+        for step in (1, 7):
+            p0 = t.randn(n, d, generator=g).to(DEV)
+            m0, v0 = (t.randn(n, d, generator=g) * 0.01).to(DEV), (t.rand(n, d, generator=g) * 1e-3).to(DEV)
+            p1, m1, v1 = p0.clone(), m0.clone(), v0.clone()
+            G = t.empty(n, d, device=DEV)
+            ops.spmm(a, Xin, S=G, scale=0.25, **kw)
+            ops.adam_step(p1, G, m1, v1, step=step, reg_w=reg_w, **hyp)
+            p2, m2, v2 = p0.clone(), m0.clone(), v0.clone()
+            ops.spmm(a, Xin, scale=0.25, adam=dict(p=p2, m=m2, v=v2, step=step, reg_w=reg_w, **hyp), **kw)
+            assert t.equal(p1, p2) and t.equal(m1, m2) and t.equal(v1, v2)
+            assert not t.equal(p1, p0)
+            # S may be kept as well
+            p3, m3, v3, G3 = p0.clone(), m0.clone(), v0.clone(), t.empty(n, d, device=DEV)
+            ops.spmm(a, Xin, S=G3, scale=0.25, adam=dict(p=p3, m=m3, v=v3, step=step, reg_w=None, **hyp), **kw)
+            p4, m4, v4 = p0.clone(), m0.clone(), v0.clone()
+            ops.adam_step(p4, G, m4, v4, step=step, **hyp)
+            assert t.equal(G3, G) and t.equal(p3, p4) and t.equal(v3, v4)
+
+
 def test_spmm_epilogue_forms_and_strides():
     ops = _ops()
     n, d = 1500, 64
@@ -669,6 +709,26 @@ def test_sparse_batch_step_equals_plain_step(K):
         assert t.equal(plain.batch_idx[0], fast.batch_idx[0]) and t.equal(plain.batch_idx[2], fast.batch_idx[2])
     # identical up to the order of the float atomics that combine repeated batch nodes
     assert (plain.table - fast.table).abs().max() <= 2e-6
+
+
+@pytest.mark.parametrize("K", [1, 3])
+def test_adam_in_the_backward_epilogue_equals_separate_adam(K):
+    """fuse_adam: the Adam update in the last backward product's epilogue vs the separate mi_adam_dense_f32 pass."""
+    from laplace_amd.trainer import LightGCNTrainer
+    U, I, E, D, B = 900, 500, 15000, 64, 512
+    ma, inter, adj, ei = _model_and_graph(U, I, E, D, K, seed=43, compat="bipartite")
+    mb, _, _, _ = _model_and_graph(U, I, E, D, K, seed=43, compat="bipartite")
+    ma.to(DEV); mb.to(DEV)
+    inter, adj = inter.to(DEV), adj.to(DEV)
+    sep = LightGCNTrainer(ma, adj, inter, lr=1e-3, Lambda=1e-4, batch_size=B, seed=9, fuse_adam=False)
+    fused = LightGCNTrainer(mb, adj, inter, lr=1e-3, Lambda=1e-4, batch_size=B, seed=9, fuse_adam=True)
+    for it in range(6):
+        la, lb = float(sep.step()), float(fused.step())
+        assert abs(la - lb) <= 1e-6, it
+    assert sep.step_count == fused.step_count == 6
+    # identical up to the order of the float atomics that combine repeated batch nodes
+    assert (sep.table - fused.table).abs().max() <= 2e-6
+    assert (sep.m - fused.m).abs().max() <= 1e-7 and (sep.v - fused.v).abs().max() <= 1e-9
 
 
 # ---------------------------------------------------------------------------- BASELINE.json configs[0] (SURVEY C1)
