@@ -62,6 +62,10 @@ __device__ __forceinline__ void mi_f4_fma(float4& acc, float w, const float4& x)
     acc.w = fmaf(w, x.w, acc.w);
 }
 
+__device__ __forceinline__ float4 mi_f4_sel(bool c, float4 a, float4 b) {  // by value: no pointer select, no scratch
+    return make_float4(c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z, c ? a.w : b.w);
+}
+
 __device__ __forceinline__ float4 mi_f4_add(const float4& a, const float4& b) {
     return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
 }

@@ -34,7 +34,9 @@ namespace {
 #define MI_SPMM_UNROLL 8   // row loads in flight per lane (VPL = 1); round-1 A/B: 4 -> 8 gains 2 % with sub-group rows
 #endif
 #ifndef MI_SPMM_ROWS_RPS
-#define MI_SPMM_ROWS_RPS 1  // rows a sub-group handles in sequence; A/B on C2: 1: 1.373 ms, 2: 1.408, 4: 1.397
+#define MI_SPMM_ROWS_RPS 1  // rows a sub-group handles in sequence; A/B on C2: 1: 1.373 ms, 2: 1.408, 4: 1.397.  Two rows walked
+                            // as ONE list per sub-group (shared (col,val) loads and gather batches): rows kernel 851 -> 916 us.
+                            // More rows per wavefront do not help: the kernel is bound by its L2-miss bytes
 #endif
 #ifndef MI_SPMM_NT
 #define MI_SPMM_NT 0   // bit 0: non-temporal (col,val) loads; bit 1: partial-sum stores; bit 2: Y / S stores; bit 3: addend
@@ -59,6 +61,9 @@ __device__ __forceinline__ float4 mi_load4(const float4* p) {
     }
     return *p;
 }
+#ifndef MI_SPMM_FIXUP_UNROLL
+#define MI_SPMM_FIXUP_UNROLL 32  // the most split row (C2: 2 100 partial rows) is one block's serial chain: 4: 81 us, 8: 65, 16: 58, 32: 51
+#endif
 constexpr int kWavesPerBlock = 4;
 constexpr int kBlock = kWavesPerBlock * MI_WAVE;
 constexpr int kPlanGroup = MI_SPMM_GROUP;  // launch slots per XCD-interleave block of a banded plan
@@ -303,10 +308,11 @@ __global__ __launch_bounds__(kBlock) void spmm_fixup_kernel(int32_t n_long, int 
     float4 acc[VPL];
 #pragma unroll
     for (int v = 0; v < VPL; ++v) acc[v] = mi_f4_zero();
-    for (int32_t s = sb + sg; s < se; s += NSG * 4) {
-        float4 x[4][VPL];
+    constexpr int FU = MI_SPMM_FIXUP_UNROLL / VPL;  // partial rows in flight per lane
+    for (int32_t s = sb + sg; s < se; s += NSG * FU) {
+        float4 x[FU][VPL];
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < FU; ++u)
 #pragma unroll
             for (int v = 0; v < VPL; ++v) {
                 const int e = li + v * LPR;
@@ -314,7 +320,7 @@ __global__ __launch_bounds__(kBlock) void spmm_fixup_kernel(int32_t n_long, int 
                 x[u][v] = (ss < se && e < d4) ? partial[(int64_t)ss * d4 + e] : mi_f4_zero();
             }
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < FU; ++u)
 #pragma unroll
             for (int v = 0; v < VPL; ++v) acc[v] = mi_f4_add(acc[v], x[u][v]);
     }
