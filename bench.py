@@ -41,6 +41,8 @@ def parse_args():
     ap.add_argument("--plain-step", action="store_true",
                     help="A/B: the straightforward step (full final, dense gradient buffer) instead of the byte-saving one")
     ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--uniform", action="store_true",
+                    help="control graph of SURVEY 8d: i.i.d. uniform endpoints instead of log-normal users x Zipf items")
     return ap.parse_args()
 
 
@@ -110,7 +112,7 @@ def main():
     from laplace_amd.model.lightgcn import LightGCN
     from laplace_amd.trainer import LightGCNTrainer
 
-    spec = S.SyntheticSpec(args.users, args.items, args.edges, seed=1)
+    spec = S.SyntheticSpec(args.users, args.items, args.edges, seed=1, uniform=args.uniform)
     if world > 1:
         spec = S.shard_spec(spec, rank)
     t_gen = time.perf_counter()
@@ -143,11 +145,16 @@ def main():
         trainer.step()
     sync()
     ops.SPMM_EVENTS = []  # (start, end) HIP events around every propagate launch, on the launch stream
+    marks = [t.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]  # per-step spread; no sync inside the loop
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for i in range(args.steps):
         loss = trainer.step()
+        marks[i + 1].record()
     sync()
     elapsed = time.perf_counter() - t0
+    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    pct = lambda q: per_step[min(len(per_step) - 1, int(q * len(per_step)))]
     events, ops.SPMM_EVENTS = ops.SPMM_EVENTS, None
     loss_val = float(loss)
 
@@ -178,7 +185,7 @@ def main():
         achieved = algo_total / (sum(spmm_ms) * 1e-3) / 1e9 if spmm_ms else 0.0
         traffic = None
         tf = os.path.join(ROOT, "profiles", "traffic.json")
-        default_workload = (args.users, args.items, args.edges, D) == (1_000_000, 100_000, 10_000_000, 128)
+        default_workload = (args.users, args.items, args.edges, D) == (1_000_000, 100_000, 10_000_000, 128) and not args.uniform
         if os.path.exists(tf) and default_workload:  # PMC bytes were collected on exactly this workload
             try:
                 traffic = json.load(open(tf)).get("spmm_hbm_bytes_per_launch")
@@ -190,10 +197,11 @@ def main():
             "unit": "positive-edges/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
+            "ms_per_step_p10_p50_p90": [round(pct(0.1), 4), round(pct(0.5), 4), round(pct(0.9), 4)],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"LightGCN train step, synthetic bipartite {U}x{I} users x items per GPU, "
-                                   f"{args.edges} edges per GPU (symmetric adjacency nnz={nnz}), "
+                                   f"{args.edges} edges per GPU{' (uniform endpoints)' if args.uniform else ''} (symmetric adjacency nnz={nnz}), "
                                    f"{K}-layer D={D}, batch {B} positive edges per GPU, on-device sampling, "
                                    f"BPR + dense Adam; BASELINE.json configs[1]",
                        "parallelism": "1 GPU" if world == 1 else f"user-sharded x{world}, items replicated, "
@@ -202,6 +210,8 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "mi_spmm_csr_f32 dense launch (spmm_items_kernel + spmm_rows_kernel + spmm_fixup_kernel, SPARSE=false)",
                          "algorithmic_bytes_per_launch": algo, "avg_launch_ms": avg_ms,
+                         # every operand read once / written once (SURVEY 8d "compulsory lower bound")
+                         "compulsory_bytes_per_launch": nnz * 8 + (n_rows + 1) * 4 + 2 * n_rows * D * 4,
                          "launches_timed": len(spmm_ms), "layers_timed": n_layers_timed,
                          "dense_launches_per_step": len(dense) / args.steps,
                          "sparse_launches_per_step": len(sparse_ms) / args.steps,

@@ -174,6 +174,8 @@ class GraphDataset:
         data = HeteroData()
         data[Constants.node_user].x = self.graph[Constants.node_user].x[t.from_numpy(user_buckets)]
         data[Constants.node_item].x = self.graph[Constants.node_item].x[t.from_numpy(article_buckets)]
+        data[Constants.node_user].n_id = t.from_numpy(user_buckets)      # global ids of the relabelled nodes: what
+        data[Constants.node_item].n_id = t.from_numpy(article_buckets)   # run_submission needs to name its picks
         edge_index = t.from_numpy(np.stack([np.searchsorted(user_buckets, sub_u), np.searchsorted(article_buckets, sub_a)]))
         label_index = t.from_numpy(np.stack([np.searchsorted(user_buckets, lab_u), np.searchsorted(article_buckets, lab_a)]))
         labels = t.cat([t.ones(n_pos, dtype=t.long), t.zeros(sampled_neg.shape[0], dtype=t.long)])

@@ -88,6 +88,8 @@ class DeviceGraphSampler:
         data = HeteroData()
         data[Constants.node_user].x = self.user_x[user_ids]
         data[Constants.node_item].x = self.article_x[article_ids]
+        data[Constants.node_user].n_id = user_ids
+        data[Constants.node_item].n_id = article_ids
         data[Constants.edge_key].edge_index = edge_index
         data[Constants.edge_key].edge_label_index = label_index
         data[Constants.edge_key].edge_label = labels

@@ -80,6 +80,9 @@ def collate(samples: Sequence[HeteroData]) -> HeteroData:
         for c in counts[:-1]:
             offsets[nt].append(offsets[nt][-1] + c)
         out[nt].x = t.cat([s[nt].x for s in samples], dim=0)
+        for attr in first[nt]:  # per-node extras, e.g. n_id (global node ids, as PyG's sampled batches carry)
+            if attr != "x" and isinstance(first[nt][attr], Tensor):
+                out[nt][attr] = t.cat([s[nt][attr] for s in samples], dim=0)
         out[nt].batch = t.cat([t.full((c,), i, dtype=t.int64) for i, c in enumerate(counts)])
     for et in first.edge_types:
         src_t, _, dst_t = et

@@ -23,6 +23,7 @@ class SyntheticSpec:
     deg_max: int = 2000
     zipf_s: float = 1.05
     item_perm_seed: int = 12345  # shared by all shards of one graph: same popular items everywhere
+    uniform: bool = False        # i.i.d. uniform endpoints (the locality-free control)
 
 
 C1 = SyntheticSpec(943, 1682, 100_000, seed=0, deg_sigma=1.0, deg_min=20, deg_max=737, zipf_s=1.0)
@@ -59,6 +60,12 @@ def generate(spec: SyntheticSpec) -> t.Tensor:
     U, I, E = spec.num_users, spec.num_items, spec.num_edges
     if E > U * I:
         raise ValueError("more edges requested than distinct pairs exist")
+    if spec.uniform:
+        keys = np.empty(0, dtype=np.int64)
+        while keys.size < E:
+            keys = np.unique(np.concatenate([keys, rng.integers(0, U * I, size=int((E - keys.size) * 1.1) + 16)]))
+        keys = keys[rng.permutation(keys.size)[:E]]
+        return t.from_numpy(np.stack([keys // I, keys % I]))
     p = item_popularity(spec)
     cdf = np.cumsum(p)
     cdf[-1] = 1.0

@@ -26,3 +26,25 @@ def NDCGatK_r(groundTruth: List[Tensor], r: Tensor, k: int) -> float:
     ndcg = dcg / idcg
     ndcg[t.isnan(ndcg)] = 0.0
     return ndcg.mean().item()
+
+
+def MAPatK(groundTruth: List[Tensor], predictions: Tensor, k: int = 12) -> float:
+    """Mean average precision @ k as the H&M Kaggle competition scores a submission (BASELINE.json's metric
+    line names it; the reference itself reports only recall / precision / NDCG):
+        AP_u = (1 / min(|GT_u|, k)) * sum_{j<=k} P_u(j) * rel_u(j),   MAP = mean over users with |GT_u| > 0,
+    P_u(j) = hits among the first j predictions / j; a repeated prediction counts once.  predictions
+    [n_users, >= k] int64, -1 = no prediction."""
+    total, n = 0.0, 0
+    for gt, pred in zip(groundTruth, predictions):
+        truth = set(int(x) for x in gt.tolist())
+        if not truth:
+            continue
+        seen, hits, ap = set(), 0, 0.0
+        for j, a in enumerate(pred[:k].tolist()):
+            if a >= 0 and a in truth and a not in seen:
+                hits += 1
+                ap += hits / (j + 1.0)
+            seen.add(a)
+        total += ap / min(len(truth), k)
+        n += 1
+    return total / max(n, 1)

@@ -70,3 +70,47 @@ def test_candidate_generation_feeds_the_ranker():
     val_loader = DataLoader(val_ds, batch_size=16, shuffle=False)
     recall, precision = test_with_dataloader("VAL", ranker, val_loader, DEV, k=cfg.k, break_at=6)
     assert 0.0 <= recall <= 1.0 and 0.0 <= precision <= 1.0
+
+    # 4. submission (row N4): newest checkpoint -> every customer of the test split -> top-k file
+    import os, tempfile
+    import pandas as pd
+    from laplace_amd import run_submission as RS
+    test_graph, test_users, test_articles = splits["test"]
+    t_matchers = [LightGCNMatcher(top, 10), PopularItemsMatcher.from_adjacency(test_articles, 10)]
+    sub_cfg = SimpleNamespace(**vars(cfg), num_gnn_layers=2, hidden_layer_size=64, encoder_layer_output_size=32,
+                              conv_agg_type="add", num_linear_layers=2, heterogeneous_prop_agg_type="sum", batch_norm=True,
+                              p_dropout_edges=0.0, p_dropout_features=0.2)
+    sub_cfg.batch_size = 16
+    with tempfile.TemporaryDirectory() as tmp:
+        t.save({"stale": t.zeros(1)}, os.path.join(tmp, "model_001.pt"))
+        t.save(ranker.state_dict(), os.path.join(tmp, "model_007.pt"))
+        state = RS.load_model(tmp)
+        assert "stale" not in state  # the largest version number wins
+        out_csv = os.path.join(tmp, "derived", "submission.csv")
+        cmap = {str(u): f"cust{u:05d}" for u in range(U)}
+        amap = {str(a): f"art{a:04d}" for a in range(I)}
+        customers, preds, df = RS.submission_pipeline(sub_cfg, splits=splits, matchers=t_matchers, model_dir=tmp,
+                                                      out_csv=out_csv, customer_id_map=cmap, article_id_map=amap,
+                                                      device=DEV, seed=5)
+        back = pd.read_csv(out_csv)
+    assert t.equal(customers, t.arange(U)) and preds.shape == (U, cfg.k)
+    assert int(preds.max()) < I and int(preds.min()) >= -1
+    for row in preds[::23].tolist():
+        real = [a for a in row if a >= 0]
+        assert len(real) == len(set(real)) and len(real) >= 1
+    assert list(back.columns) == ["customer_id", "prediction"] and len(back) == U
+    assert back.customer_id[3] == "cust00003" and back.prediction[3].split()[0] == f"art{int(preds[3, 0]):04d}"
+    # the first pick is the best label-0 candidate of the rebuilt model's own scores
+    test_ds = GraphDataset(sub_cfg, test_graph, test_users, test_articles, train=False, matchers=t_matchers, seed=5)
+    sample = test_ds[3].to(DEV)
+    ranker.eval()
+    with t.no_grad():
+        eli = sample[Constants.edge_key].edge_label_index
+        sc = ranker(sample.x_dict, sample.edge_index_dict, eli).view(-1)
+        lab0 = sample[Constants.edge_key].edge_label == 0
+        best = sample[Constants.node_item].n_id[eli[1][lab0][sc[lab0].argmax()]]
+    assert int(best) == int(preds[3, 0])
+    # MAP@k of the file against the test purchases is a number in [0, 1]
+    from laplace_amd.utils.metrics import MAPatK
+    gt = [t.from_numpy(np.asarray(test_users[u])) for u in range(U)]
+    assert 0.0 <= MAPatK(gt, preds, k=cfg.k) <= 1.0

@@ -100,3 +100,35 @@ def test_lightgcn_module_surface_on_cpu():
         m.float().forward(t.zeros(2, 3))
     with pytest.raises(ValueError):
         LightGCN(3, 4, embedding_dim=30, num_iterations=1)
+
+
+def test_map_at_k_known_answers():
+    """MAP@k (Kaggle H&M definition): hand-computed cases."""
+    from laplace_amd.utils.metrics import MAPatK
+    gt = [t.tensor([1, 2, 3]), t.tensor([7]), t.tensor([], dtype=t.int64), t.tensor([4, 5])]
+    pred = t.tensor([[1, 9, 2, 8], [5, 6, 7, 7], [1, 2, 3, 4], [-1, -1, -1, -1]])
+    ap0 = (1 / 1 + 2 / 3) / 3      # hits at ranks 1 and 3, min(|GT|, k) = 3
+    ap1 = (1 / 3) / 1              # hit at rank 3; the repeat at rank 4 does not count again
+    ap3 = 0.0                      # no predictions
+    assert abs(MAPatK(gt, pred, k=4) - (ap0 + ap1 + ap3) / 3) < 1e-12   # the user without ground truth is skipped
+    assert abs(MAPatK(gt, pred, k=2) - ((1 / 1) / 2 + 0 + 0) / 3) < 1e-12
+
+
+def test_collate_carries_global_node_ids():
+    """Samples carry n_id (global ids of their relabelled nodes); the collate concatenates it like x."""
+    from types import SimpleNamespace
+    from laplace_amd import synthetic as S
+    from laplace_amd.data.dataset import GraphDataset
+    from laplace_amd.hetero import collate
+    from laplace_amd.utils.constants import Constants
+    graph, users, articles = S.generate_hetero(S.SyntheticSpec(60, 40, 400, seed=3, deg_min=2, deg_max=30),
+                                               customer_cards=(20, 2), article_cards=(10, 5))
+    cfg = SimpleNamespace(k=4, num_neighbors=4, n_hop_neighbors=2, positive_edges_ratio=0.5, negative_edges_ratio=2.0, batch_size=3)
+    ds = GraphDataset(cfg, graph, users, articles, train=True, seed=1)
+    a, b = ds[5], ds[9]
+    batch = collate([a, b])
+    for nt in (Constants.node_user, Constants.node_item):
+        assert t.equal(batch[nt].n_id, t.cat([a[nt].n_id, b[nt].n_id]))
+        assert t.equal(batch[nt].x, graph[nt].x[batch[nt].n_id])
+    eli = batch[Constants.edge_key].edge_label_index
+    assert set(batch[Constants.node_user].n_id[eli[0]].tolist()) == {5, 9}
