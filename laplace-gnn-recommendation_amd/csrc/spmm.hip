@@ -148,11 +148,11 @@ __device__ __forceinline__ void subgroup_accumulate(const int32_t* __restrict__ 
 }
 
 // Y / S rows of one sub-group (li = lane within the sub-group); r = output row (compact position in row_list mode).
-template <int LPR, int VPL>
+template <int LPR, int VPL, bool ADAM>
 __device__ __forceinline__ void store_epilogue(const Epilogue& ep, int64_t r, int d4, int li,
                                                const float4 (&acc)[VPL], const float4 (&a)[VPL]) {
-    const bool adam = ep.p != nullptr;
-    const float w = (adam && ep.reg_w) ? ep.reg_w[r] : 0.f;
+    constexpr bool adam = ADAM;
+    const float w = (adam && ep.reg_w) ? ep.reg_w[r] : 0.f;  // ADAM launches are their own instantiations: profiles list them apart
 #pragma unroll
     for (int v = 0; v < VPL; ++v) {
         const int e = li + v * LPR;
@@ -191,7 +191,7 @@ __device__ __forceinline__ void load_addend(const Epilogue& ep, int64_t ar, int 
 // SPARSE = false: the dense product (every entry gathered; addend_map allowed) — the kernel the
 // roofline is quoted on.  SPARSE = true: x_map / row_list launches of the fused train step, kept as a
 // separate instantiation so that profiles list them apart.
-template <int LPR, int VPL, int UNROLL, int RPS, bool SPARSE>
+template <int LPR, int VPL, int UNROLL, int RPS, bool SPARSE, bool ADAM>
 __global__ __launch_bounds__(kBlock) void spmm_rows_kernel(int64_t n_out, int d4,
                                                            const int32_t* __restrict__ rowptr,
                                                            const int32_t* __restrict__ col,
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(kBlock) void spmm_rows_kernel(int64_t n_out, int d4
         const int64_t ar = !mine ? -1 : (listed ? i : (ex.addend_map ? (int64_t)ex.addend_map[r] : r));
         load_addend<LPR, VPL>(ep, ar, d4, li, a);
         subgroup_accumulate<LPR, VPL, UNROLL, SPARSE>(col, val, X4, ldx4, d4, beg, n, nmax, li, ex.x_map, acc);
-        if (mine) store_epilogue<LPR, VPL>(ep, listed ? i : r, d4, li, acc, a);
+        if (mine) store_epilogue<LPR, VPL, ADAM>(ep, listed ? i : r, d4, li, acc, a);
     }
 }
 
@@ -276,7 +276,7 @@ __global__ __launch_bounds__(kBlock) void spmm_items_kernel(int64_t n_launch, in
 // One 256-thread block per split row.  Its 4 wavefronts x NB sub-groups stride over the row's
 // partial sums (several loads in flight each), then combine through LDS in a fixed order, so the
 // result does not depend on scheduling.  Wave 0 applies the epilogue.
-template <int LPR, int VPL, bool SPARSE>
+template <int LPR, int VPL, bool SPARSE, bool ADAM>
 __global__ __launch_bounds__(kBlock) void spmm_fixup_kernel(int32_t n_long, int d4,
                                                             const int32_t* __restrict__ long_rows,
                                                             const int32_t* __restrict__ item_ptr,
@@ -343,7 +343,7 @@ __global__ __launch_bounds__(kBlock) void spmm_fixup_kernel(int32_t n_long, int 
         for (int w = 1; w < kWavesPerBlock; ++w) t = mi_f4_add(t, red[w][v][lane]);
         acc[v] = t;
     }
-    store_epilogue<LPR, VPL>(ep, out_row, d4, lane, acc, a);
+    store_epilogue<LPR, VPL, ADAM>(ep, out_row, d4, lane, acc, a);
 }
 
 // ---- plan construction --------------------------------------------------------------------
@@ -522,7 +522,7 @@ __global__ void plan_items_kernel(int32_t n_seg, int32_t banded, const uint64_t*
 
 dim3 plan_grid(int64_t n) { return dim3((unsigned)mi_ceil_div(n > 0 ? n : 1, 256)); }
 
-template <int LPR, int VPL, bool SPARSE>
+template <int LPR, int VPL, bool SPARSE, bool ADAM>
 int launch_spmm_mode(int64_t n_rows, int d4, const int32_t* rowptr, const int32_t* col, const float* val,
                      const float4* X4, int64_t ldx4, const Epilogue& ep, const mi_spmm_plan* plan,
                      float4* partial, const Ex& ex, int64_t n_list, hipStream_t s) {
@@ -545,13 +545,13 @@ int launch_spmm_mode(int64_t n_rows, int d4, const int32_t* rowptr, const int32_
     const int64_t n_out = listed ? n_list : n_rows;
     if (n_out > 0) {
         dim3 gr((unsigned)mi_ceil_div(n_out, SG * ROWS_RPS));
-        hipLaunchKernelGGL((spmm_rows_kernel<LPR, VPL, UNROLL, ROWS_RPS, SPARSE>), gr, dim3(kBlock), 0, s, n_out, d4,
+        hipLaunchKernelGGL((spmm_rows_kernel<LPR, VPL, UNROLL, ROWS_RPS, SPARSE, ADAM>), gr, dim3(kBlock), 0, s, n_out, d4,
                            rowptr, col, val, X4, ldx4, ep, chunk, ex);
     }
     if (plan && plan->n_long_rows > 0) {
         const int64_t nf = listed ? n_list : (int64_t)plan->n_long_rows;
         if (nf > 0)
-            hipLaunchKernelGGL((spmm_fixup_kernel<LPR, VPL, SPARSE>), dim3((unsigned)nf), dim3(kBlock), 0, s,
+            hipLaunchKernelGGL((spmm_fixup_kernel<LPR, VPL, SPARSE, ADAM>), dim3((unsigned)nf), dim3(kBlock), 0, s,
                                (int32_t)nf, d4, plan->long_rows, plan->item_ptr, partial, ep, ex);
     }
     return mi_launch_status();
@@ -561,9 +561,16 @@ template <int LPR, int VPL>
 int launch_spmm(int64_t n_rows, int d4, const int32_t* rowptr, const int32_t* col, const float* val,
                 const float4* X4, int64_t ldx4, const Epilogue& ep, const mi_spmm_plan* plan,
                 float4* partial, const Ex& ex, int64_t n_list, hipStream_t s) {
-    if (ex.x_map || ex.row_list)
-        return launch_spmm_mode<LPR, VPL, true>(n_rows, d4, rowptr, col, val, X4, ldx4, ep, plan, partial, ex, n_list, s);
-    return launch_spmm_mode<LPR, VPL, false>(n_rows, d4, rowptr, col, val, X4, ldx4, ep, plan, partial, ex, n_list, s);
+    const bool sparse = ex.x_map || ex.row_list;
+#define MI_SPMM_GO(SP, AD) \
+    return launch_spmm_mode<LPR, VPL, SP, AD>(n_rows, d4, rowptr, col, val, X4, ldx4, ep, plan, partial, ex, n_list, s)
+    if (ep.p) {
+        if (sparse) MI_SPMM_GO(true, true);
+        MI_SPMM_GO(false, true);
+    }
+    if (sparse) MI_SPMM_GO(true, false);
+    MI_SPMM_GO(false, false);
+#undef MI_SPMM_GO
 }
 
 }  // namespace
