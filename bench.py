@@ -112,6 +112,8 @@ def main():
     from laplace_amd.model.lightgcn import LightGCN
     from laplace_amd.trainer import LightGCNTrainer
 
+    if os.environ.get("LAPLACE_SPMM_TWO_STREAMS") is not None:  # A/B switch
+        ops.SPMM_TWO_STREAMS = os.environ["LAPLACE_SPMM_TWO_STREAMS"] == "1"
     spec = S.SyntheticSpec(args.users, args.items, args.edges, seed=1, uniform=args.uniform)
     if world > 1:
         spec = S.shard_spec(spec, rank)

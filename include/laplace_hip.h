@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MI_ABI_VERSION 3
+#define MI_ABI_VERSION 4
 
 #define MI_ERR_BAD_ARG      (-1)  /* null pointer, negative size, misaligned buffer   */
 #define MI_ERR_TOO_LARGE    (-2)  /* a size does not fit int32 indexing                */
@@ -197,7 +197,13 @@ typedef struct mi_spmm_ex {
     const int32_t* n_list_dev;
     int64_t        n_list;
     const mi_adam_args* adam;       /* nullable; not with row_list */
+    int32_t        parts;           /* 0 = the whole product; else a mask: MI_SPMM_SHORT_ROWS computes the rows of at most
+                                       plan->chunk entries, MI_SPMM_SPLIT_ROWS the split rows (work items + fix-up).  The two
+                                       halves touch disjoint output rows, so a caller may enqueue them on two streams */
+    int32_t        reserved;
 } mi_spmm_ex;
+#define MI_SPMM_SHORT_ROWS 1
+#define MI_SPMM_SPLIT_ROWS 2
 
 int mi_spmm_csr_ex_f32(int64_t n_rows, int64_t d,
                        const int32_t* rowptr, const int32_t* col, const float* val,

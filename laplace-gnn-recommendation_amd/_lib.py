@@ -8,7 +8,7 @@ from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int32, c_i
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG_DIR, "liblaplace_hip.so")
 
-MI_ABI_VERSION = 3
+MI_ABI_VERSION = 4
 MI_SPMM_GROUP = 32
 
 
@@ -37,7 +37,10 @@ class AdamArgs(Structure):
 
 class SpmmExStruct(Structure):
     _fields_ = [("x_map", c_void_p), ("addend_map", c_void_p), ("row_list", c_void_p), ("n_list_dev", c_void_p),
-                ("n_list", c_int64), ("adam", POINTER(AdamArgs))]
+                ("n_list", c_int64), ("adam", POINTER(AdamArgs)), ("parts", c_int32), ("reserved", c_int32)]
+
+
+MI_SPMM_SHORT_ROWS, MI_SPMM_SPLIT_ROWS = 1, 2
 
 
 class SamplerDesc(Structure):

@@ -88,6 +88,7 @@ struct Ex {
     const int32_t* row_list;    // [n_list]: compute only these rows; Y / S / addend are compact, indexed by list position
     const int32_t* n_list_dev;  // device count of valid row_list entries (<= the launch bound), or null
     const int32_t* long_index;  // [n_rows]: index into the plan's long rows, -1 for short rows (row_list mode)
+    int32_t parts;              // mask of MI_SPMM_SHORT_ROWS / MI_SPMM_SPLIT_ROWS (host side only)
 };
 
 // Largest n over the sub-groups of the wavefront (loop bounds must be wave-uniform around __shfl).
@@ -535,7 +536,8 @@ int launch_spmm_mode(int64_t n_rows, int d4, const int32_t* rowptr, const int32_
     constexpr int ITEMS_RPS = (SG >= MI_SPMM_ITEMS_SLOTS) ? 1 : MI_SPMM_ITEMS_SLOTS / SG;  // launch slots per workgroup
     const int32_t chunk = plan ? plan->chunk : INT32_MAX;
     const bool listed = SPARSE && ex.row_list != nullptr;
-    if (plan && plan->n_items > 0) {  // row_list mode still reduces every split row: hubs are few and almost always wanted
+    const bool do_short = (ex.parts & MI_SPMM_SHORT_ROWS) != 0, do_split = (ex.parts & MI_SPMM_SPLIT_ROWS) != 0;
+    if (do_split && plan && plan->n_items > 0) {  // row_list mode still reduces every split row: hubs are few and almost always wanted
         const int64_t n_launch = plan->n_launch;
         dim3 gi((unsigned)mi_ceil_div(n_launch, SG * ITEMS_RPS));
         hipLaunchKernelGGL((spmm_items_kernel<LPR, VPL, UNROLL, ITEMS_RPS, SPARSE>), gi, dim3(kBlock), 0, s, n_launch,
@@ -543,12 +545,12 @@ int launch_spmm_mode(int64_t n_rows, int d4, const int32_t* rowptr, const int32_
                            partial, ex.x_map);
     }
     const int64_t n_out = listed ? n_list : n_rows;
-    if (n_out > 0) {
+    if (do_short && n_out > 0) {
         dim3 gr((unsigned)mi_ceil_div(n_out, SG * ROWS_RPS));
         hipLaunchKernelGGL((spmm_rows_kernel<LPR, VPL, UNROLL, ROWS_RPS, SPARSE, ADAM>), gr, dim3(kBlock), 0, s, n_out, d4,
                            rowptr, col, val, X4, ldx4, ep, chunk, ex);
     }
-    if (plan && plan->n_long_rows > 0) {
+    if (do_split && plan && plan->n_long_rows > 0) {
         const int64_t nf = listed ? n_list : (int64_t)plan->n_long_rows;
         if (nf > 0)
             hipLaunchKernelGGL((spmm_fixup_kernel<LPR, VPL, SPARSE, ADAM>), dim3((unsigned)nf), dim3(kBlock), 0, s,
@@ -720,7 +722,7 @@ int mi_spmm_csr_ex_f32(int64_t n_rows, int64_t d, const int32_t* rowptr, const i
     MI_CHECK_ARG(!Y || (ldy % 4 == 0 && ldy >= d && mi_aligned16(Y) && Y != X));
     MI_CHECK_ARG(!S || (lds % 4 == 0 && lds >= d && mi_aligned16(S) && S != X));
     MI_CHECK_ARG(!addend || (lda % 4 == 0 && lda >= d && mi_aligned16(addend)));
-    Ex ex = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    Ex ex = {nullptr, nullptr, nullptr, nullptr, nullptr, MI_SPMM_SHORT_ROWS | MI_SPMM_SPLIT_ROWS};
     int64_t n_list = 0;
     if (exh) {
         ex.x_map = exh->x_map;
@@ -728,6 +730,10 @@ int mi_spmm_csr_ex_f32(int64_t n_rows, int64_t d, const int32_t* rowptr, const i
         ex.row_list = exh->row_list;
         ex.n_list_dev = exh->n_list_dev;
         n_list = exh->n_list;
+        if (exh->parts) {
+            MI_CHECK_ARG((exh->parts & ~(MI_SPMM_SHORT_ROWS | MI_SPMM_SPLIT_ROWS)) == 0);
+            ex.parts = exh->parts;
+        }
         if (ex.row_list) {
             MI_CHECK_ARG(n_list >= 0 && !ex.addend_map);
             if (n_list == 0) return 0;

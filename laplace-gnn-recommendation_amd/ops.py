@@ -23,6 +23,20 @@ MIN_BANDS = 16       # narrower adjacencies keep the row-major plan (nothing to 
 # recorded on the stream the kernels are launched on.  None = no timing overhead.
 SPMM_EVENTS = None
 
+# True: the short-row kernel of a planned product runs on a side stream beside the split-row kernels (mi_spmm_ex.parts).
+# Measured on C2 (bench.py, LAPLACE_SPMM_TWO_STREAMS=1): step 5.855 -> 5.782 ms — dense launch 1.023 -> 0.995, sparse
+# 0.605 -> 0.586, the Adam-epilogue launch 1.39 -> 1.44.  Off by default: 1 % does not pay for a second stream
+# beside RCCL's in the sharded step.
+SPMM_TWO_STREAMS = False
+_SIDE = {}
+
+
+def _side_stream(device) -> "t.cuda.Stream":
+    key = t.device(device).index
+    if key not in _SIDE:
+        _SIDE[key] = t.cuda.Stream(device=device)
+    return _SIDE[key]
+
 # Adjacencies smaller than this run without a split-row plan (one wavefront per row whatever its
 # length): building a plan reads two counters back to the host, which per-batch subgraphs of the
 # ranker cannot afford and do not need.
@@ -273,16 +287,28 @@ def spmm(a: DeviceCSR, X: Tensor, *, Y: Optional[Tensor] = None, addend: Optiona
     if SPMM_EVENTS is not None:
         ev = (t.cuda.Event(enable_timing=True), t.cuda.Event(enable_timing=True))
         ev[0].record()
-    exs = None
-    if x_map is not None or addend_map is not None or row_list is not None or adam_args is not None:
-        exs = SpmmExStruct(_ptr(x_map), _ptr(addend_map), _ptr(row_list), _ptr(n_list_dev),
-                           row_list.numel() if row_list is not None else 0,
-                           ctypes.pointer(adam_args) if adam_args is not None else None)
-    check(L.mi_spmm_csr_ex_f32(a.n_rows, d, _ptr(a.rowptr), col_ptr, val_ptr, X.data_ptr(), ldx,
-                               _ptr(Y), ldy, _ptr(addend), lda, _ptr(S), lds, float(scale),
-                               ctypes.byref(plan.struct) if plan is not None else None,
-                               ctypes.byref(exs) if exs is not None else None, ws_ptr, ws_bytes,
-                               _stream()), "mi_spmm_csr_ex_f32")
+    def launch(parts: int, stream: int) -> None:
+        exs = None
+        if x_map is not None or addend_map is not None or row_list is not None or adam_args is not None or parts:
+            exs = SpmmExStruct(_ptr(x_map), _ptr(addend_map), _ptr(row_list), _ptr(n_list_dev),
+                               row_list.numel() if row_list is not None else 0,
+                               ctypes.pointer(adam_args) if adam_args is not None else None, parts, 0)
+        check(L.mi_spmm_csr_ex_f32(a.n_rows, d, _ptr(a.rowptr), col_ptr, val_ptr, X.data_ptr(), ldx,
+                                   _ptr(Y), ldy, _ptr(addend), lda, _ptr(S), lds, float(scale),
+                                   ctypes.byref(plan.struct) if plan is not None else None,
+                                   ctypes.byref(exs) if exs is not None else None, ws_ptr, ws_bytes,
+                                   stream), "mi_spmm_csr_ex_f32")
+
+    if SPMM_TWO_STREAMS and plan is not None and plan.n_items > 0:
+        # short rows beside the split rows' work items + fix-up: disjoint output rows, joined before returning
+        cur = t.cuda.current_stream()
+        side = _side_stream(a.device)
+        side.wait_stream(cur)
+        launch(_lib.MI_SPMM_SHORT_ROWS, side.cuda_stream)
+        launch(_lib.MI_SPMM_SPLIT_ROWS, cur.cuda_stream)
+        cur.wait_stream(side)
+    else:
+        launch(0, _stream())
     if ev is not None:
         ev[1].record()
         kind = "sparse" if (x_map is not None or row_list is not None) else ("dense_adam" if adam is not None else "dense")

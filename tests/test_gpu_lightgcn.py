@@ -264,6 +264,28 @@ def test_spmm_adam_epilogue_equals_spmm_then_adam(d, band):
             assert t.equal(G3, G) and t.equal(p3, p4) and t.equal(v3, v4)
 
 
+def test_spmm_halves_on_two_streams_equal_the_whole_product():
+    """mi_spmm_ex.parts: short rows and split rows write disjoint output rows; enqueued on two streams (ops.SPMM_TWO_STREAMS)
+    they give the bits of the single call."""
+    ops = _ops()
+    n, d = 600, 128
+    rows, cols = _hub_graph(seed=21)
+    a = _csr_with_vals(rows, cols, n, n, seed=22)
+    a.plan = ops.build_spmm_plan(a, chunk=64, band=37)
+    g = t.Generator().manual_seed(5)
+    X, A = t.randn(n, d, generator=g).to(DEV), t.randn(n, d, generator=g).to(DEV)
+    Y0, S0 = t.empty(n, d, device=DEV), t.empty(n, d, device=DEV)
+    ops.spmm(a, X, Y=Y0, addend=A, S=S0, scale=0.5)
+    Y1, S1 = t.full((n, d), float("nan"), device=DEV), t.full((n, d), float("nan"), device=DEV)
+    ops.SPMM_TWO_STREAMS = True
+    try:
+        ops.spmm(a, X, Y=Y1, addend=A, S=S1, scale=0.5)
+    finally:
+        ops.SPMM_TWO_STREAMS = False
+    t.cuda.synchronize()
+    assert t.equal(Y0, Y1) and t.equal(S0, S1)
+
+
 def test_spmm_epilogue_forms_and_strides():
     ops = _ops()
     n, d = 1500, 64
