@@ -215,18 +215,21 @@ class ShardedLightGCNTrainer:
         self.items_g.zero_()
         ops.scatter_rows(self.items_g, self.gc_c, nodes, cnt, begin_dev=cnt_u, row_offset=U)
         flag = (gmap[U:] >= 0).to(t.int32)
-        self._allreduce(self.items_g)
-        self._allreduce(self.reg_w[U:])
+        pending = [self._allreduce(self.items_g, async_op=True), self._allreduce(self.reg_w[U:], async_op=True)]
         if self.world > 1:
-            dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.group)
-        self.imap[U:] = t.where(flag > 0, self._item_ids, t.full_like(self._item_ids, -1))
+            pending.append(dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.group, async_op=True))
         gmap_u = gmap[:U]
         cur = None
         users_done = False
         for i in range(K):
             nxt = self.bufs[i % 2]
             if i == 0:  # input = the batch gradient: item rows gather local batch users, user rows the non-zero item rows
-                ops.spmm(self.a_items, self.gc_c, Y=nxt[U:], x_map=gmap)
+                ops.spmm(self.a_items, self.gc_c, Y=nxt[U:], x_map=gmap)   # local operands only: runs beside the exchanges above
+                for w in pending:
+                    if w is not None:
+                        w.wait()
+                pending = []
+                self.imap[U:] = t.where(flag > 0, self._item_ids, t.full_like(self._item_ids, -1))
                 work = self._allreduce(nxt[U:], async_op=True)
                 ops.spmm(self.a_users, self.items_g, addend=self.gc_c, S=nxt[:U], x_map=self.imap, addend_map=gmap_u)
             else:
@@ -243,6 +246,9 @@ class ShardedLightGCNTrainer:
                 work.wait()
             nxt[U:].add_(self.items_g)
             cur = nxt
+        for w in pending:  # K == 0: nothing consumed them above
+            if w is not None:
+                w.wait()
         self.step_count += 1
         lo = U if users_done else 0  # item rows (summed over ranks above), and the user rows unless already updated
         ops.adam_step(tab[lo:], cur[lo:], self.m[lo:], self.v[lo:], step=self.step_count, lr=self.lr,
