@@ -399,6 +399,9 @@ int mi_embed_concat_f32(int64_t n, int32_t n_cols, const int64_t* x,
  * Two calls per batch because the output sizes are data dependent:
  *   mi_sampler_count  runs the walk, SYNCHRONISES, returns totals_host[4] = {user nodes,
  *                     article nodes, message-passing edges, label edges} of the collated batch;
+ *   mi_sampler_count_async  the same without the wait: the four totals land in caller-owned host
+ *                     memory (pin it) when `stream` reaches that point — the caller waits on an event
+ *                     of its own, so a batch can be sampled on a side stream while the previous one trains;
  *   mi_sampler_emit   writes user_ids int64[tot0], article_ids int64[tot1] (global ids, sorted
  *                     within each sample), edge_index int64[2, tot2], edge_label_index
  *                     int64[2, tot3] (batch-local ids), edge_label int64[tot3],
@@ -422,6 +425,8 @@ typedef struct mi_sampler_desc {
 size_t mi_sampler_workspace_bytes(const mi_sampler_desc* d);
 int    mi_sampler_count(const mi_sampler_desc* d, const int64_t* seed_users, uint64_t seed, uint64_t step,
                         void* ws, size_t ws_bytes, int64_t* totals_host, mi_stream_t stream);
+int    mi_sampler_count_async(const mi_sampler_desc* d, const int64_t* seed_users, uint64_t seed, uint64_t step,
+                              void* ws, size_t ws_bytes, int32_t* totals_pinned, mi_stream_t stream);
 int    mi_sampler_emit(const mi_sampler_desc* d, const int64_t* seed_users, void* ws, size_t ws_bytes,
                        const int64_t* totals_host, int64_t* user_ids, int64_t* article_ids,
                        int64_t* edge_index, int64_t* edge_label_index, int64_t* edge_label,

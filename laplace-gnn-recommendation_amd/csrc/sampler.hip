@@ -578,12 +578,12 @@ size_t mi_sampler_workspace_bytes(const mi_sampler_desc* d) {
 
 // Phase A: everything up to the per-sample counts; writes totals[4] (users, articles, edges, labels)
 // to the HOST array after synchronising the stream.
-int mi_sampler_count(const mi_sampler_desc* d, const int64_t* seed_users, uint64_t seed, uint64_t step, void* ws,
-                     size_t ws_bytes, int64_t* totals_host, mi_stream_t stream) {
+int mi_sampler_count_async(const mi_sampler_desc* d, const int64_t* seed_users, uint64_t seed, uint64_t step, void* ws,
+                           size_t ws_bytes, int32_t* totals_pinned, mi_stream_t stream) {
     Smp p;
     int rc = fill_params(p, d);
     if (rc) return rc;
-    MI_CHECK_ARG(seed_users && ws && totals_host);
+    MI_CHECK_ARG(seed_users && ws && totals_pinned);
     if (ws_bytes < smp_scratch_layout(p, nullptr, nullptr)) return MI_ERR_WORKSPACE;
     smp_scratch_layout(p, &p, static_cast<char*>(ws));
     p.seeds = seed_users; p.seed = seed; p.step = step;
@@ -598,10 +598,18 @@ int mi_sampler_count(const mi_sampler_desc* d, const int64_t* seed_users, uint64
     hipLaunchKernelGGL(smp_mark_articles_kernel, dim3(1 + p.H * p.n, p.B), dim3(256), 0, s, p);
     hipLaunchKernelGGL(smp_count_kernel, dim3(p.B), dim3(kSelThreads), 0, s, p);
     hipLaunchKernelGGL(smp_offsets_kernel, dim3(1), dim3(64), 0, s, p);
-    int32_t tot[4];
     for (int c = 0; c < 4; ++c)
-        MI_HIP(hipMemcpyAsync(&tot[c], p.off + c * (p.B + 1) + p.B, sizeof(int32_t), hipMemcpyDeviceToHost, s));
-    MI_HIP(hipStreamSynchronize(s));
+        MI_HIP(hipMemcpyAsync(&totals_pinned[c], p.off + c * (p.B + 1) + p.B, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    return mi_launch_status();
+}
+
+int mi_sampler_count(const mi_sampler_desc* d, const int64_t* seed_users, uint64_t seed, uint64_t step, void* ws,
+                     size_t ws_bytes, int64_t* totals_host, mi_stream_t stream) {
+    MI_CHECK_ARG(totals_host);
+    int32_t tot[4] = {0, 0, 0, 0};
+    int rc = mi_sampler_count_async(d, seed_users, seed, step, ws, ws_bytes, tot, stream);
+    if (rc) return rc;
+    MI_HIP(hipStreamSynchronize((hipStream_t)stream));
     for (int c = 0; c < 4; ++c) totals_host[c] = tot[c];
     return mi_launch_status();
 }

@@ -21,8 +21,9 @@ from .dataset import AdjList
 
 class DeviceGraphSampler:
     def __init__(self, config, graph: HeteroData, users_adj_list, articles_adj_list, batch_size: Optional[int] = None,
-                 randomization: bool = True, device: str = "cuda", seed: int = 0):
+                 randomization: bool = True, device: str = "cuda", seed: int = 0, prefetch: bool = True):
         self.config, self.device, self.seed = config, t.device(device), int(seed)
+        self.prefetch, self._side = bool(prefetch), None
         self.batch_size = int(batch_size if batch_size is not None else config.batch_size)
         self.randomization = randomization
         ux, ax = graph[Constants.node_user].x, graph[Constants.node_item].x
@@ -69,7 +70,14 @@ class DeviceGraphSampler:
         totals = (ctypes.c_int64 * 4)()
         check(L.mi_sampler_count(ctypes.byref(desc), seeds.data_ptr(), self.seed & (2**64 - 1), int(step) & (2**64 - 1),
                                  self._ws.data_ptr(), self._ws.numel(), totals, stream), "mi_sampler_count")
-        nu, na, ne, nl = (int(x) for x in totals)
+        return self._emit(seeds, desc, [int(x) for x in totals], stream, raw)
+
+    def _emit(self, seeds: Tensor, desc: SamplerDesc, totals, stream: int, raw: bool = False):
+        """Phase B on `stream` (the current torch stream must be that stream: the feature gathers follow it)."""
+        nu, na, ne, nl = totals
+        B = seeds.numel()
+        L = _lib.lib()
+        tot = (ctypes.c_int64 * 4)(nu, na, ne, nl)
         dev = self.device
         user_ids = t.empty(nu, dtype=t.int64, device=dev)
         article_ids = t.empty(na, dtype=t.int64, device=dev)
@@ -78,7 +86,7 @@ class DeviceGraphSampler:
         labels = t.empty(nl, dtype=t.int64, device=dev)
         user_ptr = t.empty(B + 1, dtype=t.int64, device=dev)
         article_ptr = t.empty(B + 1, dtype=t.int64, device=dev)
-        check(L.mi_sampler_emit(ctypes.byref(desc), seeds.data_ptr(), self._ws.data_ptr(), self._ws.numel(), totals,
+        check(L.mi_sampler_emit(ctypes.byref(desc), seeds.data_ptr(), self._ws.data_ptr(), self._ws.numel(), tot,
                                 user_ids.data_ptr(), article_ids.data_ptr(), edge_index.data_ptr() if ne else None,
                                 label_index.data_ptr(), labels.data_ptr(), user_ptr.data_ptr(), article_ptr.data_ptr(),
                                 stream), "mi_sampler_emit")
@@ -99,8 +107,52 @@ class DeviceGraphSampler:
         return data
 
     def __iter__(self) -> Iterator[HeteroData]:
-        """One epoch: every user once, shuffled on device (DataLoader(shuffle=True) semantics)."""
+        """One epoch: every user once, shuffled (DataLoader(shuffle=True) semantics).  With `prefetch` (default)
+        the walk of batch i+1 runs on a side stream while the consumer trains on batch i: only the short emit
+        phase sits between two steps.  Same batches, same order, same Philox steps as the serial loop."""
         g = t.Generator(device="cpu").manual_seed(self.seed + self.step)
         order = t.randperm(self.num_users, generator=g)
-        for b in range(0, self.num_users, self.batch_size):
-            yield self.sample(order[b:b + self.batch_size])
+        batches = [order[b:b + self.batch_size] for b in range(0, self.num_users, self.batch_size)]
+        if not getattr(self, "prefetch", True) or not batches:
+            for seeds in batches:
+                yield self.sample(seeds)
+            return
+        L = _lib.lib()
+        main = t.cuda.current_stream(self.device)
+        if getattr(self, "_side", None) is None:
+            self._side = t.cuda.Stream(device=self.device)
+            self._pinned = [t.empty(4, dtype=t.int32).pin_memory() for _ in range(2)]
+        side = self._side
+        step0 = self.step
+
+        def start(i: int):  # phase A of batch i, enqueued on the side stream, no host wait
+            with t.cuda.stream(side):
+                seeds = batches[i].to(self.device, t.int64).contiguous()
+                desc = self._desc if seeds.numel() == self.batch_size else self._make_desc(seeds.numel())
+                check(L.mi_sampler_count_async(ctypes.byref(desc), seeds.data_ptr(), self.seed & (2**64 - 1),
+                                               int(step0 + i) & (2**64 - 1), self._ws.data_ptr(), self._ws.numel(),
+                                               self._pinned[i % 2].data_ptr(), side.cuda_stream), "mi_sampler_count_async")
+                ev = t.cuda.Event()
+                ev.record(side)
+            return seeds, desc, ev
+
+        side.wait_stream(main)
+        pend = start(0)
+        for i in range(len(batches)):
+            seeds, desc, ev = pend
+            ev.synchronize()
+            totals = self._pinned[i % 2].tolist()
+            with t.cuda.stream(side):
+                data = self._emit(seeds, desc, totals, side.cuda_stream)
+                ready = t.cuda.Event()
+                ready.record(side)
+            self.step = step0 + i + 1
+            if i + 1 < len(batches):  # the workspace is free again once emit(i) has run: same stream, in order
+                pend = start(i + 1)
+            main.wait_event(ready)
+            for store in (data[Constants.node_user], data[Constants.node_item], data[Constants.edge_key],
+                          data[Constants.rev_edge_key]):
+                for v in store.values():
+                    if isinstance(v, Tensor):
+                        v.record_stream(main)
+            yield data

@@ -96,3 +96,26 @@ def test_ranker_trains_from_device_sampled_batches():
     for ep in range(1, 4):
         losses = train_with_dataloader(model, opt, smp, ep, DEV)
     assert np.isfinite(losses).all() and np.mean(losses) < np.mean(first_epoch)
+
+
+def test_prefetching_epoch_equals_the_serial_epoch():
+    """Iterating the sampler with the walk of batch i+1 on a side stream gives, batch for batch, the tensors of
+    the serial loop (same order, same Philox steps), also while another stream keeps the GPU busy."""
+    from laplace_amd.data.device_sampler import DeviceGraphSampler
+    from laplace_amd.utils.constants import Constants
+    graph, users, articles = _graph(seed=31, U=210, A=90, E=4000)
+    cfg = _cfg(n_hop_neighbors=3, num_neighbors=6)
+    serial = DeviceGraphSampler(cfg, graph, users, articles, batch_size=16, device=DEV, seed=77, prefetch=False)
+    ahead = DeviceGraphSampler(cfg, graph, users, articles, batch_size=16, device=DEV, seed=77, prefetch=True)
+    busy = t.randn(2048, 2048, device=DEV)
+    n = 0
+    for epoch in range(2):
+        for a, b in zip(serial, ahead):
+            busy = busy @ busy * 1e-3  # work on the consumer's stream between two batches
+            for nt in (Constants.node_user, Constants.node_item):
+                assert t.equal(a[nt].x, b[nt].x) and t.equal(a[nt].n_id, b[nt].n_id)
+            for key in ("edge_index", "edge_label_index", "edge_label"):
+                assert t.equal(a[Constants.edge_key][key], b[Constants.edge_key][key])
+                assert t.equal(a[Constants.rev_edge_key][key], b[Constants.rev_edge_key][key])
+            n += 1
+    assert n == 2 * len(serial) and serial.step == ahead.step == n
