@@ -7,16 +7,25 @@
 // non-ignored items in score order, so the kernel computes that directly:
 //   1. scores = U[uid] @ I^T on the f32 MFMA (gemm.hip; k-ordered fma chain, bitwise = oracle)
 //   2. scores[q, excl(q)] = -inf
-//   3. per query row: 4-pass radix select of the k-th largest key, ordered collection of the
-//      winners (ties at the threshold resolved towards smaller item ids), bitonic sort by
-//      (score desc, id asc) in LDS.
+//   3. per query row, one read of the row in the common case: a 4 096-element sample of the row fixes a
+//      threshold below the k-th largest score with overwhelming probability, one pass collects the few
+//      hundred entries at or above it into LDS, a bitonic sort on (score desc, id asc) orders them and the
+//      first k are the answer.  When the sample misleads (fewer than k collected, or more than LDS holds:
+//      massive ties, tiny item sets) the row falls back to the exact 4-pass radix select over the row
+//      (ties at the threshold resolved towards smaller item ids).  Either way the result is the same.
 // Integer/index work throughout after step 1: results are exact and deterministic.
 #include "gemm.hpp"
 
 namespace {
 
+#ifndef MI_TOPK_ONE_PASS
+#define MI_TOPK_ONE_PASS 1  // 0: always the multi-pass radix select (A/B, tests of the fallback)
+#endif
 constexpr int kBlock = 256;
 constexpr int kMaxK = 1024;
+constexpr int kCand = 4096;     // LDS candidate capacity of the one-pass path (>= kMaxK)
+constexpr int kSample = 4096;   // sampled scores per row: 32 runs of 128 consecutive items
+constexpr int kSampleRun = 128;
 
 __device__ __forceinline__ uint32_t score_key(float x) {
     x = x + 0.0f;  // -0 -> +0 so that equal scores compare equal
@@ -59,14 +68,31 @@ __device__ __forceinline__ int block_excl_scan(int v, int* sh /*[kBlock/64 + 1]*
     return base + x - v;
 }
 
+// Descending bitonic sort of cand[0, p2) (p2 a power of two) on (key, ~id)  =>  score desc, id asc.
+__device__ __forceinline__ void bitonic_desc(unsigned long long* cand, int p2) {
+    const int tid = threadIdx.x;
+    for (int size = 2; size <= p2; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int i = tid; i < p2 / 2; i += kBlock) {
+                const int lo = 2 * i - (i & (stride - 1));
+                const int hi = lo + stride;
+                const bool desc = ((lo & size) == 0);
+                const unsigned long long a = cand[lo], b = cand[hi];
+                if ((a < b) == desc) { cand[lo] = b; cand[hi] = a; }
+            }
+            __syncthreads();
+        }
+    }
+}
+
 // One block per query row.
 __global__ __launch_bounds__(kBlock) void select_kernel(int64_t n_q, int64_t n_items, int k, int kpow2,
                                                         const float* __restrict__ scores,
                                                         int64_t* __restrict__ out_idx,
-                                                        float* __restrict__ out_score) {
+                                                        float* __restrict__ out_score, int allow_fast) {
     __shared__ int hist[256];
     __shared__ int scan_sh[kBlock / 64 + 1];
-    __shared__ unsigned long long cand[kMaxK];
+    __shared__ unsigned long long cand[kCand];
     __shared__ uint32_t sh_prefix;
     __shared__ int sh_need, sh_count, sh_eq_total;
     const int64_t q = blockIdx.x;
@@ -74,6 +100,106 @@ __global__ __launch_bounds__(kBlock) void select_kernel(int64_t n_q, int64_t n_i
     const float* row = scores + q * n_items;
     const int tid = threadIdx.x;
     const int kk = (int)min((int64_t)k, n_items);
+
+    // ---- one-pass path ----------------------------------------------------------------------------
+    if (allow_fast && n_items >= 8 * kSample) {
+        // (a) sample: kSample / kSampleRun runs spread evenly over the row, keys kept in LDS (aliasing cand)
+        uint32_t* skey = reinterpret_cast<uint32_t*>(cand);
+        const int64_t n_runs = kSample / kSampleRun, gap = n_items / n_runs;
+        for (int i = tid; i < kSample; i += kBlock)
+            skey[i] = score_key(row[(i / kSampleRun) * gap + (i % kSampleRun)]);
+        // rank m in the sample such that, with p = kk / n_items the chance of an item to be a winner, more than m of
+        // the sample being winners is a > 6-sigma event: then at least kk items of the row are >= the m-th sample key
+        const float mu = (float)kSample * (float)kk / (float)n_items;
+        int m = (int)(mu + 4.f * sqrtf(mu) + 8.f);
+        if (tid == 0) { sh_prefix = 0u; sh_need = min(m, kSample); }
+        __syncthreads();
+        for (int pass = 0; pass < 4; ++pass) {
+            const int shift = 24 - 8 * pass;
+            const uint32_t hi_mask = pass == 0 ? 0u : (0xFFFFFFFFu << (shift + 8));
+            hist[tid] = 0;
+            __syncthreads();
+            const uint32_t prefix = sh_prefix;
+            for (int i = tid; i < kSample; i += kBlock) {
+                const uint32_t key = skey[i];
+                if ((key & hi_mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1);
+            }
+            __syncthreads();
+            if (tid == 0) {
+                int need = sh_need, b = 255;
+                for (; b > 0; --b) {
+                    if (hist[b] >= need) break;
+                    need -= hist[b];
+                }
+                sh_prefix = prefix | ((uint32_t)b << shift);
+                sh_need = need;
+            }
+            __syncthreads();
+        }
+        const uint32_t t_lo = sh_prefix;
+        if (tid == 0) sh_count = 0;
+        __syncthreads();  // skey is dead from here on: cand may be written
+        // (b) the one pass over the row
+        const bool vec = ((reinterpret_cast<uintptr_t>(row) & 15u) == 0);
+        if (vec) {
+            const float4* row4 = reinterpret_cast<const float4*>(row);
+            const int64_t n4 = n_items / 4;
+            for (int64_t i4 = tid; i4 < n4; i4 += kBlock) {
+                const float4 x = row4[i4];
+                const float xs[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const uint32_t key = score_key(xs[c]);
+                    if (key >= t_lo) {
+                        const int slot = atomicAdd(&sh_count, 1);
+                        if (slot < kCand)
+                            cand[slot] = ((unsigned long long)key << 32) |
+                                         (unsigned long long)(0xFFFFFFFFu - (uint32_t)(4 * i4 + c));
+                    }
+                }
+            }
+            for (int64_t i = 4 * n4 + tid; i < n_items; i += kBlock) {
+                const uint32_t key = score_key(row[i]);
+                if (key >= t_lo) {
+                    const int slot = atomicAdd(&sh_count, 1);
+                    if (slot < kCand) cand[slot] = ((unsigned long long)key << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)i);
+                }
+            }
+        } else {
+            for (int64_t i = tid; i < n_items; i += kBlock) {
+                const uint32_t key = score_key(row[i]);
+                if (key >= t_lo) {
+                    const int slot = atomicAdd(&sh_count, 1);
+                    if (slot < kCand) cand[slot] = ((unsigned long long)key << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)i);
+                }
+            }
+        }
+        __syncthreads();
+        const int cnt = sh_count;
+        if (cnt >= kk && cnt <= kCand) {  // block-uniform: every winner is among the candidates
+            int p2 = kpow2;
+            while (p2 < cnt) p2 <<= 1;
+            for (int i = cnt + tid; i < p2; i += kBlock) cand[i] = 0ull;  // pads sort last
+            __syncthreads();
+            bitonic_desc(cand, p2);
+            for (int j = tid; j < k; j += kBlock) {
+                int64_t id = -1;
+                float sc = -INFINITY;
+                if (j < kk) {
+                    const unsigned long long c = cand[j];
+                    const float s = key_score((uint32_t)(c >> 32));
+                    if (s != -INFINITY) {  // excluded items never surface: pad instead
+                        id = (int64_t)(0xFFFFFFFFu - (uint32_t)c);
+                        sc = s;
+                    }
+                }
+                out_idx[q * k + j] = id;
+                if (out_score) out_score[q * k + j] = sc;
+            }
+            return;
+        }
+        __syncthreads();  // fall through to the exact multi-pass path
+    }
 
     // ---- radix select: after the 4 passes sh_prefix is the key of the kk-th largest score and
     // sh_need how many elements equal to it are wanted.
@@ -142,19 +268,7 @@ __global__ __launch_bounds__(kBlock) void select_kernel(int64_t n_q, int64_t n_i
     for (int i = got + tid; i < kpow2; i += kBlock) cand[i] = 0ull;  // pads sort last
     __syncthreads();
 
-    // ---- bitonic sort, descending on (key, ~id)  =>  score desc, id asc
-    for (int size = 2; size <= kpow2; size <<= 1) {
-        for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            for (int i = tid; i < kpow2 / 2; i += kBlock) {
-                const int lo = 2 * i - (i & (stride - 1));
-                const int hi = lo + stride;
-                const bool desc = ((lo & size) == 0);
-                const unsigned long long a = cand[lo], b = cand[hi];
-                if ((a < b) == desc) { cand[lo] = b; cand[hi] = a; }
-            }
-            __syncthreads();
-        }
-    }
+    bitonic_desc(cand, kpow2);
     for (int j = tid; j < k; j += kBlock) {
         int64_t id = -1;
         float sc = -INFINITY;
@@ -206,7 +320,7 @@ int mi_topk_excl_f32(int64_t n_q, int64_t n_items, int64_t d, int64_t k, const i
     int kpow2 = 2;
     while (kpow2 < k) kpow2 <<= 1;
     hipLaunchKernelGGL(select_kernel, dim3((unsigned)n_q), dim3(kBlock), 0, s, n_q, n_items, (int)k, kpow2, scores,
-                       out_idx, out_score);
+                       out_idx, out_score, MI_TOPK_ONE_PASS);
     return mi_launch_status();
 }
 

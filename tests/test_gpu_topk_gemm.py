@@ -71,7 +71,10 @@ def test_topk_matches_reference_golden(golden_dir):
         assert got == pytest.approx(want, abs=1e-6)
 
 
-@pytest.mark.parametrize("n_items,k", [(1000, 12), (5000, 256), (100_000, 256), (70, 100), (3000, 1)])
+@pytest.mark.parametrize("n_items,k", [(1000, 12), (5000, 256), (100_000, 256), (70, 100), (3000, 1),
+                                       # one-pass path (sample threshold + single collect pass): rows >= 32 768 items, also
+                                       # rows that are not 16-byte aligned, k = 1 and the largest k
+                                       (40_000, 1), (50_001, 12), (33_333, 256), (100_000, 1024)])
 def test_topk_exact_vs_oracle(n_items, k):
     from laplace_amd import ops
     g = t.Generator().manual_seed(n_items + k)
@@ -103,6 +106,34 @@ def test_topk_ties_resolved_by_item_id():
     assert t.equal(ids.cpu(), want)
     zeros = ops.topk_excl(uid.to(DEV), t.zeros(7, D, device=DEV), ie.to(DEV), k, None)  # all scores equal (+-0)
     assert t.equal(zeros.cpu(), t.arange(k).repeat(7, 1))
+
+
+def test_topk_large_rows_with_massive_ties_and_exclusions_fall_back_exactly():
+    """Rows where the sampled threshold cannot work — thousands of equal scores at the cut, all scores equal,
+    almost everything excluded — take the multi-pass path and still return the exact lists."""
+    from laplace_amd import ops
+    g = t.Generator().manual_seed(9)
+    D, n_items, k = 32, 50_000, 100
+    base = t.randn(25, D, generator=g)
+    ie = base[t.randint(0, 25, (n_items,), generator=g)]  # 25 distinct rows: ~2 000-way ties
+    ue = t.randn(5, D, generator=g)
+    uid = t.arange(5)
+    none = [t.empty(0, dtype=t.int64)] * 5
+    ids = ops.topk_excl(uid.to(DEV), ue.to(DEV), ie.to(DEV), k, None)
+    assert t.equal(ids.cpu(), R.topk_excl_exact(R.scores_fma(ue, ie), none, k))
+    zeros = ops.topk_excl(uid.to(DEV), t.zeros(5, D, device=DEV), ie.to(DEV), k, None)
+    assert t.equal(zeros.cpu(), t.arange(k).repeat(5, 1))
+    # all but 60 items excluded for user 0, all but 3 000 for user 1: padded with -1 / exact
+    ie2 = t.randn(n_items, D, generator=g)
+    keep0, keep1 = t.randperm(n_items, generator=g)[:60], t.randperm(n_items, generator=g)[:3000]
+    mask0, mask1 = t.ones(n_items, dtype=t.bool), t.ones(n_items, dtype=t.bool)
+    mask0[keep0] = False; mask1[keep1] = False
+    excl = [mask0.nonzero().view(-1), mask1.nonzero().view(-1)]
+    rows = t.cat([t.full((len(e),), i) for i, e in enumerate(excl)]).long()
+    ex = ops.coo_to_csr(rows.to(DEV), t.cat(excl).to(DEV), 2, n_items, want_perm=False)
+    got = ops.topk_excl(uid[:2].to(DEV), ue.to(DEV), ie2.to(DEV), k, ex).cpu()
+    want = R.topk_excl_exact(R.scores_fma(ue[:2], ie2), excl, k)
+    assert t.equal(got, want) and int((got[0] >= 0).sum()) == 60
 
 
 def test_pipeline_end_to_end_small():
