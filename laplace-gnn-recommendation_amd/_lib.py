@@ -114,6 +114,9 @@ def lib() -> ctypes.CDLL:
             raise MiError(
                 f"{LIB_PATH} is missing: build it with `python -c \"import __graft_entry__ as g; g.build()\"` "
                 "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        # torch first: the process must hold ONE HIP runtime, the one torch ships; loaded after ours, torch's copy
+        # would be a second runtime that sees no device ("no ROCm-capable device is detected" from our calls)
+        import torch  # noqa: F401
         handle = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in _PROTOTYPES.items():
             fn = getattr(handle, name)  # AttributeError if the symbol is not exported
