@@ -18,6 +18,9 @@
 
 namespace {
 
+#ifndef MI_TOPK_FUSED
+#define MI_TOPK_FUSED 1     // 0: always materialise the score block (A/B)
+#endif
 #ifndef MI_TOPK_ONE_PASS
 #define MI_TOPK_ONE_PASS 1  // 0: always the multi-pass radix select (A/B, tests of the fallback)
 #endif
@@ -85,197 +88,29 @@ __device__ __forceinline__ void bitonic_desc(unsigned long long* cand, int p2) {
     }
 }
 
-// One block per query row.
-__global__ __launch_bounds__(kBlock) void select_kernel(int64_t n_q, int64_t n_items, int k, int kpow2,
-                                                        const float* __restrict__ scores,
-                                                        int64_t* __restrict__ out_idx,
-                                                        float* __restrict__ out_score, int allow_fast) {
-    __shared__ int hist[256];
-    __shared__ int scan_sh[kBlock / 64 + 1];
-    __shared__ unsigned long long cand[kCand];
-    __shared__ uint32_t sh_prefix;
-    __shared__ int sh_need, sh_count, sh_eq_total;
-    const int64_t q = blockIdx.x;
-    if (q >= n_q) return;
-    const float* row = scores + q * n_items;
-    const int tid = threadIdx.x;
-    const int kk = (int)min((int64_t)k, n_items);
+// Shared state of one row's selection (one block per row).
+struct SelectShared {
+    int hist[256];
+    int scan_sh[kBlock / 64 + 1];
+    unsigned long long cand[kCand];
+    uint32_t prefix;
+    int need, count, eq_total;
+};
 
-    // ---- one-pass path ----------------------------------------------------------------------------
-    if (allow_fast && n_items >= 8 * kSample) {
-        // (a) sample: kSample / kSampleRun runs spread evenly over the row, keys kept in LDS (aliasing cand)
-        uint32_t* skey = reinterpret_cast<uint32_t*>(cand);
-        const int64_t n_runs = kSample / kSampleRun, gap = n_items / n_runs;
-        for (int i = tid; i < kSample; i += kBlock)
-            skey[i] = score_key(row[(i / kSampleRun) * gap + (i % kSampleRun)]);
-        // rank m in the sample such that, with p = kk / n_items the chance of an item to be a winner, more than m of
-        // the sample being winners is a > 6-sigma event: then at least kk items of the row are >= the m-th sample key
-        const float mu = (float)kSample * (float)kk / (float)n_items;
-        int m = (int)(mu + 4.f * sqrtf(mu) + 8.f);
-        if (tid == 0) { sh_prefix = 0u; sh_need = min(m, kSample); }
-        __syncthreads();
-        for (int pass = 0; pass < 4; ++pass) {
-            const int shift = 24 - 8 * pass;
-            const uint32_t hi_mask = pass == 0 ? 0u : (0xFFFFFFFFu << (shift + 8));
-            hist[tid] = 0;
-            __syncthreads();
-            const uint32_t prefix = sh_prefix;
-            for (int i = tid; i < kSample; i += kBlock) {
-                const uint32_t key = skey[i];
-                if ((key & hi_mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1);
-            }
-            __syncthreads();
-            if (tid == 0) {
-                int need = sh_need, b = 255;
-                for (; b > 0; --b) {
-                    if (hist[b] >= need) break;
-                    need -= hist[b];
-                }
-                sh_prefix = prefix | ((uint32_t)b << shift);
-                sh_need = need;
-            }
-            __syncthreads();
-        }
-        const uint32_t t_lo = sh_prefix;
-        if (tid == 0) sh_count = 0;
-        __syncthreads();  // skey is dead from here on: cand may be written
-        // (b) the one pass over the row
-        const bool vec = ((reinterpret_cast<uintptr_t>(row) & 15u) == 0);
-        if (vec) {
-            const float4* row4 = reinterpret_cast<const float4*>(row);
-            const int64_t n4 = n_items / 4;
-            for (int64_t i4 = tid; i4 < n4; i4 += kBlock) {
-                const float4 x = row4[i4];
-                const float xs[4] = {x.x, x.y, x.z, x.w};
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const uint32_t key = score_key(xs[c]);
-                    if (key >= t_lo) {
-                        const int slot = atomicAdd(&sh_count, 1);
-                        if (slot < kCand)
-                            cand[slot] = ((unsigned long long)key << 32) |
-                                         (unsigned long long)(0xFFFFFFFFu - (uint32_t)(4 * i4 + c));
-                    }
-                }
-            }
-            for (int64_t i = 4 * n4 + tid; i < n_items; i += kBlock) {
-                const uint32_t key = score_key(row[i]);
-                if (key >= t_lo) {
-                    const int slot = atomicAdd(&sh_count, 1);
-                    if (slot < kCand) cand[slot] = ((unsigned long long)key << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)i);
-                }
-            }
-        } else {
-            for (int64_t i = tid; i < n_items; i += kBlock) {
-                const uint32_t key = score_key(row[i]);
-                if (key >= t_lo) {
-                    const int slot = atomicAdd(&sh_count, 1);
-                    if (slot < kCand) cand[slot] = ((unsigned long long)key << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)i);
-                }
-            }
-        }
-        __syncthreads();
-        const int cnt = sh_count;
-        if (cnt >= kk && cnt <= kCand) {  // block-uniform: every winner is among the candidates
-            int p2 = kpow2;
-            while (p2 < cnt) p2 <<= 1;
-            for (int i = cnt + tid; i < p2; i += kBlock) cand[i] = 0ull;  // pads sort last
-            __syncthreads();
-            bitonic_desc(cand, p2);
-            for (int j = tid; j < k; j += kBlock) {
-                int64_t id = -1;
-                float sc = -INFINITY;
-                if (j < kk) {
-                    const unsigned long long c = cand[j];
-                    const float s = key_score((uint32_t)(c >> 32));
-                    if (s != -INFINITY) {  // excluded items never surface: pad instead
-                        id = (int64_t)(0xFFFFFFFFu - (uint32_t)c);
-                        sc = s;
-                    }
-                }
-                out_idx[q * k + j] = id;
-                if (out_score) out_score[q * k + j] = sc;
-            }
-            return;
-        }
-        __syncthreads();  // fall through to the exact multi-pass path
-    }
+__device__ __forceinline__ unsigned long long composite(uint32_t key, uint32_t item) {
+    return ((unsigned long long)key << 32) | (unsigned long long)(0xFFFFFFFFu - item);  // key desc, then id asc
+}
 
-    // ---- radix select: after the 4 passes sh_prefix is the key of the kk-th largest score and
-    // sh_need how many elements equal to it are wanted.
-    if (tid == 0) { sh_prefix = 0u; sh_need = kk; }
-    __syncthreads();
-    for (int pass = 0; pass < 4; ++pass) {
-        const int shift = 24 - 8 * pass;
-        const uint32_t hi_mask = pass == 0 ? 0u : (0xFFFFFFFFu << (shift + 8));
-        hist[tid] = 0;
-        __syncthreads();
-        const uint32_t prefix = sh_prefix;
-        for (int64_t i = tid; i < n_items; i += kBlock) {
-            const uint32_t key = score_key(row[i]);
-            if ((key & hi_mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1);
-        }
-        __syncthreads();
-        if (tid == 0) {
-            int need = sh_need, b = 255;
-            for (; b > 0; --b) {
-                if (hist[b] >= need) break;
-                need -= hist[b];
-            }
-            sh_prefix = prefix | ((uint32_t)b << shift);
-            sh_need = need;
-            sh_eq_total = hist[b];  // after the last pass: how many scores equal the threshold
-        }
-        __syncthreads();
-    }
-    const uint32_t thr = sh_prefix;
-    const int need_eq = sh_need;
-
-    // ---- collect winners.  Everything above the threshold is appended in arrival order (the sort
-    // below keys on (score, id), so arrival order cannot leak into the result).  Ties AT the
-    // threshold: when all of them are wanted they are appended the same way; otherwise only the
-    // need_eq smallest ids qualify and they are picked by an ordered block scan (rare path).
-    const int eq_total = sh_eq_total;
-    const bool ordered_ties = eq_total > need_eq;
-    if (tid == 0) sh_count = 0;
-    __syncthreads();
-    for (int64_t i = tid; i < n_items; i += kBlock) {
-        const uint32_t key = score_key(row[i]);
-        if (key > thr || (key == thr && !ordered_ties)) {
-            const int slot = atomicAdd(&sh_count, 1);
-            cand[slot] = ((unsigned long long)key << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)i);
-        }
-    }
-    __syncthreads();
-    if (ordered_ties) {
-        int eq_taken = 0;
-        for (int64_t base = 0; base < n_items && eq_taken < need_eq; base += kBlock) {
-            const int64_t i = base + tid;
-            const bool eq = (i < n_items) && score_key(row[i]) == thr;
-            int tot_eq;
-            const int pos_eq = block_excl_scan(eq ? 1 : 0, scan_sh, &tot_eq);
-            const int cnt = sh_count;
-            const int eq_take = min(tot_eq, need_eq - eq_taken);
-            if (eq && pos_eq < eq_take)
-                cand[cnt + pos_eq] = ((unsigned long long)thr << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)i);
-            __syncthreads();
-            if (tid == 0) sh_count = cnt + eq_take;
-            eq_taken += eq_take;
-            __syncthreads();
-        }
-    }
-    const int got = sh_count;  // == kk
-    for (int i = got + tid; i < kpow2; i += kBlock) cand[i] = 0ull;  // pads sort last
-    __syncthreads();
-
-    bitonic_desc(cand, kpow2);
-    for (int j = tid; j < k; j += kBlock) {
+// out row <- the first kk entries of the sorted candidate list; excluded items (-inf) never surface.
+__device__ __forceinline__ void write_row(const unsigned long long* cand, int got, int k, int64_t q,
+                                          int64_t* __restrict__ out_idx, float* __restrict__ out_score) {
+    for (int j = threadIdx.x; j < k; j += kBlock) {
         int64_t id = -1;
         float sc = -INFINITY;
         if (j < got) {
             const unsigned long long c = cand[j];
             const float s = key_score((uint32_t)(c >> 32));
-            if (s != -INFINITY) {  // excluded items never surface: pad instead
+            if (s != -INFINITY) {
                 id = (int64_t)(0xFFFFFFFFu - (uint32_t)c);
                 sc = s;
             }
@@ -285,14 +120,413 @@ __global__ __launch_bounds__(kBlock) void select_kernel(int64_t n_q, int64_t n_i
     }
 }
 
+// m-th largest of kSample keys held in LDS (4-pass radix select); every thread returns it.
+__device__ __forceinline__ uint32_t sample_threshold(const uint32_t* skey, int m, SelectShared& sh) {
+    const int tid = threadIdx.x;
+    if (tid == 0) { sh.prefix = 0u; sh.need = min(m, kSample); }
+    __syncthreads();
+    for (int pass = 0; pass < 4; ++pass) {
+        const int shift = 24 - 8 * pass;
+        const uint32_t hi_mask = pass == 0 ? 0u : (0xFFFFFFFFu << (shift + 8));
+        sh.hist[tid] = 0;
+        __syncthreads();
+        const uint32_t prefix = sh.prefix;
+        for (int i = tid; i < kSample; i += kBlock) {
+            const uint32_t key = skey[i];
+            if ((key & hi_mask) == prefix) atomicAdd(&sh.hist[(key >> shift) & 255u], 1);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int need = sh.need, b = 255;
+            for (; b > 0; --b) {
+                if (sh.hist[b] >= need) break;
+                need -= sh.hist[b];
+            }
+            sh.prefix = prefix | ((uint32_t)b << shift);
+            sh.need = need;
+        }
+        __syncthreads();
+    }
+    return sh.prefix;
+}
+
+// rank in the sample such that, with p = kk / n_items the chance of an item to be a winner, more than m of the
+// sample being winners is a > 6-sigma event: then at least kk items of the row are >= the m-th sample key
+__device__ __forceinline__ int sample_rank(int kk, int64_t n_items) {
+    const float mu = (float)kSample * (float)kk / (float)n_items;
+    return (int)(mu + 4.f * sqrtf(mu) + 8.f);
+}
+
+// Exact multi-pass selection over a materialised score row: 4-pass radix select of the kk-th largest key,
+// collection of the winners (ties at the threshold towards smaller ids), sort, write.
+__device__ void select_row_exact(const float* __restrict__ row, int64_t n_items, int k, int kk, int kpow2, int64_t q,
+                                 int64_t* __restrict__ out_idx, float* __restrict__ out_score, SelectShared& sh) {
+    const int tid = threadIdx.x;
+    if (tid == 0) { sh.prefix = 0u; sh.need = kk; }
+    __syncthreads();
+    for (int pass = 0; pass < 4; ++pass) {
+        const int shift = 24 - 8 * pass;
+        const uint32_t hi_mask = pass == 0 ? 0u : (0xFFFFFFFFu << (shift + 8));
+        sh.hist[tid] = 0;
+        __syncthreads();
+        const uint32_t prefix = sh.prefix;
+        for (int64_t i = tid; i < n_items; i += kBlock) {
+            const uint32_t key = score_key(row[i]);
+            if ((key & hi_mask) == prefix) atomicAdd(&sh.hist[(key >> shift) & 255u], 1);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int need = sh.need, b = 255;
+            for (; b > 0; --b) {
+                if (sh.hist[b] >= need) break;
+                need -= sh.hist[b];
+            }
+            sh.prefix = prefix | ((uint32_t)b << shift);
+            sh.need = need;
+            sh.eq_total = sh.hist[b];  // after the last pass: how many scores equal the threshold
+        }
+        __syncthreads();
+    }
+    const uint32_t thr = sh.prefix;
+    const int need_eq = sh.need;
+    // Everything above the threshold is appended in arrival order (the sort below keys on (score, id), so arrival
+    // order cannot leak into the result).  Ties AT the threshold: when all of them are wanted they are appended the
+    // same way; otherwise only the need_eq smallest ids qualify and they are picked by an ordered block scan.
+    const int eq_total = sh.eq_total;
+    const bool ordered_ties = eq_total > need_eq;
+    if (tid == 0) sh.count = 0;
+    __syncthreads();
+    for (int64_t i = tid; i < n_items; i += kBlock) {
+        const uint32_t key = score_key(row[i]);
+        if (key > thr || (key == thr && !ordered_ties)) {
+            const int slot = atomicAdd(&sh.count, 1);
+            sh.cand[slot] = composite(key, (uint32_t)i);
+        }
+    }
+    __syncthreads();
+    if (ordered_ties) {
+        int eq_taken = 0;
+        for (int64_t base = 0; base < n_items && eq_taken < need_eq; base += kBlock) {
+            const int64_t i = base + tid;
+            const bool eq = (i < n_items) && score_key(row[i]) == thr;
+            int tot_eq;
+            const int pos_eq = block_excl_scan(eq ? 1 : 0, sh.scan_sh, &tot_eq);
+            const int cnt = sh.count;
+            const int eq_take = min(tot_eq, need_eq - eq_taken);
+            if (eq && pos_eq < eq_take) sh.cand[cnt + pos_eq] = composite(thr, (uint32_t)i);
+            __syncthreads();
+            if (tid == 0) sh.count = cnt + eq_take;
+            eq_taken += eq_take;
+            __syncthreads();
+        }
+    }
+    const int got = sh.count;  // == kk
+    for (int i = got + tid; i < kpow2; i += kBlock) sh.cand[i] = 0ull;  // pads sort last
+    __syncthreads();
+    bitonic_desc(sh.cand, kpow2);
+    write_row(sh.cand, got, k, q, out_idx, out_score);
+}
+
+// Sort cnt candidates (cnt >= kk) already in sh.cand and write the row.
+__device__ __forceinline__ void finish_candidates(int cnt, int k, int kk, int kpow2, int64_t q,
+                                                  int64_t* __restrict__ out_idx, float* __restrict__ out_score,
+                                                  SelectShared& sh) {
+    int p2 = kpow2;
+    while (p2 < cnt) p2 <<= 1;
+    for (int i = cnt + threadIdx.x; i < p2; i += kBlock) sh.cand[i] = 0ull;
+    __syncthreads();
+    bitonic_desc(sh.cand, p2);
+    write_row(sh.cand, kk, k, q, out_idx, out_score);
+}
+
+// One block per query row of a materialised score block.
+__global__ __launch_bounds__(kBlock) void select_kernel(int64_t n_q, int64_t n_items, int k, int kpow2,
+                                                        const float* __restrict__ scores,
+                                                        int64_t* __restrict__ out_idx,
+                                                        float* __restrict__ out_score, int allow_fast) {
+    __shared__ SelectShared sh;
+    const int64_t q = blockIdx.x;
+    if (q >= n_q) return;
+    const float* row = scores + q * n_items;
+    const int tid = threadIdx.x;
+    const int kk = (int)min((int64_t)k, n_items);
+
+    // ---- one-pass path ----------------------------------------------------------------------------
+    if (allow_fast && n_items >= 8 * kSample) {
+        // (a) sample: kSample / kSampleRun runs spread evenly over the row, keys kept in LDS (aliasing cand)
+        uint32_t* skey = reinterpret_cast<uint32_t*>(sh.cand);
+        const int64_t n_runs = kSample / kSampleRun, gap = n_items / n_runs;
+        for (int i = tid; i < kSample; i += kBlock)
+            skey[i] = score_key(row[(i / kSampleRun) * gap + (i % kSampleRun)]);
+        __syncthreads();
+        const uint32_t t_lo = sample_threshold(skey, sample_rank(kk, n_items), sh);
+        if (tid == 0) sh.count = 0;
+        __syncthreads();  // skey is dead from here on: cand may be written
+        // (b) the one pass over the row
+        const bool vec = ((reinterpret_cast<uintptr_t>(row) & 15u) == 0);
+        const int64_t n4 = vec ? n_items / 4 : 0;
+        const float4* row4 = reinterpret_cast<const float4*>(row);
+        for (int64_t i4 = tid; i4 < n4; i4 += kBlock) {
+            const float4 x = row4[i4];
+            const float xs[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const uint32_t key = score_key(xs[c]);
+                if (key >= t_lo) {
+                    const int slot = atomicAdd(&sh.count, 1);
+                    if (slot < kCand) sh.cand[slot] = composite(key, (uint32_t)(4 * i4 + c));
+                }
+            }
+        }
+        for (int64_t i = 4 * n4 + tid; i < n_items; i += kBlock) {
+            const uint32_t key = score_key(row[i]);
+            if (key >= t_lo) {
+                const int slot = atomicAdd(&sh.count, 1);
+                if (slot < kCand) sh.cand[slot] = composite(key, (uint32_t)i);
+            }
+        }
+        __syncthreads();
+        const int cnt = sh.count;
+        if (cnt >= kk && cnt <= kCand) {  // block-uniform: every winner is among the candidates
+            finish_candidates(cnt, k, kk, kpow2, q, out_idx, out_score, sh);
+            return;
+        }
+        __syncthreads();  // fall through to the exact multi-pass path
+    }
+    select_row_exact(row, n_items, k, kk, kpow2, q, out_idx, out_score, sh);
+}
+
+// ---- fused path: the score block is never written ---------------------------------------------------------
+// For n_items >= 8 * kSample and d <= 128 (multiple of 4, float4-addressable operands):
+//   1. scores of every query against the kSample sampled items (plain GEMM, 4 % of the work) -> per-row threshold
+//      (exclusions knocked out of the sample first, so that a user's own purchases cannot lift it);
+//   2. topk_scores_filter_kernel: each workgroup keeps a 64-query panel of U in LDS, streams 64-item panels of
+//      I past it (next panel's global loads in flight under the current panel's 64 MFMAs) and, instead of storing
+//      the 64x64 scores, appends the few that reach their row's threshold and are not excluded (bitmap test) to
+//      that row's candidate list in global memory;
+//   3. topk_finalize_kernel: sorts a row's candidates and writes the answer; a row whose list came out short or
+//      overflowed (massive ties, nearly everything excluded) recomputes its scores with a scalar fma chain —
+//      the same bits as the MFMA — and takes the exact multi-pass selection.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int FM = 64, FN = 64, FKC = 128, FKPAD = 129;   // query / item panel rows, panel width, padded LDS row
+constexpr int kCap = kCand;                                // candidate slots per query in global memory
+
+struct FusedArgs {
+    int64_t n_q, n_items;
+    int d;
+    const int64_t* uid;
+    const float* U; int64_t ldu;
+    const float* I; int64_t ldi;
+    const uint32_t* thr;        // [n_q] threshold keys
+    const uint32_t* bitmap;     // [n_q, words] exclusion bits
+    int64_t words;
+    unsigned long long* cand;   // [n_q, kCap]
+    int* cnt;                   // [n_q]
+    int64_t tiles_per_slice;    // item panels per workgroup along blockIdx.x
+};
+
+__global__ void gather_sample_rows_kernel(int64_t n_items, int d, const float* __restrict__ I, int64_t ldi,
+                                          float* __restrict__ Is) {
+    const int p = blockIdx.x;  // sample position
+    const int64_t gap = n_items / (kSample / kSampleRun);
+    const int64_t item = (int64_t)(p / kSampleRun) * gap + (p % kSampleRun);
+    for (int c = threadIdx.x; c < d; c += blockDim.x) Is[(int64_t)p * d + c] = I[item * ldi + c];
+}
+
+__global__ void exclude_bitmap_kernel(int64_t n_q, int64_t n_items, const int32_t* __restrict__ excl_ptr,
+                                      const int32_t* __restrict__ excl_idx, uint32_t* __restrict__ bitmap, int64_t words,
+                                      float* __restrict__ sample_scores) {
+    const int64_t q = blockIdx.x;
+    if (q >= n_q) return;
+    const int64_t gap = n_items / (kSample / kSampleRun);
+    for (int32_t p = excl_ptr[q] + threadIdx.x; p < excl_ptr[q + 1]; p += blockDim.x) {
+        const int32_t i = excl_idx[p];
+        if (i < 0 || i >= n_items) continue;
+        atomicOr(&bitmap[q * words + (i >> 5)], 1u << (i & 31));
+        const int64_t run = i / gap, off = i - run * gap;
+        if (run < kSample / kSampleRun && off < kSampleRun) sample_scores[q * kSample + run * kSampleRun + off] = -INFINITY;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void threshold_kernel(int64_t n_q, int64_t n_items, int k,
+                                                           const float* __restrict__ sample_scores,
+                                                           uint32_t* __restrict__ thr) {
+    __shared__ SelectShared sh;
+    const int64_t q = blockIdx.x;
+    if (q >= n_q) return;
+    uint32_t* skey = reinterpret_cast<uint32_t*>(sh.cand);
+    for (int i = threadIdx.x; i < kSample; i += kBlock) skey[i] = score_key(sample_scores[q * kSample + i]);
+    __syncthreads();
+    const uint32_t t_lo = sample_threshold(skey, sample_rank((int)min((int64_t)k, n_items), n_items), sh);
+    if (threadIdx.x == 0) thr[q] = t_lo;
+}
+
+// 64 x FKC panel rows [row0, row0 + 64) of a K-contiguous operand into registers / LDS (zero beyond n_rows and d).
+__device__ __forceinline__ void fpanel_issue(float4 (&v)[8], const float* __restrict__ base, int64_t ld,
+                                             const int64_t* __restrict__ row_map, int64_t row0, int64_t n_rows, int d,
+                                             int tid) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int idx = tid + 256 * j;
+        const int r = idx / (FKC / 4), c4 = idx % (FKC / 4);
+        const int64_t gr = row0 + r;
+        v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (gr < n_rows && c4 * 4 < d) {
+            const int64_t row = row_map ? row_map[gr] : gr;
+            v[j] = *reinterpret_cast<const float4*>(base + row * ld + c4 * 4);
+        }
+    }
+}
+// (A/B, round 1: one float per lane and load -> conflict-free LDS writes but 32 address computations spill;
+// rotating the float4 component by lane / 8 -> 32 distinct banks but the selects cost more than the conflicts:
+// 2.01 -> 1.71 M users/s.  The plain four-word write below stays.)
+__device__ __forceinline__ void fpanel_commit(float (*panel)[FKPAD], const float4 (&v)[8], int tid) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int idx = tid + 256 * j;
+        const int r = idx / (FKC / 4), c = (idx % (FKC / 4)) * 4;
+        panel[r][c] = v[j].x; panel[r][c + 1] = v[j].y; panel[r][c + 2] = v[j].z; panel[r][c + 3] = v[j].w;
+    }
+}
+
+constexpr int kStage = 1024;  // per-workgroup staging slots in LDS
+
+// Staged candidates -> their rows' lists in global memory (exclusion bitmap tested here, off the MFMA path).
+__device__ __forceinline__ void flush_stage(const FusedArgs& a, int64_t m0, const unsigned long long* st_val,
+                                            const unsigned char* st_row, int n) {
+    for (int e = threadIdx.x; e < n; e += 256) {
+        const unsigned long long c = st_val[e];
+        const int64_t q = m0 + st_row[e];
+        const uint32_t item = 0xFFFFFFFFu - (uint32_t)c;
+        if ((a.bitmap[q * a.words + (item >> 5)] >> (item & 31)) & 1u) continue;
+        const int slot = atomicAdd(&a.cnt[q], 1);
+        if (slot < kCap) a.cand[q * kCap + slot] = c;
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void topk_scores_filter_kernel(FusedArgs a) {
+    __shared__ float As[FM][FKPAD];
+    __shared__ float Bs[FN][FKPAD];
+    __shared__ unsigned long long st_val[kStage];
+    __shared__ unsigned char st_row[kStage];
+    __shared__ int st_cnt;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int64_t m0 = (int64_t)blockIdx.y * FM;
+    const int64_t n_tiles = (a.n_items + FN - 1) / FN;
+    const int64_t t0 = (int64_t)blockIdx.x * a.tiles_per_slice;
+    const int64_t t1 = min(n_tiles, t0 + a.tiles_per_slice);
+    if (t0 >= t1) return;
+    float4 va[8], vb[8];
+    fpanel_issue(va, a.U, a.ldu, a.uid, m0, a.n_q, a.d, tid);
+    fpanel_issue(vb, a.I, a.ldi, nullptr, t0 * FN, a.n_items, a.d, tid);
+    fpanel_commit(As, va, tid);
+    fpanel_commit(Bs, vb, tid);
+    if (tid == 0) st_cnt = 0;
+    // this lane's 16 accumulator rows are fixed for the whole launch: their thresholds live in registers
+    // (rows beyond n_q get a threshold no key reaches... except NaN patterns, hence the explicit row test)
+    uint32_t thr[16];
+    const int row_base = wm * 32 + 4 * (lane >> 5);
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const int64_t gm = m0 + row_base + (reg & 3) + 8 * (reg >> 2);
+        thr[reg] = gm < a.n_q ? a.thr[gm] : 0xFFFFFFFFu;
+    }
+    const int rows_here = (int)min((int64_t)FM, a.n_q - m0);
+    __syncthreads();
+    const float* ap = &As[wm * 32 + (lane & 31)][lane >> 5];
+    const float* bp = &Bs[wn * 32 + (lane & 31)][lane >> 5];
+    const int n_mfma = (a.d + 1) / 2;  // the panels are zero beyond d
+    for (int64_t t = t0; t < t1; ++t) {
+        const bool more = t + 1 < t1;
+        if (more) fpanel_issue(vb, a.I, a.ldi, nullptr, (t + 1) * FN, a.n_items, a.d, tid);  // in flight under the MFMAs
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        if (n_mfma == FKC / 2) {
+#pragma unroll 16
+            for (int s = 0; s < FKC / 2; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * s], bp[2 * s], acc, 0, 0, 0);
+        } else {
+            for (int s = 0; s < n_mfma; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * s], bp[2 * s], acc, 0, 0, 0);
+        }
+        const int64_t gn = t * FN + wn * 32 + (lane & 31);
+        if (gn < a.n_items) {
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const uint32_t key = score_key(acc[reg]);
+                const int rl = row_base + (reg & 3) + 8 * (reg >> 2);
+                if (key >= thr[reg] && rl < rows_here) {  // rare: LDS only on the hot path
+                    const unsigned long long c = composite(key, (uint32_t)gn);
+                    const int slot = atomicAdd(&st_cnt, 1);
+                    if (slot < kStage) {
+                        st_val[slot] = c;
+                        st_row[slot] = (unsigned char)rl;
+                    } else if (!((a.bitmap[(m0 + rl) * a.words + (gn >> 5)] >> (gn & 31)) & 1u)) {  // staging full
+                        const int gs = atomicAdd(&a.cnt[m0 + rl], 1);
+                        if (gs < kCap) a.cand[(m0 + rl) * kCap + gs] = c;
+                    }
+                }
+            }
+        }
+        __syncthreads();  // every wavefront is done reading Bs and appending
+        if (more) fpanel_commit(Bs, vb, tid);
+        const int staged = min(st_cnt, kStage);
+        if (staged >= kStage / 2 || !more) {  // block-uniform
+            flush_stage(a, m0, st_val, st_row, staged);
+            __syncthreads();
+            if (tid == 0) st_cnt = 0;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void topk_finalize_kernel(FusedArgs a, int k, int kpow2, float* __restrict__ scores,
+                                                               int64_t* __restrict__ out_idx,
+                                                               float* __restrict__ out_score) {
+    __shared__ SelectShared sh;
+    const int64_t q = blockIdx.x;
+    if (q >= a.n_q) return;
+    const int tid = threadIdx.x;
+    const int kk = (int)min((int64_t)k, a.n_items);
+    const int cnt = a.cnt[q];
+    if (cnt >= kk && cnt <= kCap) {  // every winner is in the list
+        for (int i = tid; i < cnt; i += kBlock) sh.cand[i] = a.cand[q * kCap + i];
+        __syncthreads();
+        finish_candidates(cnt, k, kk, kpow2, q, out_idx, out_score, sh);
+        return;
+    }
+    // rare: materialise this row's scores — sequential fma chain over k, bit for bit the MFMA's — then select exactly
+    float* row = scores + q * a.n_items;
+    const float* u = a.U + a.uid[q] * a.ldu;
+    for (int64_t i = tid; i < a.n_items; i += kBlock) {
+        const float* it = a.I + i * a.ldi;
+        float acc = 0.f;
+        for (int c = 0; c < a.d; ++c) acc = fmaf(u[c], it[c], acc);
+        if ((a.bitmap[q * a.words + (i >> 5)] >> (i & 31)) & 1u) acc = -INFINITY;
+        row[i] = acc;
+    }
+    __syncthreads();  // workgroup-scope: the row just written is read back by the whole block
+    select_row_exact(row, a.n_items, k, kk, kpow2, q, out_idx, out_score, sh);
+}
+
 }  // namespace
 
 extern "C" {
 
+static size_t topk_fused_extra_bytes(int64_t n_q, int64_t n_items) {
+    const size_t words = (size_t)((n_items + 31) / 32);
+    return mi_align_up((size_t)kSample * 128 * sizeof(float), 256) +             // sampled item rows (d <= 128)
+           mi_align_up((size_t)n_q * kSample * sizeof(float), 256) +             // sample scores
+           mi_align_up((size_t)n_q * words * sizeof(uint32_t), 256) +            // exclusion bitmap
+           2 * mi_align_up((size_t)n_q * sizeof(uint32_t), 256) +                // thresholds, counters
+           mi_align_up((size_t)n_q * kCap * sizeof(unsigned long long), 256);    // candidate lists
+}
+
 size_t mi_topk_workspace_bytes(int64_t n_q, int64_t n_items, int64_t k) {
     (void)k;
     if (n_q <= 0 || n_items <= 0) return 256;
-    return mi_align_up((size_t)n_q * (size_t)n_items * sizeof(float), 256);
+    return mi_align_up((size_t)n_q * (size_t)n_items * sizeof(float), 256) + topk_fused_extra_bytes(n_q, n_items);
 }
 
 int mi_topk_excl_f32(int64_t n_q, int64_t n_items, int64_t d, int64_t k, const int64_t* uid,
@@ -308,6 +542,50 @@ int mi_topk_excl_f32(int64_t n_q, int64_t n_items, int64_t d, int64_t k, const i
     if (ws_bytes < mi_topk_workspace_bytes(n_q, n_items, k)) return MI_ERR_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     float* scores = static_cast<float*>(ws);
+    int kpow2 = 2;
+    while (kpow2 < k) kpow2 <<= 1;
+    const bool fused = MI_TOPK_FUSED && n_items >= 8 * kSample && d <= FKC && d % 4 == 0 && ldu % 4 == 0 && ldi % 4 == 0 &&
+                       mi_aligned16(user_emb) && mi_aligned16(item_emb);
+    if (fused) {
+        MiArena ar(static_cast<char*>(ws) + mi_align_up((size_t)n_q * (size_t)n_items * sizeof(float), 256),
+                   topk_fused_extra_bytes(n_q, n_items));
+        const int64_t words = (n_items + 31) / 32;
+        float* Is = ar.take<float>((size_t)kSample * 128);
+        float* sample_scores = ar.take<float>((size_t)n_q * kSample);
+        uint32_t* bitmap = ar.take<uint32_t>((size_t)n_q * words);
+        uint32_t* thr = ar.take<uint32_t>((size_t)n_q);
+        int* cnt = ar.take<int>((size_t)n_q);
+        unsigned long long* cand = ar.take<unsigned long long>((size_t)n_q * kCap);
+        if (!Is || !sample_scores || !bitmap || !thr || !cnt || !cand) return MI_ERR_WORKSPACE;
+        hipLaunchKernelGGL(gather_sample_rows_kernel, dim3(kSample), dim3(64), 0, s, n_items, (int)d, item_emb, ldi, Is);
+        MiGemmArgs g;
+        g.M = n_q; g.N = kSample; g.K = d;
+        g.A = user_emb; g.sa_m = ldu; g.sa_k = 1; g.a_rows = uid;
+        g.B = Is; g.sb_n = d; g.sb_k = 1;
+        g.bias = nullptr; g.C = sample_scores; g.ldc = kSample; g.accumulate = 0; g.act = 0;
+        int rc = mi_gemm_launch(g, nullptr, 0, s);
+        if (rc) return rc;
+        MI_HIP(hipMemsetAsync(bitmap, 0, (size_t)n_q * words * sizeof(uint32_t), s));
+        MI_HIP(hipMemsetAsync(cnt, 0, (size_t)n_q * sizeof(int), s));
+        if (excl_ptr)
+            hipLaunchKernelGGL(exclude_bitmap_kernel, dim3((unsigned)n_q), dim3(kBlock), 0, s, n_q, n_items, excl_ptr,
+                               excl_idx, bitmap, words, sample_scores);
+        hipLaunchKernelGGL(threshold_kernel, dim3((unsigned)n_q), dim3(kBlock), 0, s, n_q, n_items, (int)k, sample_scores,
+                           thr);
+        FusedArgs a;
+        a.n_q = n_q; a.n_items = n_items; a.d = (int)d; a.uid = uid;
+        a.U = user_emb; a.ldu = ldu; a.I = item_emb; a.ldi = ldi;
+        a.thr = thr; a.bitmap = bitmap; a.words = words; a.cand = cand; a.cnt = cnt;
+        const int64_t strips = mi_ceil_div(n_q, FM), n_tiles = mi_ceil_div(n_items, FN);
+        int64_t slices = mi_ceil_div(4 * 256, strips);  // >= 4 workgroups per CU in the grid
+        if (slices > n_tiles) slices = n_tiles;
+        a.tiles_per_slice = mi_ceil_div(n_tiles, slices);
+        slices = mi_ceil_div(n_tiles, a.tiles_per_slice);
+        hipLaunchKernelGGL(topk_scores_filter_kernel, dim3((unsigned)slices, (unsigned)strips), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(topk_finalize_kernel, dim3((unsigned)n_q), dim3(kBlock), 0, s, a, (int)k, kpow2, scores, out_idx,
+                           out_score);
+        return mi_launch_status();
+    }
     MiGemmArgs g;
     g.M = n_q; g.N = n_items; g.K = d;
     g.A = user_emb; g.sa_m = ldu; g.sa_k = 1; g.a_rows = uid;
@@ -317,8 +595,6 @@ int mi_topk_excl_f32(int64_t n_q, int64_t n_items, int64_t d, int64_t k, const i
     if (rc) return rc;
     if (excl_ptr)
         hipLaunchKernelGGL(exclude_kernel, dim3((unsigned)n_q), dim3(kBlock), 0, s, n_q, n_items, excl_ptr, excl_idx, scores);
-    int kpow2 = 2;
-    while (kpow2 < k) kpow2 <<= 1;
     hipLaunchKernelGGL(select_kernel, dim3((unsigned)n_q), dim3(kBlock), 0, s, n_q, n_items, (int)k, kpow2, scores,
                        out_idx, out_score, MI_TOPK_ONE_PASS);
     return mi_launch_status();
