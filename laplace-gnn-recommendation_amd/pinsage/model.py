@@ -118,8 +118,14 @@ class PinSAGEModel(nn.Module):
         return (self.score(h, seeds, neg) - self.score(h, seeds, pos) + 1).clamp(min=0)
 
 
-def train_epoch(model: PinSAGEModel, optimizer: t.optim.Optimizer, sampler, batches: int) -> List[float]:
-    """pinsage/model.py:118-131: hinge loss mean over the batch's pairs, Adam."""
+def train_epoch(model: PinSAGEModel, optimizer: t.optim.Optimizer, sampler, batches: int, group=None) -> List[float]:
+    """pinsage/model.py:118-131: hinge loss mean over the batch's pairs, Adam.
+
+    Under torch.distributed (BASELINE configs[4]: 4 GPUs) the run is data-parallel: every rank owns a replica and a
+    sampler with its own seed (the item-item walks need the whole graph, 0.4 GB of int32 CSR, so it is replicated),
+    and the gradients — dense layers plus the id-embedding table — are averaged with one flat all-reduce per
+    step (dist_ranker.allreduce_gradients; a no-op when not initialised)."""
+    from ..dist_ranker import allreduce_gradients
     losses = []
     model.train()
     for _ in range(batches):
@@ -127,6 +133,7 @@ def train_epoch(model: PinSAGEModel, optimizer: t.optim.Optimizer, sampler, batc
         loss = model(b["seeds"], b["pos"], b["neg"], b["blocks"]).mean()
         optimizer.zero_grad()
         loss.backward()
+        allreduce_gradients(model.parameters(), group)
         optimizer.step()
         losses.append(float(loss.detach()))
     return losses
