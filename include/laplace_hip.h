@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MI_ABI_VERSION 4
+#define MI_ABI_VERSION 5
 
 #define MI_ERR_BAD_ARG      (-1)  /* null pointer, negative size, misaligned buffer   */
 #define MI_ERR_TOO_LARGE    (-2)  /* a size does not fit int32 indexing                */
@@ -420,6 +420,12 @@ typedef struct mi_sampler_desc {
     const int32_t* articles_ptr; const int32_t* articles_idx;
     double positive_edges_ratio, negative_edges_ratio;
     int64_t reject_min_entries; /* 0 = default 4*n*(n*(hops+1)+1); must be >= n*(n*(hops+1)+1) */
+    /* evaluation mode (data/dataset.py:94-105, train=False): when cand_ptr is non-null the label-0 edges of seed
+     * user u are not sampled but the ids that occur exactly once in cat(unique(candidates of u), items of u) —
+     * candidates that are not purchases plus, as the reference writes it, purchases no matcher proposed — in
+     * ascending order.  cand_ptr int32[num_users + 1] / cand_idx int32[]: the matchers' proposals per user
+     * (duplicates allowed, any order).  max_neg >= max_u(candidates of u + items of u). */
+    const int32_t* cand_ptr;     const int32_t* cand_idx;
 } mi_sampler_desc;
 
 size_t mi_sampler_workspace_bytes(const mi_sampler_desc* d);

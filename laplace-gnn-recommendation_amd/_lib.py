@@ -8,7 +8,7 @@ from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int32, c_i
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG_DIR, "liblaplace_hip.so")
 
-MI_ABI_VERSION = 4
+MI_ABI_VERSION = 5
 MI_SPMM_GROUP = 32
 
 
@@ -48,7 +48,8 @@ class SamplerDesc(Structure):
                 ("randomization", c_int32), ("max_pos", c_int32), ("max_neg", c_int32), ("reserved", c_int32),
                 ("num_users", c_int64), ("num_articles", c_int64), ("num_edges", c_int64), ("id_max", c_int64),
                 ("users_ptr", c_void_p), ("users_idx", c_void_p), ("articles_ptr", c_void_p), ("articles_idx", c_void_p),
-                ("positive_edges_ratio", c_double), ("negative_edges_ratio", c_double), ("reject_min_entries", c_int64)]
+                ("positive_edges_ratio", c_double), ("negative_edges_ratio", c_double), ("reject_min_entries", c_int64),
+                ("cand_ptr", c_void_p), ("cand_idx", c_void_p)]
 
 
 P = c_void_p

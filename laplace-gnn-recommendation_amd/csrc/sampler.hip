@@ -29,6 +29,7 @@ struct Smp {
     int64_t U, A, E, id_max;
     const int32_t* uptr; const int32_t* uidx;
     const int32_t* aptr; const int32_t* aidx;
+    const int32_t* cptr; const int32_t* cidx;  // evaluation mode: matcher candidates per user (null = train mode)
     const int64_t* seeds;
     double pos_ratio, neg_ratio;
     int32_t k, randomization;
@@ -138,7 +139,7 @@ __global__ __launch_bounds__(256) void smp_seed_kernel(Smp p) {
     if (p.randomization) {
         for (int i = tid; i < npos; i += blockDim.x)
             pos_items[i] = p.uidx[beg + (int32_t)rand_below((uint64_t)deg, P_POS, (uint32_t)u, (uint32_t)i, 0, p.seed, p.step)];
-        if (sh_fast) {
+        if (sh_fast && !p.cptr) {
             for (int i = tid; i < nneg; i += blockDim.x)
                 neg_items[i] = (int32_t)rand_below((uint64_t)p.id_max, P_NEG, (uint32_t)u, (uint32_t)i, 0, p.seed, p.step);
         }
@@ -153,6 +154,52 @@ __global__ __launch_bounds__(256) void smp_seed_kernel(Smp p) {
         neg_items[0] = (int32_t)p.id_max;
     }
     __syncthreads();
+    if (p.cptr) {
+        // evaluation mode: label-0 ids = symmetric difference of the distinct candidates and the user's items, ascending.
+        // The sample's article bitmap (all zero here) is the scratch: OR the candidates in, XOR the (distinct) items,
+        // enumerate the set bits in order, clear them again.
+        __shared__ int32_t wscan[256 + 1];
+        uint32_t* bm = p.bm_art + (int64_t)s * p.WA;
+        for (int32_t q = p.cptr[u] + tid; q < p.cptr[u + 1]; q += blockDim.x) {
+            const int32_t c = p.cidx[q];
+            if (c >= 0 && c < p.A) atomicOr(bm + (c >> 5), 1u << (c & 31));
+        }
+        __syncthreads();
+        for (int i = tid; i < deg; i += blockDim.x) {
+            const int32_t v = p.uidx[beg + i];
+            atomicXor(bm + (v >> 5), 1u << (v & 31));
+        }
+        __syncthreads();
+        int base = 0;
+        for (int w0 = 0; w0 < p.WA; w0 += blockDim.x) {
+            const int w = w0 + tid;
+            uint32_t word = w < p.WA ? bm[w] : 0u;
+            // block-wide exclusive scan of the popcounts of this slab of words
+            wscan[tid] = __popc(word);
+            __syncthreads();
+            if (tid == 0) {
+                int run = 0;
+                for (int x = 0; x < (int)blockDim.x; ++x) { const int c = wscan[x]; wscan[x] = run; run += c; }
+                wscan[blockDim.x] = run;
+            }
+            __syncthreads();
+            int r = base + wscan[tid];
+            while (word) {
+                const int b = __ffs(word) - 1;
+                if (r < p.max_neg) neg_items[r] = w * 32 + b;
+                ++r;
+                word &= word - 1;
+            }
+            if (w < p.WA) bm[w] = 0u;
+            base += wscan[blockDim.x];
+            __syncthreads();
+        }
+        if (tid == 0) {
+            p.n_neg[s] = deg > 0 ? (base < p.max_neg ? base : p.max_neg) : 0;
+            if (p.H >= 2 && deg > 0) cut_articles(p, &u, 1, (uint32_t)u, 0, sel, p.aq + (int64_t)s * p.n, p.aq_n + s);
+        }
+        return;
+    }
     if (tid == 0) {
         int nn = nneg;
         if (p.randomization && !sh_fast) {
@@ -554,6 +601,8 @@ int fill_params(Smp& p, const mi_sampler_desc* d) {
     p.B = d->batch; p.H = d->n_hops; p.n = d->num_neighbors;
     p.U = d->num_users; p.A = d->num_articles; p.E = d->num_edges; p.id_max = d->id_max;
     p.uptr = d->users_ptr; p.uidx = d->users_idx; p.aptr = d->articles_ptr; p.aidx = d->articles_idx;
+    p.cptr = d->cand_ptr; p.cidx = d->cand_idx;
+    MI_CHECK_ARG(!p.cptr || p.cidx);
     p.pos_ratio = d->positive_edges_ratio; p.neg_ratio = d->negative_edges_ratio; p.k = d->k;
     p.randomization = d->randomization;
     p.max_pos = d->max_pos; p.max_neg = d->max_neg;

@@ -19,11 +19,42 @@ from ..utils.constants import Constants
 from .dataset import AdjList
 
 
+def candidate_csr(matchers, num_users: int):
+    """(ptr int64[U + 1], idx int64[]) of cat(m.get_matches(u) for m in matchers) per user.  Matchers that can
+    answer for all users at once (`matches_for_all`) are not looped over."""
+    per_user_counts = np.zeros(num_users, dtype=np.int64)
+    blocks = []
+    for m in matchers:
+        dense = m.matches_for_all(num_users) if hasattr(m, "matches_for_all") else None
+        if dense is not None:  # [U, k] int64, -1 = no proposal
+            dense = np.asarray(dense, dtype=np.int64)
+            keep = dense >= 0
+            blocks.append((np.repeat(np.arange(num_users), dense.shape[1])[keep.reshape(-1)], dense[keep]))
+            per_user_counts += keep.sum(axis=1)
+        else:
+            us, its = [], []
+            for u in range(num_users):
+                got = np.asarray(m.get_matches(u)).astype(np.int64).reshape(-1)
+                us.append(np.full(got.shape[0], u, dtype=np.int64))
+                its.append(got)
+                per_user_counts[u] += got.shape[0]
+            blocks.append((np.concatenate(us), np.concatenate(its)))
+    users = np.concatenate([b[0] for b in blocks]) if blocks else np.empty(0, dtype=np.int64)
+    items = np.concatenate([b[1] for b in blocks]) if blocks else np.empty(0, dtype=np.int64)
+    order = np.argsort(users, kind="stable")
+    ptr = np.concatenate([[0], np.cumsum(per_user_counts)]).astype(np.int64)
+    return ptr, items[order]
+
+
 class DeviceGraphSampler:
     def __init__(self, config, graph: HeteroData, users_adj_list, articles_adj_list, batch_size: Optional[int] = None,
-                 randomization: bool = True, device: str = "cuda", seed: int = 0, prefetch: bool = True):
+                 randomization: bool = True, device: str = "cuda", seed: int = 0, prefetch: bool = True,
+                 train: bool = True, matchers=None, shuffle: bool = True):
+        """train=False: evaluation samples as GraphDataset(train=False) builds them — the label-0 edges are the
+        matchers' candidates (minus purchases, plus purchases no matcher proposed; data/dataset.py:94-105)."""
         self.config, self.device, self.seed = config, t.device(device), int(seed)
         self.prefetch, self._side = bool(prefetch), None
+        self.train, self.shuffle = bool(train), bool(shuffle)
         self.batch_size = int(batch_size if batch_size is not None else config.batch_size)
         self.randomization = randomization
         ux, ax = graph[Constants.node_user].x, graph[Constants.node_item].x
@@ -40,6 +71,12 @@ class DeviceGraphSampler:
         max_deg = int(np.diff(users.ptr).max()) if n_users else 1
         self.max_pos = max(2, math.floor(max_deg * config.positive_edges_ratio) if randomization else 2)
         self.max_neg = max(1, config.k - 1, int(config.negative_edges_ratio * self.max_pos))
+        self.cptr = self.cidx = None
+        if not self.train:
+            assert matchers is not None, "Must provide matchers for test"
+            cptr, cidx = candidate_csr(matchers, n_users)
+            self.cptr, self.cidx = to32(cptr), to32(cidx if cidx.size else np.zeros(1, dtype=np.int64))
+            self.max_neg = max(self.max_neg, int(np.diff(cptr).max()) + max_deg)
         self._desc = self._make_desc(self.batch_size)
         self._ws = t.empty(int(_lib.lib().mi_sampler_workspace_bytes(ctypes.byref(self._desc))), dtype=t.uint8, device=dev)
         self.step = 0
@@ -50,7 +87,9 @@ class DeviceGraphSampler:
                            self.max_pos, self.max_neg, 0, self.num_users, self.num_articles, self.num_edges, self.id_max,
                            self.uptr.data_ptr(), self.uidx.data_ptr(), self.aptr.data_ptr(), self.aidx.data_ptr(),
                            float(c.positive_edges_ratio), float(c.negative_edges_ratio),
-                           int(getattr(c, "reject_min_entries", 0) or 0))
+                           int(getattr(c, "reject_min_entries", 0) or 0),
+                           self.cptr.data_ptr() if self.cptr is not None else None,
+                           self.cidx.data_ptr() if self.cidx is not None else None)
 
     def __len__(self) -> int:
         return (self.num_users + self.batch_size - 1) // self.batch_size
@@ -111,7 +150,7 @@ class DeviceGraphSampler:
         the walk of batch i+1 runs on a side stream while the consumer trains on batch i: only the short emit
         phase sits between two steps.  Same batches, same order, same Philox steps as the serial loop."""
         g = t.Generator(device="cpu").manual_seed(self.seed + self.step)
-        order = t.randperm(self.num_users, generator=g)
+        order = t.randperm(self.num_users, generator=g) if self.shuffle else t.arange(self.num_users)
         batches = [order[b:b + self.batch_size] for b in range(0, self.num_users, self.batch_size)]
         if not getattr(self, "prefetch", True) or not batches:
             for seeds in batches:

@@ -33,6 +33,10 @@ class LightGCNMatcher(Matcher):
         row = self.top[user_id][: self.k]
         return row[row >= 0]
 
+    def matches_for_all(self, num_users: int):
+        """[num_users, k] proposals at once (-1 = none): what the device sampler's evaluation mode consumes."""
+        return self.top[:num_users, : self.k].numpy()
+
 
 class PopularItemsMatcher(Matcher):
     def __init__(self, popular_items, k: int):
@@ -47,6 +51,9 @@ class PopularItemsMatcher(Matcher):
 
     def get_matches(self, user_id: int) -> Tensor:
         return self.popular_items[: self.k]
+
+    def matches_for_all(self, num_users: int):
+        return np.broadcast_to(self.popular_items[: self.k].numpy(), (num_users, min(self.k, self.popular_items.numel())))
 
 
 class UsersWithCommonItemsMatcher(Matcher):

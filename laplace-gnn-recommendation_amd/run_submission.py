@@ -109,13 +109,21 @@ def save_csv(df, path: str = "data/derived/submission.csv") -> None:
 
 def submission_pipeline(config: Config = link_pred_config, *, splits: dict, matchers, model_dir: str = "model/saved",
                         out_csv: str = "data/derived/submission.csv", customer_id_map: Optional[dict] = None,
-                        article_id_map: Optional[dict] = None, device: str = "cuda", seed: int = 0):
-    """splits / matchers as run_pipeline takes them; every customer of the test split is scored once, in id order."""
+                        article_id_map: Optional[dict] = None, device: str = "cuda", seed: int = 0,
+                        device_sampler: bool = False):
+    """splits / matchers as run_pipeline takes them; every customer of the test split is scored once, in id order.
+    device_sampler: build the evaluation samples on the GPU (csrc/sampler.hip, evaluation mode) instead of with the
+    host GraphDataset — the only practical way at 10^6 customers."""
     from .data.data_loader import to_undirected
     graph, users_adj, articles_adj = splits["test"]
-    ds = GraphDataset(config, graph, users_adj, articles_adj, train=False, matchers=matchers, split_type="test",
-                      seed=seed)
-    loader = DataLoader(ds, batch_size=config.batch_size, shuffle=False)
+    if device_sampler:
+        from .data.device_sampler import DeviceGraphSampler
+        loader = DeviceGraphSampler(config, graph, users_adj, articles_adj, device=device, seed=seed, train=False,
+                                    matchers=matchers, shuffle=False)
+    else:
+        ds = GraphDataset(config, graph, users_adj, articles_adj, train=False, matchers=matchers, split_type="test",
+                          seed=seed)
+        loader = DataLoader(ds, batch_size=config.batch_size, shuffle=False)
     g_tr, u_tr, a_tr = splits["train"]
     full = to_undirected(GraphDataset(config, g_tr, u_tr, a_tr, train=True, split_type="train", seed=seed).graph)
     model = build_model(config, full, next(iter(loader)), load_model(model_dir), device)

@@ -103,7 +103,9 @@ class CsrAdj:
 
 
 def sample_one(u: int, users: CsrAdj, articles: CsrAdj, num_edges: int, id_max: int, cfg, seed: int, step: int,
-               randomization: bool = True) -> Dict[str, np.ndarray]:
+               randomization: bool = True, cand: "CsrAdj | None" = None) -> Dict[str, np.ndarray]:
+    """cand (evaluation mode, data/dataset.py:94-105 with train=False): the matchers' proposals per user; the
+    label-0 ids are then the ids occurring exactly once in cat(unique(cand[u]), items of u), ascending."""
     pos = users[u]
     deg = len(pos)
     samp_cut = max(1, math.floor(deg * cfg.positive_edges_ratio))
@@ -114,7 +116,10 @@ def sample_one(u: int, users: CsrAdj, articles: CsrAdj, num_edges: int, id_max: 
     n_pos = len(sampled_pos)
     ratio = cfg.k - 1 if n_pos <= 1 else cfg.negative_edges_ratio
     n_neg = int(ratio * n_pos)
-    if not randomization:
+    if cand is not None:
+        ids, counts = np.unique(np.concatenate([np.unique(cand[u]), pos]), return_counts=True)
+        neg = ids[counts == 1].astype(np.int64)
+    elif not randomization:
         neg = np.array([id_max], dtype=np.int64)
     elif n_neg == 0 or num_edges / n_neg > 100:
         neg = np.array([rand_below(id_max, P_NEG, u, i, 0, seed, step) for i in range(n_neg)], dtype=np.int64)
@@ -172,9 +177,9 @@ def sample_one(u: int, users: CsrAdj, articles: CsrAdj, num_edges: int, id_max: 
 
 
 def sample_batch(seed_users, users: CsrAdj, articles: CsrAdj, num_edges: int, id_max: int, cfg, seed: int, step: int,
-                 randomization: bool = True) -> Dict[str, np.ndarray]:
+                 randomization: bool = True, cand: "CsrAdj | None" = None) -> Dict[str, np.ndarray]:
     """The collated batch (disjoint union, data/data_loader.py:48 + PyG collate) as flat arrays."""
-    parts = [sample_one(int(u), users, articles, num_edges, id_max, cfg, seed, step, randomization) for u in seed_users]
+    parts = [sample_one(int(u), users, articles, num_edges, id_max, cfg, seed, step, randomization, cand) for u in seed_users]
     ou = np.cumsum([0] + [len(p["user_ids"]) for p in parts])
     oa = np.cumsum([0] + [len(p["article_ids"]) for p in parts])
     off = lambda i: np.array([[ou[i]], [oa[i]]])

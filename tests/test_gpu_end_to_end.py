@@ -110,6 +110,18 @@ def test_candidate_generation_feeds_the_ranker():
         lab0 = sample[Constants.edge_key].edge_label == 0
         best = sample[Constants.node_item].n_id[eli[1][lab0][sc[lab0].argmax()]]
     assert int(best) == int(preds[3, 0])
+    # the same file from device-built evaluation samples: every customer once, in order, valid distinct ids
+    with tempfile.TemporaryDirectory() as tmp:
+        t.save(ranker.state_dict(), os.path.join(tmp, "model_007.pt"))
+        c2, p2, _ = RS.submission_pipeline(sub_cfg, splits=splits, matchers=t_matchers, model_dir=tmp,
+                                           out_csv=os.path.join(tmp, "s.csv"), device=DEV, seed=5, device_sampler=True)
+    assert t.equal(c2, t.arange(U)) and p2.shape == (U, cfg.k) and int(p2.max()) < I and int(p2.min()) >= -1
+    for row in p2[::31].tolist():
+        real = [a for a in row if a >= 0]
+        assert len(real) == len(set(real)) and len(real) >= 1
+    # the candidate sets are the same whichever sampler built the batch: every pick is a candidate or a missed purchase
+    cand3 = set(np.concatenate([np.asarray(m.get_matches(3)) for m in t_matchers]).tolist()) | set(np.asarray(test_users[3]).tolist())
+    assert set(a for a in p2[3].tolist() if a >= 0) <= cand3 and set(a for a in preds[3].tolist() if a >= 0) <= cand3
     # MAP@k of the file against the test purchases is a number in [0, 1]
     from laplace_amd.utils.metrics import MAPatK
     gt = [t.from_numpy(np.asarray(test_users[u])) for u in range(U)]

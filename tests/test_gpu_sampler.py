@@ -119,3 +119,44 @@ def test_prefetching_epoch_equals_the_serial_epoch():
                 assert t.equal(a[Constants.rev_edge_key][key], b[Constants.rev_edge_key][key])
             n += 1
     assert n == 2 * len(serial) and serial.step == ahead.step == n
+
+
+@pytest.mark.parametrize("rand", [True, False])
+def test_device_sampler_evaluation_mode_vs_mirror_and_host_dataset(rand):
+    """train=False: label-0 edges = ids occurring once in cat(unique(candidates), purchases) (data/dataset.py:94-105).
+    Bit-exact vs the mirror; in randomization=False mode also equal, sample by sample, to the host GraphDataset."""
+    from laplace_amd.data.dataset import GraphDataset
+    from laplace_amd.data.device_sampler import DeviceGraphSampler, candidate_csr
+    from laplace_amd.data.matching import LightGCNMatcher, PopularItemsMatcher, UsersWithCommonItemsMatcher
+    from laplace_amd.hetero import collate
+    from laplace_amd.utils.constants import Constants
+    U, A = 150, 80
+    graph, users, articles = _graph(seed=41, U=U, A=A, E=2500)
+    g = t.Generator().manual_seed(3)
+    top = t.stack([t.randperm(A, generator=g)[:12] for _ in range(U)])
+    top[5, 7:] = -1  # a user with fewer proposals
+    matchers = [LightGCNMatcher(top, 10), PopularItemsMatcher.from_adjacency(articles, 6),
+                UsersWithCommonItemsMatcher(users, articles, 5)]
+    cfg = _cfg(n_hop_neighbors=2, num_neighbors=6 if rand else 1000)  # no frontier cuts in the deterministic mode: the host
+    smp = DeviceGraphSampler(cfg, graph, users, articles, batch_size=16, randomization=rand, device=DEV, seed=9,  # cuts by its own RNG
+                             train=False, matchers=matchers)
+    cptr, cidx = candidate_csr(matchers, U)
+    for u in (0, 5, 77):  # the CSR is the concatenation of the matchers' answers
+        want = np.concatenate([np.asarray(m.get_matches(u)).astype(np.int64) for m in matchers])
+        assert np.array_equal(np.sort(cidx[cptr[u]:cptr[u + 1]]), np.sort(want))
+    ei = graph[Constants.edge_key].edge_index
+    ucsr, acsr, ccsr = SR.CsrAdj(users.ptr, users.idx), SR.CsrAdj(articles.ptr, articles.idx), SR.CsrAdj(cptr, cidx)
+    seeds = t.tensor([3, 5, 77, 149, 0, 20, 21, 22, 100, 101, 9, 64, 65, 66, 130, 5])
+    raw = smp.sample(seeds, step=4, raw=True)
+    want = SR.sample_batch(seeds.numpy(), ucsr, acsr, int(ei.shape[1]), int(ei[1].max()), cfg, 9, 4, randomization=rand, cand=ccsr)
+    for key in ("user_ids", "article_ids", "edge_index", "edge_label_index", "edge_label"):
+        assert np.array_equal(raw[key].cpu().numpy(), want[key]), key
+    assert int((raw["edge_label"] == 0).sum()) > 16
+    if not rand:  # deterministic positives: the host dataset produces the very same samples
+        ds = GraphDataset(cfg, graph, users, articles, train=False, randomization=False, matchers=matchers, seed=1)
+        host = collate([ds[int(u)] for u in seeds.tolist()])
+        dev_batch = smp.sample(seeds, step=4)
+        for nt in (Constants.node_user, Constants.node_item):
+            assert t.equal(dev_batch[nt].n_id.cpu(), host[nt].n_id)
+        for key in ("edge_index", "edge_label_index", "edge_label"):
+            assert t.equal(dev_batch[Constants.edge_key][key].cpu(), host[Constants.edge_key][key]), key
