@@ -22,14 +22,19 @@ from .dataset import AdjList
 def candidate_csr(matchers, num_users: int):
     """(ptr int64[U + 1], idx int64[]) of cat(m.get_matches(u) for m in matchers) per user.  Matchers that can
     answer for all users at once (`matches_for_all`) are not looped over."""
+    dense = [m.matches_for_all(num_users) if hasattr(m, "matches_for_all") else None for m in matchers]
+    if matchers and all(d is not None for d in dense):  # all vectorised: concatenate per user, drop the -1 pads
+        cat = np.concatenate([np.asarray(d, dtype=np.int64) for d in dense], axis=1)
+        keep = cat >= 0
+        ptr = np.concatenate([[0], np.cumsum(keep.sum(axis=1))]).astype(np.int64)
+        return ptr, cat[keep]
     per_user_counts = np.zeros(num_users, dtype=np.int64)
     blocks = []
-    for m in matchers:
-        dense = m.matches_for_all(num_users) if hasattr(m, "matches_for_all") else None
-        if dense is not None:  # [U, k] int64, -1 = no proposal
-            dense = np.asarray(dense, dtype=np.int64)
-            keep = dense >= 0
-            blocks.append((np.repeat(np.arange(num_users), dense.shape[1])[keep.reshape(-1)], dense[keep]))
+    for m, d in zip(matchers, dense):
+        if d is not None:  # [U, k] int64, -1 = no proposal
+            d = np.asarray(d, dtype=np.int64)
+            keep = d >= 0
+            blocks.append((np.repeat(np.arange(num_users), d.shape[1])[keep.reshape(-1)], d[keep]))
             per_user_counts += keep.sum(axis=1)
         else:
             us, its = [], []
