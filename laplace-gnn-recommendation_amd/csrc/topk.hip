@@ -379,7 +379,10 @@ __device__ __forceinline__ void fpanel_issue(float4 (&v)[8], const float* __rest
 }
 // (A/B, round 1: one float per lane and load -> conflict-free LDS writes but 32 address computations spill;
 // rotating the float4 component by lane / 8 -> 32 distinct banks but the selects cost more than the conflicts:
-// 2.01 -> 1.71 M users/s.  The plain four-word write below stays.)
+// 2.01 -> 1.71 M users/s; 132-float rows with ds_write_b128 / ds_read_b128 (conflict-free both ways, one float4
+// per two MFMAs) plus a float compare against the threshold: 950 -> 1 010 us per chunk.  Stage timings of this
+// kernel per 2 621-query chunk: MFMA loop + barriers alone 586 us (114 TF/s), + panel prefetch / commit 721,
+// + threshold epilogue and staging 950.  The plain four-word write below stays.)
 __device__ __forceinline__ void fpanel_commit(float (*panel)[FKPAD], const float4 (&v)[8], int tid) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
