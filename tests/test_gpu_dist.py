@@ -1,0 +1,99 @@
+"""GPU: the user-sharded trainer with the HIP kernels, two ranks sharing the one card (gloo for the exchanges,
+as in bench.py's rehearsal switch): together they must reproduce the single-process reference loop on the union
+graph.  tests/test_dist_cpu.py checks the same host logic on the CPU with an oracle-backed kernel provider; this
+one runs the product's own kernels — row-sliced CSRs with split rows, x_map / addend_map / row_list launches,
+the Adam epilogue on the user rows — under a process group."""
+import os
+import socket
+import sys
+
+import pytest
+import torch as t
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+U0, U1, I, D, K, B, STEPS = 2500, 1800, 150, 64, 3, 512, 4
+
+
+def _shards():
+    g = t.Generator().manual_seed(0)
+    out = []
+    for U, E in ((U0, 60_000), (U1, 45_000)):  # ~700 users per item: item rows are split rows (> 256 entries)
+        keys = t.randperm(U * I, generator=g)[:E]
+        out.append(t.stack([keys // I, keys % I]))
+    return out
+
+
+def _tables():
+    g = t.Generator().manual_seed(1)
+    return t.randn(U0, D, generator=g) * 0.1, t.randn(U1, D, generator=g) * 0.1, t.randn(I, D, generator=g) * 0.1
+
+
+def _batches(step):
+    g = t.Generator().manual_seed(100 + step)
+    return [(t.randint(0, U, (B,), generator=g), t.randint(0, I, (B,), generator=g), t.randint(0, I, (B,), generator=g))
+            for U in (U0, U1)]
+
+
+def _worker(rank, world, port, ret, sparse_batch):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    t.cuda.set_device(0)
+    from laplace_amd.dist import ShardedLightGCNTrainer
+    from laplace_amd.interactions import Interactions
+    from laplace_amd.model.lightgcn import LightGCN
+    ei = _shards()[rank]
+    tu0, tu1, ti = _tables()
+    U = (U0, U1)[rank]
+    model = LightGCN(U, I, D, K)
+    with t.no_grad():
+        model.users_emb.weight.copy_((tu0, tu1)[rank])
+        model.items_emb.weight.copy_(ti if rank == 0 else t.zeros_like(ti))  # the constructor's broadcast must fix rank 1
+    model.to("cuda")
+    tr = ShardedLightGCNTrainer(model, Interactions(ei.cuda(), U, I), lr=1e-2, Lambda=1e-4, batch_size=B, seed=3,
+                                sparse_batch=sparse_batch)
+    assert tr.a_items.plan.n_long_rows > 0
+    losses = []
+    for s in range(STEPS):
+        losses.append(float(tr.step(tuple(x.cuda() for x in _batches(s)[rank]))))
+    fin = tr.forward().clone()
+    ret[rank] = {"table": tr.table.cpu(), "final": fin.cpu(), "losses": losses}
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.parametrize("sparse_batch", [True, False])
+def test_two_ranks_on_one_gpu_equal_the_single_process_reference(sparse_batch):
+    from oracle import lightgcn_ref as R
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(2, _free_port(), ret, sparse_batch), nprocs=2, join=True)
+    e0, e1 = _shards()
+    eu, ei = t.cat([e0[0], e1[0] + U0]), t.cat([e0[1], e1[1]])
+    row, col = R.bipartite_edges(eu, ei, U0 + U1)
+    tu0, tu1, ti = _tables()
+    uw, iw = t.nn.Parameter(t.cat([tu0, tu1])), t.nn.Parameter(ti.clone())
+    opt = t.optim.Adam([uw, iw], lr=1e-2)
+    for s in range(STEPS):
+        b0, b1 = _batches(s)
+        R.train_step(uw, iw, opt, row, col, K, (t.cat([b0[0], b1[0] + U0]), t.cat([b0[1], b1[1]]), t.cat([b0[2], b1[2]])), 1e-4)
+    wu, _, wi, _ = R.lightgcn_forward(uw.detach(), iw.detach(), row, col, K)
+    r0, r1 = ret[0], ret[1]
+    assert t.equal(r0["table"][U0:], r1["table"][U1:])  # item replicas stay bitwise identical across ranks
+    tol = 5e-6
+    assert (r0["table"][:U0] - uw.detach()[:U0]).abs().max() <= tol and (r1["table"][:U1] - uw.detach()[U0:]).abs().max() <= tol
+    assert (r0["table"][U0:] - iw.detach()).abs().max() <= tol
+    assert (r0["final"][:U0] - wu[:U0]).abs().max() <= tol and (r1["final"][:U1] - wu[U0:]).abs().max() <= tol
+    assert (r0["final"][U0:] - wi).abs().max() <= tol and (r1["final"][U1:] - wi).abs().max() <= tol
