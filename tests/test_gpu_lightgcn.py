@@ -286,6 +286,32 @@ def test_spmm_halves_on_two_streams_equal_the_whole_product():
     assert t.equal(Y0, Y1) and t.equal(S0, S1)
 
 
+@pytest.mark.parametrize("band", [0, 16])
+def test_spmm_plan_without_split_rows_and_with_every_row_split(band):
+    """Both ends: no row longer than the chunk (the plan is empty, row_list launches still work) and every row split."""
+    ops = _ops()
+    n, d = 300, 64
+    row, col = _rand_graph(n, n, 3000, seed=31)
+    a = _csr_with_vals(row, col, n, n, seed=32)
+    X = t.randn(n, d, generator=t.Generator().manual_seed(1)).to(DEV)
+    want = _oracle_spmm(a, X)
+    a.plan = ops.build_spmm_plan(a, chunk=256, band=band)
+    assert a.plan.n_long_rows == 0 and a.plan.n_items == 0 and bool((a.plan.long_index == -1).all())
+    Y = t.empty(n, d, device=DEV)
+    ops.spmm(a, X, Y=Y)
+    assert t.allclose(Y.cpu(), want, atol=2e-5, rtol=1e-5)
+    rows = t.tensor([5, 17, 299, 0], dtype=t.int32, device=DEV)
+    Ys = t.empty(4, d, device=DEV)
+    ops.spmm(a, X, Y=Ys, row_list=rows)
+    assert t.equal(Ys, Y[rows.long()])
+    deg = (a.rowptr[1:] - a.rowptr[:-1])
+    a.plan = ops.build_spmm_plan(a, chunk=1, band=band)  # every non-trivial row is a split row, one entry per work item
+    assert a.plan.n_long_rows == int((deg > 1).sum()) and a.plan.n_items >= int(deg[deg > 1].sum()) // 1
+    Y2 = t.full((n, d), float("nan"), device=DEV)
+    ops.spmm(a, X, Y=Y2)
+    assert t.allclose(Y2.cpu(), want, atol=2e-5, rtol=1e-5)
+
+
 def test_spmm_epilogue_forms_and_strides():
     ops = _ops()
     n, d = 1500, 64
