@@ -145,7 +145,9 @@ class DeviceGraphSampler:
         data[Constants.edge_key].edge_index = edge_index
         data[Constants.edge_key].edge_label_index = label_index
         data[Constants.edge_key].edge_label = labels
-        data[Constants.rev_edge_key].edge_index = edge_index.flip(0)
+        rev = edge_index.flip(0)
+        rev._reverse_of = edge_index  # lets the encoder reuse the forward relation's sorted CSRs (model/layers.py)
+        data[Constants.rev_edge_key].edge_index = rev
         data[Constants.rev_edge_key].edge_label_index = label_index.flip(0)
         data[Constants.rev_edge_key].edge_label = labels
         return data

@@ -70,11 +70,18 @@ class HeteroGNNEncoder(nn.Module):
 
     def forward(self, x_dict: Dict[str, Tensor], edge_index_dict: Dict[Tuple[str, str, str], Tensor]):
         graphs = {}
+        built = {}  # id(edge_index tensor) -> its graph, for relations declared to be another one reversed
         for et, ei in edge_index_dict.items():
             et = tuple(et)
             if _key(et) in self.layers[0]:
-                graphs[et] = ei if isinstance(ei, BipartiteGraph) else BipartiteGraph(
-                    ei, x_dict[et[0]].shape[0], x_dict[et[2]].shape[0])
+                fwd = getattr(ei, "_reverse_of", None)
+                if isinstance(ei, BipartiteGraph):
+                    graphs[et] = ei
+                elif fwd is not None and id(fwd) in built:
+                    graphs[et] = built[id(fwd)].reversed()
+                else:
+                    graphs[et] = BipartiteGraph(ei, x_dict[et[0]].shape[0], x_dict[et[2]].shape[0])
+                    built[id(ei)] = graphs[et]
         n_layers = len(self.layers)
         for index, convs in enumerate(self.layers):
             last = index == n_layers - 1

@@ -88,12 +88,21 @@ class BipartiteGraph:
     """One relation of a batch: edges src -> dst as two sorted CSRs (by dst for the forward aggregate,
     by src for its backward), built once per batch on device and shared by all layers."""
 
-    def __init__(self, edge_index: Tensor, n_src: int, n_dst: int):
-        src, dst = edge_index[0].contiguous(), edge_index[1].contiguous()
+    def __init__(self, edge_index: Optional[Tensor], n_src: int, n_dst: int):
         self.n_src, self.n_dst = int(n_src), int(n_dst)
+        self._vals = {}
+        if edge_index is None:  # filled by reversed()
+            return
+        src, dst = edge_index[0].contiguous(), edge_index[1].contiguous()
         self.by_dst = ops.coo_to_csr(dst, src, self.n_dst, self.n_src, want_perm=False)
         self.by_src = ops.coo_to_csr(src, dst, self.n_src, self.n_dst, want_perm=False)
-        self._vals = {}
+
+    def reversed(self) -> "BipartiteGraph":
+        """The relation with every edge turned round (the reference's `rev_*` relation is `edge_index.flip(0)`,
+        data/dataset.py:176-182): the same two CSRs with their roles swapped — no second pair of sorts."""
+        g = BipartiteGraph(None, self.n_dst, self.n_src)
+        g.by_dst, g.by_src = self.by_src, self.by_dst
+        return g
 
     def weights(self, aggr: str) -> Tuple[Tensor, Tensor]:
         """(values for by_dst, values for by_src) realising `aggr` as a weighted sum."""

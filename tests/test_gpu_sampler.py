@@ -160,3 +160,36 @@ def test_device_sampler_evaluation_mode_vs_mirror_and_host_dataset(rand):
             assert t.equal(dev_batch[nt].n_id.cpu(), host[nt].n_id)
         for key in ("edge_index", "edge_label_index", "edge_label"):
             assert t.equal(dev_batch[Constants.edge_key][key].cpu(), host[Constants.edge_key][key]), key
+
+
+def test_reversed_relation_reuses_the_forward_csrs():
+    """Batches of the device sampler declare `rev_buys` to be `buys` reversed; the encoder then swaps the two sorted
+    CSRs instead of sorting again.  Same logits and gradients, bit for bit, as with four independent sorts."""
+    from laplace_amd.data.device_sampler import DeviceGraphSampler
+    from laplace_amd.model.encoder_decoder import Encoder_Decoder_Model
+    from laplace_amd.model.layers import get_SAGEConv_layers, get_linear_layers
+    from laplace_amd.utils.constants import Constants
+    from laplace_amd.utils.get_info import get_feature_info, select_properties
+    graph, users, articles = _graph(seed=51, U=200, A=90, E=3000)
+    cfg = _cfg(n_hop_neighbors=2, num_neighbors=6)
+    smp = DeviceGraphSampler(cfg, graph, users, articles, batch_size=16, device=DEV, seed=5)
+    batch = smp.sample(t.arange(16), step=0)
+    rev = batch[Constants.rev_edge_key].edge_index
+    assert rev._reverse_of is batch[Constants.edge_key].edge_index
+    t.manual_seed(0)
+    model = Encoder_Decoder_Model(get_SAGEConv_layers(2, 32, 16, "mean"), get_linear_layers(2, 32, 32, 1),
+                                  get_feature_info(graph), batch.metadata(), True, "sum", True, 0.0, 0.0).to(DEV)
+    model.initialize_encoder_input_size(batch)
+    model.eval()
+
+    def run():
+        model.zero_grad()
+        x, ei, eli, _ = select_properties(batch)
+        out = model(x, ei, eli).view(-1)
+        out.square().sum().backward()
+        return out.detach().clone(), [p.grad.clone() for p in model.parameters() if p.grad is not None]
+
+    out_a, grads_a = run()
+    del rev._reverse_of  # plain tensors: four sorts
+    out_b, grads_b = run()
+    assert t.equal(out_a, out_b) and len(grads_a) == len(grads_b) and all(t.equal(a, b) for a, b in zip(grads_a, grads_b))
