@@ -10,6 +10,8 @@ Per propagate layer, on rank p (local node space: U_p user rows, then I item row
     1. item rows:  partial[i] = sum_{u in U_p} a(i,u) x[u]      local SpMM over rows [U_p, U_p+I)
     2. all-reduce(sum, fp32) of the I x D partials                 the ONE exchange of the layer
     3. user rows:  y[u] = sum_i a(u,i) x[i]  (+ epilogue)          local SpMM, overlaps with 2
+(step 1 of the NEXT layer reads only user rows, so in the default step form exchange 2 is waited for after it:
+each all-reduce has a user-row and an item-row product to hide behind)
 Backward mirrors it (the normalised bipartite adjacency is symmetric).  The BPR gradient of the
 item rows and the L2 weights are all-reduced once per step; every rank then applies the same Adam
 update to its item replica, so replicas stay bitwise identical.  User rows never leave their rank.
@@ -193,14 +195,26 @@ class ShardedLightGCNTrainer:
                                             count=self.n_nodes)
         cnt, cnt_u = cnt2[0:1], cnt2[1:2]
         # ---- forward: final only at this rank's batch rows, kept in sum_c
+        # The item-row product of a layer reads only the USER rows of its input, so it does not need the previous
+        # layer's exchange: each all-reduce is waited for one product later than it is issued and runs beside the
+        # user-row product of its own layer AND the item-row product of the next.
         ops.gather_rows(self.sum_c, tab, nodes, cnt)
-        x = tab
+        x, pending = tab, None   # pending: the exchange whose result is x[U:]
         for k in range(1, K):
             y = self.bufs[(k - 1) % 2]
-            self._layer(x, y, addend_users=None, s_users=None, scale=1.0, items_out=y[U:])
-            ops.gather_rows(self.sum_c, y, nodes, cnt, accumulate=True)
-            x = y
+            ops.spmm(self.a_items, x, Y=y[U:])
+            if pending is not None:
+                pending.wait()
+            if k > 1:
+                ops.gather_rows(self.sum_c, x, nodes, cnt, accumulate=True)   # layer k-1, now complete
+            work = self._allreduce(y[U:], async_op=True)
+            ops.spmm(self.a_users, x, Y=y[:U])
+            x, pending = y, work
         ops.spmm(self.a_items, x, Y=self.items_y)                      # layer K, item rows: every rank contributes
+        if pending is not None:
+            pending.wait()
+        if K > 1:
+            ops.gather_rows(self.sum_c, x, nodes, cnt, accumulate=True)
         work = self._allreduce(self.items_y, async_op=True)
         ops.spmm(self.a_users, x, addend=self.sum_c, S=self.sum_c, scale=c, row_list=nodes, n_list_dev=cnt_u)
         if work is not None:
@@ -221,6 +235,7 @@ class ShardedLightGCNTrainer:
         gmap_u = gmap[:U]
         cur = None
         users_done = False
+        layer_work = None  # the exchange whose result is cur[U:] (item rows of the previous backward layer)
         for i in range(K):
             nxt = self.bufs[i % 2]
             if i == 0:  # input = the batch gradient: item rows gather local batch users, user rows the non-zero item rows
@@ -233,7 +248,10 @@ class ShardedLightGCNTrainer:
                 work = self._allreduce(nxt[U:], async_op=True)
                 ops.spmm(self.a_users, self.items_g, addend=self.gc_c, S=nxt[:U], x_map=self.imap, addend_map=gmap_u)
             else:
-                ops.spmm(self.a_items, cur, Y=nxt[U:])
+                ops.spmm(self.a_items, cur, Y=nxt[U:])                      # reads the user rows of cur only
+                if layer_work is not None:
+                    layer_work.wait()
+                cur[U:].add_(self.items_g)                                  # previous layer's item rows, now complete
                 work = self._allreduce(nxt[U:], async_op=True)
                 if i == K - 1:  # user rows are local: their gradient goes straight into Adam (mi_adam_args)
                     hyp = dict(step=self.step_count + 1, lr=self.lr, beta1=self.betas[0], beta2=self.betas[1], eps=self.eps)
@@ -242,10 +260,11 @@ class ShardedLightGCNTrainer:
                     users_done = True
                 else:
                     ops.spmm(self.a_users, cur, addend=self.gc_c, S=nxt[:U], addend_map=gmap_u)
-            if work is not None:
-                work.wait()
-            nxt[U:].add_(self.items_g)
-            cur = nxt
+            layer_work, cur = work, nxt
+        if K >= 1:
+            if layer_work is not None:
+                layer_work.wait()
+            cur[U:].add_(self.items_g)
         for w in pending:  # K == 0: nothing consumed them above
             if w is not None:
                 w.wait()
