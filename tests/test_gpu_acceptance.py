@@ -1,0 +1,78 @@
+"""Acceptance runs with the reference's own configurations and floors (tests/test_acceptance_lightgcn.py:33-55,
+tests/test_acceptance_movielens.py:16-60): same hyper-parameters, same asserted bounds.  The datasets those tests
+download (H&M first 1 000 rows, MovieLens-1M first 1 000 ratings) are not reachable here; seeded synthetic graphs of
+the same size stand in (1 000 interactions, popularity-skewed items, users with repeat tastes)."""
+from dataclasses import replace
+
+import numpy as np
+import pytest
+import torch as t
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _tastes_graph(U, I, E, seed):
+    """E distinct (user, item) pairs in 'time' order: every user draws most items from one of 8 item groups."""
+    rng = np.random.default_rng(seed)
+    group_of_user = rng.integers(0, 8, U)
+    items_by_group = np.array_split(rng.permutation(I), 8)
+    pairs = set()
+    while len(pairs) < E:
+        u = int(rng.integers(0, U))
+        grp = items_by_group[group_of_user[u]] if rng.random() < 0.85 else items_by_group[int(rng.integers(0, 8))]
+        # inside a group the first items are the popular ones
+        i = int(grp[min(int(rng.zipf(1.6)) - 1, len(grp) - 1)])
+        pairs.add((u, i))
+    pairs = np.array(sorted(pairs), dtype=np.int64)
+    return pairs[rng.permutation(len(pairs))]
+
+
+def test_lightgcn_pipeline_acceptance():
+    """tests/test_acceptance_lightgcn.py: 1 000 iterations, k=12, D=32, 4 layers, B=128, lr 1e-3 decayed every 100,
+    lambda 1e-6; floors loss < -0.8, recall_test > 0.01, precision_test > 0.0008."""
+    from laplace_amd.config import lightgcn_config
+    from laplace_amd.run_pipeline_lightgcn import train
+    cfg = replace(lightgcn_config, epochs=1000, k=12, hidden_layer_size=32, learning_rate=1e-3, save_model=False,
+                  batch_size=128, num_iterations=4, eval_every=100, lr_decay_every=100, Lambda=1e-6, show_graph=False,
+                  num_recommendations=256)
+    pairs = _tastes_graph(300, 200, 1000, seed=42)
+    ei = t.from_numpy(pairs.T.copy())
+    t.manual_seed(42)
+    stats = train(cfg, edge_index=ei, num_users=300, num_articles=200, compat="bipartite", device=DEV, seed=42, verbose=False)
+    assert stats.loss < -0.8
+    assert stats.recall_test > 0.01
+    assert stats.precision_test > 0.0008
+
+
+def test_ranker_pipeline_acceptance():
+    """tests/test_acceptance_movielens.py: 100 epochs, k=12, 2 SAGE layers 128 -> 64 (add / sum), 2 linear layers,
+    lr 0.01, 128 users per batch, fan-out 64, 3 hops, positives 0.5, negatives 3.0, dropout 0.3, batch norm; floors
+    loss < 0.5, recall_test > 0.0015, precision_test > 0.01."""
+    from laplace_amd.config import link_pred_config
+    from laplace_amd.data import graph_io
+    from laplace_amd.data.matching import PopularItemsMatcher, UsersWithCommonItemsMatcher
+    from laplace_amd.run_pipeline import run_pipeline
+    cfg = replace(link_pred_config, matchers="movielens", wandb_enabled=False, epochs=100, k=12, num_gnn_layers=2,
+                  num_linear_layers=2, hidden_layer_size=128, encoder_layer_output_size=64, conv_agg_type="add",
+                  heterogeneous_prop_agg_type="sum", learning_rate=0.01, save_model=False, batch_size=128, num_neighbors=64,
+                  n_hop_neighbors=3, num_workers=1, candidate_pool_size=20, positive_edges_ratio=0.5,
+                  negative_edges_ratio=3.0, eval_every=5, save_every=0.2, profiler=None, evaluate_break_at=None,
+                  p_dropout_edges=0.2, p_dropout_features=0.3, batch_norm=True, neo4j=False)
+    U, I = 12, 400   # MovieLens-1M's first 1 000 ratings come from about a dozen heavy raters
+    # (the reference's recall / precision compare top-k POSITIONS with batch-local item ids — SURVEY Appendix A.8 —
+    # so, as upstream, these floors are cleared by the first samples of the batch only)
+    pairs = _tastes_graph(U, I, 1000, seed=7)
+    g = t.Generator().manual_seed(1)
+    cust_x = t.stack([t.randint(0, 2, (U,), generator=g), t.randint(0, 7, (U,), generator=g), t.randint(0, 21, (U,), generator=g)], 1)
+    art_x = t.stack([t.randint(0, 18, (I,), generator=g), t.randint(0, 80, (I,), generator=g)], 1)
+    splits = graph_io.build_splits(cust_x, art_x, pairs[:, 0], pairs[:, 1])
+    matchers = {}
+    for name in ("val", "test"):
+        _, users_adj, articles_adj = splits[name]
+        matchers[name] = [PopularItemsMatcher.from_adjacency(articles_adj, cfg.candidate_pool_size),
+                          UsersWithCommonItemsMatcher(users_adj, articles_adj, cfg.candidate_pool_size)]
+    stats = run_pipeline(cfg, splits=splits, matchers=matchers, device=DEV, seed=42, verbose=False)
+    assert stats.loss < 0.5
+    assert stats.recall_test > 0.0015
+    assert stats.precision_test > 0.01
