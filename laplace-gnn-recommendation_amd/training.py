@@ -1,9 +1,17 @@
-"""Ranker train / eval loops with the reference's signatures (training.py:19-106)."""
-from typing import List, Optional, Tuple
+"""Epoch drivers of the ranker.  Call surface of the reference's training.py (`train_with_dataloader`,
+`test_with_dataloader`: same arguments, same return types), different plumbing:
 
-import numpy as np
+  * the per-batch losses stay on the device and are read back ONCE per epoch — the reference synchronises the host
+    after every step (training.py:75), which here would also stall the sampler that prepares the next batch on a
+    side stream (data/device_sampler.py);
+  * the criterion object is built once per epoch, not once per batch.
+
+Objective and evaluation arithmetic are the reference's: BCE-with-logits (mean) on the label edges, Adam step per
+batch (training.py:19-34); recall / precision @ k of `infer`'s per-user candidate matrix (training.py:37-57).
+"""
+from typing import Iterable, List, Optional, Tuple
+
 import torch as t
-from torch import Tensor
 from torch.nn import Module
 from torch.optim import Optimizer
 
@@ -12,41 +20,56 @@ from .utils.get_info import select_properties
 from .utils.metrics_encoder_decoder import get_metrics_universal
 
 
-def _train(train_data, model: Module, optimizer: Optimizer) -> Tensor:
-    x, edge_index, edge_label_index, edge_label = select_properties(train_data)
-    criterion = t.nn.BCEWithLogitsLoss()
+class _EpochMeter:
+    """Collects 0-d device tensors; one host transfer when the values are asked for."""
+
+    def __init__(self) -> None:
+        self._vals: List[t.Tensor] = []
+
+    def add(self, value: t.Tensor) -> None:
+        self._vals.append(value.detach().reshape(()))
+
+    def tolist(self) -> List[float]:
+        return t.stack(self._vals).cpu().tolist() if self._vals else []
+
+
+def _optimise_on(batch, model: Module, optimizer: Optimizer, objective) -> t.Tensor:
+    features, graph, label_pairs, labels = select_properties(batch)
     optimizer.zero_grad()
-    out = model(x, edge_index, edge_label_index).view(-1)
-    loss = criterion(out, edge_label)
-    loss.backward()
+    logits = model(features, graph, label_pairs).view(-1)
+    value = objective(logits, labels)
+    value.backward()
     optimizer.step()
-    return loss
+    return value
+
+
+def train_with_dataloader(model: Module, optimizer: Optimizer, data_loader: Iterable, epoch: int, device: str
+                          ) -> List[float]:
+    """One pass over `data_loader`; the mean-BCE of every batch, in order."""
+    del epoch  # progress display only upstream
+    objective = t.nn.BCEWithLogitsLoss()
+    meter = _EpochMeter()
+    for batch in data_loader:
+        meter.add(_optimise_on(batch.to(device), model, optimizer, objective))
+    return meter.tolist()
 
 
 @t.no_grad()
-def _test(data, model, exclude_edge_indices: list, k: int) -> Tuple[float, float]:
-    x, edge_index_dict, edge_label_index, _ = select_properties(data)
-    output = model.infer(x, edge_index_dict, edge_label_index)
-    recall, precision, _ = get_metrics_universal(output, edge_index_dict[Constants.edge_key], edge_label_index,
-                                                 exclude_edge_indices, k=k)
+def _rank_quality(batch, model, k: int) -> Tuple[float, float]:
+    features, graph, label_pairs, _ = select_properties(batch)
+    per_user_scores = model.infer(features, graph, label_pairs)
+    recall, precision, _ndcg = get_metrics_universal(per_user_scores, graph[Constants.edge_key], label_pairs, [], k=k)
     return recall, precision
 
 
-def train_with_dataloader(model: Module, optimizer: Optimizer, data_loader, epoch: int, device: str) -> List[float]:
-    losses = []
-    for data in data_loader:
-        loss = _train(data.to(device), model, optimizer)
-        losses.append(loss.detach().cpu().item())
-    return losses
-
-
-def test_with_dataloader(mode: str, model, data_loader, device: str, k: int, break_at: Optional[int]
+def test_with_dataloader(mode: str, model, data_loader: Iterable, device: str, k: int, break_at: Optional[int]
                          ) -> Tuple[float, float]:
-    recalls, precisions = [], []
-    for i, data in enumerate(data_loader):
-        if break_at and i == break_at:
+    """Mean recall@k and precision@k over the batches of `data_loader` (at most `break_at` of them when given)."""
+    del mode  # "VAL" / "TEST": progress display only upstream
+    seen, recall_sum, precision_sum = 0, 0.0, 0.0
+    for index, batch in enumerate(data_loader):
+        if break_at and index == break_at:
             break
-        recall, precision = _test(data.to(device), model, [], k=k)
-        recalls.append(recall)
-        precisions.append(precision)
-    return float(np.mean(recalls)), float(np.mean(precisions))
+        r, p = _rank_quality(batch.to(device), model, k)
+        recall_sum, precision_sum, seen = recall_sum + r, precision_sum + p, seen + 1
+    return (recall_sum / seen, precision_sum / seen) if seen else (float("nan"), float("nan"))
