@@ -18,6 +18,9 @@
 
 namespace {
 
+#ifndef MI_TOPK_MFMA_UNROLL
+#define MI_TOPK_MFMA_UNROLL 64  // A/B on C2-sized items, k = 12 / 256: 8: 1.96 / 1.80, 16: 2.01 / 1.82, 32: 2.03 / 1.84, 64: 2.07 / 1.87
+#endif                          // M users/s; s_setprio around the MFMA run: no change
 #ifndef MI_TOPK_FUSED
 #define MI_TOPK_FUSED 1     // 0: always materialise the score block (A/B)
 #endif
@@ -448,7 +451,7 @@ __global__ __launch_bounds__(256, 2) void topk_scores_filter_kernel(FusedArgs a)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[i] = 0.f;
         if (n_mfma == FKC / 2) {
-#pragma unroll 16
+#pragma unroll MI_TOPK_MFMA_UNROLL
             for (int s = 0; s < FKC / 2; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * s], bp[2 * s], acc, 0, 0, 0);
         } else {
             for (int s = 0; s < n_mfma; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * s], bp[2 * s], acc, 0, 0, 0);
