@@ -385,7 +385,8 @@ __device__ __forceinline__ void fpanel_issue(float4 (&v)[8], const float* __rest
 // 2.01 -> 1.71 M users/s; 132-float rows with ds_write_b128 / ds_read_b128 (conflict-free both ways, one float4
 // per two MFMAs) plus a float compare against the threshold: 950 -> 1 010 us per chunk.  Stage timings of this
 // kernel per 2 621-query chunk: MFMA loop + barriers alone 586 us (114 TF/s), + panel prefetch / commit 721,
-// + threshold epilogue and staging 950.  The plain four-word write below stays.)
+// + threshold epilogue and staging 950.  A 128-item panel with two accumulators per wavefront (one workgroup per CU):
+// 2.06 -> 1.74 M users/s.  The plain four-word write below stays.)
 __device__ __forceinline__ void fpanel_commit(float (*panel)[FKPAD], const float4 (&v)[8], int tid) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
