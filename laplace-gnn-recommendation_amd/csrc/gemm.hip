@@ -106,6 +106,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(MiGemmArgs g) {
 // dimension (dX = dY @ W, dW = dY^T @ X): the float4 is loaded along whichever dimension is contiguous
 // and written to the same [row][k] LDS panel.  Rows are padded to 129 floats: conflict-free fragment
 // reads (bank = (row + k) mod 32).
+#ifndef MI_GEMM_MFMA_UNROLL
+#define MI_GEMM_MFMA_UNROLL 16  // 64: +1 % (tools/bench_gemm.py: 2 621 x 100 K x 128 53.0 -> 53.3, 4 096^3 72.4 -> 72.9 TF/s)
+#endif
 constexpr int KC = 128, KPAD = 129;
 
 // A 64 x KC panel of an operand whose element (row, k) sits at base[row * s_row + k * s_k]; rows >= n_rows
@@ -186,7 +189,7 @@ __global__ __launch_bounds__(256, 2) void gemm_fast_kernel(MiGemmArgs g) {
         const float* ap = &As[wm * 32 + (lane & 31)][lane >> 5];
         const float* bp = &Bs[wn * 32 + (lane & 31)][lane >> 5];
         if (kw == KC) {
-#pragma unroll 16
+#pragma unroll MI_GEMM_MFMA_UNROLL
             for (int s = 0; s < KC / 2; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * s], bp[2 * s], acc, 0, 0, 0);
         } else {
             // the panel is zero beyond kw, so an odd tail pairs its last k with a zero
