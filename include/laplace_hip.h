@@ -338,10 +338,15 @@ int    mi_gemm_f32(int32_t trans_a, int32_t trans_b, int64_t m, int64_t n, int64
  * replaces: make_predictions_for_user at utils/metrics_lightgcn.py:125-142
  *           (scores = e_u @ E_i^T; topk(k+|ignore|); order-preserving setdiff; [:k]).
  * scores[u, i] = fmaf-chain over d ascending of user_emb[uid[u], :] . item_emb[i, :]
- * (bitwise equal to oracle/score_ref.c); excluded items (excl_ptr/excl_idx: CSR by
+ * (bitwise equal to oracle/spmm_ref.c:ref_scores_fma_f32); excluded items (excl_ptr/excl_idx: CSR by
  * position in uid, item ids sorted or not) never appear; output int64[n_q, k] item ids
  * by descending score, ties by ascending item id; -1 pads when fewer than k remain.
- * k <= 1024.  Workspace holds the [n_q, n_items] fp32 score block: callers chunk n_q.
+ * k <= 1024.  For n_items >= 32 768 and d <= 128 (multiple of 4, 16-byte aligned tables) the score block is never
+ * written: scores are compared in the MFMA epilogue with a per-row threshold taken from a 4 096-item sample and only the
+ * survivors are kept; a row whose survivors are fewer than k or overflow its list recomputes its scores and takes
+ * the exact multi-pass selection, so the result is the same as on the materialised path (smaller item sets).
+ * Workspace (mi_topk_workspace_bytes): address space for the [n_q, n_items] fp32 score block (touched only by
+ * fallback rows on the fused path) + sample scores, exclusion bitmap, candidate lists: callers chunk n_q.
  * ---------------------------------------------------------------------------------- */
 size_t mi_topk_workspace_bytes(int64_t n_q, int64_t n_items, int64_t k);
 int    mi_topk_excl_f32(int64_t n_q, int64_t n_items, int64_t d, int64_t k,
