@@ -193,3 +193,26 @@ def test_reversed_relation_reuses_the_forward_csrs():
     del rev._reverse_of  # plain tensors: four sorts
     out_b, grads_b = run()
     assert t.equal(out_a, out_b) and len(grads_a) == len(grads_b) and all(t.equal(a, b) for a, b in zip(grads_a, grads_b))
+
+
+def test_linkneighbor_loader_call_shape_is_the_device_sampler():
+    """`LinkNeighborLoader(data, num_neighbors=[n] * hops, batch_size=..., shuffle=...)` (the keyword surface of
+    data/linkneighbor_loader.py:50-64) yields the batches of DeviceGraphSampler with the same settings."""
+    from laplace_amd.data.device_sampler import DeviceGraphSampler
+    from laplace_amd.data.linkneighbor_loader import LinkNeighborLoader
+    from laplace_amd.utils.constants import Constants
+    graph, users, articles = _graph(seed=61, U=120, A=70, E=2000)
+    cfg = _cfg(n_hop_neighbors=3, num_neighbors=5)
+    want = DeviceGraphSampler(cfg, graph, users, articles, batch_size=16, device=DEV, seed=11, shuffle=False)
+    got = LinkNeighborLoader(graph, num_neighbors=[5] * 3, batch_size=16, edge_label_index=(Constants.edge_key, None),
+                             edge_label=None, directed=False, replace=False, shuffle=False, num_workers=1, pin_memory=True,
+                             k=cfg.k, positive_edges_ratio=0.5, negative_edges_ratio=3.0, device=DEV, seed=11)
+    n = 0
+    for a, b in zip(want, got):
+        for key in ("edge_index", "edge_label_index", "edge_label"):
+            assert t.equal(a[Constants.edge_key][key], b[Constants.edge_key][key])
+        assert t.equal(a[Constants.node_user].n_id, b[Constants.node_user].n_id)
+        n += 1
+    assert n == len(want) == 8
+    with pytest.raises(ValueError):
+        LinkNeighborLoader(graph, num_neighbors=[5, 3], batch_size=16, device=DEV)
