@@ -14,7 +14,7 @@ import torch as t
 from torch import Tensor, nn
 
 from .. import ops
-from ..sparse import SparseTensor
+from ..sparse import SparseTensor, as_sparse_tensor
 
 
 def _joint_view(a: Tensor, b: Tensor) -> Optional[Tensor]:
@@ -144,8 +144,7 @@ class LightGCN(nn.Module):
 
     def forward(self, edge_index: SparseTensor):
         """Returns e_u^K, e_u^0, e_i^K, e_i^0 exactly like model/lightgcn.py:46-80."""
-        if not isinstance(edge_index, SparseTensor):
-            raise TypeError("edge_index must be a laplace_amd.sparse.SparseTensor(row=, col=, sparse_sizes=)")
+        edge_index = as_sparse_tensor(edge_index)   # also torch sparse CSR / COO and torch_sparse-like objects
         n = self.num_users + self.num_items
         if edge_index.sparse_sizes() != (n, n):
             raise ValueError(f"adjacency must be ({n}, {n}), got {edge_index.sparse_sizes()}")

@@ -98,3 +98,39 @@ def _with_self_loops(a: SparseTensor) -> SparseTensor:
     if val is not None:
         v = t.cat([val[off], t.ones(n, dtype=val.dtype, device=val.device)])
     return SparseTensor(t.cat([row[off], loop]), t.cat([col[off], loop]), a._sizes, v, a.is_symmetric)
+
+
+def as_sparse_tensor(adj) -> SparseTensor:
+    """What `LightGCN.forward` accepts as its `edge_index`: this module's SparseTensor, a
+    `torch.sparse_csr_tensor` / `torch.sparse_coo_tensor`, or any object with torch_sparse's `.coo()` and
+    `.sparse_sizes()` (the real `torch_sparse.SparseTensor` where it is installed).  Edge values other than ones are
+    not part of the reference's call (data/lightgcn_loader.py:65-79 builds unit adjacencies) and are rejected.
+    Foreign objects are converted once and the result is remembered on them."""
+    if isinstance(adj, SparseTensor):
+        return adj
+    cached = getattr(adj, "_laplace_adj", None)
+    if cached is not None:
+        return cached
+    if isinstance(adj, Tensor) and adj.layout in (t.sparse_csr, t.sparse_coo):
+        if adj.layout == t.sparse_csr:
+            crow, col, val = adj.crow_indices(), adj.col_indices(), adj.values()
+            row = t.repeat_interleave(t.arange(adj.shape[0], device=col.device), crow[1:] - crow[:-1])
+        else:
+            # not coalesced on purpose: duplicate entries are kept, as torch_sparse keeps them
+            idx, val = adj._indices(), adj._values()
+            row, col = idx[0], idx[1]
+        sizes = (int(adj.shape[0]), int(adj.shape[1]))
+    elif hasattr(adj, "coo") and hasattr(adj, "sparse_sizes"):
+        row, col, val = adj.coo()
+        sizes = tuple(int(x) for x in adj.sparse_sizes())
+    else:
+        raise TypeError("edge_index must be a SparseTensor(row=, col=, sparse_sizes=), a torch sparse CSR/COO tensor, or an "
+                        f"object with .coo() / .sparse_sizes(); got {type(adj)}")
+    if val is not None and val.numel() and not bool((val == 1).all()):
+        raise ValueError("the adjacency must carry unit values (gcn_norm supplies the edge weights)")
+    out = SparseTensor(row=row, col=col, sparse_sizes=sizes)
+    try:
+        adj._laplace_adj = out
+    except AttributeError:
+        pass
+    return out

@@ -779,6 +779,44 @@ def test_adam_in_the_backward_epilogue_equals_separate_adam(K):
     assert (sep.m - fused.m).abs().max() <= 1e-7 and (sep.v - fused.v).abs().max() <= 1e-9
 
 
+def test_forward_accepts_torch_sparse_tensors_and_torch_sparse_like_objects():
+    """`edge_index` may be this repo's SparseTensor, a torch sparse CSR / COO tensor, or an object with
+    torch_sparse's .coo() / .sparse_sizes(); all give the same four outputs."""
+    from laplace_amd.model.lightgcn import LightGCN
+    from laplace_amd.sparse import SparseTensor
+    U, I, D, K = 70, 50, 32, 2
+    n = U + I
+    g = t.Generator().manual_seed(3)
+    u, i = t.randint(0, U, (600,), generator=g), t.randint(0, I, (600,), generator=g)
+    row, col = t.cat([u, i + U]).to(DEV), t.cat([i + U, u]).to(DEV)   # duplicates on purpose
+    t.manual_seed(0)
+    model = LightGCN(U, I, D, K).to(DEV)
+    want = [x.detach().clone() for x in model(SparseTensor(row=row, col=col, sparse_sizes=(n, n)))]
+    coo = t.sparse_coo_tensor(t.stack([row, col]), t.ones(row.numel(), device=DEV), (n, n))
+    order = t.argsort(row * n + col)
+    crow = t.zeros(n + 1, dtype=t.int64, device=DEV)
+    crow[1:] = t.cumsum(t.bincount(row, minlength=n), 0)
+    csr = t.sparse_csr_tensor(crow, col[order], t.ones(row.numel(), device=DEV), (n, n))
+
+    class Foreign:  # the two methods of torch_sparse.SparseTensor the conversion uses
+        def coo(self):
+            return row, col, None
+
+        def sparse_sizes(self):
+            return (n, n)
+
+    for adj in (coo, csr, Foreign()):
+        got = model(adj)
+        assert all(t.equal(a.detach(), b) for a, b in zip(got, want))
+    foreign = Foreign()
+    model(foreign)
+    assert foreign._laplace_adj is not None  # converted once
+    with pytest.raises(ValueError):
+        model(t.sparse_coo_tensor(t.stack([row, col]), t.full((row.numel(),), 2.0, device=DEV), (n, n)))
+    with pytest.raises(TypeError):
+        model(t.stack([row, col]))
+
+
 # ---------------------------------------------------------------------------- BASELINE.json configs[0] (SURVEY C1)
 @pytest.mark.parametrize("compat", ["reference", "bipartite"])
 def test_c1_movielens_shaped_parity(compat):
