@@ -312,6 +312,34 @@ def test_spmm_plan_without_split_rows_and_with_every_row_split(band):
     assert t.allclose(Y2.cpu(), want, atol=2e-5, rtol=1e-5)
 
 
+try:
+    from hypothesis import given, settings, strategies as st
+
+    @settings(max_examples=20, deadline=None)
+    @given(n_rows=st.integers(1, 200), n_cols=st.integers(1, 200), nnz=st.integers(0, 3000),
+           d=st.sampled_from([4, 8, 32, 64, 100, 128, 260]), chunk=st.sampled_from([1, 7, 64, 256]),
+           band=st.sampled_from([0, 1, 13, 64]), seed=st.integers(0, 2**31 - 1))
+    def test_spmm_property_any_shape_any_plan(n_rows, n_cols, nnz, d, chunk, band, seed):
+        """Random shapes / densities / plans (SURVEY 8c iv, on the device): plan-less and planned products agree with the
+        oracle; planned results are bitwise reproducible."""
+        ops = _ops()
+        row, col = _rand_graph(n_rows, n_cols, nnz, seed=seed % 100000)
+        a = _csr_with_vals(row, col, n_rows, n_cols, seed=seed % 1000)
+        X = t.randn(n_cols, d, generator=t.Generator().manual_seed(seed % 7919)).to(DEV)
+        want = _oracle_spmm(a, X)
+        scale = max(1.0, float(want.abs().max()))
+        Y0 = t.full((n_rows, d), float("nan"), device=DEV)
+        ops.spmm(a, X, Y=Y0)
+        assert float((Y0.cpu() - want).abs().max()) <= 2e-5 * scale
+        a.plan = ops.build_spmm_plan(a, chunk=chunk, band=band)
+        Y1, Y2 = t.full((n_rows, d), float("nan"), device=DEV), t.empty(n_rows, d, device=DEV)
+        ops.spmm(a, X, Y=Y1)
+        ops.spmm(a, X, Y=Y2)
+        assert t.equal(Y1, Y2) and float((Y1.cpu() - want).abs().max()) <= 2e-5 * scale
+except ImportError:  # pragma: no cover
+    pass
+
+
 def test_spmm_epilogue_forms_and_strides():
     ops = _ops()
     n, d = 1500, 64

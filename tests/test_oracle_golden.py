@@ -165,3 +165,37 @@ def test_sampler_oracle_is_structured_negative_sampling_in_distribution():
     # user frequency follows edge counts (edges are drawn uniformly with replacement)
     deg = np.diff(rowptr.numpy())
     assert np.abs(counts.sum(1) / counts.sum() - deg / deg.sum()).max() < 0.02
+
+
+# ---- property test (SURVEY 8c iv): the oracle's CSR SpMM against torch.sparse.mm and a dense product ----------
+try:
+    from hypothesis import given, settings, strategies as st
+    _HAVE_HYPOTHESIS = True
+except Exception:  # pragma: no cover
+    _HAVE_HYPOTHESIS = False
+
+
+if _HAVE_HYPOTHESIS:
+    @settings(max_examples=25, deadline=None)
+    @given(n_rows=st.integers(1, 40), n_cols=st.integers(1, 40), nnz=st.integers(0, 300), d=st.sampled_from([1, 3, 4, 16, 33]),
+           seed=st.integers(0, 2**31 - 1))
+    def test_oracle_spmm_property_vs_torch_sparse_and_dense(n_rows, n_cols, nnz, d, seed):
+        """Duplicates kept (torch_sparse semantics), empty rows, widths that are not multiples of 4."""
+        g = t.Generator().manual_seed(seed)
+        row = t.randint(0, n_rows, (nnz,), generator=g)
+        col = t.randint(0, n_cols, (nnz,), generator=g)
+        val = t.rand(nnz, generator=g) - 0.4
+        rowptr, cs, perm = R.sparse_tensor_csr(row, col, n_rows, n_cols)
+        vs = val[perm]
+        X = t.randn(n_cols, d, generator=g)
+        dense = t.zeros(n_rows, n_cols, dtype=t.float64)
+        dense.index_put_((row, col), val.double(), accumulate=True)
+        want = dense @ X.double()
+        got_c = R.spmm_c(rowptr, cs, vs, X)
+        got_t = R.spmm_torch(rowptr, cs, vs, X)
+        coo = t.sparse_coo_tensor(t.stack([row, col]), val, (n_rows, n_cols))
+        got_sp = t.sparse.mm(coo, X)
+        tol = 1e-5 * max(1.0, float(want.abs().max()))
+        assert (got_c.double() - want).abs().max() <= tol
+        assert (got_t.double() - want).abs().max() <= tol
+        assert (got_sp.double() - want).abs().max() <= tol
