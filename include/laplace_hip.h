@@ -277,15 +277,16 @@ int mi_sample_bpr_batch(int64_t batch, int64_t nnz,
  *   loss = -mean_b softplus(x_b) + lambda * sum_b (|u0_b|^2+|p0_b|^2+|n0_b|^2)   (rows of e0)
  * final_emb / e0: [n_users + n_items, d] tables (item i is row n_users + i).
  * loss_out: device float[1], written (fixed-order reduction).
- * When g_final is non-null (dense [n, d], zeroed by the caller) it receives
- *   g_final[row,:] += g_scale * dL/dfinal[row,:]
+ * When g_final is non-null (dense [n, d], ALL ZERO on entry) the rows the batch touches are written with
+ *   g_final[row,:] = g_scale * dL/dfinal[row,:]          (untouched rows stay zero)
  * and reg_w (float[n], zeroed by the caller; nullable) receives, per occurrence of a
  * node in the batch, reg_w[row] += 2*lambda*reg_scale, so that the L2 term's gradient is
  * reg_w[row] * e0[row,:] (applied by mi_adam_dense_f32 or by the caller).
  * node_map (nullable, from mi_batch_nodes_i32): final_emb and g_final are then COMPACT
  * [count, d] tables addressed by node_map[node]; e0 and reg_w stay addressed by node id.
- * Repeated users/items in a batch are combined with float atomics (order-dependent in
- * the last bits); everything else is deterministic.
+ * No float atomics on the gradient: the 3*batch row references are radix-sorted by row, summed in
+ * 64-reference chunks in reference order and combined in chunk order, one writer per row — the
+ * result is bitwise reproducible (reg_w adds equal constants, whose order cannot matter).  d <= 512.
  * ---------------------------------------------------------------------------------- */
 size_t mi_bpr_workspace_bytes(int64_t batch);
 int    mi_bpr_fwd_bwd_f32(int64_t batch, int64_t d, int64_t n_users,

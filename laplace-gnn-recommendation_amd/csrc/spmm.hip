@@ -592,7 +592,6 @@ int mi_spmm_plan_count(int64_t n_rows, int64_t n_cols, const int32_t* rowptr, co
                        int32_t chunk, int32_t band, void* ws, size_t ws_bytes, mi_spmm_plan_info* info,
                        mi_stream_t stream) {
     MI_CHECK_ARG(n_rows >= 0 && n_cols >= 0 && rowptr && chunk > 0 && band >= 0 && ws && info);
-    MI_CHECK_ARG(band == 0 || col);
     if (n_rows >= INT32_MAX || n_cols >= INT32_MAX) return MI_ERR_TOO_LARGE;
     hipStream_t s = (hipStream_t)stream;
     memset(info, 0, sizeof(*info));
@@ -603,6 +602,7 @@ int mi_spmm_plan_count(int64_t n_rows, int64_t n_cols, const int32_t* rowptr, co
     MI_HIP(hipMemcpyAsync(&nnz32, rowptr + n_rows, sizeof(int32_t), hipMemcpyDeviceToHost, s));
     MI_HIP(hipStreamSynchronize(s));
     const int64_t nnz = nnz32;
+    MI_CHECK_ARG(band == 0 || col || nnz == 0);  // an empty adjacency has no columns to band
     PlanWs w{};
     {
         MiArena ar(ws, ws_bytes);

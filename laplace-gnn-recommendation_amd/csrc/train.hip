@@ -73,7 +73,7 @@ __global__ __launch_bounds__(kBlock) void bpr_slot_kernel(
     const float* __restrict__ fin, int64_t ldf, const float* __restrict__ e0, int64_t lde,
     float inv_batch, float g_scale, float reg_coef /* = lambda*reg_scale */,
     float* __restrict__ softplus_out, float* __restrict__ reg_out,
-    float* __restrict__ g_final, int64_t ldg, float* __restrict__ reg_w,
+    float* __restrict__ coef_out, float* __restrict__ reg_w,
     const int32_t* __restrict__ node_map) {
     const int64_t b = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / MI_WAVE;
     if (b >= batch) return;
@@ -105,18 +105,9 @@ __global__ __launch_bounds__(kBlock) void bpr_slot_kernel(
         softplus_out[b] = softplus_ref(x);
         reg_out[b] = rg;
     }
-    if (g_final) {
-        // loss = -mean softplus(x)  =>  dL/dx = -sigmoid'(x)/B
-        const float coef = -softplus_grad_ref(x) * inv_batch * g_scale;
-        float* gu = g_final + fu * ldg;
-        float* gp = g_final + fp * ldg;
-        float* gn = g_final + fn * ldg;
-        for (int k = lane; k < d; k += MI_WAVE) {
-            float a = uf[k], pk = pf[k], nk = nf[k];
-            atomicAdd(gu + k, coef * (pk - nk));
-            atomicAdd(gp + k, coef * a);
-            atomicAdd(gn + k, -coef * a);
-        }
+    if (coef_out && lane == 0) {
+        // loss = -mean softplus(x)  =>  dL/dx = -sigmoid'(x)/B; consumed by the segmented gradient kernels below
+        coef_out[b] = -softplus_grad_ref(x) * inv_batch * g_scale;
     }
     if (reg_w && lane == 0) {
         const float w = 2.0f * reg_coef;
@@ -127,6 +118,150 @@ __global__ __launch_bounds__(kBlock) void bpr_slot_kernel(
 }
 
 // Single block, fixed order: loss = -sum(softplus)/B + lambda*sum(reg).
+// ---- gradient of the final embeddings, without float atomics -------------------------------------------------
+// A batch touches 3B rows with repeats (the most popular item is the positive of hundreds of samples).  The 3B
+// references (sample b, role) are keyed by the row they touch — its compact slot under node_map, its node id otherwise —
+// and sorted (stable radix sort: the references of a row stay in (role, b) order).  The sorted list is cut into chunks
+// of 64 references, one wavefront each: a run of equal keys that lies inside a chunk is summed in order and added to its
+// row by that wavefront alone; a run that crosses chunk borders leaves one partial row per chunk, and the wavefront of
+// the chunk where the run starts adds those up in chunk order.  One writer per row, fixed orders throughout: the whole
+// train step is bitwise reproducible.
+constexpr int kRefChunk = 64;
+constexpr int kMaxDPerLane = 8;  // d <= 512
+
+__global__ void bpr_refs_kernel(int64_t batch, int64_t n_users, const int64_t* __restrict__ users,
+                                const int64_t* __restrict__ pos, const int64_t* __restrict__ neg,
+                                const int32_t* __restrict__ node_map, uint32_t* __restrict__ keys,
+                                uint32_t* __restrict__ refs) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // reference id = role * batch + b
+    if (r >= 3 * batch) return;
+    const int role = (int)(r / batch);
+    const int64_t b = r - role * batch;
+    const int64_t node = role == 0 ? users[b] : (role == 1 ? n_users + pos[b] : n_users + neg[b]);
+    keys[r] = (uint32_t)(node_map ? node_map[node] : node);
+    refs[r] = (uint32_t)r;
+}
+
+template <int VPT>  // floats of a row per lane: ceil(d / 64)
+__global__ __launch_bounds__(kBlock) void bpr_chunk_kernel(
+    int64_t batch, int d, int64_t n_users, const int64_t* __restrict__ users, const int64_t* __restrict__ pos,
+    const int64_t* __restrict__ neg, const float* __restrict__ fin, int64_t ldf, const float* __restrict__ coef,
+    const uint32_t* __restrict__ keys, const uint32_t* __restrict__ refs, const int32_t* __restrict__ node_map,
+    float* __restrict__ g_final, int64_t ldg, float* __restrict__ part_head, float* __restrict__ part_tail) {
+    const int64_t n_ref = 3 * batch;
+    const int64_t chunk = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / MI_WAVE;
+    const int64_t j0 = chunk * kRefChunk;
+    if (j0 >= n_ref) return;
+    const int lane = mi_lane();
+    const int n_here = (int)min((int64_t)kRefChunk, n_ref - j0);
+    // this lane's reference: destination key, up to two (source row, weight) terms
+    uint32_t my_key = 0xFFFFFFFFu;
+    int64_t srcA = 0, srcB = 0;
+    float wA = 0.f, wB = 0.f;
+    if (lane < n_here) {
+        my_key = keys[j0 + lane];
+        const uint32_t r = refs[j0 + lane];
+        const int role = (int)(r / batch);
+        const int64_t b = r - (int64_t)role * batch;
+        const float c = coef[b];
+        const int64_t u = users[b], p = n_users + pos[b], n = n_users + neg[b];
+        const int64_t fu = node_map ? node_map[u] : u, fp = node_map ? node_map[p] : p, fn = node_map ? node_map[n] : n;
+        if (role == 0) { srcA = fp; wA = c; srcB = fn; wB = -c; }   // d x / d u = p - n
+        else if (role == 1) { srcA = fu; wA = c; }
+        else { srcA = fu; wA = -c; }
+    }
+    const bool head_open = j0 > 0 && keys[j0 - 1] == __shfl(my_key, 0, MI_WAVE);
+    const bool next_same = (j0 + n_here < n_ref) && keys[j0 + n_here] == __shfl(my_key, n_here - 1, MI_WAVE);
+    float acc[VPT];
+#pragma unroll
+    for (int v = 0; v < VPT; ++v) acc[v] = 0.f;
+    int run_start = 0;
+    constexpr int U = 8;  // references whose source rows are in flight together
+    for (int q0 = 0; q0 < n_here; q0 += U) {
+        float xa[U][VPT], xb[U][VPT], wa[U], wb[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int q = min(q0 + u, n_here - 1);
+            const bool live = q0 + u < n_here;
+            wa[u] = live ? __shfl(wA, q, MI_WAVE) : 0.f;
+            wb[u] = live ? __shfl(wB, q, MI_WAVE) : 0.f;
+            const float* ra = fin + __shfl(srcA, q, MI_WAVE) * ldf;
+            const float* rb = fin + __shfl(srcB, q, MI_WAVE) * ldf;
+#pragma unroll
+            for (int v = 0; v < VPT; ++v) {
+                const int k = lane + v * MI_WAVE;
+                xa[u][v] = (live && k < d) ? ra[k] : 0.f;
+                xb[u][v] = (wb[u] != 0.f && k < d) ? rb[k] : 0.f;   // wave-uniform condition
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int q = q0 + u;
+            if (q >= n_here) break;
+            const uint32_t kq = __shfl(my_key, q, MI_WAVE);
+#pragma unroll
+            for (int v = 0; v < VPT; ++v) {
+                acc[v] = fmaf(wa[u], xa[u][v], acc[v]);
+                if (wb[u] != 0.f) acc[v] = fmaf(wb[u], xb[u][v], acc[v]);
+            }
+            const bool last_of_run = (q + 1 == n_here) || __shfl(my_key, q + 1, MI_WAVE) != kq;
+            if (!last_of_run) continue;
+            const bool from_prev = run_start == 0 && head_open;
+            const bool into_next = (q + 1 == n_here) && next_same;
+            float* dst;
+            if (from_prev) dst = part_head + chunk * d;          // finished by the chunk where the run starts
+            else if (into_next) dst = part_tail + chunk * d;     // this chunk starts the run and finishes it below
+            else dst = g_final + (int64_t)kq * ldg;              // the run lies inside this chunk: the row's only writer
+#pragma unroll
+            for (int v = 0; v < VPT; ++v) {
+                const int k = lane + v * MI_WAVE;
+                if (k < d) dst[k] = acc[v];   // g_final is zero on entry (header contract): a store, not a read-modify-write
+                acc[v] = 0.f;
+            }
+            run_start = q + 1;
+        }
+    }
+}
+
+// One wavefront per chunk whose trailing run starts in it and runs on: tail partial + the head partials of the following
+// chunks, in chunk order, added to the row.
+template <int VPT>
+__global__ __launch_bounds__(kBlock) void bpr_combine_kernel(int64_t batch, int d, const uint32_t* __restrict__ keys,
+                                                             const float* __restrict__ part_head,
+                                                             const float* __restrict__ part_tail,
+                                                             float* __restrict__ g_final, int64_t ldg) {
+    const int64_t n_ref = 3 * batch;
+    const int64_t chunk = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / MI_WAVE;
+    const int64_t j0 = chunk * kRefChunk;
+    if (j0 >= n_ref) return;
+    const int64_t j_last = min(j0 + kRefChunk, n_ref) - 1;
+    if (j_last + 1 >= n_ref) return;                       // nothing after this chunk
+    const uint32_t row = keys[j_last];
+    if (keys[j_last + 1] != row) return;                   // the trailing run ends here
+    if (keys[j0] == row && j0 > 0 && keys[j0 - 1] == row) return;  // the run started in an earlier chunk: not the owner
+    const int lane = mi_lane();
+    float acc[VPT];
+#pragma unroll
+    for (int v = 0; v < VPT; ++v) {
+        const int k = lane + v * MI_WAVE;
+        acc[v] = k < d ? part_tail[chunk * d + k] : 0.f;
+    }
+    for (int64_t nb = chunk + 1; nb * kRefChunk < n_ref && keys[nb * kRefChunk] == row; ++nb) {
+#pragma unroll
+        for (int v = 0; v < VPT; ++v) {
+            const int k = lane + v * MI_WAVE;
+            if (k < d) acc[v] += part_head[nb * d + k];
+        }
+        if (keys[min((nb + 1) * kRefChunk, n_ref) - 1] != row) break;   // the run ends inside chunk nb
+    }
+    float* dst = g_final + (int64_t)row * ldg;
+#pragma unroll
+    for (int v = 0; v < VPT; ++v) {
+        const int k = lane + v * MI_WAVE;
+        if (k < d) dst[k] = acc[v];
+    }
+}
+
 __global__ __launch_bounds__(1024) void bpr_finish_kernel(int64_t batch,
                                                           const float* __restrict__ softplus_v,
                                                           const float* __restrict__ reg_v,
@@ -320,8 +455,15 @@ int mi_scatter_rows_f32(int64_t n_max, const int32_t* n_dev, const int32_t* begi
     return mi_launch_status();
 }
 
+static size_t bpr_sort_tmp_bytes(int64_t batch) { return ((size_t)1 << 20) + mi_align_up((size_t)3 * batch * 2, 256); }
+
 size_t mi_bpr_workspace_bytes(int64_t batch) {
-    return 2 * mi_align_up((size_t)(batch > 0 ? batch : 1) * sizeof(float), 256);
+    const size_t b = (size_t)(batch > 0 ? batch : 1);
+    const size_t chunks = (3 * b + 63) / 64;
+    // softplus, reg, coef per sample; (key, reference) double buffers of the 3B row references; rocPRIM scratch;
+    // head / tail partial rows per 64-reference chunk (d <= 512)
+    return 3 * mi_align_up(b * sizeof(float), 256) + 4 * mi_align_up(3 * b * sizeof(uint32_t), 256) + bpr_sort_tmp_bytes((int64_t)b) +
+           2 * mi_align_up(chunks * 512 * sizeof(float), 256);
 }
 
 int mi_bpr_fwd_bwd_f32(int64_t batch, int64_t d, int64_t n_users, const int64_t* users,
@@ -332,16 +474,57 @@ int mi_bpr_fwd_bwd_f32(int64_t batch, int64_t d, int64_t n_users, const int64_t*
     MI_CHECK_ARG(batch > 0 && d > 0 && n_users >= 0);
     MI_CHECK_ARG(users && pos && neg && final_emb && e0 && loss_out && ws);
     MI_CHECK_ARG(ldf >= d && lde >= d && (!g_final || ldg >= d));
+    if (3 * batch >= INT32_MAX) return MI_ERR_TOO_LARGE;
+    if (g_final && d > MI_WAVE * kMaxDPerLane) return MI_ERR_UNSUPPORTED;
     if (ws_bytes < mi_bpr_workspace_bytes(batch)) return MI_ERR_WORKSPACE;
+    const int64_t n_ref = 3 * batch, n_chunks = mi_ceil_div(n_ref, kRefChunk);
     MiArena arena(ws, ws_bytes);
     float* spv = arena.take<float>(batch);
     float* rgv = arena.take<float>(batch);
+    float* coef = arena.take<float>(batch);
+    uint32_t* k0 = arena.take<uint32_t>(n_ref);
+    uint32_t* k1 = arena.take<uint32_t>(n_ref);
+    uint32_t* r0 = arena.take<uint32_t>(n_ref);
+    uint32_t* r1 = arena.take<uint32_t>(n_ref);
+    const size_t tmp_cap = bpr_sort_tmp_bytes(batch);
+    char* tmp = arena.take<char>(tmp_cap);
+    float* part_head = arena.take<float>((size_t)n_chunks * 512);
+    float* part_tail = arena.take<float>((size_t)n_chunks * 512);
+    if (!spv || !rgv || !coef || !k0 || !k1 || !r0 || !r1 || !tmp || !part_head || !part_tail) return MI_ERR_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     const float inv_b = 1.0f / (float)batch;
     dim3 g((unsigned)mi_ceil_div(batch * MI_WAVE, kBlock));
     hipLaunchKernelGGL(bpr_slot_kernel, g, dim3(kBlock), 0, s, batch, (int)d, n_users, users, pos, neg,
-                       final_emb, ldf, e0, lde, inv_b, g_scale, reg_scale * lambda, spv, rgv, g_final, ldg,
-                       reg_w, node_map);
+                       final_emb, ldf, e0, lde, inv_b, g_scale, reg_scale * lambda, spv, rgv,
+                       g_final ? coef : nullptr, reg_w, node_map);
+    if (g_final) {
+        hipLaunchKernelGGL(bpr_refs_kernel, dim3((unsigned)mi_ceil_div(n_ref, 256)), dim3(256), 0, s, batch, n_users, users,
+                           pos, neg, node_map, k0, r0);
+        // compact slots are < 3B; node ids need all 32 bits
+        unsigned bits = 32;
+        if (node_map) {
+            bits = 1;
+            while (((int64_t)1 << bits) < n_ref) ++bits;
+        }
+        rocprim::double_buffer<uint32_t> keys(k0, k1), refs(r0, r1);
+        size_t need = 0;
+        MI_HIP(rocprim::radix_sort_pairs(nullptr, need, keys, refs, (size_t)n_ref, 0, bits, s));
+        if (need > tmp_cap) return MI_ERR_WORKSPACE;
+        MI_HIP(rocprim::radix_sort_pairs(tmp, need, keys, refs, (size_t)n_ref, 0, bits, s));
+        dim3 gc((unsigned)mi_ceil_div(n_chunks * MI_WAVE, kBlock));
+#define MI_BPR_GO(V)                                                                                                       \
+    do {                                                                                                                    \
+        hipLaunchKernelGGL(bpr_chunk_kernel<V>, gc, dim3(kBlock), 0, s, batch, (int)d, n_users, users, pos, neg, final_emb, \
+                           ldf, coef, keys.current(), refs.current(), node_map, g_final, ldg, part_head, part_tail);       \
+        hipLaunchKernelGGL(bpr_combine_kernel<V>, gc, dim3(kBlock), 0, s, batch, (int)d, keys.current(), part_head,         \
+                           part_tail, g_final, ldg);                                                                        \
+    } while (0)
+        if (d <= 64) MI_BPR_GO(1);
+        else if (d <= 128) MI_BPR_GO(2);
+        else if (d <= 256) MI_BPR_GO(4);
+        else MI_BPR_GO(8);
+#undef MI_BPR_GO
+    }
     hipLaunchKernelGGL(bpr_finish_kernel, dim3(1), dim3(1024), 0, s, batch, spv, rgv, inv_b, lambda, loss_out);
     return mi_launch_status();
 }

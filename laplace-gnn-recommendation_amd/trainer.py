@@ -15,7 +15,8 @@ HBM-resident state (fp32, N = U+I rows of D): table, final, two ping-pong buffer
 
 `sparse_batch=True` (default) additionally uses what is known about the operands of one step — the
 loss reads `final` only at the <= 3B batch rows, and its gradient is non-zero only there — to move
-fewer bytes for the SAME result (bit for bit up to the sign of zero and the order of the BPR atomics):
+fewer bytes for the SAME result (to rounding: the layer sum is associated differently; each form is bitwise
+reproducible run to run — no float atomics anywhere in the step):
   * the batch is drawn first (it does not depend on the embeddings); its unique node set and the
     node -> slot map are built on device (mi_batch_nodes_i32), no host read-back;
   * forward: layers 1..K-1 are plain products; the running layer sum is kept only at the batch rows

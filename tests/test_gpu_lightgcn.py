@@ -315,7 +315,7 @@ def test_spmm_plan_without_split_rows_and_with_every_row_split(band):
 try:
     from hypothesis import given, settings, strategies as st
 
-    @settings(max_examples=20, deadline=None)
+    @settings(max_examples=40, deadline=None, derandomize=True)  # the same examples on every run
     @given(n_rows=st.integers(1, 200), n_cols=st.integers(1, 200), nnz=st.integers(0, 3000),
            d=st.sampled_from([4, 8, 32, 64, 100, 128, 260]), chunk=st.sampled_from([1, 7, 64, 256]),
            band=st.sampled_from([0, 1, 13, 64]), seed=st.integers(0, 2**31 - 1))
@@ -385,6 +385,12 @@ def test_spmm_empty_adjacency():
     S = t.empty(6, 16, device=DEV)
     ops.spmm(a, X, addend=X, S=S, scale=0.5)
     assert t.allclose(S, 0.5 * X)
+    for band in (0, 3):  # a plan of nothing: no split rows, and a banded plan does not need columns to look at
+        a.plan = ops.build_spmm_plan(a, chunk=4, band=band)
+        assert a.plan.n_long_rows == 0
+        S2 = t.full((6, 16), float("nan"), device=DEV)
+        ops.spmm(a, X, addend=X, S=S2, scale=0.5)
+        assert t.equal(S2, S)
 
 
 # ---------------------------------------------------------------------------- LightGCN.forward
@@ -783,7 +789,8 @@ def test_sparse_batch_step_equals_plain_step(K):
         la, lb = float(plain.step()), float(fast.step())
         assert abs(la - lb) <= 1e-6, it
         assert t.equal(plain.batch_idx[0], fast.batch_idx[0]) and t.equal(plain.batch_idx[2], fast.batch_idx[2])
-    # identical up to the order of the float atomics that combine repeated batch nodes
+    # the final-layer sum is associated differently in the two forms (running sum over all rows vs gathers of the
+    # batch rows), so the match is to rounding, not to the bit
     assert (plain.table - fast.table).abs().max() <= 2e-6
 
 
@@ -802,9 +809,8 @@ def test_adam_in_the_backward_epilogue_equals_separate_adam(K):
         la, lb = float(sep.step()), float(fused.step())
         assert abs(la - lb) <= 1e-6, it
     assert sep.step_count == fused.step_count == 6
-    # identical up to the order of the float atomics that combine repeated batch nodes
-    assert (sep.table - fused.table).abs().max() <= 2e-6
-    assert (sep.m - fused.m).abs().max() <= 1e-7 and (sep.v - fused.v).abs().max() <= 1e-9
+    # the same arithmetic in the same order (no float atomics anywhere): identical bits
+    assert t.equal(sep.table, fused.table) and t.equal(sep.m, fused.m) and t.equal(sep.v, fused.v)
 
 
 def test_forward_accepts_torch_sparse_tensors_and_torch_sparse_like_objects():
@@ -843,6 +849,45 @@ def test_forward_accepts_torch_sparse_tensors_and_torch_sparse_like_objects():
         model(t.sparse_coo_tensor(t.stack([row, col]), t.full((row.numel(),), 2.0, device=DEV), (n, n)))
     with pytest.raises(TypeError):
         model(t.stack([row, col]))
+
+
+@pytest.mark.parametrize("D", [64, 128, 200])
+def test_train_steps_are_bitwise_reproducible(D):
+    """No float atomics anywhere in the step: two runs from the same state give identical bits, also with batches full of
+    repeated nodes (a tiny item set) and references that cross the 64-reference chunks of the gradient kernel."""
+    from laplace_amd.trainer import LightGCNTrainer
+    U, I, E, K, B = 500, 40, 6000, 2, 2048   # 40 items for 4 096 item references: runs of ~100 per row
+    tables = []
+    for run in range(2):
+        m, inter, adj, _ = _model_and_graph(U, I, E, D, K, seed=47, compat="bipartite")
+        m.to(DEV)
+        tr = LightGCNTrainer(m, adj.to(DEV), inter.to(DEV), lr=1e-2, Lambda=1e-4, batch_size=B, seed=5)
+        losses = [float(tr.step()) for _ in range(5)]
+        tables.append((tr.table.clone(), tr.m.clone(), tr.v.clone(), losses))
+    assert tables[0][3] == tables[1][3]
+    assert t.equal(tables[0][0], tables[1][0]) and t.equal(tables[0][1], tables[1][1]) and t.equal(tables[0][2], tables[1][2])
+
+
+def test_bpr_gradient_runs_across_chunks_match_float64():
+    """One item is the positive of every sample (a run of B references over B / 64 chunks), users repeat: the chunked,
+    ordered reduction against a float64 scatter."""
+    ops = _ops()
+    B, D, U, I = 1000, 128, 50, 30
+    g = t.Generator().manual_seed(2)
+    users = t.randint(0, U, (B,), generator=g)
+    pos = t.full((B,), 7, dtype=t.int64)
+    neg = t.randint(0, I, (B,), generator=g)
+    fin = t.randn(U + I, D, generator=g)
+    G = t.zeros(U + I, D, device=DEV)
+    reg = t.zeros(U + I, device=DEV)
+    ops.bpr_fwd_bwd(users.to(DEV), pos.to(DEV), neg.to(DEV), fin.to(DEV), fin.to(DEV), U, 0.0, g_final=G, reg_w=reg)
+    f64 = fin.double().requires_grad_(True)
+    x = (f64[users] * f64[U + pos]).sum(1) - (f64[users] * f64[U + neg]).sum(1)
+    (-t.nn.functional.softplus(x).mean()).backward()
+    assert (G.cpu().double() - f64.grad).abs().max() <= 2e-6 * float(f64.grad.abs().max())
+    G2 = t.zeros_like(G)
+    ops.bpr_fwd_bwd(users.to(DEV), pos.to(DEV), neg.to(DEV), fin.to(DEV), fin.to(DEV), U, 0.0, g_final=G2, reg_w=reg)
+    assert t.equal(G, G2)
 
 
 # ---------------------------------------------------------------------------- BASELINE.json configs[0] (SURVEY C1)

@@ -176,7 +176,7 @@ except Exception:  # pragma: no cover
 
 
 if _HAVE_HYPOTHESIS:
-    @settings(max_examples=25, deadline=None)
+    @settings(max_examples=25, deadline=None, derandomize=True)
     @given(n_rows=st.integers(1, 40), n_cols=st.integers(1, 40), nnz=st.integers(0, 300), d=st.sampled_from([1, 3, 4, 16, 33]),
            seed=st.integers(0, 2**31 - 1))
     def test_oracle_spmm_property_vs_torch_sparse_and_dense(n_rows, n_cols, nnz, d, seed):
