@@ -36,7 +36,8 @@ namespace {
 #ifndef MI_SPMM_ROWS_RPS
 #define MI_SPMM_ROWS_RPS 1  // rows a sub-group handles in sequence; A/B on C2: 1: 1.373 ms, 2: 1.408, 4: 1.397.  Two rows walked
                             // as ONE list per sub-group (shared (col,val) loads and gather batches): rows kernel 851 -> 916 us.
-                            // The same pairing for the sparse-operand launches only (x_map / row_list): 0.61 -> 0.73 ms per launch.
+                            // The same pairing for the sparse-operand launches only (x_map / row_list): 0.61 -> 0.73 ms per launch; packing the
+                            // entries that survive x_map to the front of the sub-group (ds_permute): 0.613 -> 0.597 ms, not kept.
                             // More rows per wavefront do not help: the kernel is bound by its L2-miss bytes
 #endif
 #ifndef MI_SPMM_NT
