@@ -46,9 +46,18 @@ namespace {
                        // of off (nt keeps the line in L2 on gfx950), write-through sc1 partial stores 0.3 %.  Kept off.
 #endif
 typedef float mi_f4v __attribute__((ext_vector_type(4)));
+#ifndef MI_SPMM_SC1
+#define MI_SPMM_SC1 6  // bit 1: partial-sum stores, bit 2: Y / S stores leave with sc1: written-once streams do not stay in the XCD's
+                       // L2 (MI355X_MICROARCH.md, store flavours), which the gathers need.  A/B on C2, round 2 (tools/exp_locality.py
+                       // under rocprofv3): Y/S only: rows kernel 839 -> 827 us, 4.80 -> 4.65 GB of L2-miss traffic; + partials: items
+                       // kernel 367 -> 360 us, 2.28 -> 2.20 GB
+#endif
 template <int BIT>
-__device__ __forceinline__ void mi_store4(float4* p, const float4& v) {
-    if ((MI_SPMM_NT >> BIT) & 1) {
+__device__ __forceinline__ void mi_store4(float4* p, const float4& v, bool streaming) {
+    if (((MI_SPMM_SC1 >> BIT) & 1) && streaming) {
+        mi_f4v x = {v.x, v.y, v.z, v.w};
+        asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(x) : "memory");
+    } else if ((MI_SPMM_NT >> BIT) & 1) {
         mi_f4v x = {v.x, v.y, v.z, v.w};
         __builtin_nontemporal_store(x, reinterpret_cast<mi_f4v*>(p));
     } else {
@@ -75,6 +84,7 @@ struct Epilogue {
     const float4* addend; int64_t lda4;
     float4* S;            int64_t lds4;
     float scale;
+    bool streaming;       // outputs far larger than the L2s: stores leave with sc1 (MI_SPMM_SC1)
     // optimizer epilogue (mi_adam_args): S's value is the gradient of parameter row r; null p = off
     float4* p;            int64_t ldp4;
     float4* m;
@@ -160,14 +170,14 @@ __device__ __forceinline__ void store_epilogue(const Epilogue& ep, int64_t r, in
     for (int v = 0; v < VPL; ++v) {
         const int e = li + v * LPR;
         if (e >= d4) continue;
-        if (ep.Y) mi_store4<2>(ep.Y + r * ep.ldy4 + e, acc[v]);
+        if (ep.Y) mi_store4<2>(ep.Y + r * ep.ldy4 + e, acc[v], ep.streaming);
         if (ep.S || adam) {
             float4 o;
             o.x = ep.scale * (a[v].x + acc[v].x);
             o.y = ep.scale * (a[v].y + acc[v].y);
             o.z = ep.scale * (a[v].z + acc[v].z);
             o.w = ep.scale * (a[v].w + acc[v].w);
-            if (ep.S) mi_store4<2>(ep.S + r * ep.lds4 + e, o);
+            if (ep.S) mi_store4<2>(ep.S + r * ep.lds4 + e, o, ep.streaming);
             if (adam) {
                 const int64_t i = r * d4 + e;
                 float4 pp = ep.p[r * ep.ldp4 + e], mm = ep.m[i], vv = ep.v[i];
@@ -242,7 +252,7 @@ __global__ __launch_bounds__(kBlock) void spmm_items_kernel(int64_t n_launch, in
                                                             const float* __restrict__ val,
                                                             const float4* __restrict__ X4, int64_t ldx4,
                                                             float4* __restrict__ partial,
-                                                            const int32_t* __restrict__ x_map) {
+                                                            const int32_t* __restrict__ x_map, bool streaming) {
     constexpr int NB = MI_WAVE / LPR, SG = NB * kWavesPerBlock, G = SG * RPS;
     static_assert(kPlanGroup % G == 0, "a workgroup serves a whole fraction of a launch block");
     const int lane = mi_lane();
@@ -270,7 +280,7 @@ __global__ __launch_bounds__(kBlock) void spmm_items_kernel(int64_t n_launch, in
 #pragma unroll
             for (int v = 0; v < VPL; ++v) {
                 const int e = li + v * LPR;
-                if (e < d4) mi_store4<1>(partial + (int64_t)slot * d4 + e, acc[v]);
+                if (e < d4) mi_store4<1>(partial + (int64_t)slot * d4 + e, acc[v], streaming);
             }
         }
     }
@@ -544,7 +554,7 @@ int launch_spmm_mode(int64_t n_rows, int d4, const int32_t* rowptr, const int32_
         dim3 gi((unsigned)mi_ceil_div(n_launch, SG * ITEMS_RPS));
         hipLaunchKernelGGL((spmm_items_kernel<LPR, VPL, UNROLL, ITEMS_RPS, SPARSE>), gi, dim3(kBlock), 0, s, n_launch,
                            plan->band > 0 ? 1 : 0, d4, reinterpret_cast<const int4*>(plan->items), col, val, X4, ldx4,
-                           partial, ex.x_map);
+                           partial, ex.x_map, ep.streaming);
     }
     const int64_t n_out = listed ? n_list : n_rows;
     if (do_short && n_out > 0) {
@@ -758,6 +768,7 @@ int mi_spmm_csr_ex_f32(int64_t n_rows, int64_t d, const int32_t* rowptr, const i
     ep.addend = reinterpret_cast<const float4*>(addend); ep.lda4 = lda / 4;
     ep.S = reinterpret_cast<float4*>(S);                 ep.lds4 = lds / 4;
     ep.scale = scale;
+    ep.streaming = (size_t)n_rows * (size_t)d * sizeof(float) >= ((size_t)64 << 20);  // 2x the aggregate L2
     ep.p = nullptr; ep.ldp4 = 0; ep.m = nullptr; ep.v = nullptr; ep.reg_w = nullptr;
     ep.adam = MiAdamConsts{};
     if (adam) {

@@ -9,6 +9,7 @@ two (U+I)x(U+I) adjacencies LightGCN can propagate over.
 """
 from __future__ import annotations
 
+from dataclasses import dataclass
 from typing import Optional
 
 import torch as t
@@ -17,6 +18,35 @@ from torch import Tensor
 from . import ops
 from .ops import DeviceCSR
 from .sparse import SparseTensor
+
+
+@dataclass
+class LocalityOrder:
+    """A relabelling of users and items chosen for gather locality (SURVEY section 7 "Gather locality").
+
+    Items are numbered by popularity (most interactions first), users by their COLDEST item (the largest new item
+    id among their interactions).  Consecutive user rows of the propagate then end their neighbour lists on the
+    same or adjacent cold item rows — the gathers that miss L2 — and a cold item row finds the users that have it
+    as their coldest item on consecutive rows of the table.  `*_new_of_old[old id] = new id`; `*_old_of_new` is the
+    inverse.  Node form (users, then items): node_new_of_old."""
+    user_new_of_old: Tensor
+    item_new_of_old: Tensor
+    user_old_of_new: Tensor
+    item_old_of_new: Tensor
+
+    @property
+    def num_users(self) -> int:
+        return int(self.user_new_of_old.numel())
+
+    def node_new_of_old(self) -> Tensor:
+        return t.cat([self.user_new_of_old, self.item_new_of_old + self.num_users])
+
+    def node_old_of_new(self) -> Tensor:
+        return t.cat([self.user_old_of_new, self.item_old_of_new + self.num_users])
+
+    def to(self, device) -> "LocalityOrder":
+        return LocalityOrder(*(x.to(device) for x in (self.user_new_of_old, self.item_new_of_old,
+                                                      self.user_old_of_new, self.item_old_of_new)))
 
 
 class Interactions:
@@ -52,6 +82,30 @@ class Interactions:
         if self._row_of_edge is None:
             self._row_of_edge = ops.expand_rows(self.csr())
         return self._row_of_edge
+
+    def locality_order(self, item_degree: Optional[Tensor] = None) -> LocalityOrder:
+        """See LocalityOrder.  item_degree: interaction counts to rank the items by (default: this edge set's; the
+        sharded trainer passes the GLOBAL counts so that every rank numbers the replicated items alike).  Stable
+        sorts: the order is a function of the edge set alone."""
+        u, i = self.edge_index[0], self.edge_index[1]
+        dev = u.device
+        U, I = self.num_users, self.num_items
+        deg = item_degree if item_degree is not None else t.bincount(i, minlength=I)
+        item_old_of_new = t.argsort(deg.to(t.int64), descending=True, stable=True)
+        item_new_of_old = t.empty(I, dtype=t.int64, device=dev)
+        item_new_of_old[item_old_of_new] = t.arange(I, dtype=t.int64, device=dev)
+        cold = t.zeros(U, dtype=t.int64, device=dev)
+        if u.numel():
+            cold.scatter_reduce_(0, u, item_new_of_old[i], "amax", include_self=True)  # integer max: order-independent
+        user_old_of_new = t.argsort(cold, stable=True)
+        user_new_of_old = t.empty(U, dtype=t.int64, device=dev)
+        user_new_of_old[user_old_of_new] = t.arange(U, dtype=t.int64, device=dev)
+        return LocalityOrder(user_new_of_old, item_new_of_old, user_old_of_new, item_old_of_new)
+
+    def permuted(self, order: LocalityOrder) -> "Interactions":
+        """The same interactions under new ids."""
+        ei = t.stack([order.user_new_of_old[self.edge_index[0]], order.item_new_of_old[self.edge_index[1]]])
+        return Interactions(ei, self.num_users, self.num_items)
 
     def adjacency(self, compat: str = "bipartite") -> SparseTensor:
         n = self.num_users + self.num_items

@@ -64,6 +64,7 @@ def train(config: LightGCNConfig = lightgcn_config, *, edge_index: Tensor, num_u
         train_loss = trainer.step()
         if it % config.eval_every == 0:
             model.eval()
+            trainer.to_original_order()  # evaluation reads the model's tables by original id; step() re-enters the training order
             val_loss, recall, precision, ndcg = evaluation(model, val_edges, val_sparse, [train_edges], config.k,
                                                            config.Lambda, seed)
             if verbose:
@@ -75,6 +76,7 @@ def train(config: LightGCNConfig = lightgcn_config, *, edge_index: Tensor, num_u
             trainer.decay_lr(0.95)
 
     model.eval()
+    trainer.finish()
     test_loss, test_recall, test_precision, test_ndcg = evaluation(
         model, test_edges, test_sparse, [train_edges, val_edges], config.k, config.Lambda, seed)
     if verbose:

@@ -58,6 +58,13 @@ class SparseTensor:
         return SparseTensor(self._row.to(device), self._col.to(device), self._sizes,
                             None if self._value is None else self._value.to(device), self.is_symmetric)
 
+    def permuted(self, node_new_of_old: Tensor) -> "SparseTensor":
+        """P A P^T: the same graph with node `v` renamed `node_new_of_old[v]` (square adjacencies)."""
+        if self._sizes[0] != self._sizes[1] or node_new_of_old.numel() != self._sizes[0]:
+            raise ValueError("a node relabelling needs a square adjacency and one new id per node")
+        p = node_new_of_old.to(self._row.device, t.int64)
+        return SparseTensor(p[self._row], p[self._col], self._sizes, self._value, self.is_symmetric)
+
     # -- device layout ------------------------------------------------------------------------
     def csr(self) -> DeviceCSR:
         """Sorted CSR of the raw (un-normalised) adjacency; val = value[perm] or None (= ones)."""

@@ -28,6 +28,11 @@ class SyntheticSpec:
 
 C1 = SyntheticSpec(943, 1682, 100_000, seed=0, deg_sigma=1.0, deg_min=20, deg_max=737, zipf_s=1.0)
 C2 = SyntheticSpec(1_000_000, 100_000, 10_000_000, seed=1)
+# C4 (BASELINE.json configs[3]): ONE fixed 100 M-edge graph, C2's generator and user/item ratio at 8x the
+# users, defined as the union of C4_BLOCKS independently seeded user blocks so that any rank can generate exactly its
+# own users (shards by user_id // ceil(U/N), N in {1,2,4,8}) and every N sees the same graph.
+C4 = SyntheticSpec(8_000_000, 100_000, 100_000_000, seed=3)
+C4_BLOCKS = 64
 
 
 def shard_spec(spec: SyntheticSpec, rank: int) -> SyntheticSpec:
@@ -98,6 +103,67 @@ def generate(spec: SyntheticSpec) -> t.Tensor:
         keys = keys[keep]
     keys = keys[rng.permutation(keys.size)]  # edge order carries no structure (a raw transaction log)
     return t.from_numpy(np.stack([keys // I, keys % I]))
+
+
+def block_spec(spec: SyntheticSpec, n_blocks: int, b: int) -> SyntheticSpec:
+    """Spec of user block b of a graph defined block-wise: U/n_blocks users, E/n_blocks edges, its own seed, the
+    shared item popularity."""
+    if spec.num_users % n_blocks or spec.num_edges % n_blocks:
+        raise ValueError("users and edges must divide into the blocks")
+    if not 0 <= b < n_blocks:
+        raise ValueError("block index out of range")
+    return replace(spec, num_users=spec.num_users // n_blocks, num_edges=spec.num_edges // n_blocks,
+                   seed=spec.seed * 100_003 + b)
+
+
+def generate_blocks(spec: SyntheticSpec, n_blocks: int, b0: int, b1: int, workers: int = 8) -> t.Tensor:
+    """Edges of user blocks [b0, b1) of the block-wise graph; user ids are LOCAL to the range (block b0's first user
+    is 0), i.e. global id = local id + b0 * (U / n_blocks).  generate_blocks(spec, n, 0, n) is the whole graph."""
+    per = spec.num_users // n_blocks
+
+    def one(b: int) -> t.Tensor:
+        ei = generate(block_spec(spec, n_blocks, b))
+        ei[0] += (b - b0) * per
+        return ei
+
+    if b1 - b0 > 1 and workers > 1:  # numpy's sort / searchsorted release the GIL
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=min(workers, b1 - b0)) as ex:
+            parts = list(ex.map(one, range(b0, b1)))
+    else:
+        parts = [one(b) for b in range(b0, b1)]
+    return t.cat(parts, dim=1) if parts else t.empty(2, 0, dtype=t.int64)
+
+
+def shard_blocks(n_blocks: int, world: int, rank: int):
+    """Block range of rank `rank`: the shard user_id // ceil(U / world) of SURVEY 8d (world divides n_blocks)."""
+    if n_blocks % world:
+        raise ValueError("the number of ranks must divide the number of blocks")
+    per = n_blocks // world
+    return rank * per, (rank + 1) * per
+
+
+def heldout_edges(spec: SyntheticSpec, ei: t.Tensor, n_eval: int, seed: int = 99) -> t.Tensor:
+    """One extra (user, item) pair for n_eval distinct users, drawn from the generator's item popularity and not
+    among the user's edges in `ei`: the held-out positives a MAP@12 is scored on.  int64 [2, n], users ascending."""
+    rng = np.random.default_rng(seed)
+    U, I = spec.num_users, spec.num_items
+    cdf = np.cumsum(item_popularity(spec))
+    cdf[-1] = 1.0
+    keys = np.sort(ei[0].numpy() * I + ei[1].numpy())
+    users = np.sort(rng.choice(U, size=min(n_eval, U), replace=False)).astype(np.int64)
+    item = np.full(users.size, -1, dtype=np.int64)
+    for _ in range(64):
+        todo = np.nonzero(item < 0)[0]
+        if todo.size == 0:
+            break
+        cand = np.minimum(np.searchsorted(cdf, rng.random(todo.size), side="right"), I - 1).astype(np.int64)
+        k = users[todo] * I + cand
+        pos = np.minimum(np.searchsorted(keys, k), keys.size - 1)
+        fresh = keys[pos] != k
+        item[todo[fresh]] = cand[fresh]
+    ok = item >= 0
+    return t.from_numpy(np.stack([users[ok], item[ok]]))
 
 
 # H&M-shaped heterogeneous graph (SURVEY §8d C3): integer categorical node features, customer -buys-> article

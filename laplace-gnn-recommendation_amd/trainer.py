@@ -30,6 +30,14 @@ reproducible run to run — no float atomics anywhere in the step):
     that product's epilogue (mi_adam_args), so the gradient is never written or read back (-1.1 GB at C2).
 `sparse_batch=False` is the straightforward form (full `final`, dense Gc) kept for A/B and for callers
 that want the full forward output of the step.
+
+`reorder` (default: on for adjacencies of >= 1M entries) trains under a LOCALITY ORDER of the nodes
+(interactions.LocalityOrder: items by popularity, users by their coldest item): the adjacency, the interaction
+CSR and — in place — the model's table are relabelled once at construction, every kernel then runs on the new ids,
+and `to_original_order()` / `to_training_order()` put the table's rows back / forth (one gather of the table each;
+`finish()` = to_original_order).  Batches passed to `step()` and returned by `sample()` are in ORIGINAL ids.  The
+result is the same training run up to the summation order inside a row (entries are summed in column order, and
+columns are renamed): equal to rounding, and still bitwise reproducible run to run.
 """
 from __future__ import annotations
 
@@ -53,19 +61,35 @@ class LightGCNTrainer:
     def __init__(self, model: LightGCN, adj: SparseTensor, train: Interactions, *, lr: float, Lambda: float,
                  batch_size: int, betas: Tuple[float, float] = (0.9, 0.999), eps: float = 1e-8, seed: int = 0,
                  neg_range: Optional[int] = None, reference_sampler_quirks: bool = False,
-                 sparse_batch: bool = True, fuse_adam: bool = True):
+                 sparse_batch: bool = True, fuse_adam: bool = True, reorder: Optional[bool] = None):
         self.model = model
         self.table = model.table()
         if not self.table.is_cuda:
             raise RuntimeError("LightGCNTrainer needs the model on the GPU (model.to('cuda')); no CPU fallback")
-        self.adj_fwd, self.adj_bwd = adj.gcn_normalized(model.add_self_loops)
-        self.train = train
         self.K = model.num_iterations
         self.lr, self.Lambda, self.batch_size = float(lr), float(Lambda), int(batch_size)
         self.betas, self.eps, self.seed = betas, float(eps), int(seed)
         # reference: num_nodes = max(train item id)  => negatives in [0, max_item_id)  (Appendix A.3)
         self.neg_range = int(neg_range) if neg_range is not None else train.num_items
         self.quirk = bool(reference_sampler_quirks)
+        # a negative range that is not "every item" names items by id: it does not survive a relabelling
+        can_reorder = self.neg_range == train.num_items and not self.quirk
+        if reorder is None:
+            reorder = can_reorder and adj.nnz() >= ops.PLAN_MIN_NNZ
+        elif reorder and not can_reorder:
+            raise ValueError("reorder=True needs neg_range == num_items and no reference sampler quirks")
+        self.order = None
+        self.in_training_order = True
+        if reorder:
+            self.order = train.locality_order()
+            self._new_of_old = self.order.node_new_of_old()
+            self._old_of_new = self.order.node_old_of_new()
+            train = train.permuted(self.order)
+            adj = adj.permuted(self._new_of_old)
+            self.in_training_order = False
+            self.to_training_order()
+        self.adj_fwd, self.adj_bwd = adj.gcn_normalized(model.add_self_loops)
+        self.train = train
         n, d = self.table.shape
         dev = self.table.device
         self.sparse_batch = bool(sparse_batch)
@@ -94,21 +118,53 @@ class LightGCNTrainer:
         self._r = train.csr()
         self._row_of_edge = train.row_of_edge()
 
+    # -- locality order --------------------------------------------------------------------------
+    def to_training_order(self) -> None:
+        """Rows of the model's table into the order the kernels train in (no-op without reorder)."""
+        if self.order is not None and not self.in_training_order:
+            self.table.copy_(self.table[self._old_of_new])  # new row r = old row old_of_new[r]
+            self.in_training_order = True
+
+    def to_original_order(self) -> None:
+        """Rows of the model's table back under their original ids (evaluation, top-K, saving)."""
+        if self.order is not None and self.in_training_order:
+            self.table.copy_(self.table[self._new_of_old])
+            self.in_training_order = False
+
+    finish = to_original_order
+
+    def _ids_to_training(self, batch):
+        if self.order is None:
+            return batch
+        users, pos, neg = batch
+        return self.order.user_new_of_old[users], self.order.item_new_of_old[pos], self.order.item_new_of_old[neg]
+
     # -- pieces (also used one by one in tests) ------------------------------------------------
     def forward(self) -> Tensor:
+        """mean_k(A^k E0) over the whole table; rows in TRAINING order (index with order.node_new_of_old())."""
+        self.to_training_order()
         return propagate_mean(self.adj_fwd, self.table, self.K, out=self.final, scratch=(self.buf_a, self.buf_b))
 
-    def sample(self) -> Tuple[Tensor, Tensor, Tensor]:
+    def _sample(self) -> Tuple[Tensor, Tensor, Tensor]:
         return ops.sample_bpr_batch(self._r, self._row_of_edge, self.batch_size, self.neg_range, self.seed,
                                     self.step_count, quirk=self.quirk, out=self.batch_idx)
 
+    def sample(self) -> Tuple[Tensor, Tensor, Tensor]:
+        """(users, pos, neg) of the next step's batch, ORIGINAL ids."""
+        users, pos, neg = self._sample()
+        if self.order is None:
+            return users, pos, neg
+        return self.order.user_old_of_new[users], self.order.item_old_of_new[pos], self.order.item_old_of_new[neg]
+
     def step(self, batch: Optional[Tuple[Tensor, Tensor, Tensor]] = None) -> Tensor:
-        """One training iteration; returns the loss as a 1-element device tensor (no sync)."""
+        """One training iteration; returns the loss as a 1-element device tensor (no sync).  batch: original ids."""
+        self.to_training_order()
+        batch = self._ids_to_training(batch) if batch is not None else None
         if self.sparse_batch:
             return self._step_sparse(batch)
         K = self.K
         self.forward()
-        users, pos, neg = batch if batch is not None else self.sample()
+        users, pos, neg = batch if batch is not None else self._sample()
         self.gc.zero_()
         self.reg_w.zero_()
         ops.bpr_fwd_bwd(users, pos, neg, self.final, self.table, self.model.num_users, self.Lambda,
@@ -121,7 +177,7 @@ class LightGCNTrainer:
 
     def _step_sparse(self, batch: Optional[Tuple[Tensor, Tensor, Tensor]]) -> Tensor:
         K, tab, adj, adj_t = self.K, self.table, self.adj_fwd, self.adj_bwd
-        users, pos, neg = batch if batch is not None else self.sample()
+        users, pos, neg = batch if batch is not None else self._sample()
         if users.numel() != self.batch_size:
             raise ValueError("batch size differs from the trainer's")
         gmap, nodes, cnt2 = ops.batch_nodes(users, pos, neg, self.model.num_users, tab.shape[0], gmap=self.gmap,

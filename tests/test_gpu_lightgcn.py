@@ -590,6 +590,55 @@ def test_trainer_ten_steps_match_reference_loop(compat):
     assert (uf.detach().cpu() - wu).abs().max() <= 1e-4 and (itf.detach().cpu() - wi).abs().max() <= 1e-4
 
 
+@pytest.mark.parametrize("sparse_batch", [False, True])
+def test_trainer_under_locality_order_matches_reference_loop(sparse_batch):
+    """reorder=True: the step runs on relabelled nodes (items by popularity, users by coldest item) with the model's
+    table permuted in place; batches go in and parameters come out under ORIGINAL ids, equal to the oracle's loop on
+    the unrelabelled graph within the same 1e-4 (only the summation order inside a row changes)."""
+    from laplace_amd.trainer import LightGCNTrainer
+    U, I, E, D, K, B = 400, 600, 8000, 64, 3, 128
+    model, inter, adj, ei = _model_and_graph(U, I, E, D, K, seed=21, compat="bipartite")
+    uw = t.nn.Parameter(model.users_emb.weight.detach().clone())
+    iw = t.nn.Parameter(model.items_emb.weight.detach().clone())
+    opt = t.optim.Adam([uw, iw], lr=1e-3)
+    row, col, _ = adj.coo()
+    model.to(DEV)
+    tr = LightGCNTrainer(model, adj.to(DEV), inter.to(DEV), lr=1e-3, Lambda=1e-6, batch_size=B, seed=5,
+                         sparse_batch=sparse_batch, reorder=True)
+    o = tr.order
+    # the order: a permutation; items by popularity, users by their coldest item
+    assert t.equal(o.user_new_of_old[o.user_old_of_new].cpu(), t.arange(U)) and t.equal(o.item_new_of_old[o.item_old_of_new].cpu(), t.arange(I))
+    deg_new = t.bincount(o.item_new_of_old.cpu()[ei[1]], minlength=I)
+    assert bool((deg_new[:-1] >= deg_new[1:]).all())
+    # the table moved with it, and comes back
+    assert tr.in_training_order and t.equal(model.users_emb.weight.detach().cpu()[o.user_new_of_old.cpu()], uw.detach())
+    tr.to_original_order()
+    assert t.equal(model.users_emb.weight.detach().cpu(), uw.detach()) and t.equal(model.items_emb.weight.detach().cpu(), iw.detach())
+    g = t.Generator().manual_seed(99)
+    for it in range(10):
+        batch = (t.randint(0, U, (B,), generator=g), t.randint(0, I, (B,), generator=g),
+                 t.randint(0, I, (B,), generator=g))
+        loss_ref = R.train_step(uw, iw, opt, row, col, K, batch, 1e-6)
+        loss = tr.step(tuple(x.to(DEV) for x in batch))
+        assert abs(float(loss) - loss_ref) < 1e-5, it
+        if it == 4:  # an evaluation in the middle of training reads the tables by original id
+            tr.to_original_order()
+            assert (model.users_emb.weight.detach().cpu() - uw.detach()).abs().max() <= 1e-4
+    # forward in training order == oracle forward, row for row
+    wu, _, wi, _ = R.lightgcn_forward(uw.detach(), iw.detach(), row, col, K)
+    fin = tr.forward()[tr.order.node_new_of_old()].cpu()
+    assert (fin[:U] - wu).abs().max() <= 1e-4 and (fin[U:] - wi).abs().max() <= 1e-4
+    tr.finish()
+    assert (model.users_emb.weight.detach().cpu() - uw.detach()).abs().max() <= 1e-4
+    assert (model.items_emb.weight.detach().cpu() - iw.detach()).abs().max() <= 1e-4
+    # sample() speaks original ids: positives are edges of the graph as given, negatives are not
+    us, ps, ns = (x.cpu() for x in tr.sample())
+    keys = set((ei[0] * I + ei[1]).tolist())
+    assert all(k in keys for k in (us * I + ps).tolist()) and not any(k in keys for k in (us * I + ns).tolist())
+    with pytest.raises(ValueError):
+        LightGCNTrainer(model, adj.to(DEV), inter.to(DEV), lr=1e-3, Lambda=1e-6, batch_size=B, reorder=True, neg_range=I - 1)
+
+
 def test_trainer_on_device_sampling_trains():
     """With the on-device sampler the BPR objective (unbounded below) goes down."""
     from laplace_amd.trainer import LightGCNTrainer
@@ -697,7 +746,9 @@ def test_full_size_sampler_and_step(c2_graph):
     model = LightGCN(U, I, 128, 3).to(DEV)
     before = model.table().clone()
     tr = LightGCNTrainer(model, inter.adjacency("bipartite"), inter, lr=1e-3, Lambda=1e-6, batch_size=16384, seed=3)
+    assert tr.order is not None  # at this size the step runs under the locality order by default
     loss = float(tr.step())
+    tr.finish()                  # rows back under their original ids
     # -softplus(~0) + lambda * 3 * B * D * 0.1^2 at initialisation
     assert abs(loss - (-0.6931 + 1e-6 * 3 * 16384 * 128 * 0.01)) < 0.01
     moved = (model.table() - before).abs().amax(dim=1) > 0

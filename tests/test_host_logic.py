@@ -132,3 +132,21 @@ def test_collate_carries_global_node_ids():
         assert t.equal(batch[nt].x, graph[nt].x[batch[nt].n_id])
     eli = batch[Constants.edge_key].edge_label_index
     assert set(batch[Constants.node_user].n_id[eli[0]].tolist()) == {5, 9}
+
+
+def test_bench_self_launch_parent_never_needs_a_gpu_and_reports_worker_failure():
+    """python bench.py --gpus 2 without a launcher: the parent starts the workers itself (it must not touch the GPU)
+    and exits non-zero when they fail — here they do, because this container has no GPU."""
+    import subprocess
+    import sys as _sys
+    import torch as _t
+    if _t.cuda.is_available():
+        import pytest as _pytest
+        _pytest.skip("CPU-only check of the launcher's failure path")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([_sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0
+    assert "needs a GPU" in r.stderr and "no result line" in r.stderr
+    assert r.stdout.strip() == ""

@@ -76,7 +76,9 @@ def main():
         fh.write(f"# {os.path.basename(out)}\n\n" + "\n".join(lines) + "\n")
     if "--traffic-json" in sys.argv and spmm:
         path = sys.argv[sys.argv.index("--traffic-json") + 1]
-        json.dump({"spmm_hbm_bytes_per_launch": spmm, "per_kernel_bytes": traffic,
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from bench import kernel_source_hash
+        json.dump({"spmm_hbm_bytes_per_launch": spmm, "kernel_source_hash": kernel_source_hash(), "per_kernel_bytes": traffic,
                    "per_kernel_avg_us": per_kernel, "source": os.path.basename(out) + ".md",
                    "formula": "(2*FETCH_SIZE + WRITE_SIZE)*1024, gfx950 correction per MI355X_MICROARCH.md"},
                   open(path, "w"), indent=1)
