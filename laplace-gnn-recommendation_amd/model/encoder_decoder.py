@@ -15,6 +15,7 @@ relu on small [n, 64..128] tensors stay torch ops.
 """
 from __future__ import annotations
 
+from collections import deque
 from copy import deepcopy
 from typing import Dict, List, Optional, Tuple
 
@@ -32,21 +33,24 @@ def _key(edge_type: Tuple[str, str, str]) -> str:
     return "__".join(edge_type)
 
 
+_PAIR = {"sum": t.add, "mean": t.add, "max": t.maximum, "min": t.minimum, "mul": t.mul}
+
+
 def _combine(outs: List[Tensor], aggr: str) -> Tensor:
+    """Outputs of the relations arriving at one destination type, reduced the way PyG's to_hetero wires it
+    (temporary_hetero.py:203-228): PAIRWISE through a queue — pop the two oldest, combine, append the result — and
+    for "mean" one division by the relation count at the end (:120-128).  Three relations [a, b, c] therefore give
+    c (+) (a (+) b); the order is kept because float addition is not associative."""
+    if aggr not in _PAIR:
+        raise ValueError(f"unknown heterogeneous aggregation {aggr!r}")
     if len(outs) == 1:
         return outs[0]
-    stack = t.stack(outs, dim=0)
-    if aggr == "sum":
-        return stack.sum(0)
-    if aggr == "mean":
-        return stack.mean(0)
-    if aggr == "min":
-        return stack.min(0)[0]
-    if aggr == "max":
-        return stack.max(0)[0]
-    if aggr == "mul":
-        return stack.prod(0)
-    raise ValueError(f"unknown heterogeneous aggregation {aggr!r}")
+    queue = deque(outs)
+    while len(queue) >= 2:
+        a, b = queue.popleft(), queue.popleft()
+        queue.append(_PAIR[aggr](a, b))
+    out = queue.popleft()
+    return t.div(out, len(outs)) if aggr == "mean" else out
 
 
 class HeteroGNNEncoder(nn.Module):

@@ -53,6 +53,25 @@ def _key(et) -> str:
     return "__".join(et)
 
 
+def hetero_reduce(outs: List[Tensor], aggr: str) -> Tensor:
+    """Destination-wise aggregation exactly as to_hetero's transformer emits it (temporary_hetero.py:203-228 with the
+    op table at :120-128): the per-relation outputs go into a queue in metadata order; while two or more are left the
+    first two are popped, combined with torch.add / torch.add / torch.max / torch.min / torch.mul for
+    sum / mean / max / min / mul, and the result is appended at the END; "mean" divides the survivor by the number of
+    relations.  A single relation is passed through untouched (:185-190)."""
+    if len(outs) == 1:
+        return outs[0]
+    op = {"sum": t.add, "mean": t.add, "max": t.max, "min": t.min, "mul": t.mul}[aggr]
+    names = list(outs)
+    while len(names) >= 2:
+        key1, key2 = names.pop(0), names.pop(0)
+        names.append(op(key1, key2))
+    out = names.pop(0)
+    if aggr == "mean":
+        out = t.div(out, len(outs))
+    return out
+
+
 class HeteroEncoderRef(nn.Module):
     def __init__(self, dims: List[Dict[str, Tuple[int, int, int]]], aggr_conv: str, aggr_hetero: str,
                  p_dropout_features: Optional[float]):
@@ -73,9 +92,7 @@ class HeteroEncoderRef(nn.Module):
                 if _key(et) not in convs:
                     continue
                 by_dst.setdefault(et[2], []).append(convs[_key(et)]((x_dict[et[0]], x_dict[et[2]]), ei))
-            comb = {"sum": lambda s: s.sum(0), "mean": lambda s: s.mean(0), "min": lambda s: s.min(0)[0],
-                    "max": lambda s: s.max(0)[0], "mul": lambda s: s.prod(0)}[self.aggr_hetero]
-            x_dict = {d: (o[0] if len(o) == 1 else comb(t.stack(o))) for d, o in by_dst.items()}
+            x_dict = {d: hetero_reduce(o, self.aggr_hetero) for d, o in by_dst.items()}
             if not last:
                 x_dict = {k: v.relu() for k, v in x_dict.items()}
         return x_dict

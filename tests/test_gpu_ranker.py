@@ -149,3 +149,42 @@ def test_train_and_test_loops_run_and_learn():
     assert np.isfinite(losses).all() and np.mean(losses) < np.mean(first_epoch)
     recall, precision = test_with_dataloader("VAL", model, loader, DEV, k=3, break_at=5)
     assert 0.0 <= recall <= 1.0 and 0.0 <= precision <= 1.0
+
+
+@pytest.mark.parametrize("hetero_aggr", ["sum", "mean", "min", "max", "mul"])
+@pytest.mark.parametrize("conv_aggr", ["add", "max"])
+def test_to_hetero_three_relations_per_destination(hetero_aggr, conv_aggr):
+    """config.py:128-129 `other_edge_types`: several relations arrive at one destination type and
+    `heterogeneous_prop_agg_type` stops being a no-op.  Three relations into `article`, two into `customer`, two
+    layers, forward and every parameter gradient against the oracle's restatement of to_hetero's pairwise
+    reduction (temporary_hetero.py:203-228)."""
+    from laplace_amd.model.encoder_decoder import HeteroGNNEncoder
+    from laplace_amd.model.layers import get_SAGEConv_layers
+    g = t.Generator().manual_seed(11)
+    n_c, n_a, C = 70, 50, 24
+    node_types = ["customer", "article"]
+    edge_types = [("customer", "buys", "article"), ("article", "rev_buys", "customer"), ("customer", "views", "article"),
+                  ("customer", "wishes", "article"), ("article", "rev_views", "customer")]
+    x = {"customer": t.randn(n_c, C, generator=g), "article": t.randn(n_a, C, generator=g)}
+    ei = {}
+    for et in edge_types:
+        n_s, n_d = (n_c, n_a) if et[0] == "customer" else (n_a, n_c)
+        e = int(t.randint(150, 400, (1,), generator=g))
+        ei[et] = t.stack([t.randint(0, n_s, (e,), generator=g), t.randint(0, n_d, (e,), generator=g)])
+    t.manual_seed(3)
+    enc = HeteroGNNEncoder(get_SAGEConv_layers(2, 32, 16, conv_aggr), (node_types, edge_types), hetero_aggr, 0.0, None).to(DEV)
+    out = enc({k: v.to(DEV) for k, v in x.items()}, {k: v.to(DEV) for k, v in ei.items()})  # sizes the lazy layers
+    dims = [{k: (c.lin_l.in_features, c.lin_r.in_features, c.out_channels) for k, c in convs.items()} for convs in enc.layers]
+    ref = RR.HeteroEncoderRef(dims, conv_aggr, hetero_aggr, None)
+    ref.load_state_dict({k: v.detach().cpu().clone() for k, v in enc.state_dict().items()})
+    want = ref({k: v.clone() for k, v in x.items()}, ei)
+    assert set(out) == set(want) == {"customer", "article"}
+    for k in want:
+        scale = float(want[k].abs().max()) + 1e-6
+        assert (out[k].detach().cpu() - want[k].detach()).abs().max() <= 1e-5 * max(1.0, scale), (k, hetero_aggr)
+    w = {k: t.randn(v.shape, generator=g) for k, v in want.items()}
+    sum((out[k] * w[k].to(DEV)).sum() for k in out).backward()
+    sum((want[k] * w[k]).sum() for k in want).backward()
+    for (n, p), (_, pr) in zip(enc.named_parameters(), ref.named_parameters()):
+        scale = float(pr.grad.abs().max()) + 1e-6
+        assert float((p.grad.cpu() - pr.grad).abs().max()) <= 2e-4 * scale + 1e-6, (n, hetero_aggr)

@@ -183,3 +183,69 @@ def test_gemm_split_k_weight_gradient_shape():
         want = want + groups[q]
     assert t.equal(got.cpu(), want)
     assert t.allclose(got.cpu().double(), dY.double().T @ X.double(), atol=2e-3, rtol=1e-5)
+
+
+def test_topk_against_the_torch_product_the_reference_calls():
+    """The reference scores with torch on the CPU, `user_emb[user] @ item_emb.T` then torch.topk
+    (utils/metrics_lightgcn.py:137-139); the device scores with a k-ascending fp32 fma chain.  Where exactness
+    against THAT product holds and where it cannot:
+
+      (a) embeddings on a dyadic grid (every product and partial sum exact in fp32): the two products are the same
+          bits in any summation order, so ids must agree exactly wherever scores are distinct, and the score lists
+          exactly; items tied in score come out id-ascending here, in torch's unspecified order there;
+      (b) generic floats with planted NEAR ties (pairs of item rows one ulp apart in one coordinate): the CPU product's
+          blocked summation and the fma chain may order such a pair differently.  Every disagreement must be such a
+          pair — the two orders differ only between scores that are within rounding distance of each other, and both
+          are permutations of the float64 ranking's top-k up to that distance."""
+    from laplace_amd import ops
+    g = t.Generator().manual_seed(31)
+    # ---- (a) exact arithmetic: integers / 64 in [-1, 1], D = 64  =>  |score| <= 64, products multiples of 2^-12
+    U, I, D, k = 48, 6000, 64, 12
+    ue = t.randint(-64, 65, (U, D), generator=g).float() / 64.0
+    ie = t.randint(-64, 65, (I, D), generator=g).float() / 64.0
+    ie[1000:1100] = ie[:100]                                   # exact ties between distinct ids
+    uid = t.arange(U)
+    ids, sc = ops.topk_excl(uid.to(DEV), ue.to(DEV), ie.to(DEV), k, None, want_scores=True)
+    ids, sc = ids.cpu(), sc.cpu()
+    prod = ue @ ie.T                                           # the reference's call
+    assert t.equal(prod, R.scores_fma(ue, ie))                 # order-independent on the grid
+    tv, ti = t.topk(prod, k, dim=1)
+    assert t.equal(sc, tv)                                     # the same k scores, in order, bit for bit
+    for u in range(U):
+        assert t.equal(prod[u, ids[u]], tv[u])
+        distinct = t.ones(k, dtype=t.bool)
+        distinct[1:] &= tv[u, 1:] != tv[u, :-1]
+        distinct[:-1] &= tv[u, :-1] != tv[u, 1:]
+        kth_unique = bool((prod[u] == tv[u, -1]).sum() == 1)
+        sel = distinct.clone()
+        sel[-1] &= kth_unique
+        assert t.equal(ids[u][sel], ti[u][sel])                # exact ids wherever the score is not shared
+        for a, b in zip(ids[u][:-1].tolist(), ids[u][1:].tolist()):  # ties: smaller id first (the documented rule)
+            if prod[u, a] == prod[u, b]:
+                assert a < b
+    # ---- (b) near ties: item 2j+1 = item 2j with one coordinate nudged by one ulp
+    I2 = 4000
+    ue2 = t.randn(U, D, generator=g) * 0.1
+    ie2 = t.randn(I2, D, generator=g) * 0.1
+    ie2[1::2] = ie2[0::2]
+    col = t.randint(0, D, (I2 // 2,), generator=g)
+    ar = t.arange(I2 // 2)
+    ie2[1::2][ar, col] = t.nextafter(ie2[0::2][ar, col], t.full((I2 // 2,), 1.0))
+    ids2 = ops.topk_excl(uid.to(DEV), ue2.to(DEV), ie2.to(DEV), k, None).cpu()
+    prod2 = ue2 @ ie2.T
+    ti2 = t.topk(prod2, k, dim=1).indices
+    exact = (ue2.double() @ ie2.double().T)
+    eps = 64 * 2.0 ** -24 * float(prod2.abs().max())          # rounding distance of a 64-term fp32 dot at this scale
+    differing = 0
+    for u in range(U):
+        if not t.equal(ids2[u], ti2[u]):
+            differing += 1
+        for lst in (ids2[u], ti2[u]):                          # both lists are the float64 top-k up to rounding distance
+            kth = float(t.topk(exact[u], k).values[-1])
+            assert float(exact[u, lst].min()) >= kth - eps
+            assert bool((exact[u, lst][:-1] >= exact[u, lst][1:] - eps).all())
+        for a, b in zip(ids2[u].tolist(), ti2[u].tolist()):    # position by position: same item, or a near-tied stand-in
+            assert a == b or abs(float(exact[u, a] - exact[u, b])) <= eps
+    # the device list is exact against its own arithmetic in every case
+    assert t.equal(ids2, R.topk_excl_exact(R.scores_fma(ue2, ie2), [t.empty(0, dtype=t.int64)] * U, k))
+    print(f"near-tie rows ordered differently by torch's CPU product and the fma chain: {differing}/{U}")

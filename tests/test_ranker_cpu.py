@@ -61,6 +61,31 @@ def test_sampler_reference_fixture():
     assert t.equal(ref["edge_label_index"], store.edge_label_index) and t.equal(ref["edge_label"], store.edge_label)
 
 
+@pytest.mark.parametrize("kind", ["random", "star"])
+def test_host_sampler_on_both_reference_fixtures_every_seed_user(kind):
+    """tests/reference_fixtures.py: hand-derived samples of every user of the reference's "random" and "star" graphs
+    (the star's hub user, one-article users that yield the same positive twice, a negative that is a positive)."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from reference_fixtures import CFG, EXPECT, fixture
+    from laplace_amd.data.dataset import GraphDataset
+    from laplace_amd.utils.constants import Constants
+    g, users, articles, ux, ax, ei = fixture(kind)
+    ds = GraphDataset(CFG, g, users, articles, train=True, randomization=False)
+    assert len(ds) == ux.shape[0] == len(EXPECT[kind])
+    for s, (ub, ab, edges, label_edges, labels) in EXPECT[kind].items():
+        item = ds[s]
+        upos, apos = {u: i for i, u in enumerate(ub)}, {a: i for i, a in enumerate(ab)}
+        assert t.equal(item[Constants.node_user].x, ux[ub]) and t.equal(item[Constants.node_item].x, ax[ab])
+        store = item[Constants.edge_key]
+        assert sorted(zip(*store.edge_index.tolist())) == sorted((upos[u], apos[a]) for u, a in edges)
+        assert store.edge_label_index.tolist() == [[upos[u] for u, _ in label_edges], [apos[a] for _, a in label_edges]]
+        assert store.edge_label.tolist() == labels
+        ref = DR.get_item(s, {"user_x": ux, "article_x": ax, "edge_index": ei}, users, articles, CFG, True, None, False)
+        assert t.equal(ref["edge_label_index"], store.edge_label_index) and t.equal(ref["edge_label"], store.edge_label)
+        assert sorted(zip(*ref["edge_index"].tolist())) == sorted(zip(*store.edge_index.tolist()))
+
+
 def _random_graph(seed, U=40, A=30, E=260):
     from laplace_amd.hetero import HeteroData
     from laplace_amd.utils.constants import Constants
@@ -322,3 +347,26 @@ def test_time_split_and_graph_files_match_reference(golden_dir, tmp_path):
     back, cmap, amap = graph_io.read_splits(str(tmp_path))
     assert back["val"][1] == splits["val"][1] and cmap["3"] == "c3" and amap["44"] == "a44"
     assert t.equal(back["test"][0][Constants.edge_key].edge_index, splits["test"][0][Constants.edge_key].edge_index)
+
+
+def test_hetero_reduce_is_the_pairwise_queue_of_to_hetero():
+    """temporary_hetero.py:203-228: [a, b, c] -> c (+) (a (+) b); [a, b, c, d] -> (a (+) b) (+) (c (+) d); mean
+    divides once at the end.  Known answers where the association shows in the last bit, and exact ones for
+    min / max / mul."""
+    a, b, c, d = (t.tensor([x], dtype=t.float32) for x in (1.0, 2.0 ** -24, 2.0 ** -24, 3.0))
+    # float32: (1 + 2^-24) rounds to 1 (ties to even), then + 2^-24 -> 1 again; 2^-24 + 2^-24 = 2^-23 first would survive
+    assert RR.hetero_reduce([a, b, c], "sum").item() == (c + (a + b)).item() == 1.0
+    assert RR.hetero_reduce([b, c, a], "sum").item() == (a + (b + c)).item() == 1.0 + 2.0 ** -23
+    assert RR.hetero_reduce([a, b, c, d], "sum").item() == ((a + b) + (c + d)).item()
+    assert RR.hetero_reduce([a, b, c, d], "mean").item() == (((a + b) + (c + d)) / 4).item()
+    xs = [t.tensor([[1.0, -2.0], [3.0, 0.5]]), t.tensor([[0.0, 4.0], [-1.0, 0.25]]), t.tensor([[2.0, -3.0], [3.5, 8.0]])]
+    assert t.equal(RR.hetero_reduce(xs, "max"), t.stack(xs).max(0)[0]) and t.equal(RR.hetero_reduce(xs, "min"), t.stack(xs).min(0)[0])
+    assert t.equal(RR.hetero_reduce(xs, "mul"), xs[2] * (xs[0] * xs[1]))
+    assert RR.hetero_reduce(xs[:1], "mul") is xs[0]
+    # the product's reduction (torch ops, no kernel) follows the same queue
+    from laplace_amd.model.encoder_decoder import _combine
+    for aggr in ("sum", "mean", "min", "max", "mul"):
+        for k in (1, 2, 3, 4, 5):
+            g = t.Generator().manual_seed(k)
+            outs = [t.randn(7, 5, generator=g) for _ in range(k)]
+            assert t.equal(_combine(outs, aggr), RR.hetero_reduce(outs, aggr)), (aggr, k)
