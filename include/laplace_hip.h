@@ -251,14 +251,20 @@ int    mi_batch_nodes_i32(int64_t batch, int64_t n_users, int64_t n_nodes,
  * item ids in [0, n_items)); the negative for edge e is drawn from [0, neg_range) by
  * Philox keyed on (seed, step, e) — the same edge drawn twice in one step gets the same
  * negative, as in the reference — and redrawn while it is a neighbour of the user
- * (binary search in the user's sorted CSR row).  `quirk_user_rows`: when non-zero,
- * also rejects negative 0 for user u if user u-1 has an edge to item `neg_range`
- * (the reference's row*num_nodes+col key collision).
+ * (binary search in the user's sorted CSR row).  `quirk_user_rows` is a bit mask:
+ * bit 0 (MI_SAMPLE_KEY_COLLISION): also rejects negative 0 for user u if user u-1 has an edge to
+ *   item `neg_range` (the reference's row*num_nodes+col key collision);
+ * bit 1 (MI_SAMPLE_NO_SELF_LOOPS): also rejects the negative whose id equals the user's id —
+ *   structured_negative_sampling(contains_neg_self_loops=False) as evaluation() calls it
+ *   (run_pipeline_lightgcn.py:40-44) puts the keys i*num_nodes+i of all i < num_nodes into the
+ *   rejection set; sample_mini_batch (data/lightgcn_loader.py:105) leaves the default, True.
  * row_of_edge int32[nnz] is the expanded row index (mi_csr_expand_rows).
  * edges_in_order != 0: slot b takes edge b of the CSR instead of a random one (batch <= nnz) —
  * one negative per edge of a split, as evaluation() does (run_pipeline_lightgcn.py:40-44).
  * Outputs int64[B] each (the reference's index dtype).
  * ---------------------------------------------------------------------------------- */
+#define MI_SAMPLE_KEY_COLLISION 1
+#define MI_SAMPLE_NO_SELF_LOOPS 2
 int mi_csr_expand_rows(int64_t n_rows, const int32_t* rowptr, int32_t* row_of_edge,
                        int64_t nnz, mi_stream_t stream);
 int mi_sample_bpr_batch(int64_t batch, int64_t nnz,
@@ -366,14 +372,17 @@ int    mi_topk_excl_f32(int64_t n_q, int64_t n_items, int64_t d, int64_t k,
  *   aggr="add":  mi_spmm_csr_f32 with val = 1          (no [E, C] message tensor, no atomics)
  *   aggr="mean": mi_spmm_csr_f32 with val = 1/in-degree (mi_scale_csr_f32); empty segment -> 0
  *   aggr="max":  mi_segment_max_f32 below; empty segment -> 0; `arg` int32[n_dst, d] (nullable)
- *                receives the winning source id (-1 for empty) for the backward:
- *                dX[arg[r,c], c] += dY[r,c]   (dX pre-zeroed; float atomics).
+ *                receives the winning source id (-1 for empty) for the backward
+ *                dX[s, c] = sum over destinations r of s with arg[r, c] == s of dY[r, c],
+ *                computed per SOURCE row over the by-source CSR of the same relation (src_rowptr over
+ *                sources, src_col = destination ids, sorted): one writer per element, fixed order,
+ *                no float atomics; every row of dX is written.
  * ---------------------------------------------------------------------------------- */
 int mi_segment_max_f32(int64_t n_dst, int64_t d, const int32_t* rowptr, const int32_t* col,
                        const float* X, int64_t ldx, float* Y, int64_t ldy, int32_t* arg,
                        mi_stream_t stream);
-int mi_segment_max_bwd_f32(int64_t n_dst, int64_t d, const int32_t* arg,
-                           const float* dY, int64_t ldy, float* dX, int64_t ldx,
+int mi_segment_max_bwd_f32(int64_t n_src, int64_t d, const int32_t* src_rowptr, const int32_t* src_col,
+                           const int32_t* arg, const float* dY, int64_t ldy, float* dX, int64_t ldx,
                            mi_stream_t stream);
 
 /* ------------------------------------------------------------------------------------

@@ -37,15 +37,30 @@ __global__ __launch_bounds__(kBlock) void segment_max_kernel(int64_t n_dst, int 
     }
 }
 
-__global__ void segment_max_bwd_kernel(int64_t total, int d, const int32_t* __restrict__ arg,
-                                       const float* __restrict__ dY, int64_t ldy, float* __restrict__ dX,
-                                       int64_t ldx) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    const int64_t r = i / d;
-    const int c = (int)(i - r * d);
-    const int32_t s = arg[i];
-    if (s >= 0) atomicAdd(dX + (int64_t)s * ldx + c, dY[r * ldy + c]);
+// Backward of the max: dX[s, c] = sum of dY[r, c] over the destinations r of source s whose arg-max at column c is s.
+// One wavefront per SOURCE row walks that source's destinations in the by-source CSR (sorted, so the sum has a fixed
+// order and a duplicated edge is seen once): one writer per element, no float atomics — bitwise reproducible.
+__global__ __launch_bounds__(kBlock) void segment_max_bwd_kernel(int64_t n_src, int d,
+                                                                 const int32_t* __restrict__ src_rowptr,
+                                                                 const int32_t* __restrict__ src_col,
+                                                                 const int32_t* __restrict__ arg,
+                                                                 const float* __restrict__ dY, int64_t ldy,
+                                                                 float* __restrict__ dX, int64_t ldx) {
+    const int64_t s = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / MI_WAVE;
+    if (s >= n_src) return;
+    const int lane = mi_lane();
+    const int32_t b = src_rowptr[s], e = src_rowptr[s + 1];
+    for (int c = lane; c < d; c += MI_WAVE) {
+        float g = 0.f;
+        int32_t prev = -1;
+        for (int32_t p = b; p < e; ++p) {
+            const int32_t r = src_col[p];
+            if (r == prev) continue;  // the same edge listed twice won the max once
+            prev = r;
+            if (arg[(int64_t)r * d + c] == (int32_t)s) g += dY[(int64_t)r * ldy + c];
+        }
+        dX[s * ldx + c] = g;
+    }
 }
 
 struct EmbedCols {
@@ -95,14 +110,15 @@ int mi_segment_max_f32(int64_t n_dst, int64_t d, const int32_t* rowptr, const in
     return mi_launch_status();
 }
 
-int mi_segment_max_bwd_f32(int64_t n_dst, int64_t d, const int32_t* arg, const float* dY, int64_t ldy,
-                           float* dX, int64_t ldx, mi_stream_t stream) {
-    MI_CHECK_ARG(n_dst >= 0 && d > 0);
-    if (n_dst == 0) return 0;
-    MI_CHECK_ARG(arg && dY && dX && ldy >= d && ldx >= d);
-    const int64_t total = n_dst * d;
-    hipLaunchKernelGGL(segment_max_bwd_kernel, dim3((unsigned)mi_ceil_div(total, kBlock)), dim3(kBlock), 0,
-                       (hipStream_t)stream, total, (int)d, arg, dY, ldy, dX, ldx);
+int mi_segment_max_bwd_f32(int64_t n_src, int64_t d, const int32_t* src_rowptr, const int32_t* src_col,
+                           const int32_t* arg, const float* dY, int64_t ldy, float* dX, int64_t ldx,
+                           mi_stream_t stream) {
+    MI_CHECK_ARG(n_src >= 0 && d > 0);
+    if (n_src == 0) return 0;
+    MI_CHECK_ARG(src_rowptr && dX && ldx >= d && (dY == nullptr || ldy >= d));
+    dim3 g((unsigned)mi_ceil_div(n_src * MI_WAVE, kBlock));
+    hipLaunchKernelGGL(segment_max_bwd_kernel, g, dim3(kBlock), 0, (hipStream_t)stream, n_src, (int)d, src_rowptr,
+                       src_col, arg, dY, ldy, dX, ldx);
     return mi_launch_status();
 }
 

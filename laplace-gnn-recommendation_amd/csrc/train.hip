@@ -48,7 +48,9 @@ __global__ void sample_bpr_kernel(int64_t batch, int64_t nnz, const int32_t* __r
         cand = (int32_t)((((uint64_t)q.c[0] << 32) | q.c[1]) % (uint64_t)neg_range);
         bool hit = csr_contains(rowptr, col, u, cand);
         // reference key collision: (u-1, item neg_range) aliases (u, 0) in row*num_nodes+col
-        if (!hit && quirk && cand == 0 && u > 0) hit = csr_contains(rowptr, col, u - 1, (int32_t)neg_range);
+        if (!hit && (quirk & 1) && cand == 0 && u > 0) hit = csr_contains(rowptr, col, u - 1, (int32_t)neg_range);
+        // contains_neg_self_loops=False: the key u*num_nodes+u of every node u < num_nodes is in the rejection set too
+        if (!hit && (quirk & 2) && (int64_t)cand == u) hit = true;
         if (!hit) break;
     }
     users[b] = u;

@@ -156,9 +156,27 @@ class Encoder_Decoder_Model(nn.Module):
             x_dict[key] = ops.embed_concat(x_dict[key].contiguous(), tables, max_norm=1.0)
         return x_dict
 
+    def validate_features(self, x_dict: dict) -> None:
+        """nn.Embedding raises on an id outside its table (model/encoder_decoder.py:116-125); the lookup kernel only
+        clamps such ids to stay memory-safe, so a mis-encoded column would train on the wrong rows in silence.  This
+        is the check, once per dataset or batch (one host read-back): call it on the full graph's x_dict; 
+        initialize_encoder_input_size() runs it on the batch it is given."""
+        for key, tables in self.embedding_layers.items():
+            x = x_dict[key]
+            if x.dim() != 2 or x.shape[1] != len(tables):
+                raise ValueError(f"{key}: expected {len(tables)} categorical columns, got shape {tuple(x.shape)}")
+            if x.numel() == 0:
+                continue
+            lo, hi = x.amin(dim=0).tolist(), x.amax(dim=0).tolist()
+            for i, tb in enumerate(tables):
+                if lo[i] < 0 or hi[i] >= tb.shape[0]:
+                    raise IndexError(f"{key} column {i}: ids span [{lo[i]}, {hi[i]}] but its embedding table has "
+                                     f"{tb.shape[0]} rows (num_cat + 1)")
+
     def initialize_encoder_input_size(self, data) -> None:
         x_dict, edge_index_dict = data.x_dict, data.edge_index_dict
         if self.embedding:
+            self.validate_features(x_dict)
             x_dict = self._embed(x_dict)
         with t.no_grad():
             self.encoder(x_dict, edge_index_dict)

@@ -148,7 +148,7 @@ class _AggregateFn(t.autograd.Function):
         graph, aggr, d = ctx.graph, ctx.aggr, ctx.d
         if aggr == "max":
             (arg,) = ctx.saved_tensors
-            return ops.segment_max_bwd(arg, dy.contiguous(), graph.n_src), None, None
+            return ops.segment_max_bwd(graph.by_src, arg, dy.contiguous()), None, None
         dyp = _pad4(dy)
         _, v_src = graph.weights(aggr)
         a = ops.DeviceCSR(graph.by_src.n_rows, graph.by_src.n_cols, graph.by_src.rowptr, graph.by_src.col, v_src, None,

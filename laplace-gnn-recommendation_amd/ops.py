@@ -324,8 +324,9 @@ def expand_rows(a: DeviceCSR) -> Tensor:
 
 def sample_bpr_batch(r: DeviceCSR, row_of_edge: Tensor, batch: int, neg_range: int, seed: int, step: int,
                      quirk: bool = False, out: Optional[Tuple[Tensor, Tensor, Tensor]] = None,
-                     edges_in_order: bool = False) -> Tuple[Tensor, Tensor, Tensor]:
-    """K9 — replaces sample_mini_batch (data/lightgcn_loader.py:95-112) on device."""
+                     edges_in_order: bool = False, no_self_loops: bool = False) -> Tuple[Tensor, Tensor, Tensor]:
+    """K9 — replaces sample_mini_batch (data/lightgcn_loader.py:95-112) on device.  quirk: the reference's key
+    collision; no_self_loops: structured_negative_sampling(contains_neg_self_loops=False) — never negative id == user id."""
     if r.nnz == 0:
         raise ValueError("cannot sample from an empty edge set")
     if neg_range <= 0:
@@ -335,7 +336,8 @@ def sample_bpr_batch(r: DeviceCSR, row_of_edge: Tensor, batch: int, neg_range: i
         out = tuple(t.empty(batch, dtype=t.int64, device=dev) for _ in range(3))
     users, pos, neg = out
     check(_lib.lib().mi_sample_bpr_batch(batch, r.nnz, _ptr(r.rowptr), _ptr(r.col), _ptr(row_of_edge),
-                                         int(neg_range), 1 if quirk else 0, 1 if edges_in_order else 0,
+                                         int(neg_range), (1 if quirk else 0) | (2 if no_self_loops else 0),
+                                         1 if edges_in_order else 0,
                                          int(seed) & (2**64 - 1),
                                          int(step) & (2**64 - 1), _ptr(users), _ptr(pos), _ptr(neg),
                                          _stream()), "mi_sample_bpr_batch")
@@ -457,14 +459,18 @@ def segment_max(a: DeviceCSR, X: Tensor, want_arg: bool = True):
     return Y, arg
 
 
-def segment_max_bwd(arg: Tensor, dY: Tensor, n_src: int) -> Tensor:
+def segment_max_bwd(by_src: DeviceCSR, arg: Tensor, dY: Tensor) -> Tensor:
+    """Gradient of segment_max wrt X: by_src is the same relation as a CSR over SOURCE nodes (col = destination ids).
+    Deterministic: each dX element has one writer that sums its destinations in CSR order."""
     _need(arg, t.int32, "arg")
     ldy = _rows_ok(dY, "dY")
     d = dY.shape[1]
-    dX = t.zeros(n_src, d, dtype=t.float32, device=dY.device)
-    if n_src and dY.shape[0]:
-        check(_lib.lib().mi_segment_max_bwd_f32(dY.shape[0], d, arg.data_ptr(), dY.data_ptr(), ldy, dX.data_ptr(), d,
-                                                _stream()), "mi_segment_max_bwd_f32")
+    dX = t.empty(by_src.n_rows, d, dtype=t.float32, device=dY.device)
+    if by_src.n_rows:
+        colp = _ptr(by_src.col) if by_src.nnz else by_src.rowptr.data_ptr()
+        check(_lib.lib().mi_segment_max_bwd_f32(by_src.n_rows, d, _ptr(by_src.rowptr), colp, arg.data_ptr(),
+                                                dY.data_ptr() if dY.numel() else None, ldy, dX.data_ptr(), d, _stream()),
+              "mi_segment_max_bwd_f32")
     return dX
 
 
@@ -480,11 +486,17 @@ def embed_concat(x: Tensor, tables, max_norm: float = 1.0) -> Tensor:
     out = t.empty(n, width, dtype=t.float32, device=x.device)
     if n == 0 or nc == 0:
         return out
-    ptrs = (ctypes.c_void_p * nc)(*[tb.data_ptr() for tb in tables])
-    rows = (ctypes.c_int64 * nc)(*[int(tb.shape[0]) for tb in tables])
-    dims = (ctypes.c_int32 * nc)(*[int(tb.shape[1]) for tb in tables])
-    check(_lib.lib().mi_embed_concat_f32(n, nc, x.data_ptr(), ptrs, rows, dims, float(max_norm), out.data_ptr(), width,
-                                         _stream()), "mi_embed_concat_f32")
+    off = 0
+    for c0 in range(0, nc, 16):  # the kernel takes up to 16 table descriptors by value: wider inputs go in groups
+        tabs = tables[c0:c0 + 16]
+        g = len(tabs)
+        xs = x if (c0 == 0 and g == nc) else x[:, c0:c0 + g].contiguous()
+        ptrs = (ctypes.c_void_p * g)(*[tb.data_ptr() for tb in tabs])
+        rows = (ctypes.c_int64 * g)(*[int(tb.shape[0]) for tb in tabs])
+        dims = (ctypes.c_int32 * g)(*[int(tb.shape[1]) for tb in tabs])
+        check(_lib.lib().mi_embed_concat_f32(n, g, xs.data_ptr(), ptrs, rows, dims, float(max_norm),
+                                             out.data_ptr() + 4 * off, width, _stream()), "mi_embed_concat_f32")
+        off += sum(int(tb.shape[1]) for tb in tabs)
     return out
 
 

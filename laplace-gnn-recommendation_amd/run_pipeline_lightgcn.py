@@ -34,7 +34,7 @@ def evaluation(model: LightGCN, edge_index: Tensor, sparse_edge_index: SparseTen
         inter = Interactions(edge_index, n_users, n_items)
         neg_range = int(edge_index[1].max())  # reference: num_nodes = max(edge_index[1])
         u, p, n = ops.sample_bpr_batch(inter.csr(), inter.row_of_edge(), inter.num_edges, neg_range, seed, 0,
-                                       quirk=True, edges_in_order=True)
+                                       quirk=True, edges_in_order=True, no_self_loops=True)  # :40-44 contains_neg_self_loops=False
         final = t.cat([users_final, items_final])
         loss = ops.bpr_fwd_bwd(u, p, n, final, model.table(), n_users, lambda_val)
     recall, precision, ndcg = get_metrics_lightgcn(model, edge_index, exclude_edge_indices, k)

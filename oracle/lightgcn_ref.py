@@ -230,12 +230,18 @@ def topk_excl_exact(scores: Tensor, excl: List[Tensor], k: int) -> Tensor:
 # ----------------------------------------------------------------------------------------------
 # sampler: data/lightgcn_loader.py:95-112 + PyG structured_negative_sampling
 # ----------------------------------------------------------------------------------------------
-def structured_negative_sampling(edge_index: Tensor, num_nodes: int, rng: np.random.Generator) -> Tensor:
+def structured_negative_sampling(edge_index: Tensor, num_nodes: int, rng: np.random.Generator,
+                                 contains_neg_self_loops: bool = True) -> Tensor:
     """torch_geometric.utils.structured_negative_sampling (PyG 2.0.4), CPU:
-    rand ~ U[0, num_nodes) per edge, redrawn while row*num_nodes+rand is in {row*num_nodes+col}.
-    Called with num_nodes = max(edge_index[1]) at data/lightgcn_loader.py:105-106."""
+    rand ~ U[0, num_nodes) per edge, redrawn while row*num_nodes+rand is in {row*num_nodes+col}; with
+    contains_neg_self_loops=False the keys i*num_nodes+i of all i in range(num_nodes) join that set.
+    Called with num_nodes = max(edge_index[1]) at data/lightgcn_loader.py:105-106 (default True) and at
+    run_pipeline_lightgcn.py:40-44 (False)."""
     row, col = edge_index[0].numpy(), edge_index[1].numpy()
     pos_idx = row * num_nodes + col
+    if not contains_neg_self_loops:
+        loop = np.arange(num_nodes, dtype=pos_idx.dtype)
+        pos_idx = np.concatenate([pos_idx, loop * num_nodes + loop])
     rand = rng.integers(0, num_nodes, size=row.shape[0])
     neg_idx = row * num_nodes + rand
     mask = np.isin(neg_idx, pos_idx)
@@ -264,7 +270,7 @@ _MAX_NEG_ATTEMPTS = 4096
 
 
 def sample_bpr_batch_philox(rowptr: Tensor, col: Tensor, batch: int, neg_range: int, seed: int, step: int,
-                            quirk: bool = False, edges_in_order: bool = False):
+                            quirk: bool = False, edges_in_order: bool = False, no_self_loops: bool = False):
     """Bit-exact restatement of csrc/train.hip:sample_bpr_kernel (integer work => exact parity).
     rowptr/col: the users x items interaction CSR with sorted columns."""
     rp, c = rowptr.numpy().astype(np.int64), col.numpy().astype(np.int64)
@@ -298,6 +304,8 @@ def sample_bpr_batch_philox(rowptr: Tensor, col: Tensor, batch: int, neg_range: 
             hit = has(u, cand)
             if (not hit) and quirk and cand == 0 and u > 0:
                 hit = has(u - 1, neg_range)
+            if (not hit) and no_self_loops and cand == u:
+                hit = True
             if not hit:
                 break
         neg[i] = cand

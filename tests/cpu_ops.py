@@ -110,9 +110,9 @@ def expand_rows(a: DeviceCSR) -> Tensor:
 
 
 def sample_bpr_batch(r: DeviceCSR, row_of_edge, batch, neg_range, seed, step, quirk=False, out=None,
-                     edges_in_order=False):
+                     edges_in_order=False, no_self_loops=False):
     u, p, n = R.sample_bpr_batch_philox(r.rowptr.long(), r.col.long(), batch, neg_range, seed, step, quirk,
-                                        edges_in_order)
+                                        edges_in_order, no_self_loops)
     if out is not None:
         for dst, src in zip(out, (u, p, n)):
             dst.copy_(src)

@@ -477,12 +477,17 @@ def test_sampler_bit_exact_vs_philox_oracle():
     assert t.equal(r.rowptr.cpu().long(), rowptr) and t.equal(r.col.cpu().long(), col_s)
     assert t.equal(roe.cpu().long(), t.repeat_interleave(t.arange(U), rowptr[1:] - rowptr[:-1]))
     neg_range = int(ei[1].max())  # reference: num_nodes = max(col)
-    for quirk in (False, True):
+    for quirk, nsl in ((False, False), (True, False), (False, True), (True, True)):
         for step in (0, 1, 12345678901):
-            us, ps, ns = ops.sample_bpr_batch(r, roe, 512, neg_range, seed=0xDEADBEEFCAFE, step=step, quirk=quirk)
+            us, ps, ns = ops.sample_bpr_batch(r, roe, 512, neg_range, seed=0xDEADBEEFCAFE, step=step, quirk=quirk,
+                                              no_self_loops=nsl)
             wu, wp, wn = R.sample_bpr_batch_philox(rowptr, col_s, 512, neg_range, seed=0xDEADBEEFCAFE, step=step,
-                                                   quirk=quirk)
+                                                   quirk=quirk, no_self_loops=nsl)
             assert t.equal(us.cpu(), wu) and t.equal(ps.cpu(), wp) and t.equal(ns.cpu(), wn)
+            assert not nsl or not bool((ns == us).any())  # contains_neg_self_loops=False: never item id == user id
+    # the flag bites: without it users < neg_range do draw their own id now and then
+    us, _, ns = ops.sample_bpr_batch(r, roe, 20000, neg_range, seed=4, step=0)
+    assert bool((ns == us).any())
     # structural properties on a bigger draw
     us, ps, ns = ops.sample_bpr_batch(r, roe, 20000, neg_range, seed=1, step=2)
     us, ps, ns = us.cpu(), ps.cpu(), ns.cpu()

@@ -188,3 +188,65 @@ def test_to_hetero_three_relations_per_destination(hetero_aggr, conv_aggr):
     for (n, p), (_, pr) in zip(enc.named_parameters(), ref.named_parameters()):
         scale = float(pr.grad.abs().max()) + 1e-6
         assert float((p.grad.cpu() - pr.grad).abs().max()) <= 2e-4 * scale + 1e-6, (n, hetero_aggr)
+
+
+def test_embed_concat_more_than_sixteen_columns_and_id_validation():
+    """The reference allows any number of categorical columns; ids outside a table raise (as nn.Embedding does) in
+    the model's validate_features instead of being clamped in silence."""
+    from laplace_amd import ops
+    from laplace_amd.model.encoder_decoder import Encoder_Decoder_Model
+    from laplace_amd.model.layers import get_SAGEConv_layers, get_linear_layers
+    g = t.Generator().manual_seed(2)
+    nc = 37
+    dims = [int(t.randint(1, 9, (1,), generator=g)) for _ in range(nc)]
+    rows = [int(t.randint(2, 50, (1,), generator=g)) for _ in range(nc)]
+    tables = [t.randn(r, d, generator=g) for r, d in zip(rows, dims)]
+    x = t.stack([t.randint(0, r, (101,), generator=g) for r in rows], dim=1)
+    got = ops.embed_concat(x.to(DEV), [tb.to(DEV) for tb in tables], max_norm=1.0).cpu()
+    want = t.cat([t.nn.functional.embedding(x[:, i], tb.clone(), max_norm=1.0) for i, tb in enumerate(tables)], dim=1)
+    assert t.allclose(got, want, atol=1e-6, rtol=1e-6)
+    info = {"customer": SimpleNamespace(num_feat=2, num_cat=[4, 9], embedding_size=[2, 4]),
+            "article": SimpleNamespace(num_feat=1, num_cat=[6], embedding_size=[4])}
+    meta = (["customer", "article"], [("customer", "buys", "article"), ("article", "rev_buys", "customer")])
+    model = Encoder_Decoder_Model(get_SAGEConv_layers(2, 16, 8, "add"), get_linear_layers(2, 16, 16, 1), info, meta, True,
+                                  "sum", True, 0.0, 0.0).to(DEV)
+    ok = {"customer": t.tensor([[0, 9], [4, 0]], device=DEV), "article": t.tensor([[6], [0]], device=DEV)}
+    model.validate_features(ok)
+    for bad in ({"customer": t.tensor([[5, 0]], device=DEV), "article": ok["article"]},
+                {"customer": ok["customer"], "article": t.tensor([[-1]], device=DEV)}):
+        with pytest.raises(IndexError):
+            model.validate_features(bad)
+    with pytest.raises(ValueError):
+        model.validate_features({"customer": t.zeros(3, 3, dtype=t.int64, device=DEV), "article": ok["article"]})
+
+
+def test_segment_max_backward_is_deterministic_and_exact():
+    """aggr="max": many destinations share one arg-max source (hub sources, duplicated edges).  The gradient is reduced
+    per source row in CSR order — equal to the float64 scatter, and the same bits on every run (no float atomics)."""
+    from laplace_amd import ops
+    g = t.Generator().manual_seed(4)
+    n_src, n_dst, d, E = 40, 3000, 70, 60000
+    src = (t.rand(E, generator=g) ** 3 * n_src).long().clamp(max=n_src - 1)     # a few very popular sources
+    dst = t.randint(0, n_dst - 7, (E,), generator=g)
+    src, dst = t.cat([src, src[:500]]), t.cat([dst, dst[:500]])                 # duplicated edges
+    by_dst = ops.coo_to_csr(dst.to(DEV), src.to(DEV), n_dst, n_src, want_perm=False)
+    by_src = ops.coo_to_csr(src.to(DEV), dst.to(DEV), n_src, n_dst, want_perm=False)
+    X = t.randn(n_src, d, generator=g)
+    X[:3] += 3.0                                                                # sources that win almost everywhere
+    Y, arg = ops.segment_max(by_dst, X.to(DEV))
+    dense = t.full((n_dst, n_src), float("-inf"))
+    dense[dst, src] = 0.0
+    want_y = (X[None, :, :] + dense[:, :, None]).amax(dim=1)
+    want_y[t.isinf(want_y)] = 0.0                                                # empty destinations -> 0
+    assert t.equal(Y.cpu(), want_y)
+    dY = t.randn(n_dst, d, generator=g)
+    dX = ops.segment_max_bwd(by_src, arg, dY.to(DEV))
+    a = arg.cpu().long()
+    ref = t.zeros(n_src, d, dtype=t.float64)
+    valid = a >= 0
+    cols = t.arange(d)[None, :].expand(n_dst, d)
+    ref.index_put_((a[valid], cols[valid]), dY.double()[valid], accumulate=True)
+    assert int((a[:, 0] == 0).sum()) > 100                                      # the contended case is really there
+    assert (dX.cpu().double() - ref).abs().max() <= 1e-4
+    for _ in range(3):
+        assert t.equal(ops.segment_max_bwd(by_src, arg, dY.to(DEV)), dX)

@@ -165,6 +165,27 @@ def test_sampler_oracle_is_structured_negative_sampling_in_distribution():
     # user frequency follows edge counts (edges are drawn uniformly with replacement)
     deg = np.diff(rowptr.numpy())
     assert np.abs(counts.sum(1) / counts.sum() - deg / deg.sum()).max() < 0.02
+    # contains_neg_self_loops=False (evaluation(), run_pipeline_lightgcn.py:40-44): item id == user id is rejected too;
+    # the PyG-semantics restatement and the Philox mirror agree on the support and on its uniform law
+    ei = t.stack([u, i])
+    rng = np.random.default_rng(0)
+    pyg = np.zeros((U, neg_range))
+    phi = np.zeros((U, neg_range))
+    for step in range(400):
+        neg = structured = R.structured_negative_sampling(ei, neg_range, rng, contains_neg_self_loops=False)
+        for a, c in zip(u.tolist(), neg.tolist()):
+            pyg[a, c] += 1
+        us, ps, ns = R.sample_bpr_batch_philox(rowptr, col_s, ei.shape[1], neg_range, seed=5, step=step, edges_in_order=True,
+                                               no_self_loops=True)
+        assert t.equal(us, u) and t.equal(ps, i)  # edges_in_order: one negative per edge of the split
+        for a, c in zip(us.tolist(), ns.tolist()):
+            phi[a, c] += 1
+    for a in range(U):
+        allowed = [c for c in range(neg_range) if c != a and c not in col_s[rowptr[a]:rowptr[a + 1]].tolist()]
+        banned = [c for c in range(neg_range) if c not in allowed]
+        assert pyg[a, banned].sum() == 0 and phi[a, banned].sum() == 0
+        assert np.abs(pyg[a, allowed] / pyg[a].sum() - 1.0 / len(allowed)).max() < 0.06
+        assert np.abs(phi[a, allowed] / phi[a].sum() - 1.0 / len(allowed)).max() < 0.06
 
 
 # ---- property test (SURVEY 8c iv): the oracle's CSR SpMM against torch.sparse.mm and a dense product ----------
