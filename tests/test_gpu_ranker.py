@@ -247,6 +247,9 @@ def test_segment_max_backward_is_deterministic_and_exact():
     cols = t.arange(d)[None, :].expand(n_dst, d)
     ref.index_put_((a[valid], cols[valid]), dY.double()[valid], accumulate=True)
     assert int((a[:, 0] == 0).sum()) > 100                                      # the contended case is really there
-    assert (dX.cpu().double() - ref).abs().max() <= 1e-4
+    mass = t.zeros(n_src, d, dtype=t.float64)
+    mass.index_put_((a[valid], cols[valid]), dY.double().abs()[valid], accumulate=True)
+    # a source wins up to ~3 000 destinations: fp32 sequential-sum bound = terms * 2^-24 * sum|terms|, in practice far inside it
+    assert bool(((dX.cpu().double() - ref).abs() <= 1e-6 * mass + 1e-6).all())
     for _ in range(3):
         assert t.equal(ops.segment_max_bwd(by_src, arg, dY.to(DEV)), dX)
