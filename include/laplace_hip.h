@@ -400,6 +400,46 @@ int mi_embed_concat_f32(int64_t n, int32_t n_cols, const int64_t* x,
                         float max_norm, float* out, int64_t ldo, mi_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
+ * K8  per-node-type BatchNorm1d over the nodes of a batch.
+ * replaces: self.encoder_layer_norm_customer / _article = BatchNorm1d(out_channels) applied at
+ *           model/encoder_decoder.py:144-150 (declared :98-99) and its autograd backward.
+ * training != 0: batch statistics (biased variance for the normalisation; running_mean /
+ * running_var updated in place with `momentum` and the UNBIASED variance, torch semantics;
+ * pass both null to skip); save_mean / save_invstd float[c] are written for the backward.
+ * training == 0: y = (x - running_mean) / sqrt(running_var + eps) * gamma + beta.
+ * gamma / beta nullable (affine=False).  Backward: dX (nullable) and dgamma / dbeta (nullable)
+ * from the saved statistics.  Sums are reduced in double in a fixed order: bitwise reproducible.
+ * ws: mi_batchnorm_workspace_bytes(c) bytes, device.  c <= 512.
+ * ---------------------------------------------------------------------------------- */
+size_t mi_batchnorm_workspace_bytes(int64_t c);
+int mi_batchnorm_fwd_f32(int64_t n, int64_t c, const float* X, int64_t ldx,
+                         const float* gamma, const float* beta,
+                         float* running_mean, float* running_var, float momentum, float eps,
+                         int32_t training, float* save_mean, float* save_invstd,
+                         float* Y, int64_t ldy, void* ws, size_t ws_bytes, mi_stream_t stream);
+int mi_batchnorm_bwd_f32(int64_t n, int64_t c, const float* X, int64_t ldx,
+                         const float* dY, int64_t ldy, const float* gamma,
+                         const float* save_mean, const float* save_invstd,
+                         float* dX, int64_t lddx, float* dgamma, float* dbeta,
+                         void* ws, size_t ws_bytes, mi_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * b7  decoder input: z = cat(z_user[row], z_item[col], dim=-1) over the label edges.
+ * replaces: EdgeDecoder.forward's two index_selects + cat at model/encoder_decoder.py:57-63
+ *           and their backward (index_add into the two node tables).
+ * out float[n_edges, cu + ci].  Backward, one call per node table: dZ[v, :] = sum over the
+ * label edges e (ascending) with idx[e] == v of dOut[e, off : off + c]; dZ must be zero-filled
+ * by the caller (rows no edge names stay zero).  One writer per row, fixed order, no atomics;
+ * supports up to mi_gather_cat_bwd_max_edges() label edges (MI_ERR_UNSUPPORTED beyond).
+ * ---------------------------------------------------------------------------------- */
+int mi_gather_cat_f32(int64_t n_edges, int64_t cu, int64_t ci, const int64_t* row, const int64_t* col,
+                      const float* Zu, int64_t ldu, const float* Zi, int64_t ldi,
+                      float* out, int64_t ldo, mi_stream_t stream);
+int64_t mi_gather_cat_bwd_max_edges(void);
+int mi_gather_cat_bwd_f32(int64_t n_edges, int64_t c, int64_t off, const int64_t* idx,
+                          const float* dOut, int64_t ldo, float* dZ, int64_t ldz, mi_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
  * N1  on-device N-hop subgraph sampler for the ranker.
  * replaces: GraphDataset.__getitem__ + helpers (data/dataset.py:39-309, train mode) for a whole
  *           batch of seed users, and the PyG collate of the resulting HeteroData items

@@ -92,6 +92,13 @@ _PROTOTYPES = {
     "mi_segment_max_bwd_f32": (c_int32, [c_int64, c_int64, P, P, P, P, c_int64, P, c_int64, P]),
     "mi_embed_concat_f32": (c_int32, [c_int64, c_int32, P, POINTER(c_void_p), POINTER(c_int64), POINTER(c_int32),
                                       c_float, P, c_int64, P]),
+    "mi_batchnorm_workspace_bytes": (c_size_t, [c_int64]),
+    "mi_batchnorm_fwd_f32": (c_int32, [c_int64, c_int64, P, c_int64, P, P, P, P, c_float, c_float, c_int32, P, P, P, c_int64,
+                                       P, c_size_t, P]),
+    "mi_batchnorm_bwd_f32": (c_int32, [c_int64, c_int64, P, c_int64, P, c_int64, P, P, P, P, c_int64, P, P, P, c_size_t, P]),
+    "mi_gather_cat_f32": (c_int32, [c_int64, c_int64, c_int64, P, P, P, c_int64, P, c_int64, P, c_int64, P]),
+    "mi_gather_cat_bwd_max_edges": (c_int64, []),
+    "mi_gather_cat_bwd_f32": (c_int32, [c_int64, c_int64, c_int64, P, P, c_int64, P, c_int64, P]),
     "mi_sampler_workspace_bytes": (c_size_t, [POINTER(SamplerDesc)]),
     "mi_sampler_count": (c_int32, [POINTER(SamplerDesc), P, c_uint64, c_uint64, P, c_size_t, POINTER(c_int64), P]),
     "mi_sampler_count_async": (c_int32, [POINTER(SamplerDesc), P, c_uint64, c_uint64, P, c_size_t, P, P]),

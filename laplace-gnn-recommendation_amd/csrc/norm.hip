@@ -1,0 +1,266 @@
+// Ranker head kernels: per-type BatchNorm1d over a batch's nodes (K8) and the decoder's gather + concat.
+//   mi_batchnorm_*     BatchNorm1d(out_channels) in training and eval mode, model/encoder_decoder.py:98-99,144-150
+//   mi_gather_cat_*    z = cat(z_user[row], z_item[col]) of EdgeDecoder.forward, model/encoder_decoder.py:57-63
+// A batch is ~10^4 nodes x 64 channels (a few MB): these kernels are launch-bound, so the design goal is FEW launches
+// with fixed reduction orders (no float atomics): statistics are reduced by kBnParts workgroups into per-part double
+// sums, and every workgroup of the second kernel re-reduces those few partials itself (32 x C doubles from L2) instead
+// of paying a third launch — forward = 2 launches, backward = 2 launches.
+#include "common.hpp"
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kWaves = kBlock / MI_WAVE;
+constexpr int kBnParts = 32;    // partial workgroups of a reduction
+constexpr int kBnMaxC = 512;    // channels (lanes loop in chunks of 64)
+
+// part p, wave w: rows p*kWaves + w, then + kBnParts*kWaves, ... ; lane = channel.  A wave-load reads one row of C
+// floats: coalesced.  Sums are kept in double per lane and combined across the block's waves through LDS in wave order.
+template <bool BWD>
+__global__ __launch_bounds__(kBlock) void bn_partial_kernel(int64_t n, int c, const float* __restrict__ X, int64_t ldx,
+                                                            const float* __restrict__ dY, int64_t ldy,
+                                                            const float* __restrict__ mean,
+                                                            const float* __restrict__ invstd,
+                                                            double* __restrict__ part /* [kBnParts, 2, c] */) {
+    __shared__ double red[kWaves][2][MI_WAVE];
+    const int lane = mi_lane(), wave = threadIdx.x / MI_WAVE, p = blockIdx.x;
+    for (int c0 = 0; c0 < c; c0 += MI_WAVE) {
+        const int ch = c0 + lane;
+        double a = 0.0, b = 0.0;
+        float mu = 0.f, is = 0.f;
+        if (BWD && ch < c) { mu = mean[ch]; is = invstd[ch]; }
+        for (int64_t r = (int64_t)p * kWaves + wave; r < n; r += (int64_t)kBnParts * kWaves) {
+            if (ch < c) {
+                const float x = X[r * ldx + ch];
+                if (BWD) {  // a = sum dy, b = sum dy * xhat
+                    const float g = dY[r * ldy + ch];
+                    a += (double)g;
+                    b += (double)g * (double)((x - mu) * is);
+                } else {    // a = sum x, b = sum x^2
+                    a += (double)x;
+                    b += (double)x * (double)x;
+                }
+            }
+        }
+        red[wave][0][lane] = a;
+        red[wave][1][lane] = b;
+        __syncthreads();
+        if (wave == 0 && ch < c) {
+            double sa = red[0][0][lane], sb = red[0][1][lane];
+#pragma unroll
+            for (int w = 1; w < kWaves; ++w) { sa += red[w][0][lane]; sb += red[w][1][lane]; }
+            part[((int64_t)p * 2 + 0) * c + ch] = sa;
+            part[((int64_t)p * 2 + 1) * c + ch] = sb;
+        }
+        __syncthreads();
+    }
+}
+
+// y = (x - mean) * invstd * gamma + beta.  TRAIN: mean / invstd come from the partial sums (re-reduced by every block
+// in part order); block 0 also stores them for the backward and updates the running statistics (momentum, unbiased
+// variance) exactly as torch.nn.BatchNorm1d does.  Eval: mean / var are the running statistics.
+template <bool TRAIN>
+__global__ __launch_bounds__(kBlock) void bn_apply_kernel(int64_t n, int c, const float* __restrict__ X, int64_t ldx,
+                                                          const double* __restrict__ part,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          float* __restrict__ run_mean, float* __restrict__ run_var,
+                                                          float momentum, float eps, float* __restrict__ save_mean,
+                                                          float* __restrict__ save_invstd, float* __restrict__ Y,
+                                                          int64_t ldy) {
+    __shared__ float s_scale[kBnMaxC], s_shift[kBnMaxC];
+    for (int ch = threadIdx.x; ch < c; ch += kBlock) {
+        float mu, is;
+        if (TRAIN) {
+            double sa = 0.0, sb = 0.0;
+            for (int p = 0; p < kBnParts; ++p) {
+                sa += part[((int64_t)p * 2 + 0) * c + ch];
+                sb += part[((int64_t)p * 2 + 1) * c + ch];
+            }
+            const double m = sa / (double)n;
+            double var = sb / (double)n - m * m;  // biased; double sums: no cancellation at fp32 resolution
+            if (var < 0.0) var = 0.0;
+            mu = (float)m;
+            is = (float)(1.0 / sqrt(var + (double)eps));
+            if (blockIdx.x == 0) {
+                save_mean[ch] = mu;
+                save_invstd[ch] = is;
+                if (run_mean) {
+                    const double unb = n > 1 ? var * ((double)n / (double)(n - 1)) : var;
+                    run_mean[ch] = (1.f - momentum) * run_mean[ch] + momentum * mu;
+                    run_var[ch] = (1.f - momentum) * run_var[ch] + momentum * (float)unb;
+                }
+            }
+        } else {
+            mu = run_mean[ch];
+            is = 1.0f / sqrtf(run_var[ch] + eps);
+        }
+        const float g = gamma ? gamma[ch] : 1.f, b = beta ? beta[ch] : 0.f;
+        s_scale[ch] = is * g;
+        s_shift[ch] = b - mu * is * g;
+    }
+    __syncthreads();
+    const int64_t total = n * (int64_t)c;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
+        const int64_t r = i / c;
+        const int ch = (int)(i - r * c);
+        Y[r * ldy + ch] = fmaf(X[r * ldx + ch], s_scale[ch], s_shift[ch]);
+    }
+}
+
+// dx = gamma * invstd * (dy - mean(dy) - xhat * mean(dy * xhat)); block 0 writes dgamma = sum dy*xhat, dbeta = sum dy.
+__global__ __launch_bounds__(kBlock) void bn_bwd_apply_kernel(int64_t n, int c, const float* __restrict__ X, int64_t ldx,
+                                                              const float* __restrict__ dY, int64_t ldy,
+                                                              const double* __restrict__ part,
+                                                              const float* __restrict__ gamma,
+                                                              const float* __restrict__ mean,
+                                                              const float* __restrict__ invstd, float* __restrict__ dX,
+                                                              int64_t lddx, float* __restrict__ dgamma,
+                                                              float* __restrict__ dbeta) {
+    __shared__ float s_a[kBnMaxC], s_b[kBnMaxC], s_mu[kBnMaxC], s_is[kBnMaxC], s_g[kBnMaxC];
+    for (int ch = threadIdx.x; ch < c; ch += kBlock) {
+        double sa = 0.0, sb = 0.0;
+        for (int p = 0; p < kBnParts; ++p) {
+            sa += part[((int64_t)p * 2 + 0) * c + ch];
+            sb += part[((int64_t)p * 2 + 1) * c + ch];
+        }
+        if (blockIdx.x == 0) {
+            if (dbeta) dbeta[ch] = (float)sa;
+            if (dgamma) dgamma[ch] = (float)sb;
+        }
+        s_a[ch] = (float)(sa / (double)n);
+        s_b[ch] = (float)(sb / (double)n);
+        s_mu[ch] = mean[ch];
+        s_is[ch] = invstd[ch];
+        s_g[ch] = (gamma ? gamma[ch] : 1.f) * invstd[ch];
+    }
+    __syncthreads();
+    if (!dX) return;
+    const int64_t total = n * (int64_t)c;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
+        const int64_t r = i / c;
+        const int ch = (int)(i - r * c);
+        const float xh = (X[r * ldx + ch] - s_mu[ch]) * s_is[ch];
+        dX[r * lddx + ch] = s_g[ch] * (dY[r * ldy + ch] - s_a[ch] - xh * s_b[ch]);
+    }
+}
+
+// out[e, 0:cu] = Zu[row[e], :], out[e, cu:cu+ci] = Zi[col[e], :]; one wavefront per label edge
+__global__ __launch_bounds__(kBlock) void gather_cat_kernel(int64_t n_e, int cu, int ci, const int64_t* __restrict__ row,
+                                                            const int64_t* __restrict__ col, const float* __restrict__ Zu,
+                                                            int64_t ldu, const float* __restrict__ Zi, int64_t ldi,
+                                                            float* __restrict__ out, int64_t ldo) {
+    const int64_t e = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / MI_WAVE;
+    if (e >= n_e) return;
+    const int lane = mi_lane();
+    const float* su = Zu + row[e] * ldu;
+    const float* si = Zi + col[e] * ldi;
+    float* dst = out + e * ldo;
+    for (int k = lane; k < cu; k += MI_WAVE) dst[k] = su[k];
+    for (int k = lane; k < ci; k += MI_WAVE) dst[cu + k] = si[k];
+}
+
+// Backward of the gather: dZ[v, :] = sum over the label edges e (ascending) with idx[e] == v of dOut[e, off:off+c].
+// One wavefront per label edge: the FIRST edge naming a node owns that node's row and sums all later edges naming it,
+// in edge order — one writer per row, fixed order, no atomics, no sort.  The all-pairs scan costs n_e^2 / 64 compares
+// per wavefront: meant for the decoder's label edges (10^3..10^4 per batch); the host falls back to a sorted reduction
+// beyond kGatherBwdMaxEdges.  Rows no edge names stay zero (dZ is zero-filled by the caller).
+__global__ __launch_bounds__(kBlock) void gather_cat_bwd_kernel(int64_t n_e, int c, int off, const int64_t* __restrict__ idx,
+                                                                const float* __restrict__ dOut, int64_t ldo,
+                                                                float* __restrict__ dZ, int64_t ldz) {
+    const int64_t e = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / MI_WAVE;
+    if (e >= n_e) return;
+    const int lane = mi_lane();
+    const int64_t v = idx[e];
+    bool seen = false;  // does an earlier edge name v?
+    for (int64_t q = lane; q < e; q += MI_WAVE) seen |= (idx[q] == v);
+    if (__ballot(seen) != 0ull) return;
+    for (int k0 = 0; k0 < c; k0 += MI_WAVE) {
+        const int k = k0 + lane;
+        float acc = (k < c) ? dOut[e * ldo + off + k] : 0.f;
+        for (int64_t q0 = e + 1; q0 < n_e; q0 += MI_WAVE) {
+            const int64_t q = q0 + lane;
+            unsigned long long m = __ballot(q < n_e && idx[q] == v);
+            while (m) {  // matching edges of this chunk, ascending
+                const int l = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                if (k < c) acc += dOut[(q0 + l) * ldo + off + k];
+            }
+        }
+        if (k < c) dZ[v * ldz + k] = acc;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t mi_batchnorm_workspace_bytes(int64_t c) { return (size_t)kBnParts * 2 * (size_t)(c > 0 ? c : 1) * sizeof(double); }
+
+int mi_batchnorm_fwd_f32(int64_t n, int64_t c, const float* X, int64_t ldx, const float* gamma, const float* beta,
+                         float* running_mean, float* running_var, float momentum, float eps, int32_t training,
+                         float* save_mean, float* save_invstd, float* Y, int64_t ldy, void* ws, size_t ws_bytes,
+                         mi_stream_t stream) {
+    MI_CHECK_ARG(n >= 0 && c > 0);
+    if (c > kBnMaxC) return MI_ERR_UNSUPPORTED;
+    if (n == 0) return 0;
+    MI_CHECK_ARG(X && Y && ldx >= c && ldy >= c);
+    hipStream_t s = (hipStream_t)stream;
+    const unsigned grid = (unsigned)std::min<int64_t>(1024, mi_ceil_div(n * c, kBlock * 4));
+    if (training) {
+        MI_CHECK_ARG(save_mean && save_invstd && ws && ws_bytes >= mi_batchnorm_workspace_bytes(c));
+        MI_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr));
+        double* part = reinterpret_cast<double*>(ws);
+        hipLaunchKernelGGL(bn_partial_kernel<false>, dim3(kBnParts), dim3(kBlock), 0, s, n, (int)c, X, ldx, nullptr, 0,
+                           nullptr, nullptr, part);
+        hipLaunchKernelGGL(bn_apply_kernel<true>, dim3(grid ? grid : 1), dim3(kBlock), 0, s, n, (int)c, X, ldx, part, gamma,
+                           beta, running_mean, running_var, momentum, eps, save_mean, save_invstd, Y, ldy);
+    } else {
+        MI_CHECK_ARG(running_mean && running_var);
+        hipLaunchKernelGGL(bn_apply_kernel<false>, dim3(grid ? grid : 1), dim3(kBlock), 0, s, n, (int)c, X, ldx, nullptr,
+                           gamma, beta, running_mean, running_var, momentum, eps, nullptr, nullptr, Y, ldy);
+    }
+    return mi_launch_status();
+}
+
+int mi_batchnorm_bwd_f32(int64_t n, int64_t c, const float* X, int64_t ldx, const float* dY, int64_t ldy,
+                         const float* gamma, const float* save_mean, const float* save_invstd, float* dX, int64_t lddx,
+                         float* dgamma, float* dbeta, void* ws, size_t ws_bytes, mi_stream_t stream) {
+    MI_CHECK_ARG(n >= 0 && c > 0);
+    if (c > kBnMaxC) return MI_ERR_UNSUPPORTED;
+    if (n == 0) return 0;
+    MI_CHECK_ARG(X && dY && save_mean && save_invstd && ldx >= c && ldy >= c && (!dX || lddx >= c));
+    MI_CHECK_ARG(ws && ws_bytes >= mi_batchnorm_workspace_bytes(c));
+    hipStream_t s = (hipStream_t)stream;
+    double* part = reinterpret_cast<double*>(ws);
+    hipLaunchKernelGGL(bn_partial_kernel<true>, dim3(kBnParts), dim3(kBlock), 0, s, n, (int)c, X, ldx, dY, ldy, save_mean,
+                       save_invstd, part);
+    const unsigned grid = dX ? (unsigned)std::min<int64_t>(1024, mi_ceil_div(n * c, kBlock * 4)) : 1u;
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid ? grid : 1), dim3(kBlock), 0, s, n, (int)c, X, ldx, dY, ldy, part,
+                       gamma, save_mean, save_invstd, dX, lddx, dgamma, dbeta);
+    return mi_launch_status();
+}
+
+int mi_gather_cat_f32(int64_t n_edges, int64_t cu, int64_t ci, const int64_t* row, const int64_t* col, const float* Zu,
+                      int64_t ldu, const float* Zi, int64_t ldi, float* out, int64_t ldo, mi_stream_t stream) {
+    MI_CHECK_ARG(n_edges >= 0 && cu >= 0 && ci >= 0 && cu + ci > 0);
+    if (n_edges == 0) return 0;
+    MI_CHECK_ARG(row && col && out && ldo >= cu + ci && (cu == 0 || (Zu && ldu >= cu)) && (ci == 0 || (Zi && ldi >= ci)));
+    hipLaunchKernelGGL(gather_cat_kernel, dim3((unsigned)mi_ceil_div(n_edges * MI_WAVE, kBlock)), dim3(kBlock), 0,
+                       (hipStream_t)stream, n_edges, (int)cu, (int)ci, row, col, Zu, ldu, Zi, ldi, out, ldo);
+    return mi_launch_status();
+}
+
+int64_t mi_gather_cat_bwd_max_edges(void) { return 1 << 15; }
+
+int mi_gather_cat_bwd_f32(int64_t n_edges, int64_t c, int64_t off, const int64_t* idx, const float* dOut, int64_t ldo,
+                          float* dZ, int64_t ldz, mi_stream_t stream) {
+    MI_CHECK_ARG(n_edges >= 0 && c > 0 && off >= 0);
+    if (n_edges == 0) return 0;
+    if (n_edges > mi_gather_cat_bwd_max_edges()) return MI_ERR_UNSUPPORTED;
+    MI_CHECK_ARG(idx && dOut && dZ && ldo >= off + c && ldz >= c);
+    hipLaunchKernelGGL(gather_cat_bwd_kernel, dim3((unsigned)mi_ceil_div(n_edges * MI_WAVE, kBlock)), dim3(kBlock), 0,
+                       (hipStream_t)stream, n_edges, (int)c, (int)off, idx, dOut, ldo, dZ, ldz);
+    return mi_launch_status();
+}
+
+}  // extern "C"

@@ -10,8 +10,9 @@ relation (s, r, d) sees (x_s, x_d), and the outputs arriving at one destination 
 with `aggr` (text spec: temporary_hetero.py:171-228,337-360).
 
 Faithful quirks: the categorical embedding tables live in a plain dict (not parameters, not in the
-state_dict, frozen) — here they are at least moved by .to(device); BatchNorm, dropout,
-relu on small [n, 64..128] tensors stay torch ops.
+state_dict, frozen) — here they are at least moved by .to(device).  BatchNorm (K8) and the decoder's
+gather + concat run on csrc/norm.hip behind torch's own BatchNorm1d modules (parameters, running statistics and
+state_dict keys unchanged); dropout stays torch's (its mask is torch's RNG stream, as in the reference).
 """
 from __future__ import annotations
 
@@ -53,6 +54,70 @@ def _combine(outs: List[Tensor], aggr: str) -> Tensor:
     return t.div(out, len(outs)) if aggr == "mean" else out
 
 
+class _BatchNormFn(t.autograd.Function):
+    """BatchNorm1d on csrc/norm.hip: 2 launches forward, 2 backward, sums in double in a fixed order."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, weight: Optional[Tensor], bias: Optional[Tensor], running_mean: Optional[Tensor],
+                running_var: Optional[Tensor], momentum: float, eps: float, training: bool):
+        x = x if x.stride(-1) == 1 else x.contiguous()
+        y, mean, invstd = ops.batchnorm_fwd(x, weight, bias, running_mean, running_var, momentum, eps, training)
+        if not training:
+            invstd = t.rsqrt(running_var + eps)
+            mean = running_mean
+        ctx.save_for_backward(x, weight, mean, invstd)
+        ctx.training = training
+        return y
+
+    @staticmethod
+    def backward(ctx, dy: Tensor):
+        x, weight, mean, invstd = ctx.saved_tensors
+        dy = dy.contiguous()
+        need_dw = weight is not None and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
+        if ctx.training:
+            dx, dg, db = ops.batchnorm_bwd(x, dy, weight, mean, invstd, need_dx=ctx.needs_input_grad[0], need_dw=need_dw)
+        else:  # eval-mode statistics are constants (not a training path): plain tensor arithmetic
+            scale = invstd if weight is None else invstd * weight
+            dx = dy * scale if ctx.needs_input_grad[0] else None
+            dg = (dy * (x - mean) * invstd).sum(0) if need_dw else None
+            db = dy.sum(0) if need_dw else None
+        return dx, dg, db, None, None, None, None, None
+
+
+def batch_norm(bn: BatchNorm1d, x: Tensor) -> Tensor:
+    """bn(x) for a torch BatchNorm1d module (its parameters, buffers and state_dict stay torch's), computed by the
+    hand-written kernels."""
+    training = bn.training or not bn.track_running_stats
+    momentum = 0.0
+    if training and bn.track_running_stats:
+        bn.num_batches_tracked.add_(1)
+        momentum = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+    rm, rv = (bn.running_mean, bn.running_var) if bn.track_running_stats else (None, None)
+    return _BatchNormFn.apply(x, bn.weight, bn.bias, rm, rv, float(momentum), float(bn.eps), training)
+
+
+class _GatherCatFn(t.autograd.Function):
+    """cat(z_user[row], z_item[col], dim=-1) in one launch; backward = one deterministic segmented sum per table."""
+
+    @staticmethod
+    def forward(ctx, zu: Tensor, zi: Tensor, row: Tensor, col: Tensor):
+        zu = zu if zu.stride(-1) == 1 else zu.contiguous()
+        zi = zi if zi.stride(-1) == 1 else zi.contiguous()
+        row, col = row.contiguous(), col.contiguous()
+        ctx.save_for_backward(row, col)
+        ctx.shapes = (zu.shape, zi.shape)
+        return ops.gather_cat(zu, zi, row, col)
+
+    @staticmethod
+    def backward(ctx, dz: Tensor):
+        row, col = ctx.saved_tensors
+        (nu, cu), (ni, ci) = ctx.shapes
+        dz = dz.contiguous()
+        du = ops.gather_cat_bwd(dz, row, nu, cu, 0) if ctx.needs_input_grad[0] else None
+        di = ops.gather_cat_bwd(dz, col, ni, ci, cu) if ctx.needs_input_grad[1] else None
+        return du, di, None, None
+
+
 class HeteroGNNEncoder(nn.Module):
     """GNNEncoder.forward (model/encoder_decoder.py:29-46) applied per edge type."""
 
@@ -91,13 +156,18 @@ class HeteroGNNEncoder(nn.Module):
             last = index == n_layers - 1
             if not last and self.p_dropout_features is not None:
                 x_dict = {k: F.dropout(v, p=self.p_dropout_features, training=self.training) for k, v in x_dict.items()}
+            arriving: Dict[str, int] = {}
+            for et in graphs:
+                arriving[et[2]] = arriving.get(et[2], 0) + 1
             by_dst: Dict[str, List[Tensor]] = {}
             for et, graph in graphs.items():
-                out = convs[_key(et)]((x_dict[et[0]], x_dict[et[2]]), graph)
+                # one relation into this destination (the default metadata): the relu rides in the conv's GEMM epilogue
+                act = (not last) and arriving[et[2]] == 1
+                out = convs[_key(et)]((x_dict[et[0]], x_dict[et[2]]), graph, relu=act)
                 by_dst.setdefault(et[2], []).append(out)
-            x_dict = {dst: _combine(outs, self.aggr) for dst, outs in by_dst.items()}
+            x_dict = {dst: (outs[0] if len(outs) == 1 else _combine(outs, self.aggr)) for dst, outs in by_dst.items()}
             if not last:
-                x_dict = {k: v.relu() for k, v in x_dict.items()}
+                x_dict = {k: (v if arriving[k] == 1 else v.relu()) for k, v in x_dict.items()}
         return x_dict
 
 
@@ -109,7 +179,7 @@ class EdgeDecoder(nn.Module):
 
     def forward(self, z_dict: dict, edge_label_index) -> Tensor:
         customer_index, article_index = edge_label_index
-        z = t.cat([z_dict[Constants.node_user][customer_index], z_dict[Constants.node_item][article_index]], dim=-1)
+        z = _GatherCatFn.apply(z_dict[Constants.node_user], z_dict[Constants.node_item], customer_index, article_index)
         n_layers = len(self.layers)
         for index, layer in enumerate(self.layers):
             if index == n_layers - 1:
@@ -186,8 +256,8 @@ class Encoder_Decoder_Model(nn.Module):
             x_dict = self._embed(x_dict)
         z_dict = self.encoder(x_dict, edge_index_dict)
         if self.batch_normalize:
-            z_dict[Constants.node_user] = self.encoder_layer_norm_customer(z_dict[Constants.node_user])
-            z_dict[Constants.node_item] = self.encoder_layer_norm_article(z_dict[Constants.node_item])
+            z_dict[Constants.node_user] = batch_norm(self.encoder_layer_norm_customer, z_dict[Constants.node_user])
+            z_dict[Constants.node_item] = batch_norm(self.encoder_layer_norm_article, z_dict[Constants.node_item])
         return self.decoder(z_dict, edge_label_index)
 
     def infer(self, x_dict, edge_index_dict: dict, edge_label_index: Tensor) -> Tensor:

@@ -500,6 +500,72 @@ def embed_concat(x: Tensor, tables, max_norm: float = 1.0) -> Tensor:
     return out
 
 
+_BN_WS = {}
+
+
+def _bn_ws(c: int, device) -> Tensor:
+    key = (t.device(device).index, int(c))
+    if key not in _BN_WS:
+        _BN_WS[key] = _ws(_lib.lib().mi_batchnorm_workspace_bytes(int(c)), device)
+    return _BN_WS[key]
+
+
+def batchnorm_fwd(x: Tensor, gamma: Optional[Tensor], beta: Optional[Tensor], running_mean: Optional[Tensor],
+                  running_var: Optional[Tensor], momentum: float, eps: float, training: bool):
+    """K8 — BatchNorm1d over the rows of x [n, c].  Returns (y, save_mean, save_invstd); the running statistics are
+    updated in place in training mode (torch semantics: unbiased variance, momentum)."""
+    ldx = _rows_ok(x, "x")
+    n, c = x.shape
+    y = t.empty(n, c, dtype=t.float32, device=x.device)
+    sm = t.empty(c, dtype=t.float32, device=x.device) if training else None
+    si = t.empty(c, dtype=t.float32, device=x.device) if training else None
+    ws = _bn_ws(c, x.device)
+    check(_lib.lib().mi_batchnorm_fwd_f32(n, c, _ptr(x), ldx, _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var),
+                                          float(momentum), float(eps), 1 if training else 0, _ptr(sm), _ptr(si), _ptr(y), c,
+                                          ws.data_ptr(), ws.numel(), _stream()), "mi_batchnorm_fwd_f32")
+    return y, sm, si
+
+
+def batchnorm_bwd(x: Tensor, dy: Tensor, gamma: Optional[Tensor], save_mean: Tensor, save_invstd: Tensor,
+                  need_dx: bool = True, need_dw: bool = True):
+    """(dx, dgamma, dbeta) of batchnorm_fwd in training mode."""
+    ldx, ldy = _rows_ok(x, "x"), _rows_ok(dy, "dy")
+    n, c = x.shape
+    dx = t.empty(n, c, dtype=t.float32, device=x.device) if need_dx else None
+    dg = t.empty(c, dtype=t.float32, device=x.device) if need_dw else None
+    db = t.empty(c, dtype=t.float32, device=x.device) if need_dw else None
+    ws = _bn_ws(c, x.device)
+    check(_lib.lib().mi_batchnorm_bwd_f32(n, c, _ptr(x), ldx, _ptr(dy), ldy, _ptr(gamma), _ptr(save_mean), _ptr(save_invstd),
+                                          _ptr(dx), c, _ptr(dg), _ptr(db), ws.data_ptr(), ws.numel(), _stream()),
+          "mi_batchnorm_bwd_f32")
+    return dx, dg, db
+
+
+def gather_cat(zu: Tensor, zi: Tensor, row: Tensor, col: Tensor) -> Tensor:
+    """b7 — cat(zu[row], zi[col], dim=-1) in one launch (model/encoder_decoder.py:57-63)."""
+    _need(row, t.int64, "row")
+    _need(col, t.int64, "col")
+    ldu, ldi = _rows_ok(zu, "zu"), _rows_ok(zi, "zi")
+    cu, ci, ne = zu.shape[1], zi.shape[1], row.numel()
+    out = t.empty(ne, cu + ci, dtype=t.float32, device=zu.device)
+    check(_lib.lib().mi_gather_cat_f32(ne, cu, ci, _ptr(row), _ptr(col), _ptr(zu), ldu, _ptr(zi), ldi, _ptr(out), cu + ci,
+                                       _stream()), "mi_gather_cat_f32")
+    return out
+
+
+def gather_cat_bwd(d_out: Tensor, idx: Tensor, n_rows: int, c: int, off: int) -> Tensor:
+    """dZ [n_rows, c]: rows of d_out[:, off:off+c] summed per idx value, in edge order (deterministic)."""
+    _need(idx, t.int64, "idx")
+    ldo = _rows_ok(d_out, "d_out")
+    dz = t.zeros(n_rows, c, dtype=t.float32, device=d_out.device)
+    ne = idx.numel()
+    if ne > int(_lib.lib().mi_gather_cat_bwd_max_edges()):  # beyond the all-pairs kernel's range: torch's sorted index_add
+        return dz.index_add_(0, idx, d_out[:, off:off + c])
+    check(_lib.lib().mi_gather_cat_bwd_f32(ne, c, off, _ptr(idx), _ptr(d_out), ldo, _ptr(dz), c, _stream()),
+          "mi_gather_cat_bwd_f32")
+    return dz
+
+
 def batch_nodes(users: Tensor, pos: Tensor, neg: Tensor, n_users: int, n_nodes: int, *, gmap: Optional[Tensor] = None,
                 nodes: Optional[Tensor] = None, count: Optional[Tensor] = None, ws: Optional[Tensor] = None):
     """Unique node set of a BPR batch: (gmap int32[n_nodes], nodes int32[3B], count int32[2] on device:

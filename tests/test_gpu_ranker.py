@@ -253,3 +253,70 @@ def test_segment_max_backward_is_deterministic_and_exact():
     assert bool(((dX.cpu().double() - ref).abs() <= 1e-6 * mass + 1e-6).all())
     for _ in range(3):
         assert t.equal(ops.segment_max_bwd(by_src, arg, dY.to(DEV)), dX)
+
+
+@pytest.mark.parametrize("n,c", [(1, 64), (2, 64), (777, 64), (30011, 64), (500, 37), (3000, 200)])
+def test_batchnorm_kernels_match_torch_batchnorm1d(n, c):
+    """K8: training-mode forward (batch statistics), running statistics, backward (dx, dgamma, dbeta) and eval mode
+    against torch.nn.BatchNorm1d on the CPU; bitwise reproducible."""
+    from laplace_amd.model.encoder_decoder import batch_norm
+    g = t.Generator().manual_seed(n + c)
+    x = (t.randn(n, c, generator=g) * 2.0 + 3.0 * t.randn(1, c, generator=g))
+    w = t.randn(n, c, generator=g)
+    ref = t.nn.BatchNorm1d(c)
+    with t.no_grad():
+        ref.weight.copy_(t.rand(c, generator=g) + 0.5)
+        ref.bias.copy_(t.randn(c, generator=g))
+    mine = t.nn.BatchNorm1d(c)
+    mine.load_state_dict(ref.state_dict())
+    mine.to(DEV)
+    if n == 1:  # torch refuses a single row in training mode; so does the reference's BatchNorm1d
+        ref.eval(); mine.eval()
+    for it in range(3):
+        xr = x.clone().requires_grad_(True)
+        xg = x.clone().to(DEV).requires_grad_(True)
+        yr, yg = ref(xr), batch_norm(mine, xg)
+        assert (yg.detach().cpu() - yr.detach()).abs().max() <= 2e-5
+        ref.zero_grad(); mine.zero_grad()
+        (yr * w).sum().backward()
+        (yg * w.to(DEV)).sum().backward()
+        scale = float(xr.grad.abs().max()) + 1e-6
+        assert (xg.grad.cpu() - xr.grad).abs().max() <= 1e-4 * scale + 1e-6
+        for a, b in ((mine.weight.grad, ref.weight.grad), (mine.bias.grad, ref.bias.grad)):
+            assert (a.cpu() - b).abs().max() <= 1e-4 * (float(b.abs().max()) + 1.0)
+        for k in ("running_mean", "running_var", "num_batches_tracked"):
+            assert t.allclose(getattr(mine, k).cpu().float(), getattr(ref, k).float(), rtol=1e-5, atol=1e-6), k
+        again = batch_norm(mine, xg) if not mine.training else None
+    ref.eval(); mine.eval()
+    assert (batch_norm(mine, x.to(DEV)).cpu() - ref(x)).abs().max() <= 2e-5
+    mine.train()
+    if n > 1:
+        s0 = {k: v.clone() for k, v in mine.state_dict().items()}
+        y1 = batch_norm(mine, x.to(DEV))
+        mine.load_state_dict(s0)
+        y2 = batch_norm(mine, x.to(DEV))
+        assert t.equal(y1, y2)
+
+
+def test_gather_cat_forward_and_deterministic_backward():
+    from laplace_amd.model.encoder_decoder import _GatherCatFn
+    g = t.Generator().manual_seed(8)
+    nu, ni, cu, ci, ne = 40, 300, 64, 48, 2500
+    zu, zi = t.randn(nu, cu, generator=g), t.randn(ni, ci, generator=g)
+    row = t.randint(0, 5, (ne,), generator=g)          # a handful of users named by hundreds of label edges
+    col = t.randint(0, ni, (ne,), generator=g)
+    w = t.randn(ne, cu + ci, generator=g)
+    a, b = zu.clone().requires_grad_(True), zi.clone().requires_grad_(True)
+    (t.cat([a[row], b[col]], dim=-1) * w).sum().backward()
+    ag, bg = zu.clone().to(DEV).requires_grad_(True), zi.clone().to(DEV).requires_grad_(True)
+    out = _GatherCatFn.apply(ag, bg, row.to(DEV), col.to(DEV))
+    assert t.equal(out.detach().cpu(), t.cat([zu[row], zi[col]], dim=-1))
+    (out * w.to(DEV)).sum().backward()
+    assert (ag.grad.cpu() - a.grad).abs().max() <= 1e-4 * float(a.grad.abs().max())
+    assert (bg.grad.cpu() - b.grad).abs().max() <= 1e-5 * float(b.grad.abs().max()) + 1e-6
+    assert bool((ag.grad[5:] == 0).all())
+    first = ag.grad.clone()
+    for _ in range(3):
+        ag.grad = None
+        (_GatherCatFn.apply(ag, bg, row.to(DEV), col.to(DEV)) * w.to(DEV)).sum().backward()
+        assert t.equal(ag.grad, first)
