@@ -145,3 +145,22 @@ def check(rc: int, what: str) -> None:
 
 def exported_symbols() -> list[str]:
     return sorted(_PROTOTYPES)
+
+
+_raw_stream = None
+_cur_device = None
+
+
+def current_stream() -> int:
+    """The current HIP stream of the current device as a raw handle.  torch.cuda.current_stream() builds a Stream object
+    through several Python layers (~10 us per call, measured: 0.2 ms of a 2 ms ranker iteration); torch's raw getter
+    is ~0.3 us."""
+    global _raw_stream, _cur_device
+    if _raw_stream is None:
+        import torch as t
+        _raw_stream = getattr(t._C, "_cuda_getCurrentRawStream", False)
+        _cur_device = getattr(t._C, "_cuda_getDevice", False)
+    if _raw_stream and _cur_device:
+        return _raw_stream(_cur_device())
+    import torch as t
+    return t.cuda.current_stream().cuda_stream

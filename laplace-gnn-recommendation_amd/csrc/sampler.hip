@@ -266,10 +266,21 @@ __global__ __launch_bounds__(kSelThreads) void smp_select_users_kernel(Smp p, in
         __shared__ int32_t aq_sorted[kMaxFan];  // ascending: multiplicity lookups by binary search
         __shared__ int32_t cand_v[kSelThreads];
         __shared__ int32_t cand_ok[kSelThreads];
-        __shared__ int sh_np, sh_t0;
+        __shared__ int32_t cand_b[kSelThreads], cand_e[kSelThreads];
+        __shared__ int32_t expl[4 * kMaxFan];  // users explored so far (hops 0..hop), staged once
+        __shared__ int sh_np, sh_t0, sh_nexpl;
         volatile int32_t* picked = sel;
         const int naq = p.aq_n[s];
         for (int q = tid; q < naq; q += blockDim.x) aq[q] = p.aq[(int64_t)s * p.n + q];
+        if (tid == 0) {
+            int ne = 0;
+            for (int h = 0; h <= hop && ne >= 0; ++h)
+                for (int q = 0; q < uq_n[h]; ++q) {
+                    if (ne == 4 * kMaxFan) { ne = -1; break; }  // does not fit: read the lists from memory below
+                    expl[ne++] = uq[h * p.n + q];
+                }
+            sh_nexpl = ne;
+        }
         __syncthreads();
         if (tid == 0) {
             int64_t run = 0;
@@ -287,6 +298,7 @@ __global__ __launch_bounds__(kSelThreads) void smp_select_users_kernel(Smp p, in
         }
         __syncthreads();
         const int64_t L = pre[naq];
+        const int n_expl = sh_nexpl;
         const uint32_t c3 = (P_USER_REJ & 0xFFu) | ((uint32_t)(p.step & 0xFFFFFFu) << 8);
         const uint32_t k0 = (uint32_t)p.seed, k1 = (uint32_t)((p.seed >> 32) ^ (p.step >> 24));
         while (true) {  // one round = kSelThreads draws evaluated in parallel, committed in counter order
@@ -300,19 +312,40 @@ __global__ __launch_bounds__(kSelThreads) void smp_select_users_kernel(Smp p, in
                 if (pre[mid] <= pos) lo = mid; else hi = mid;
             }
             const int32_t v = p.aidx[p.aptr[aq[lo]] + (pos - pre[lo])];
-            uint32_t m = 0;  // number of queued articles (duplicates counted) that v bought
-            for (int32_t x = p.uptr[v]; x < p.uptr[v + 1]; ++x) {
-                const int32_t a = p.uidx[x];
-                int l2 = 0, h2 = naq;
-                while (l2 < h2) {
-                    const int mid = (l2 + h2) >> 1;
-                    if (aq_sorted[mid] < a) l2 = mid + 1; else h2 = mid;
+            // m = number of queued articles (duplicates counted) that v bought.  Positions are drawn in proportion to
+            // list length, so the 1 024 candidates of a round are the HEAVY users (10^3 articles): one thread walking
+            // its own candidate's list made the round as slow as the heaviest of them (round 1: 0.5-1.2 ms per launch).
+            // Each wavefront now walks the lists of its 64 candidates with all its lanes, one candidate after the other.
+            cand_v[tid] = v;
+            cand_b[tid] = p.uptr[v];
+            cand_e[tid] = p.uptr[v + 1];
+            uint32_t m = 0;
+            {
+                const int lane = tid & (MI_WAVE - 1), wbase = tid & ~(MI_WAVE - 1);
+                for (int ci = 0; ci < MI_WAVE; ++ci) {
+                    const int32_t xb = cand_b[wbase + ci], xe = cand_e[wbase + ci];  // written by this wavefront itself
+                    uint32_t cnt = 0;
+                    for (int32_t x = xb + lane; x < xe; x += MI_WAVE) {
+                        const int32_t a = p.uidx[x];
+                        int l2 = 0, h2 = naq;
+                        while (l2 < h2) {
+                            const int mid = (l2 + h2) >> 1;
+                            if (aq_sorted[mid] < a) l2 = mid + 1; else h2 = mid;
+                        }
+                        while (l2 < naq && aq_sorted[l2] == a) { ++cnt; ++l2; }
+                    }
+#pragma unroll
+                    for (int off = MI_WAVE / 2; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off, MI_WAVE);
+                    if (lane == ci) m = cnt;
                 }
-                while (l2 < naq && aq_sorted[l2] == a) { ++m; ++l2; }
             }
             bool ok = (m > 0) && (w.c[2] % m == 0);
-            for (int h = 0; ok && h <= hop; ++h)
-                for (int q = 0; q < uq_n[h]; ++q) ok &= (uq[h * p.n + q] != v);
+            if (n_expl >= 0) {
+                for (int q = 0; ok && q < n_expl; ++q) ok &= (expl[q] != v);
+            } else {
+                for (int h = 0; ok && h <= hop; ++h)
+                    for (int q = 0; q < uq_n[h]; ++q) ok &= (uq[h * p.n + q] != v);
+            }
             cand_v[tid] = v;
             cand_ok[tid] = ok ? 1 : 0;
             __syncthreads();

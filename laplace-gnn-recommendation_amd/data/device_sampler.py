@@ -110,7 +110,7 @@ class DeviceGraphSampler:
             raise ValueError("more seed users than the sampler's batch size")
         desc = self._desc if B == self.batch_size else self._make_desc(B)
         L = _lib.lib()
-        stream = t.cuda.current_stream().cuda_stream
+        stream = _lib.current_stream()
         totals = (ctypes.c_int64 * 4)()
         check(L.mi_sampler_count(ctypes.byref(desc), seeds.data_ptr(), self.seed & (2**64 - 1), int(step) & (2**64 - 1),
                                  self._ws.data_ptr(), self._ws.numel(), totals, stream), "mi_sampler_count")

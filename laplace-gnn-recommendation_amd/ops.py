@@ -43,8 +43,7 @@ def _side_stream(device) -> "t.cuda.Stream":
 PLAN_MIN_NNZ = 1 << 20
 
 
-def _stream() -> int:
-    return t.cuda.current_stream().cuda_stream
+_stream = _lib.current_stream
 
 
 def _ptr(x: Optional[Tensor]) -> Optional[int]:

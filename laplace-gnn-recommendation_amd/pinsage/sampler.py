@@ -35,7 +35,7 @@ class PinSAGESampler:
         self.step = 0
 
     def _stream(self):
-        return t.cuda.current_stream().cuda_stream
+        return _lib.current_stream()
 
     def item_pairs(self, step: int) -> Tuple[Tensor, Tensor, Tensor]:
         """(heads, tails, neg_tails), pairs whose walk died removed (pinsage/sampler.py:26-41)."""

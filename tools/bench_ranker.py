@@ -54,7 +54,7 @@ def main():
     model = Encoder_Decoder_Model(get_SAGEConv_layers(2, 128, 64, "add"), get_linear_layers(2, 128, 128, 1),
                                   get_feature_info(graph), first.metadata(), True, "sum", True, 0.2, 0.3).to(dev)
     model.initialize_encoder_input_size(first.to(dev))
-    opt = t.optim.Adam(model.parameters(), lr=0.01)
+    opt = t.optim.Adam(model.parameters(), lr=0.01, fused=True)  # one multi-tensor launch, same update
     crit = t.nn.BCEWithLogitsLoss()
     model.train()
 
