@@ -440,6 +440,21 @@ int mi_gather_cat_bwd_f32(int64_t n_edges, int64_t c, int64_t off, const int64_t
                           const float* dOut, int64_t ldo, float* dZ, int64_t ldz, mi_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
+ * N3  candidate matcher: items bought by users who share an item with the query user.
+ * replaces: UsersWithCommonItemsMatcher.get_matches at
+ *           data/matching/users_with_common_purchases.py:14-26 (flatten of the co-purchasers'
+ *           lists, t.cat of all their article lists, [:k]).
+ * users_ptr/users_idx and articles_ptr/articles_idx: the adjacency lists IN LIST ORDER (the
+ * reference's edges_*.pt / rev_edges_*.pt) as int32 CSR on device.  query_users int64[n] (null =
+ * users 0..n-1).  out int32[n, k]: the first k entries of the concatenation, -1 padded;
+ * out_count int32[n] (nullable): entries written.  One wavefront per query, stops at k.
+ * ---------------------------------------------------------------------------------- */
+int mi_match_common_items_i32(int64_t n_queries, const int64_t* query_users,
+                              const int32_t* users_ptr, const int32_t* users_idx,
+                              const int32_t* articles_ptr, const int32_t* articles_idx,
+                              int32_t k, int32_t* out, int32_t* out_count, mi_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
  * N1  on-device N-hop subgraph sampler for the ranker.
  * replaces: GraphDataset.__getitem__ + helpers (data/dataset.py:39-309, train mode) for a whole
  *           batch of seed users, and the PyG collate of the resulting HeteroData items

@@ -99,6 +99,7 @@ _PROTOTYPES = {
     "mi_gather_cat_f32": (c_int32, [c_int64, c_int64, c_int64, P, P, P, c_int64, P, c_int64, P, c_int64, P]),
     "mi_gather_cat_bwd_max_edges": (c_int64, []),
     "mi_gather_cat_bwd_f32": (c_int32, [c_int64, c_int64, c_int64, P, P, c_int64, P, c_int64, P]),
+    "mi_match_common_items_i32": (c_int32, [c_int64, P, P, P, P, P, c_int32, P, P, P]),
     "mi_sampler_workspace_bytes": (c_size_t, [POINTER(SamplerDesc)]),
     "mi_sampler_count": (c_int32, [POINTER(SamplerDesc), P, c_uint64, c_uint64, P, c_size_t, POINTER(c_int64), P]),
     "mi_sampler_count_async": (c_int32, [POINTER(SamplerDesc), P, c_uint64, c_uint64, P, c_size_t, P, P]),

@@ -254,9 +254,15 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(MiGemmArgs g) {
 // products dW = dY^T X of the ranker: a 128 x 84 output over K = tens of thousands of nodes).
 int mi_gemm_splits(int64_t M, int64_t N, int64_t K) {
     const int64_t blocks = mi_ceil_div(M, BM) * mi_ceil_div(N, BN);
-    if (blocks >= 128 || K < 2048) return 1;
+    // Round 2: the threshold was K >= 2048 with >= 256 of K per slice, which left the article-side weight gradients of
+    // a ranker batch (K = ~2 000 article nodes) and the decoder's 1-wide products (K = ~1 000 label edges) to 2-4
+    // workgroups walking K alone: 50-60 us per launch (profiles/r2_ranker_v1.md).  One KC panel per slice is enough work.
+    // The finer rule is kept to outputs of at most 8 tiles (weight-gradient shapes): wider outputs are forward products,
+    // which stay one k-ascending chain (bitwise the oracle's) until K >= 2048 as before.
+    const bool tiny = blocks <= 8;
+    if (blocks >= 128 || K < (tiny ? 512 : 2048)) return 1;
     int64_t s = mi_ceil_div(512, blocks);
-    const int64_t max_s = K / 256;  // at least 256 of K per slice
+    const int64_t max_s = K / (tiny ? KC : 256);  // at least one 128-wide panel (256 of K for wider outputs) per slice
     if (s > max_s) s = max_s;
     return s < 2 ? 1 : (int)s;
 }

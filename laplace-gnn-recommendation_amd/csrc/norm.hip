@@ -11,7 +11,7 @@ namespace {
 
 constexpr int kBlock = 256;
 constexpr int kWaves = kBlock / MI_WAVE;
-constexpr int kBnParts = 32;    // partial workgroups of a reduction
+constexpr int kBnParts = 64;    // partial workgroups of a reduction
 constexpr int kBnMaxC = 512;    // channels (lanes loop in chunks of 64)
 
 // part p, wave w: rows p*kWaves + w, then + kBnParts*kWaves, ... ; lane = channel.  A wave-load reads one row of C
@@ -29,16 +29,25 @@ __global__ __launch_bounds__(kBlock) void bn_partial_kernel(int64_t n, int c, co
         double a = 0.0, b = 0.0;
         float mu = 0.f, is = 0.f;
         if (BWD && ch < c) { mu = mean[ch]; is = invstd[ch]; }
-        for (int64_t r = (int64_t)p * kWaves + wave; r < n; r += (int64_t)kBnParts * kWaves) {
-            if (ch < c) {
-                const float x = X[r * ldx + ch];
+        constexpr int U = 4;  // rows in flight per lane: the walk is latency-bound, not bandwidth-bound
+        const int64_t stride = (int64_t)kBnParts * kWaves;
+        for (int64_t r0 = (int64_t)p * kWaves + wave; r0 < n; r0 += U * stride) {
+            float x[U], g[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t r = r0 + u * stride;
+                const bool ok = ch < c && r < n;
+                x[u] = ok ? X[r * ldx + ch] : 0.f;
+                g[u] = (BWD && ok) ? dY[r * ldy + ch] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {  // rows beyond n contribute exact zeros; order = ascending row
                 if (BWD) {  // a = sum dy, b = sum dy * xhat
-                    const float g = dY[r * ldy + ch];
-                    a += (double)g;
-                    b += (double)g * (double)((x - mu) * is);
+                    a += (double)g[u];
+                    b += (double)g[u] * (double)((x[u] - mu) * is);
                 } else {    // a = sum x, b = sum x^2
-                    a += (double)x;
-                    b += (double)x * (double)x;
+                    a += (double)x[u];
+                    b += (double)x[u] * (double)x[u];
                 }
             }
         }

@@ -51,6 +51,18 @@ def candidate_csr(matchers, num_users: int):
     return ptr, items[order]
 
 
+def candidate_csr_device(matchers, num_users: int, device):
+    """candidate_csr with every stage on the device: (ptr int32[U + 1], idx int32[]) tensors, or None when a matcher
+    has no device form.  Row u = cat(m.get_matches(u) for m in matchers), -1 pads dropped, order kept."""
+    if not matchers or not all(hasattr(m, "matches_for_all_device") for m in matchers):
+        return None
+    cat = t.cat([m.matches_for_all_device(num_users, device) for m in matchers], dim=1)
+    keep = cat >= 0
+    ptr = t.zeros(num_users + 1, dtype=t.int64, device=device)
+    t.cumsum(keep.sum(dim=1), dim=0, out=ptr[1:])
+    return ptr.to(t.int32), cat[keep].to(t.int32)
+
+
 class DeviceGraphSampler:
     def __init__(self, config, graph: HeteroData, users_adj_list, articles_adj_list, batch_size: Optional[int] = None,
                  randomization: bool = True, device: str = "cuda", seed: int = 0, prefetch: bool = True,
@@ -79,9 +91,17 @@ class DeviceGraphSampler:
         self.cptr = self.cidx = None
         if not self.train:
             assert matchers is not None, "Must provide matchers for test"
-            cptr, cidx = candidate_csr(matchers, n_users)
-            self.cptr, self.cidx = to32(cptr), to32(cidx if cidx.size else np.zeros(1, dtype=np.int64))
-            self.max_neg = max(self.max_neg, int(np.diff(cptr).max()) + max_deg)
+            on_dev = candidate_csr_device(matchers, n_users, dev) if dev.type == "cuda" else None
+            if on_dev is not None:  # N3: proposals computed and kept on the device
+                self.cptr, self.cidx = on_dev
+                widest = int((self.cptr[1:] - self.cptr[:-1]).max()) if n_users else 0
+                if self.cidx.numel() == 0:
+                    self.cidx = t.zeros(1, dtype=t.int32, device=dev)
+            else:
+                cptr, cidx = candidate_csr(matchers, n_users)
+                self.cptr, self.cidx = to32(cptr), to32(cidx if cidx.size else np.zeros(1, dtype=np.int64))
+                widest = int(np.diff(cptr).max())
+            self.max_neg = max(self.max_neg, widest + max_deg)
         self._desc = self._make_desc(self.batch_size)
         self._ws = t.empty(int(_lib.lib().mi_sampler_workspace_bytes(ctypes.byref(self._desc))), dtype=t.uint8, device=dev)
         self.step = 0

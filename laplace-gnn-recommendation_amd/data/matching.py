@@ -8,6 +8,12 @@ the reference materialises every article of every co-purchasing user and then ke
   UsersWithCommonItemsMatcher  first k entries of: for each article of the user (list order), for each
                                user of that article (list order, the user itself included), all their
                                articles (data/matching/users_with_common_purchases.py:14-26)
+
+Device forms: every matcher also answers for ALL users at once as a device tensor [U, k] (int64, -1 = no
+proposal) through `matches_for_all_device(num_users, device)` — the common-purchase expansion is the HIP kernel
+mi_match_common_items_i32, popularity is a device argsort of the degrees, the LightGCN rows are a slice of the top-K
+dump that is already on the device — and `device_sampler.candidate_csr_device` turns them into the candidate CSR the
+evaluation sampler reads, with no per-user host loop.  The host `get_matches` stays as the checker.
 """
 from __future__ import annotations
 
@@ -27,6 +33,7 @@ class Matcher:
 
 class LightGCNMatcher(Matcher):
     def __init__(self, top_articles_per_user: Tensor, k: int):
+        self._top_dev = top_articles_per_user if top_articles_per_user.is_cuda else None  # save_predictions' dump, kept where it is
         self.top, self.k = top_articles_per_user.cpu(), int(k)
 
     def get_matches(self, user_id: int) -> Tensor:
@@ -36,6 +43,10 @@ class LightGCNMatcher(Matcher):
     def matches_for_all(self, num_users: int):
         """[num_users, k] proposals at once (-1 = none): what the device sampler's evaluation mode consumes."""
         return self.top[:num_users, : self.k].numpy()
+
+    def matches_for_all_device(self, num_users: int, device) -> Tensor:
+        src = self._top_dev if getattr(self, "_top_dev", None) is not None else self.top
+        return src[:num_users, : self.k].to(device=device, dtype=t.int64)
 
 
 class PopularItemsMatcher(Matcher):
@@ -55,12 +66,29 @@ class PopularItemsMatcher(Matcher):
     def matches_for_all(self, num_users: int):
         return np.broadcast_to(self.popular_items[: self.k].numpy(), (num_users, min(self.k, self.popular_items.numel())))
 
+    @classmethod
+    def from_degrees_device(cls, article_degrees: Tensor, k: int) -> "PopularItemsMatcher":
+        """Most popular first, ties by id (stable), computed where the degrees live."""
+        return cls(t.argsort(article_degrees.to(t.int64), descending=True, stable=True), k)
+
+    def matches_for_all_device(self, num_users: int, device) -> Tensor:
+        row = self.popular_items[: self.k].to(device)
+        return row[None, :].expand(num_users, row.numel())
+
 
 class UsersWithCommonItemsMatcher(Matcher):
     def __init__(self, users_adj, articles_adj, k: int):
         self.users = users_adj if isinstance(users_adj, AdjList) else AdjList(users_adj)
         self.articles = articles_adj if isinstance(articles_adj, AdjList) else AdjList(articles_adj)
         self.k = int(k)
+
+    def matches_for_all_device(self, num_users: int, device) -> Tensor:
+        from .. import ops
+        if getattr(self, "_dev", None) is None or self._dev[0].device != t.device(device):
+            to32 = lambda a: t.from_numpy(np.ascontiguousarray(a.astype(np.int32))).to(device)
+            self._dev = (to32(self.users.ptr), to32(self.users.idx), to32(self.articles.ptr), to32(self.articles.idx))
+        out, _ = ops.match_common_items(*self._dev, self.k, n_queries=num_users)
+        return out.to(t.int64)
 
     def get_matches(self, user_id: int) -> Tensor:
         out: List[np.ndarray] = []

@@ -499,6 +499,24 @@ def embed_concat(x: Tensor, tables, max_norm: float = 1.0) -> Tensor:
     return out
 
 
+def match_common_items(users_ptr: Tensor, users_idx: Tensor, articles_ptr: Tensor, articles_idx: Tensor, k: int,
+                       query_users: Optional[Tensor] = None, n_queries: Optional[int] = None):
+    """N3 — UsersWithCommonItemsMatcher for many users at once: (out int32[n, k] with -1 pads, counts int32[n])."""
+    for n, x in (("users_ptr", users_ptr), ("users_idx", users_idx), ("articles_ptr", articles_ptr), ("articles_idx", articles_idx)):
+        _need(x, t.int32, n)
+    if query_users is not None:
+        _need(query_users, t.int64, "query_users")
+        n_queries = query_users.numel()
+    elif n_queries is None:
+        n_queries = users_ptr.numel() - 1
+    out = t.empty(n_queries, int(k), dtype=t.int32, device=users_ptr.device)
+    cnt = t.empty(n_queries, dtype=t.int32, device=users_ptr.device)
+    check(_lib.lib().mi_match_common_items_i32(n_queries, _ptr(query_users), users_ptr.data_ptr(), users_idx.data_ptr() if users_idx.numel() else users_ptr.data_ptr(),
+                                               articles_ptr.data_ptr(), articles_idx.data_ptr() if articles_idx.numel() else articles_ptr.data_ptr(),
+                                               int(k), _ptr(out), _ptr(cnt), _stream()), "mi_match_common_items_i32")
+    return out, cnt
+
+
 _BN_WS = {}
 
 

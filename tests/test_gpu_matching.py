@@ -1,0 +1,88 @@
+"""GPU: candidate matchers on device against the host matchers of data/matching.py (the checker, itself equal
+to the reference's eager semantics, tests/test_ranker_cpu.py) — bit-exact: integer work."""
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch as t
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _adj(seed, U=300, A=90, E=2500, empty_users=(0, 7, 299)):
+    from laplace_amd.data.dataset import AdjList
+    g = np.random.default_rng(seed)
+    keys = g.choice(U * A, size=E, replace=False)
+    g.shuffle(keys)                                   # list order = transaction order, not sorted
+    u, a = keys // A, keys % A
+    keep = ~np.isin(u, np.asarray(empty_users))
+    u, a = u[keep], a[keep]
+    users, articles = {}, {}
+    for x, y in zip(u.tolist(), a.tolist()):
+        users.setdefault(x, []).append(y)
+        articles.setdefault(y, []).append(x)
+    return AdjList(users, U), AdjList(articles, A), U, A
+
+
+@pytest.mark.parametrize("k", [1, 5, 20, 257])
+def test_common_items_matcher_device_equals_host(k):
+    from laplace_amd.data.matching import UsersWithCommonItemsMatcher
+    users, articles, U, A = _adj(k)
+    m = UsersWithCommonItemsMatcher(users, articles, k)
+    got = m.matches_for_all_device(U, DEV).cpu()
+    assert got.shape == (U, k) and got.dtype == t.int64
+    for u in range(U):
+        want = m.get_matches(u)
+        assert t.equal(got[u, : want.numel()], want), u
+        assert bool((got[u, want.numel():] == -1).all())
+    assert int((got[0] >= 0).sum()) == 0             # a user without purchases proposes nothing
+
+
+def test_popular_and_lightgcn_matchers_device_and_candidate_csr():
+    from laplace_amd.data.device_sampler import candidate_csr, candidate_csr_device
+    from laplace_amd.data.matching import LightGCNMatcher, PopularItemsMatcher, UsersWithCommonItemsMatcher
+    users, articles, U, A = _adj(3)
+    deg = t.from_numpy(np.diff(articles.ptr)).to(DEV)
+    pop_host = PopularItemsMatcher.from_adjacency(articles, 12)
+    pop_dev = PopularItemsMatcher.from_degrees_device(deg, 12)
+    assert t.equal(pop_dev.popular_items.cpu(), pop_host.popular_items)
+    g = t.Generator().manual_seed(1)
+    top = t.stack([t.randperm(A, generator=g)[:30] for _ in range(U)])
+    top[5, 10:] = -1                                  # a row the top-K padded
+    lg = LightGCNMatcher(top.to(DEV), 16)
+    assert t.equal(lg.matches_for_all_device(U, DEV).cpu(), t.from_numpy(lg.matches_for_all(U)))
+    ms = [pop_dev, UsersWithCommonItemsMatcher(users, articles, 20), lg]
+    ptr_h, idx_h = candidate_csr(ms, U)
+    ptr_d, idx_d = candidate_csr_device(ms, U, DEV)
+    assert np.array_equal(ptr_d.cpu().numpy(), ptr_h) and np.array_equal(idx_d.cpu().numpy(), idx_h)
+    # per user: exactly cat(m.get_matches(u)) — the reference's candidates before .unique()
+    for u in (0, 5, 17, 298):
+        want = t.cat([m.get_matches(u) for m in ms])
+        assert t.equal(idx_d[int(ptr_d[u]):int(ptr_d[u + 1])].cpu().long(), want)
+
+
+def test_evaluation_sampler_with_device_candidates_equals_host_candidates():
+    """DeviceGraphSampler(train=False): candidates built on device (N3) vs the same matchers answered on the host."""
+    from laplace_amd import synthetic as S
+    from laplace_amd.data.device_sampler import DeviceGraphSampler
+    from laplace_amd.data.matching import PopularItemsMatcher, UsersWithCommonItemsMatcher
+    spec = S.SyntheticSpec(400, 150, 5000, seed=11, deg_min=1, deg_max=80)
+    graph, users, articles = S.generate_hetero(spec, customer_cards=(50, 2, 84), article_cards=(40, 9))
+    cfg = SimpleNamespace(k=12, num_neighbors=8, n_hop_neighbors=2, positive_edges_ratio=0.5, negative_edges_ratio=3.0, batch_size=16)
+    ms = [PopularItemsMatcher.from_adjacency(articles, 10), UsersWithCommonItemsMatcher(users, articles, 10)]
+
+    class HostOnly:  # hides the device form: forces candidate_csr's host path
+        def __init__(self, m):
+            self.m = m
+        def get_matches(self, u):
+            return self.m.get_matches(u)
+
+    a = DeviceGraphSampler(cfg, graph, users, articles, batch_size=16, randomization=False, device=DEV, seed=3, train=False, matchers=ms)
+    b = DeviceGraphSampler(cfg, graph, users, articles, batch_size=16, randomization=False, device=DEV, seed=3, train=False,
+                           matchers=[HostOnly(m) for m in ms])
+    assert t.equal(a.cptr.cpu(), b.cptr.cpu()) and t.equal(a.cidx.cpu(), b.cidx.cpu())
+    seeds = t.arange(32, 48)
+    ra, rb = a.sample(seeds, step=0, raw=True), b.sample(seeds, step=0, raw=True)
+    for key in ra:
+        assert t.equal(ra[key], rb[key]), key

@@ -167,7 +167,7 @@ def test_gemm_split_k_weight_gradient_shape():
     again = ops.gemm(dY.to(DEV), X.to(DEV), trans_a=True, trans_b=False)
     assert t.equal(got, again)
     blocks = ((M + 63) // 64) * ((N + 63) // 64)
-    s = min(-(-512 // blocks), K // 256)
+    s = min(-(-512 // blocks), K // 128)  # outputs of <= 8 tiles: one 128-wide panel of K per slice at least
     kps = -(-(-(-K // s)) // 32) * 32
     # slabs = one fma chain per K slice; the reduce adds every 8th slab in order per lane group, then the 8
     # group sums in group order (csrc/gemm.hip:gemm_splitk_reduce_kernel)
