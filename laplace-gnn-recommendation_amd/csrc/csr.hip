@@ -12,39 +12,42 @@ namespace {
 
 constexpr int kBlock = 256;
 
+// Sort keys are PACKED: (row << cb) | col with cb = bits of the column range, so the radix sort walks
+// bits(rows) + bits(cols) key bits instead of 32 + bits(rows) — a per-batch subgraph of the ranker (2^15 x 2^15)
+// sorts in 4 digit passes instead of 6 (round 2: the two sorts per batch were ~100 us of a 1.3 ms iteration).
 __global__ void make_keys_coo(int64_t nnz, const int64_t* __restrict__ row,
-                              const int64_t* __restrict__ col, uint64_t* __restrict__ keys,
+                              const int64_t* __restrict__ col, unsigned cb, uint64_t* __restrict__ keys,
                               int32_t* __restrict__ vals) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nnz) return;
-    keys[i] = ((uint64_t)(uint32_t)row[i] << 32) | (uint64_t)(uint32_t)col[i];
+    keys[i] = ((uint64_t)(uint32_t)row[i] << cb) | (uint64_t)(uint32_t)col[i];
     vals[i] = (int32_t)i;
 }
 
-// first position p in [0, n) with (keys[p] >> 32) >= r
-__device__ __forceinline__ int32_t lower_bound_hi(const uint64_t* __restrict__ keys, int64_t n,
+// first position p in [0, n) with (keys[p] >> cb) >= r
+__device__ __forceinline__ int32_t lower_bound_hi(const uint64_t* __restrict__ keys, int64_t n, unsigned cb,
                                                   uint32_t r) {
     int64_t lo = 0, hi = n;
     while (lo < hi) {
         int64_t mid = (lo + hi) >> 1;
-        if ((uint32_t)(keys[mid] >> 32) < r) lo = mid + 1; else hi = mid;
+        if ((uint32_t)(keys[mid] >> cb) < r) lo = mid + 1; else hi = mid;
     }
     return (int32_t)lo;
 }
 
-__global__ void rowptr_from_keys(int64_t n_rows, int64_t nnz, const uint64_t* __restrict__ keys,
+__global__ void rowptr_from_keys(int64_t n_rows, int64_t nnz, unsigned cb, const uint64_t* __restrict__ keys,
                                  int32_t* __restrict__ rowptr) {
     int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r > n_rows) return;
-    rowptr[r] = (r == n_rows) ? (int32_t)nnz : lower_bound_hi(keys, nnz, (uint32_t)r);
+    rowptr[r] = (r == n_rows) ? (int32_t)nnz : lower_bound_hi(keys, nnz, cb, (uint32_t)r);
 }
 
-__global__ void decode_keys(int64_t nnz, const uint64_t* __restrict__ keys,
+__global__ void decode_keys(int64_t nnz, unsigned cb, const uint64_t* __restrict__ keys,
                             const int32_t* __restrict__ vals, int32_t* __restrict__ col_out,
                             int32_t* __restrict__ perm) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nnz) return;
-    col_out[i] = (int32_t)(uint32_t)keys[i];
+    col_out[i] = (int32_t)(uint32_t)(keys[i] & (((uint64_t)1 << cb) - 1));
     if (perm) perm[i] = vals[i];
 }
 
@@ -60,12 +63,12 @@ __device__ __forceinline__ int32_t row_of(const int32_t* __restrict__ rowptr, in
 }
 
 __global__ void make_keys_transpose(int64_t n_rows, int64_t nnz, const int32_t* __restrict__ rowptr,
-                                    const int32_t* __restrict__ col, uint64_t* __restrict__ keys,
+                                    const int32_t* __restrict__ col, unsigned cb, uint64_t* __restrict__ keys,
                                     int32_t* __restrict__ vals) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nnz) return;
     uint32_t r = (uint32_t)row_of(rowptr, n_rows, (int32_t)i);
-    keys[i] = ((uint64_t)(uint32_t)col[i] << 32) | (uint64_t)r;
+    keys[i] = ((uint64_t)(uint32_t)col[i] << cb) | (uint64_t)r;
     vals[i] = (int32_t)i;
 }
 
@@ -168,12 +171,13 @@ int mi_coo_to_csr_i32(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t
     int32_t* v0 = arena.take<int32_t>(nnz);
     int32_t* v1 = arena.take<int32_t>(nnz);
     if (!k0 || !k1 || !v0 || !v1) return MI_ERR_WORKSPACE;
-    hipLaunchKernelGGL(make_keys_coo, grid_for(nnz), dim3(kBlock), 0, s, nnz, row, col, k0, v0);
+    const unsigned cb = bits_for(n_cols);
+    hipLaunchKernelGGL(make_keys_coo, grid_for(nnz), dim3(kBlock), 0, s, nnz, row, col, cb, k0, v0);
     uint64_t* ks; int32_t* vs;
-    int rc = sort_pairs(k0, k1, v0, v1, nnz, 32u + bits_for(n_rows), arena, s, &ks, &vs);
+    int rc = sort_pairs(k0, k1, v0, v1, nnz, cb + bits_for(n_rows), arena, s, &ks, &vs);
     if (rc) return rc;
-    hipLaunchKernelGGL(rowptr_from_keys, grid_for(n_rows + 1), dim3(kBlock), 0, s, n_rows, nnz, ks, rowptr);
-    hipLaunchKernelGGL(decode_keys, grid_for(nnz), dim3(kBlock), 0, s, nnz, ks, vs, col_out, perm);
+    hipLaunchKernelGGL(rowptr_from_keys, grid_for(n_rows + 1), dim3(kBlock), 0, s, n_rows, nnz, cb, ks, rowptr);
+    hipLaunchKernelGGL(decode_keys, grid_for(nnz), dim3(kBlock), 0, s, nnz, cb, ks, vs, col_out, perm);
     return mi_launch_status();
 }
 
@@ -199,12 +203,13 @@ int mi_csr_transpose_i32(int64_t n_rows, int64_t n_cols, int64_t nnz, const int3
     int32_t* v0 = arena.take<int32_t>(nnz);
     int32_t* v1 = arena.take<int32_t>(nnz);
     if (!k0 || !k1 || !v0 || !v1) return MI_ERR_WORKSPACE;
-    hipLaunchKernelGGL(make_keys_transpose, grid_for(nnz), dim3(kBlock), 0, s, n_rows, nnz, rowptr, col, k0, v0);
+    const unsigned cb = bits_for(n_rows);  // transposed: the old row is the minor key
+    hipLaunchKernelGGL(make_keys_transpose, grid_for(nnz), dim3(kBlock), 0, s, n_rows, nnz, rowptr, col, cb, k0, v0);
     uint64_t* ks; int32_t* vs;
-    int rc = sort_pairs(k0, k1, v0, v1, nnz, 32u + bits_for(n_cols), arena, s, &ks, &vs);
+    int rc = sort_pairs(k0, k1, v0, v1, nnz, cb + bits_for(n_cols), arena, s, &ks, &vs);
     if (rc) return rc;
-    hipLaunchKernelGGL(rowptr_from_keys, grid_for(n_cols + 1), dim3(kBlock), 0, s, n_cols, nnz, ks, rowptr_t);
-    hipLaunchKernelGGL(decode_keys, grid_for(nnz), dim3(kBlock), 0, s, nnz, ks, vs, col_t, perm_t);
+    hipLaunchKernelGGL(rowptr_from_keys, grid_for(n_cols + 1), dim3(kBlock), 0, s, n_cols, nnz, cb, ks, rowptr_t);
+    hipLaunchKernelGGL(decode_keys, grid_for(nnz), dim3(kBlock), 0, s, nnz, cb, ks, vs, col_t, perm_t);
     return mi_launch_status();
 }
 

@@ -204,14 +204,27 @@ __device__ __forceinline__ void load_addend(const Epilogue& ep, int64_t ar, int 
 // SPARSE = false: the dense product (every entry gathered; addend_map allowed) — the kernel the
 // roofline is quoted on.  SPARSE = true: x_map / row_list launches of the fused train step, kept as a
 // separate instantiation so that profiles list them apart.
+#ifndef MI_SPMM_COOP_MIN
+#define MI_SPMM_COOP_MIN 512  // plan-less launches: rows longer than this are summed by the whole workgroup
+#endif
 template <int LPR, int VPL, int UNROLL, int RPS, bool SPARSE, bool ADAM>
 __global__ __launch_bounds__(kBlock) void spmm_rows_kernel(int64_t n_out, int d4,
                                                            const int32_t* __restrict__ rowptr,
                                                            const int32_t* __restrict__ col,
                                                            const float* __restrict__ val,
                                                            const float4* __restrict__ X4, int64_t ldx4,
-                                                           Epilogue ep, int32_t chunk, Ex ex) {
+                                                           Epilogue ep, int32_t chunk, Ex ex, int32_t coop) {
     constexpr int NB = MI_WAVE / LPR, SG = NB * kWavesPerBlock;
+    // coop (plan-less dense launches only: the per-batch subgraphs of the ranker, which cannot afford a plan's host
+    // read-backs): a hub row of such a graph — an article bought by thousands of the batch's users — used to be one
+    // sub-group's serial walk (135 us of a 35 us average launch, profiles/r2_ranker_v2.md).  Rows longer than
+    // MI_SPMM_COOP_MIN are set aside in the first pass and then summed by all SG sub-groups of the block over equal
+    // consecutive pieces, reduced through LDS in sub-group order: fixed association, no atomics on data.
+    constexpr bool kCoop = !SPARSE && !ADAM && RPS == 1;
+    __shared__ float4 coop_red[kCoop ? SG : 1][VPL][LPR];
+    __shared__ int32_t coop_beg[kCoop ? SG : 1], coop_len[kCoop ? SG : 1];
+    __shared__ int64_t coop_row[kCoop ? SG : 1];
+    __shared__ int coop_n;
     const int lane = mi_lane();
     const int li = lane % LPR;
     const int sgi = (threadIdx.x / MI_WAVE) * NB + lane / LPR;
@@ -219,6 +232,10 @@ __global__ __launch_bounds__(kBlock) void spmm_rows_kernel(int64_t n_out, int d4
     int64_t n_valid = n_out;
     if (listed && ex.n_list_dev) n_valid = min(n_out, (int64_t)*ex.n_list_dev);
     const int64_t base = (int64_t)blockIdx.x * (SG * RPS);
+    if (kCoop && coop) {
+        if (threadIdx.x == 0) coop_n = 0;
+        __syncthreads();
+    }
 #pragma unroll
     for (int k = 0; k < RPS; ++k) {
         const int64_t i = base + k * SG + sgi;  // output position
@@ -232,6 +249,15 @@ __global__ __launch_bounds__(kBlock) void spmm_rows_kernel(int64_t n_out, int d4
             n = rowptr[r + 1] - beg;
             mine = n <= chunk;  // split rows belong to the items / fix-up kernels
         }
+        if (kCoop && coop && mine && n > MI_SPMM_COOP_MIN) {
+            if (li == 0) {
+                const int q = atomicAdd(&coop_n, 1);  // list order is irrelevant: each row is finished on its own
+                coop_row[q] = r;
+                coop_beg[q] = beg;
+                coop_len[q] = n;
+            }
+            mine = false;
+        }
         if (!mine) n = 0;
         const int nmax = wave_max_over_subgroups<LPR>(n);
         float4 a[VPL], acc[VPL];
@@ -239,6 +265,35 @@ __global__ __launch_bounds__(kBlock) void spmm_rows_kernel(int64_t n_out, int d4
         load_addend<LPR, VPL>(ep, ar, d4, li, a);
         subgroup_accumulate<LPR, VPL, UNROLL, SPARSE>(col, val, X4, ldx4, d4, beg, n, nmax, li, ex.x_map, acc);
         if (mine) store_epilogue<LPR, VPL, ADAM>(ep, listed ? i : r, d4, li, acc, a);
+    }
+    if (kCoop && coop) {
+        __syncthreads();
+        const int n_long = coop_n;  // block-uniform
+        for (int q = 0; q < n_long; ++q) {
+            const int32_t beg = coop_beg[q], len = coop_len[q];
+            const int64_t r = coop_row[q];
+            const int32_t per = (len + SG - 1) / SG;
+            const int32_t b = min(sgi * per, len);
+            const int n = min(per, len - b);
+            const int nmax = wave_max_over_subgroups<LPR>(n);
+            float4 acc[VPL];
+            subgroup_accumulate<LPR, VPL, UNROLL, false>(col, val, X4, ldx4, d4, beg + b, n, nmax, li, nullptr, acc);
+#pragma unroll
+            for (int v = 0; v < VPL; ++v) coop_red[sgi][v][li] = acc[v];
+            __syncthreads();
+            if (sgi == 0) {
+                float4 a[VPL];
+                load_addend<LPR, VPL>(ep, ex.addend_map ? (int64_t)ex.addend_map[r] : r, d4, li, a);
+#pragma unroll
+                for (int v = 0; v < VPL; ++v) {
+                    float4 t = coop_red[0][v][li];
+                    for (int g = 1; g < SG; ++g) t = mi_f4_add(t, coop_red[g][v][li]);
+                    acc[v] = t;
+                }
+                store_epilogue<LPR, VPL, ADAM>(ep, r, d4, li, acc, a);
+            }
+            __syncthreads();
+        }
     }
 }
 
@@ -560,7 +615,7 @@ int launch_spmm_mode(int64_t n_rows, int d4, const int32_t* rowptr, const int32_
     if (do_short && n_out > 0) {
         dim3 gr((unsigned)mi_ceil_div(n_out, SG * ROWS_RPS));
         hipLaunchKernelGGL((spmm_rows_kernel<LPR, VPL, UNROLL, ROWS_RPS, SPARSE, ADAM>), gr, dim3(kBlock), 0, s, n_out, d4,
-                           rowptr, col, val, X4, ldx4, ep, chunk, ex);
+                           rowptr, col, val, X4, ldx4, ep, chunk, ex, plan ? 0 : 1);
     }
     if (do_split && plan && plan->n_long_rows > 0) {
         const int64_t nf = listed ? n_list : (int64_t)plan->n_long_rows;

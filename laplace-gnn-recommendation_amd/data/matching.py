@@ -61,10 +61,10 @@ class PopularItemsMatcher(Matcher):
         return cls(order.copy(), k)
 
     def get_matches(self, user_id: int) -> Tensor:
-        return self.popular_items[: self.k]
+        return self.popular_items[: self.k].cpu()
 
     def matches_for_all(self, num_users: int):
-        return np.broadcast_to(self.popular_items[: self.k].numpy(), (num_users, min(self.k, self.popular_items.numel())))
+        return np.broadcast_to(self.popular_items[: self.k].cpu().numpy(), (num_users, min(self.k, self.popular_items.numel())))
 
     @classmethod
     def from_degrees_device(cls, article_degrees: Tensor, k: int) -> "PopularItemsMatcher":

@@ -151,6 +151,39 @@ def _hub_graph(seed, n=600, hubs=(2000, 700, 300)):
     return rows, cols
 
 
+@pytest.mark.parametrize("d", [8, 32, 64, 128, 256, 320])
+def test_spmm_planless_long_rows_are_summed_by_the_workgroup(d):
+    """Adjacencies below PLAN_MIN_NNZ run without a split-row plan (per-batch subgraphs of the ranker); rows longer
+    than 512 entries are then summed cooperatively by the block's sub-groups.  Against float64, with every epilogue
+    form, on rows of 513 .. 20 000 entries placed at both ends of a workgroup's row range; bitwise reproducible."""
+    ops = _ops()
+    g = t.Generator().manual_seed(d)
+    n_rows, n_cols = 300, 4000
+    lens = {0: 513, 7: 20000, 8: 512, 31: 3000, 32: 1500, 150: 5000, 299: 700}
+    rows = [t.full((L,), r) for r, L in lens.items()] + [t.randint(0, n_rows, (3000,), generator=g)]
+    row = t.cat(rows)
+    col = t.randint(0, n_cols, (row.numel(),), generator=g)
+    a = ops.coo_to_csr(row.to(DEV), col.to(DEV), n_rows, n_cols, want_perm=False)
+    assert a.nnz < ops.PLAN_MIN_NNZ
+    a.val = (t.rand(a.nnz, generator=g) + 0.5).to(DEV)
+    X = t.randn(n_cols, d, generator=g).to(DEV)
+    A = t.randn(n_rows, d, generator=g).to(DEV)
+    Y, Sx = t.empty(n_rows, d, device=DEV), t.empty(n_rows, d, device=DEV)
+    ops.spmm(a, X, Y=Y, addend=A, S=Sx, scale=0.25)
+    assert a.plan is None
+    rp, cc, vv = a.rowptr.cpu().long(), a.col.cpu().long(), a.val.cpu().double()
+    Xd = X.cpu().double()
+    for r in list(lens) + [1, 100, 298]:
+        b, e = int(rp[r]), int(rp[r + 1])
+        want = (vv[b:e, None] * Xd[cc[b:e]]).sum(0)
+        tol = 1e-6 * float((vv[b:e, None] * Xd[cc[b:e]].abs()).sum(0).max()) + 1e-6
+        assert (Y[r].cpu().double() - want).abs().max() <= tol, r
+        assert (Sx[r].cpu().double() - 0.25 * (A[r].cpu().double() + want)).abs().max() <= tol, r
+    Y2 = t.empty_like(Y)
+    ops.spmm(a, X, Y=Y2)
+    assert t.equal(Y2, Y)
+
+
 @pytest.mark.parametrize("band,chunk", [(0, 256), (64, 256), (7, 50), (100, 1000), (1, 256)])
 def test_spmm_plan_structure(band, chunk):
     """The work items partition the entries of every split row, slots are contiguous per row, banded items stay
