@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MI_ABI_VERSION 5
+#define MI_ABI_VERSION 6
 
 #define MI_ERR_BAD_ARG      (-1)  /* null pointer, negative size, misaligned buffer   */
 #define MI_ERR_TOO_LARGE    (-2)  /* a size does not fit int32 indexing                */
@@ -339,6 +339,31 @@ int    mi_gemm_f32(int32_t trans_a, int32_t trans_b, int64_t m, int64_t n, int64
                    const float* A, int64_t lda, const float* B, int64_t ldb,
                    const float* bias, float* C, int64_t ldc,
                    int32_t accumulate, int32_t act, void* ws, size_t ws_bytes, mi_stream_t stream);
+
+/* Grouped form: any number of independent products, one launch per 8 (the ranker's per-batch products are
+ * launch-bound, see csrc/gemm.hip).  Problem i:
+ *     C = act( A @ B  [+ A2 @ B2]  + bias + (accumulate ? C : 0) )
+ * with op(A) [m, k], op(B) [k, n] as in mi_gemm_f32 and an optional second pair sharing m, n and the trans flags
+ * (k2 = 0: none) — lin_l(agg) + lin_r(x_dst) of SAGEConv (model/layers.py:11-24) as ONE product.  a_mask (nullable):
+ * same storage layout as A; A's element is read as 0 where the mask element is <= 0 — the backward of a relu fused
+ * into the producing product.  Operands must be float4-addressable (leading dimensions and k multiples of 4, 16-byte
+ * aligned bases); otherwise MI_ERR_UNSUPPORTED and the caller uses mi_gemm_f32.  Long-k / tiny-output problems are
+ * split over k like mi_gemm_f32 (same slice rule, one grouped reduce).  ws: mi_gemm_group_workspace_bytes(). */
+typedef struct mi_gemm_problem {
+    int32_t trans_a, trans_b;
+    int64_t m, n, k;
+    const float* A; int64_t lda;
+    const float* B; int64_t ldb;
+    int64_t k2;
+    const float* A2; int64_t lda2;
+    const float* B2; int64_t ldb2;
+    const float* a_mask;
+    const float* bias;
+    float* C; int64_t ldc;
+    int32_t accumulate, act;
+} mi_gemm_problem;
+size_t mi_gemm_group_workspace_bytes(const mi_gemm_problem* problems, int32_t n);
+int mi_gemm_group_f32(const mi_gemm_problem* problems, int32_t n, void* ws, size_t ws_bytes, mi_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * K10  batched exact top-K with per-user exclusion.

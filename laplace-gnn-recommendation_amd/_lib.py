@@ -8,7 +8,7 @@ from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int32, c_i
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG_DIR, "liblaplace_hip.so")
 
-MI_ABI_VERSION = 5
+MI_ABI_VERSION = 6
 MI_SPMM_GROUP = 32
 
 
@@ -41,6 +41,15 @@ class SpmmExStruct(Structure):
 
 
 MI_SPMM_SHORT_ROWS, MI_SPMM_SPLIT_ROWS = 1, 2
+MI_ERR_UNSUPPORTED = -4
+
+
+class GemmProblem(Structure):
+    _fields_ = [("trans_a", c_int32), ("trans_b", c_int32), ("m", c_int64), ("n", c_int64), ("k", c_int64),
+                ("A", c_void_p), ("lda", c_int64), ("B", c_void_p), ("ldb", c_int64),
+                ("k2", c_int64), ("A2", c_void_p), ("lda2", c_int64), ("B2", c_void_p), ("ldb2", c_int64),
+                ("a_mask", c_void_p), ("bias", c_void_p), ("C", c_void_p), ("ldc", c_int64),
+                ("accumulate", c_int32), ("act", c_int32)]
 
 
 class SamplerDesc(Structure):
@@ -85,6 +94,8 @@ _PROTOTYPES = {
     "mi_gemm_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int64]),
     "mi_gemm_f32": (c_int32, [c_int32, c_int32, c_int64, c_int64, c_int64, P, c_int64, P, c_int64, P, P, c_int64,
                               c_int32, c_int32, P, c_size_t, P]),
+    "mi_gemm_group_workspace_bytes": (c_size_t, [POINTER(GemmProblem), c_int32]),
+    "mi_gemm_group_f32": (c_int32, [POINTER(GemmProblem), c_int32, P, c_size_t, P]),
     "mi_topk_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int64]),
     "mi_topk_excl_f32": (c_int32, [c_int64, c_int64, c_int64, c_int64, P, P, c_int64, P, c_int64, P, P, P, P, P,
                                    c_size_t, P]),

@@ -223,6 +223,162 @@ __global__ __launch_bounds__(256, 2) void gemm_fast_kernel(MiGemmArgs g) {
     }
 }
 
+// ---- grouped launch -------------------------------------------------------------------------------------------
+// A ranker batch is ~10^4 nodes: its ~45 small products per iteration cost more in launches (host and device, 5-15 us
+// each) than in arithmetic.  One launch of gemm_group_kernel runs up to kMaxGroup independent problems, each
+//     C = act( sum over up to two (A, B) pairs of A_p @ B_p  + bias + (accumulate ? C : 0) ),   A optionally masked,
+// e.g. all of a hetero layer's lin_l(agg) + lin_r(x_dst) products forward (two pairs per problem, no separate add),
+// all its dX products backward, all its weight gradients (split-K, one grouped reduce).  `a_mask` (same layout as
+// pair 0's A) zeroes A where mask <= 0: the relu backward dY * (out > 0) without its own pass.  Same tile body as
+// gemm_fast_kernel (fast-path operands only), K ascending within a pair, pairs in order: one fma chain per output.
+constexpr int kMaxGroup = 8;
+
+struct MiGemmPairArgs {
+    const float* A; int64_t sa_m, sa_k;
+    const float* B; int64_t sb_n, sb_k;
+    int64_t K;
+};
+struct MiGemmGroupProblem {
+    int64_t M, N;
+    MiGemmPairArgs pair[2];
+    int n_pairs;
+    const float* a_mask;
+    const float* bias;
+    float* C; int64_t ldc;
+    int accumulate, act;
+    int splits; int64_t k_per_split; float* partial;  // split-K of pair 0 (single-pair problems only)
+    int tiles_n, tiles_mn;                            // tile grid of this problem
+};
+struct MiGemmGroupArgs {
+    int n;
+    int64_t block_start[kMaxGroup + 1];   // first linear workgroup of each problem
+    int64_t out_start[kMaxGroup + 1];     // first linear output element of each split problem (reduce kernel)
+    MiGemmGroupProblem p[kMaxGroup];
+};
+
+template <bool KFAST>
+__device__ __forceinline__ void panel_mask(float4 (&v)[kN4], const float* __restrict__ mask, int64_t s_row, int64_t s_k,
+                                           int64_t row0, int64_t n_rows, int64_t kc, int kw, int tid) {
+    float4 m[kN4];
+    panel_issue<KFAST>(m, mask, s_row, s_k, nullptr, row0, n_rows, kc, kw, tid);
+#pragma unroll
+    for (int j = 0; j < kN4; ++j) {
+        if (!(m[j].x > 0.f)) v[j].x = 0.f;
+        if (!(m[j].y > 0.f)) v[j].y = 0.f;
+        if (!(m[j].z > 0.f)) v[j].z = 0.f;
+        if (!(m[j].w > 0.f)) v[j].w = 0.f;
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_group_kernel(MiGemmGroupArgs ga) {
+    __shared__ float As[BM][KPAD];
+    __shared__ float Bs[BN][KPAD];
+    int pi = 0;
+#pragma unroll
+    for (int q = 1; q < kMaxGroup; ++q)
+        if (q < ga.n && (int64_t)blockIdx.x >= ga.block_start[q]) pi = q;
+    const MiGemmGroupProblem& g = ga.p[pi];
+    const int64_t local = (int64_t)blockIdx.x - ga.block_start[pi];
+    const int z = (int)(local / g.tiles_mn);
+    const int t2 = (int)(local % g.tiles_mn);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int64_t m0 = (int64_t)(t2 / g.tiles_n) * BM, n0 = (int64_t)(t2 % g.tiles_n) * BN;
+
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+
+    for (int pp = 0; pp < g.n_pairs; ++pp) {
+        const MiGemmPairArgs& pr = g.pair[pp];
+        const bool a_kfast = pr.sa_k == 1, b_kfast = pr.sb_k == 1;
+        int64_t k_lo = 0, k_hi = pr.K;
+        if (g.splits > 1) {
+            k_lo = (int64_t)z * g.k_per_split;
+            k_hi = min(pr.K, k_lo + g.k_per_split);
+        }
+        for (int64_t kc = k_lo; kc < k_hi; kc += KC) {
+            const int kw = (int)min((int64_t)KC, k_hi - kc);
+            float4 va[kN4], vb[kN4];
+            if (a_kfast) panel_issue<true>(va, pr.A, pr.sa_m, pr.sa_k, nullptr, m0, g.M, kc, kw, tid);
+            else         panel_issue<false>(va, pr.A, pr.sa_m, pr.sa_k, nullptr, m0, g.M, kc, kw, tid);
+            if (b_kfast) panel_issue<true>(vb, pr.B, pr.sb_n, pr.sb_k, nullptr, n0, g.N, kc, kw, tid);
+            else         panel_issue<false>(vb, pr.B, pr.sb_n, pr.sb_k, nullptr, n0, g.N, kc, kw, tid);
+            if (pp == 0 && g.a_mask) {
+                if (a_kfast) panel_mask<true>(va, g.a_mask, pr.sa_m, pr.sa_k, m0, g.M, kc, kw, tid);
+                else         panel_mask<false>(va, g.a_mask, pr.sa_m, pr.sa_k, m0, g.M, kc, kw, tid);
+            }
+            if (a_kfast) panel_commit<true>(As, va, tid); else panel_commit<false>(As, va, tid);
+            if (b_kfast) panel_commit<true>(Bs, vb, tid); else panel_commit<false>(Bs, vb, tid);
+            __syncthreads();
+            const float* ap = &As[wm * 32 + (lane & 31)][lane >> 5];
+            const float* bp = &Bs[wn * 32 + (lane & 31)][lane >> 5];
+            if (kw == KC) {
+#pragma unroll MI_GEMM_MFMA_UNROLL
+                for (int s = 0; s < KC / 2; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * s], bp[2 * s], acc, 0, 0, 0);
+            } else {
+                for (int s = 0; s < (kw + 1) / 2; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * s], bp[2 * s], acc, 0, 0, 0);
+            }
+            __syncthreads();
+        }
+    }
+
+    const int64_t gn = n0 + wn * 32 + (lane & 31);
+    if (gn >= g.N) return;
+    if (g.splits > 1) {
+        float* slab = g.partial + (int64_t)z * g.M * g.N;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int64_t gm = m0 + wm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+            if (gm < g.M) slab[gm * g.N + gn] = acc[reg];
+        }
+        return;
+    }
+    const float bv = g.bias ? g.bias[gn] : 0.f;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const int64_t gm = m0 + wm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+        if (gm >= g.M) continue;
+        float v = acc[reg];
+        if (g.bias) v += bv;
+        float* c = g.C + gm * g.ldc + gn;
+        if (g.accumulate) v += *c;
+        if (g.act == 1) v = v > 0.f ? v : 0.f;
+        *c = v;
+    }
+}
+
+// The slab reduce of gemm_splitk_reduce_kernel for every split problem of a group in one launch.
+__global__ __launch_bounds__(256) void gemm_group_reduce_kernel(MiGemmGroupArgs ga, int64_t total_all) {
+    __shared__ float part[8][32];
+    const int o = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const int64_t i_all = (int64_t)blockIdx.x * 32 + o;
+    int pi = 0;
+#pragma unroll
+    for (int q = 1; q < kMaxGroup; ++q)
+        if (q < ga.n && i_all >= ga.out_start[q]) pi = q;
+    const MiGemmGroupProblem& g = ga.p[pi];
+    const int64_t total = g.M * g.N;
+    const int64_t i = i_all - ga.out_start[pi];
+    const bool live = i_all < total_all && g.splits > 1 && i < total;
+    float v = 0.f;
+    if (live)
+        for (int zz = grp; zz < g.splits; zz += 8) v += g.partial[(int64_t)zz * total + i];
+    part[grp][o] = v;
+    __syncthreads();
+    if (grp != 0 || !live) return;
+    float acc = part[0][o];
+#pragma unroll
+    for (int q = 1; q < 8; ++q) acc += part[q][o];
+    const int64_t m = i / g.N, n = i - m * g.N;
+    if (g.bias) acc += g.bias[n];
+    float* c = g.C + m * g.ldc + n;
+    if (g.accumulate) acc += *c;
+    if (g.act == 1) acc = acc > 0.f ? acc : 0.f;
+    *c = acc;
+}
+
 // Sums the K-slice slabs, then the epilogue.  32 outputs per block, 8 lane groups each summing every
 // 8th slice in ascending order; the 8 group sums are added in group order: a fixed association, so the
 // result is bitwise reproducible (and equals summing the slices in order only up to fp32 rounding).
@@ -303,6 +459,100 @@ int mi_gemm_launch(MiGemmArgs g, void* ws, size_t ws_bytes, hipStream_t stream) 
     if (g.splits > 1) {
         const int64_t total = g.M * g.N;
         hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((unsigned)mi_ceil_div(total, 32)), dim3(256), 0, stream, g);
+    }
+    return mi_launch_status();
+}
+
+namespace {
+
+// fills one problem from the C-ABI descriptor; false = not eligible for the grouped (fast-path) kernel
+bool group_fill(const mi_gemm_problem& d, MiGemmGroupProblem& g) {
+    if (d.m <= 0 || d.n <= 0 || !d.C || d.ldc < d.n || d.k <= 0 || !d.A || !d.B) return false;
+    g.M = d.m; g.N = d.n;
+    g.n_pairs = d.k2 > 0 ? 2 : 1;
+    const float* As[2] = {d.A, d.A2};
+    const float* Bs[2] = {d.B, d.B2};
+    const int64_t lda[2] = {d.lda, d.lda2}, ldb[2] = {d.ldb, d.ldb2}, K[2] = {d.k, d.k2};
+    for (int p = 0; p < g.n_pairs; ++p) {
+        MiGemmPairArgs& pr = g.pair[p];
+        if (!As[p] || !Bs[p]) return false;
+        pr.A = As[p]; pr.B = Bs[p]; pr.K = K[p];
+        if (d.trans_a) { pr.sa_m = 1; pr.sa_k = lda[p]; if (lda[p] < d.m) return false; }
+        else           { pr.sa_m = lda[p]; pr.sa_k = 1; if (lda[p] < K[p]) return false; }
+        if (d.trans_b) { pr.sb_n = ldb[p]; pr.sb_k = 1; if (ldb[p] < K[p]) return false; }
+        else           { pr.sb_n = 1; pr.sb_k = ldb[p]; if (ldb[p] < d.n) return false; }
+        const bool a_kfast = pr.sa_k == 1, b_kfast = pr.sb_k == 1;
+        const bool a_ok = a_kfast ? (pr.sa_m % 4 == 0) : (pr.sa_k % 4 == 0);
+        const bool b_ok = b_kfast ? (pr.sb_n % 4 == 0) : (pr.sb_k % 4 == 0);
+        const bool k_ok = (!a_kfast && !b_kfast) || (K[p] % 4 == 0);
+        if (!(a_ok && b_ok && k_ok && mi_aligned16(pr.A) && mi_aligned16(pr.B))) return false;
+    }
+    if (d.a_mask && !mi_aligned16(d.a_mask)) return false;
+    g.a_mask = d.a_mask; g.bias = d.bias; g.C = d.C; g.ldc = d.ldc;
+    g.accumulate = d.accumulate; g.act = d.act;
+    g.splits = 1; g.k_per_split = d.k; g.partial = nullptr;
+    g.tiles_n = (int)mi_ceil_div(d.n, BN);
+    g.tiles_mn = g.tiles_n * (int)mi_ceil_div(d.m, BM);
+    return true;
+}
+
+int group_splits(const mi_gemm_problem& d) { return d.k2 > 0 ? 1 : mi_gemm_splits(d.m, d.n, d.k); }
+
+}  // namespace
+
+extern "C" size_t mi_gemm_group_workspace_bytes(const mi_gemm_problem* probs, int32_t n) {
+    size_t total = 0;
+    for (int i = 0; probs && i < n; ++i) {
+        const int s = group_splits(probs[i]);
+        if (s > 1) total += mi_align_up((size_t)s * (size_t)probs[i].m * (size_t)probs[i].n * sizeof(float), 256);
+    }
+    return total;
+}
+
+extern "C" int mi_gemm_group_f32(const mi_gemm_problem* probs, int32_t n, void* ws, size_t ws_bytes,
+                                 mi_stream_t stream) {
+    MI_CHECK_ARG(n >= 0 && (n == 0 || probs));
+    hipStream_t s = (hipStream_t)stream;
+    char* wp = static_cast<char*>(ws);
+    size_t left = ws_bytes;
+    for (int base = 0; base < n; base += kMaxGroup) {
+        const int cnt = std::min(kMaxGroup, n - base);
+        MiGemmGroupArgs ga;
+        memset(&ga, 0, sizeof(ga));
+        int64_t blocks = 0, outs = 0;
+        bool any_split = false;
+        for (int i = 0; i < cnt; ++i) {
+            const mi_gemm_problem& d = probs[base + i];
+            MI_CHECK_ARG(d.act == 0 || d.act == 1);
+            if (d.m == 0 || d.n == 0) {  // nothing to write: an empty problem occupies no workgroups
+                ga.block_start[i] = blocks; ga.out_start[i] = outs;
+                ga.p[i].M = 0; ga.p[i].N = 0; ga.p[i].tiles_n = 1; ga.p[i].tiles_mn = 1; ga.p[i].splits = 1;
+                continue;
+            }
+            if (!group_fill(d, ga.p[i])) return MI_ERR_UNSUPPORTED;
+            MiGemmGroupProblem& g = ga.p[i];
+            int sp = group_splits(d);
+            if (sp > 1) {
+                g.k_per_split = mi_ceil_div(mi_ceil_div(d.k, sp), BK) * BK;
+                if (g.pair[0].sa_k == 1 || g.pair[0].sb_k == 1) g.k_per_split = mi_ceil_div(g.k_per_split, 4) * 4;
+                sp = (int)mi_ceil_div(d.k, g.k_per_split);
+                const size_t need = mi_align_up((size_t)sp * (size_t)d.m * (size_t)d.n * sizeof(float), 256);
+                if (sp > 1 && (!wp || left < need)) return MI_ERR_WORKSPACE;
+                if (sp > 1) { g.partial = reinterpret_cast<float*>(wp); wp += need; left -= need; any_split = true; }
+            }
+            g.splits = sp > 1 ? sp : 1;
+            ga.block_start[i] = blocks;
+            ga.out_start[i] = outs;
+            blocks += (int64_t)g.tiles_mn * g.splits;
+            if (g.splits > 1) outs += d.m * d.n;
+        }
+        ga.n = cnt;
+        for (int i = cnt; i <= kMaxGroup; ++i) { ga.block_start[i] = blocks; ga.out_start[i] = outs; }
+        if (blocks == 0) continue;
+        if (blocks >= INT32_MAX) return MI_ERR_TOO_LARGE;
+        hipLaunchKernelGGL(gemm_group_kernel, dim3((unsigned)blocks), dim3(256), 0, s, ga);
+        if (any_split)
+            hipLaunchKernelGGL(gemm_group_reduce_kernel, dim3((unsigned)mi_ceil_div(outs, 32)), dim3(256), 0, s, ga, outs);
     }
     return mi_launch_status();
 }

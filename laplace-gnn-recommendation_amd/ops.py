@@ -413,6 +413,48 @@ def gemm(A: Tensor, B: Tensor, *, trans_a: bool = False, trans_b: bool = True, b
     return out
 
 
+def gemm_problem(A: Tensor, B: Tensor, out: Tensor, *, trans_a: bool = False, trans_b: bool = True,
+                 A2: Optional[Tensor] = None, B2: Optional[Tensor] = None, a_mask: Optional[Tensor] = None,
+                 bias: Optional[Tensor] = None, accumulate: bool = False, relu: bool = False):
+    """One problem of gemm_group: out = act(op(A) @ op(B) [+ op(A2) @ op(B2)] + bias (+ out)); a_mask: A is read as 0
+    where a_mask <= 0 (same shape and strides as A).  Shapes as in gemm().  Returns (descriptor, tensors): the
+    descriptor holds raw pointers, the tuple keeps their storage alive until the launch has been enqueued."""
+    lda, ldb, ldc = _rows_ok(A, "A"), _rows_ok(B, "B"), _rows_ok(out, "out")
+    m, k = (A.shape[1], A.shape[0]) if trans_a else (A.shape[0], A.shape[1])
+    n, kb = (B.shape[0], B.shape[1]) if trans_b else (B.shape[1], B.shape[0])
+    if k != kb or tuple(out.shape) != (m, n):
+        raise ValueError(f"gemm problem shapes differ: A {tuple(A.shape)}, B {tuple(B.shape)}, out {tuple(out.shape)}")
+    k2 = lda2 = ldb2 = 0
+    if A2 is not None:
+        lda2, ldb2 = _rows_ok(A2, "A2"), _rows_ok(B2, "B2")
+        m2, k2 = (A2.shape[1], A2.shape[0]) if trans_a else (A2.shape[0], A2.shape[1])
+        n2, kb2 = (B2.shape[0], B2.shape[1]) if trans_b else (B2.shape[1], B2.shape[0])
+        if (m2, n2) != (m, n) or k2 != kb2:
+            raise ValueError("second pair must share m, n")
+    if a_mask is not None and (_rows_ok(a_mask, "a_mask") != lda or a_mask.shape != A.shape):
+        raise ValueError("a_mask must have A's shape and leading dimension")
+    return (_lib.GemmProblem(1 if trans_a else 0, 1 if trans_b else 0, m, n, k, A.data_ptr(), lda, B.data_ptr(), ldb,
+                             k2, _ptr(A2), lda2, _ptr(B2), ldb2, _ptr(a_mask), _ptr(bias), out.data_ptr(), ldc,
+                             1 if accumulate else 0, 1 if relu else 0), (A, B, out, A2, B2, a_mask, bias))
+
+
+def gemm_group(problems) -> bool:
+    """Runs a list of gemm_problem()s in one launch per 8 (+ one grouped split-K reduce).  Returns False — nothing
+    launched for that call — when an operand is not float4-addressable: the caller then issues gemm()s."""
+    n = len(problems)
+    if n == 0:
+        return True
+    arr = (_lib.GemmProblem * n)(*[p[0] for p in problems])  # p[1] keeps the operands alive across the allocation below
+    L = _lib.lib()
+    ws_bytes = L.mi_gemm_group_workspace_bytes(arr, n)
+    ws = _ws(ws_bytes, t.cuda.current_device()) if ws_bytes else None
+    rc = L.mi_gemm_group_f32(arr, n, ws.data_ptr() if ws is not None else None, ws_bytes, _stream())
+    if rc == _lib.MI_ERR_UNSUPPORTED:
+        return False
+    check(rc, "mi_gemm_group_f32")
+    return True
+
+
 TOPK_WS_BYTES = 1 << 30  # score block per launch; queries are processed in chunks of this size
 
 

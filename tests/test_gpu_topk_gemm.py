@@ -249,3 +249,52 @@ def test_topk_against_the_torch_product_the_reference_calls():
     # the device list is exact against its own arithmetic in every case
     assert t.equal(ids2, R.topk_excl_exact(R.scores_fma(ue2, ie2), [t.empty(0, dtype=t.int64)] * U, k))
     print(f"near-tie rows ordered differently by torch's CPU product and the fma chain: {differing}/{U}")
+
+
+def test_gemm_group_pairs_mask_split_and_layouts():
+    """mi_gemm_group_f32: several problems in one launch — two-pair products (lin_l + lin_r as one fma chain), a masked
+    A (relu backward), every operand layout, split-K weight-gradient shapes, an empty problem — each against the
+    oracle's fma chain evaluated the same way (bitwise where no split is involved) and against float64."""
+    from laplace_amd import ops
+    g = t.Generator().manual_seed(12)
+    n_d, cs, cd, co = 3001, 76, 84, 128
+    agg, xd = t.randn(n_d, cs, generator=g), t.randn(n_d, cd, generator=g)
+    wl, wr, bl = t.randn(co, cs, generator=g), t.randn(co, cd, generator=g), t.randn(co, generator=g)
+    dy, outm = t.randn(n_d, co, generator=g), t.randn(n_d, co, generator=g)
+    small_a, small_b = t.randn(40, 64, generator=g), t.randn(24, 64, generator=g)
+    dev = lambda x: x.to(DEV)
+    A, X, WL, WR, BL, DY, OM, SA, SB = map(dev, (agg, xd, wl, wr, bl, dy, outm, small_a, small_b))
+    out_fwd = t.empty(n_d, co, device=DEV)
+    out_dagg, out_dx = t.empty(n_d, cs, device=DEV), t.empty(n_d, cd, device=DEV)
+    out_dwl, out_dwr = t.empty(co, cs, device=DEV), t.empty(co, cd, device=DEV)
+    out_small = t.randn(40, 24, generator=g).to(DEV)
+    small_before = out_small.cpu().clone()
+    empty_out = t.empty(0, co, device=DEV)
+    probs = [
+        ops.gemm_problem(A, WL, out_fwd, A2=X, B2=WR, bias=BL, relu=True),                 # forward, two pairs
+        ops.gemm_problem(DY, WL, out_dagg, trans_b=False, a_mask=OM),                      # dAgg = (dY * (out>0)) @ W_l
+        ops.gemm_problem(DY, WR, out_dx, trans_b=False, a_mask=OM),
+        ops.gemm_problem(DY, A, out_dwl, trans_a=True, trans_b=False, a_mask=OM),          # dW_l: split-K, masked
+        ops.gemm_problem(DY, X, out_dwr, trans_a=True, trans_b=False, a_mask=OM),
+        ops.gemm_problem(SA, SB, out_small, accumulate=True),                              # += on a small output
+        ops.gemm_problem(t.empty(0, cs, device=DEV), WL, empty_out),                       # nothing to do
+        ops.gemm_problem(A, WL, t.empty(n_d, co, device=DEV)),                             # a ninth... (eighth) problem
+        ops.gemm_problem(X, WR, out_dx.new_empty(n_d, co)),                                # spills into a second launch
+    ]
+    assert ops.gemm_group(probs)
+    dym = dy * (outm > 0)
+    # two pairs = one chain: pair 0's k ascending, then pair 1's — the oracle's chain over the concatenated operands
+    want_fwd = R.gemm_fma(t.cat([agg, xd], 1), t.cat([wl, wr], 1), bias=bl, relu=True)
+    assert t.equal(out_fwd.cpu(), want_fwd)
+    assert t.equal(out_dagg.cpu(), R.gemm_fma(dym, wl, trans_b=False))
+    assert t.equal(out_dx.cpu(), R.gemm_fma(dym, wr, trans_b=False))
+    assert t.equal(out_small.cpu(), R.gemm_fma(small_a, small_b, out=small_before.clone(), accumulate=True))
+    for got, xx in ((out_dwl, agg), (out_dwr, xd)):
+        want = dym.double().T @ xx.double()
+        assert (got.cpu().double() - want).abs().max() <= 1e-5 * float(want.abs().max()) + 1e-4
+    again = t.empty_like(out_dwl)
+    assert ops.gemm_group([ops.gemm_problem(DY, A, again, trans_a=True, trans_b=False, a_mask=OM)])
+    assert t.equal(again, out_dwl)                                                        # split-K reduce: fixed order
+    # unaligned operands are refused as a whole (the caller falls back to gemm())
+    odd = t.randn(50, 7, device=DEV)
+    assert not ops.gemm_group([ops.gemm_problem(odd, t.randn(9, 7, device=DEV), t.empty(50, 9, device=DEV))])

@@ -32,10 +32,27 @@ def step(batch):
 for _ in range(10): step(next(it))
 t.cuda.synchronize()
 import time
+def timed(tag, n=200):
+    t0 = time.perf_counter()
+    for _ in range(n): step(next(it))
+    t1 = time.perf_counter(); t.cuda.synchronize(); t2 = time.perf_counter()
+    print(f"{tag}: host {1e3*(t1-t0)/n:.3f} ms/iter, with drain {1e3*(t2-t0)/n:.3f} ms/iter", flush=True)
+timed("multithreaded autograd (default)")
+with t.autograd.set_multithreading_enabled(False):
+    timed("autograd in the calling thread  ")
+timed("multithreaded autograd (default)")
+with t.autograd.set_multithreading_enabled(False):
+    timed("autograd in the calling thread  ")
+# forward only / no-grad forward, to split the host cost
+def fwd_only(batch):
+    x, ei, eli, y = select_properties(batch)
+    return crit(model(x, ei, eli).view(-1), y)
 t0 = time.perf_counter()
-for _ in range(100): step(next(it))
-t1 = time.perf_counter(); t.cuda.synchronize(); t2 = time.perf_counter()
-print(f"100 iterations: host {1e3*(t1-t0)/100:.3f} ms/iter, with drain {1e3*(t2-t0)/100:.3f} ms/iter")
+for _ in range(200): fwd_only(next(it))
+t.cuda.synchronize(); print(f"sampler + forward + loss only: {1e3*(time.perf_counter()-t0)/200:.3f} ms/iter")
+t0 = time.perf_counter()
+for _ in range(200): next(it)
+t.cuda.synchronize(); print(f"sampler only: {1e3*(time.perf_counter()-t0)/200:.3f} ms/iter", flush=True)
 pr = cProfile.Profile(); pr.enable()
 for _ in range(100): step(next(it))
 pr.disable(); t.cuda.synchronize()
