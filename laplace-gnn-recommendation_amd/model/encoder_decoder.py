@@ -27,7 +27,7 @@ from torch.nn import BatchNorm1d, ModuleDict, ModuleList
 
 from .. import ops
 from ..utils.constants import Constants
-from .layers import BipartiteGraph
+from .layers import BipartiteGraph, hetero_sage_layer
 
 
 def _key(edge_type: Tuple[str, str, str]) -> str:
@@ -156,6 +156,10 @@ class HeteroGNNEncoder(nn.Module):
             last = index == n_layers - 1
             if not last and self.p_dropout_features is not None:
                 x_dict = {k: F.dropout(v, p=self.p_dropout_features, training=self.training) for k, v in x_dict.items()}
+            fused = hetero_sage_layer({et: convs[_key(et)] for et in graphs}, graphs, x_dict, relu=not last)
+            if fused is not None:  # one autograd node, grouped GEMM launches (model/layers.py)
+                x_dict = fused
+                continue
             arriving: Dict[str, int] = {}
             for et in graphs:
                 arriving[et[2]] = arriving.get(et[2], 0) + 1

@@ -228,6 +228,192 @@ class _SAGEConvFn(t.autograd.Function):
         return dx_src, dx_dst, dw_l, db, dw_r, None, None, None
 
 
+# ------------------------------------------------------------------------------------------------
+# one hetero layer (all relations) as one autograd node on the grouped GEMM
+# ------------------------------------------------------------------------------------------------
+_ONES4 = {}
+
+
+def _ones4(n: int, device) -> Tensor:
+    """[>= n, 4] of ones: dY^T @ ones gives the bias gradient inside the grouped weight-gradient launch."""
+    key = t.device(device).index
+    cur = _ONES4.get(key)
+    if cur is None or cur.shape[0] < n:
+        cur = t.ones(max(n, 1 << 16), 4, device=device)
+        _ONES4[key] = cur
+    return cur[:n]
+
+
+def _run_products(specs) -> None:
+    """specs: dicts(A, B, out, trans_a, trans_b, A2, B2, mask, bias, relu).  One grouped launch when every operand is
+    float4-addressable, else one gemm() per product with the mask applied as a tensor op."""
+    if not specs:
+        return
+    probs = [ops.gemm_problem(s["A"], s["B"], s["out"], trans_a=s.get("trans_a", False), trans_b=s.get("trans_b", True),
+                              A2=s.get("A2"), B2=s.get("B2"), a_mask=s.get("mask"), bias=s.get("bias"),
+                              relu=s.get("relu", False)) for s in specs]
+    if ops.gemm_group(probs):
+        return
+    masked = {}
+    for s in specs:
+        A = s["A"]
+        m = s.get("mask")
+        if m is not None:
+            key = (A.data_ptr(), m.data_ptr())
+            if key not in masked:
+                masked[key] = A * (m > 0)
+            A = masked[key]
+        two = s.get("A2") is not None
+        ops.gemm(A, s["B"], trans_a=s.get("trans_a", False), trans_b=s.get("trans_b", True), bias=s.get("bias"),
+                 out=s["out"], relu=s.get("relu", False) and not two)
+        if two:
+            ops.gemm(s["A2"], s["B2"], trans_a=s.get("trans_a", False), trans_b=s.get("trans_b", True), out=s["out"],
+                     accumulate=True, relu=s.get("relu", False))
+
+
+class _HeteroSAGELayerFn(t.autograd.Function):
+    """Every relation of one hetero SAGEConv layer — `to_hetero`'s per-edge-type copies of the layer
+    (model/encoder_decoder.py:29-46,93-95) — as ONE autograd node, for the case the default metadata gives: each
+    destination type receives exactly one relation (so the destination-wise reduction is the identity and the relu can
+    ride in the producing product).  Forward: one aggregate launch per relation + ONE grouped GEMM launch computing
+    act(agg_r W_l^T + b_l + x_dst W_r^T) for all relations.  Backward: one grouped launch for all dAgg / dX_dst
+    (relu mask fused into the A operand), one transposed aggregate per relation, one grouped split-K launch for all
+    dW_l / dW_r / db (+ one grouped reduce).  Layer 0 reads frozen embeddings: its dX half is never launched.
+
+    apply(rels, relu, n_x, x_0..x_{n_x-1}, (w_l, b_l, w_r) per relation); rels[i] = (src index, dst index, graph, aggr)."""
+
+    @staticmethod
+    def forward(ctx, rels, relu: bool, n_x: int, *tensors):
+        xs = [x if x.stride(-1) == 1 else x.contiguous() for x in tensors[:n_x]]
+        wts = tensors[n_x:]
+        aggs, args, outs, specs = [], [], [], []
+        for i, (si, di, graph, aggr) in enumerate(rels):
+            w_l, b_l, w_r = wts[3 * i: 3 * i + 3]
+            x_src, x_dst = xs[si], xs[di]
+            d = x_src.shape[1]
+            arg = None
+            if aggr == "max":
+                agg, arg = ops.segment_max(graph.by_dst, x_src)
+            else:
+                xp = _pad4(x_src)
+                v_dst, _ = graph.weights(aggr)
+                a = ops.DeviceCSR(graph.by_dst.n_rows, graph.by_dst.n_cols, graph.by_dst.rowptr, graph.by_dst.col, v_dst, None,
+                                  graph.by_dst.plan)
+                agg = t.empty(graph.n_dst, xp.shape[1], device=x_src.device)
+                ops.spmm(a, xp, Y=agg)
+                graph.by_dst.plan = a.plan
+                if xp.shape[1] != d:
+                    agg = agg[:, :d]
+            out = t.empty(graph.n_dst, w_l.shape[0], device=x_src.device)
+            specs.append(dict(A=agg, B=w_l, out=out, A2=x_dst, B2=w_r, bias=b_l, relu=relu))
+            aggs.append(agg); args.append(arg); outs.append(out)
+        _run_products(specs)
+        ctx.rels, ctx.relu, ctx.n_x, ctx.n_rel = rels, relu, n_x, len(rels)
+        ctx.save_for_backward(*xs, *wts, *aggs, *[a for a in args if a is not None], *(outs if relu else []))
+        ctx.has_arg = [a is not None for a in args]
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        rels, relu, n_x, n_rel = ctx.rels, ctx.relu, ctx.n_x, ctx.n_rel
+        sv = list(ctx.saved_tensors)
+        xs, sv = sv[:n_x], sv[n_x:]
+        wts, sv = sv[:3 * n_rel], sv[3 * n_rel:]
+        aggs, sv = sv[:n_rel], sv[n_rel:]
+        args = []
+        for h in ctx.has_arg:
+            args.append(sv.pop(0) if h else None)
+        outs = sv[:n_rel] if relu else [None] * n_rel
+        need = ctx.needs_input_grad[3:]
+        dev = xs[0].device
+        dys = [None if dy is None else dy.contiguous() for dy in dys]
+        # ---- dX half: dAgg_r = dY W_l, dXdst_r = dY W_r for every relation in one launch
+        dx = [None] * n_x
+        d_aggs = [None] * n_rel
+        specs = []
+        for i, (si, di, graph, aggr) in enumerate(rels):
+            dy = dys[i]
+            if dy is None:
+                continue
+            w_l, _, w_r = wts[3 * i: 3 * i + 3]
+            if need[si]:
+                d_aggs[i] = t.empty(graph.n_dst, w_l.shape[1], device=dev)
+                specs.append(dict(A=dy, B=w_l, out=d_aggs[i], trans_b=False, mask=outs[i]))
+            if need[di]:
+                buf = t.empty(graph.n_dst, w_r.shape[1], device=dev)
+                specs.append(dict(A=dy, B=w_r, out=buf, trans_b=False, mask=outs[i]))
+                dx[di] = buf if dx[di] is None else dx[di] + buf
+        _run_products(specs)
+        for i, (si, di, graph, aggr) in enumerate(rels):
+            if d_aggs[i] is None:
+                continue
+            d = xs[si].shape[1]
+            if aggr == "max":
+                g_src = ops.segment_max_bwd(graph.by_src, args[i], d_aggs[i])
+                dx[si] = g_src if dx[si] is None else dx[si] + g_src
+            else:
+                dp = _pad4(d_aggs[i])
+                _, v_src = graph.weights(aggr)
+                a = ops.DeviceCSR(graph.by_src.n_rows, graph.by_src.n_cols, graph.by_src.rowptr, graph.by_src.col, v_src,
+                                  None, graph.by_src.plan)
+                if dx[si] is not None and dp.shape[1] == d:   # A^T dAgg + the dX_dst already there, in the epilogue
+                    ops.spmm(a, dp, addend=dx[si], S=dx[si])
+                else:
+                    g_src = t.empty(graph.n_src, dp.shape[1], device=dev)
+                    ops.spmm(a, dp, Y=g_src)
+                    if dp.shape[1] != d:
+                        g_src = g_src[:, :d]
+                    dx[si] = g_src if dx[si] is None else dx[si] + g_src
+                graph.by_src.plan = a.plan
+        # ---- dW half: dW_l = dY^T agg, dW_r = dY^T x_dst, db = dY^T 1 for every relation in one split-K launch
+        grads_w = [None] * (3 * n_rel)
+        specs, db4 = [], {}
+        for i, (si, di, graph, aggr) in enumerate(rels):
+            dy = dys[i]
+            if dy is None:
+                continue
+            w_l, b_l, w_r = wts[3 * i: 3 * i + 3]
+            if need[n_x + 3 * i]:
+                grads_w[3 * i] = t.empty_like(w_l)
+                specs.append(dict(A=dy, B=aggs[i], out=grads_w[3 * i], trans_a=True, trans_b=False, mask=outs[i]))
+            if b_l is not None and need[n_x + 3 * i + 1]:
+                db4[i] = t.empty(w_l.shape[0], 4, device=dev)
+                specs.append(dict(A=dy, B=_ones4(dy.shape[0], dev), out=db4[i], trans_a=True, trans_b=False, mask=outs[i]))
+            if w_r is not None and need[n_x + 3 * i + 2]:
+                grads_w[3 * i + 2] = t.empty_like(w_r)
+                specs.append(dict(A=dy, B=xs[di], out=grads_w[3 * i + 2], trans_a=True, trans_b=False, mask=outs[i]))
+        _run_products(specs)
+        for i, b in db4.items():
+            grads_w[3 * i + 1] = b[:, 0].contiguous()
+        return (None, None, None, *[dx[j] if need[j] else None for j in range(n_x)], *grads_w)
+
+
+def hetero_sage_layer(convs: dict, graphs: dict, x_dict: dict, relu: bool) -> Optional[dict]:
+    """x_dict after one hetero layer, through _HeteroSAGELayerFn — or None when the layer is not of the fused form
+    (several relations into one destination type, normalize=True, no root weight): the caller then runs the relations
+    one by one.  convs: {edge type: SAGEConv}; graphs: {edge type: BipartiteGraph}."""
+    types = list(x_dict)
+    arriving = {}
+    for et in graphs:
+        arriving[et[2]] = arriving.get(et[2], 0) + 1
+    if not graphs or any(v != 1 for v in arriving.values()):
+        return None
+    rels, wts = [], []
+    for et, graph in graphs.items():
+        conv = convs[et]
+        if conv.normalize or not conv.root_weight:
+            return None
+        x_src, x_dst = x_dict[et[0]], x_dict[et[2]]
+        if conv.lin_l.weight is None:
+            conv.lin_l._materialize(int(x_src.shape[-1]), x_src.device)
+        if conv.lin_r.weight is None:
+            conv.lin_r._materialize(int(x_dst.shape[-1]), x_dst.device)
+        rels.append((types.index(et[0]), types.index(et[2]), graph, conv.aggr))
+        wts += [conv.lin_l.weight, conv.lin_l.bias, conv.lin_r.weight]
+    outs = _HeteroSAGELayerFn.apply(tuple(rels), relu, len(types), *[x_dict[k] for k in types], *wts)
+    return {et[2]: o for et, o in zip(graphs, outs)}
+
+
 class SAGEConv(nn.Module):
     def __init__(self, in_channels: Union[int, Tuple[int, ...]], out_channels: int, aggr: str = "mean",
                  normalize: bool = False, root_weight: bool = True, bias: bool = True):

@@ -66,6 +66,7 @@ def main():
         opt.step()
         return loss
 
+    t.autograd.set_multithreading_enabled(False)  # as training.train_with_dataloader does
     if args.pipelined:
         assert args.device_sampler
         labels = []
