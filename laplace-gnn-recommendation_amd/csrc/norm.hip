@@ -11,7 +11,7 @@ namespace {
 
 constexpr int kBlock = 256;
 constexpr int kWaves = kBlock / MI_WAVE;
-constexpr int kBnParts = 64;    // partial workgroups of a reduction
+constexpr int kBnParts = 128;   // partial workgroups of a reduction
 constexpr int kBnMaxC = 512;    // channels (lanes loop in chunks of 64)
 
 // part p, wave w: rows p*kWaves + w, then + kBnParts*kWaves, ... ; lane = channel.  A wave-load reads one row of C
@@ -189,10 +189,19 @@ __global__ __launch_bounds__(kBlock) void gather_cat_bwd_kernel(int64_t n_e, int
         for (int64_t q0 = e + 1; q0 < n_e; q0 += MI_WAVE) {
             const int64_t q = q0 + lane;
             unsigned long long m = __ballot(q < n_e && idx[q] == v);
-            while (m) {  // matching edges of this chunk, ascending
-                const int l = __ffsll((long long)m) - 1;
-                m &= m - 1;
-                if (k < c) acc += dOut[(q0 + l) * ldo + off + k];
+            while (m) {  // matching edges of this chunk, ascending; four rows in flight, added in edge order
+                int l[4];
+                float x[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    l[u] = m ? __ffsll((long long)m) - 1 : -1;
+                    if (m) m &= m - 1;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) x[u] = (l[u] >= 0 && k < c) ? dOut[(q0 + l[u]) * ldo + off + k] : 0.f;
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (l[u] >= 0) acc += x[u];
             }
         }
         if (k < c) dZ[v * ldz + k] = acc;

@@ -205,7 +205,8 @@ __device__ __forceinline__ void load_addend(const Epilogue& ep, int64_t ar, int 
 // roofline is quoted on.  SPARSE = true: x_map / row_list launches of the fused train step, kept as a
 // separate instantiation so that profiles list them apart.
 #ifndef MI_SPMM_COOP_MIN
-#define MI_SPMM_COOP_MIN 512  // plan-less launches: rows longer than this are summed by the whole workgroup
+#define MI_SPMM_COOP_MIN 128  // plan-less launches: rows longer than this are summed by the whole workgroup (512: a 500-entry
+                              // row was still a 60 us serial walk inside a 31 us average launch, profiles/r2_ranker_v4.md)
 #endif
 template <int LPR, int VPL, int UNROLL, int RPS, bool SPARSE, bool ADAM>
 __global__ __launch_bounds__(kBlock) void spmm_rows_kernel(int64_t n_out, int d4,

@@ -154,12 +154,12 @@ def _hub_graph(seed, n=600, hubs=(2000, 700, 300)):
 @pytest.mark.parametrize("d", [8, 32, 64, 128, 256, 320])
 def test_spmm_planless_long_rows_are_summed_by_the_workgroup(d):
     """Adjacencies below PLAN_MIN_NNZ run without a split-row plan (per-batch subgraphs of the ranker); rows longer
-    than 512 entries are then summed cooperatively by the block's sub-groups.  Against float64, with every epilogue
+    than 128 entries are then summed cooperatively by the block's sub-groups.  Against float64, with every epilogue
     form, on rows of 513 .. 20 000 entries placed at both ends of a workgroup's row range; bitwise reproducible."""
     ops = _ops()
     g = t.Generator().manual_seed(d)
     n_rows, n_cols = 300, 4000
-    lens = {0: 513, 7: 20000, 8: 512, 31: 3000, 32: 1500, 150: 5000, 299: 700}
+    lens = {0: 129, 7: 20000, 8: 128, 31: 3000, 32: 1500, 150: 5000, 299: 700, 200: 513}
     rows = [t.full((L,), r) for r, L in lens.items()] + [t.randint(0, n_rows, (3000,), generator=g)]
     row = t.cat(rows)
     col = t.randint(0, n_cols, (row.numel(),), generator=g)
