@@ -190,6 +190,27 @@ typedef struct mi_adam_args {
     int64_t      step;              /* counts from 1 */
 } mi_adam_args;
 
+/* SWEEP form of the split-row half (round 2).  The banded work items above pay one partial row per (row, band)
+ * pair, which forbids bands small enough to sit comfortably in an XCD's 4 MB L2, and their short (col, val) segments
+ * are re-fetched by every XCD that holds a neighbouring band.  Here the entries of the long rows are re-laid out ONCE
+ * into 8 * n_streams STREAMS — stream (x, k) = everything sub-group k of XCD x will ever process: the entries whose
+ * column band is congruent to x mod 8, of the <= 8 row parts ("slots") that sub-group owns, sorted by band, then slot —
+ * so each sub-group reads its (col, val) pairs as one contiguous run, walks the bands in step with its XCD's other
+ * sub-groups (streams are balanced per band), keeps its <= 8 accumulators in LDS across ALL bands, and writes one
+ * partial row per (slot, XCD) at the end: 8 * n_slots partial rows whatever the band size.  The plan's long_rows /
+ * item_ptr / long_index / chunk keep their meaning (item_ptr[i] = 8 * first slot of long row i; n_items = 8 * n_slots)
+ * and the same fix-up kernel reduces them in (slot, XCD) order: no float atomics, bitwise reproducible.
+ * Feature widths up to 128 (one float4 per lane); wider products use the work-item form. */
+typedef struct mi_spmm_sweep {
+    const int32_t* col;         /* int32[nnz_long], stream order: bits 28..30 = accumulator of the owning sub-group (0..7),
+                                   bits 0..27 = column                                                                  */
+    const float*   val;         /* float[nnz_long], stream order                                                        */
+    const int32_t* stream_ptr;  /* int32[8 * n_streams + 1]: stream (x, k) = entries [ptr[x*n_streams+k], ptr[..+1])    */
+    const int32_t* slot_of;     /* int32[n_streams * 8]: slot held in accumulator q of sub-group k; < 0 = unused        */
+    int32_t        n_streams;   /* sub-groups per XCD: a multiple of 32, at most 32 * 32                                */
+    int32_t        n_slots;
+} mi_spmm_sweep;
+
 typedef struct mi_spmm_ex {
     const int32_t* x_map;
     const int32_t* addend_map;
@@ -201,6 +222,7 @@ typedef struct mi_spmm_ex {
                                        plan->chunk entries, MI_SPMM_SPLIT_ROWS the split rows (work items + fix-up).  The two
                                        halves touch disjoint output rows, so a caller may enqueue them on two streams */
     int32_t        reserved;
+    const mi_spmm_sweep* sweep;     /* nullable: the split rows run in SWEEP form (plan->items is then unused) */
 } mi_spmm_ex;
 #define MI_SPMM_SHORT_ROWS 1
 #define MI_SPMM_SPLIT_ROWS 2

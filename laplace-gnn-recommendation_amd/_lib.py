@@ -35,9 +35,15 @@ class AdamArgs(Structure):
                 ("lr", c_double), ("beta1", c_double), ("beta2", c_double), ("eps", c_double), ("step", c_int64)]
 
 
+class SpmmSweepStruct(Structure):
+    _fields_ = [("col", c_void_p), ("val", c_void_p), ("stream_ptr", c_void_p), ("slot_of", c_void_p),
+                ("n_streams", c_int32), ("n_slots", c_int32)]
+
+
 class SpmmExStruct(Structure):
     _fields_ = [("x_map", c_void_p), ("addend_map", c_void_p), ("row_list", c_void_p), ("n_list_dev", c_void_p),
-                ("n_list", c_int64), ("adam", POINTER(AdamArgs)), ("parts", c_int32), ("reserved", c_int32)]
+                ("n_list", c_int64), ("adam", POINTER(AdamArgs)), ("parts", c_int32), ("reserved", c_int32),
+                ("sweep", POINTER(SpmmSweepStruct))]
 
 
 MI_SPMM_SHORT_ROWS, MI_SPMM_SPLIT_ROWS = 1, 2

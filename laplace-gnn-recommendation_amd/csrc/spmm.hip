@@ -342,6 +342,75 @@ __global__ __launch_bounds__(kBlock) void spmm_items_kernel(int64_t n_launch, in
     }
 }
 
+// Split rows, SWEEP form (mi_spmm_sweep): workgroup w serves XCD w & 7 and holds 32 consecutive streams of it; every
+// sub-group walks its own stream front to back — (col, val) read LPR at a time, coalesced; rows gathered UNROLL at a
+// time — adding each product into the accumulator its column's tag names.  A run of entries with the same tag is summed
+// in registers and meets its LDS accumulator once.  Streams are sorted by band, so the XCD's sub-groups gather from
+// the same band of X at about the same time without any synchronisation (nothing depends on it but the L2 hit rate).
+template <int LPR, int UNROLL, bool SPARSE>
+__global__ __launch_bounds__(1024) void spmm_sweep_kernel(mi_spmm_sweep sw, int d4, const float4* __restrict__ X4, int64_t ldx4,
+                                  float4* __restrict__ partial, const int32_t* __restrict__ x_map, bool streaming) {
+    extern __shared__ float4 sweep_acc[];  // [32 sub-groups][8 accumulators][LPR]
+    constexpr int NB = MI_WAVE / LPR;
+    const int lane = mi_lane();
+    const int li = lane % LPR;
+    const int sg = (threadIdx.x / MI_WAVE) * NB + lane / LPR;  // 0..31
+    const int x = blockIdx.x & 7;
+    const int k = (blockIdx.x >> 3) * 32 + sg;
+    float4* mine = sweep_acc + sg * 8 * LPR;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) mine[q * LPR + li] = mi_f4_zero();
+    const int32_t beg = sw.stream_ptr[x * sw.n_streams + k];
+    const int n = sw.stream_ptr[x * sw.n_streams + k + 1] - beg;
+    const int nmax = wave_max_over_subgroups<LPR>(n);
+    int cur = -1;                 // tag of the run being summed in registers
+    float4 run = mi_f4_zero();
+    for (int base = 0; base < nmax; base += LPR) {
+        int32_t my_c = -1;
+        float my_v = 0.f;
+        if (base + li < n) {
+            my_c = sw.col[beg + base + li];
+            my_v = sw.val[beg + base + li];
+            if (SPARSE && x_map) {
+                const int32_t mapped = x_map[my_c & 0x0FFFFFFF];
+                my_c = mapped < 0 ? -1 : ((my_c & 0x70000000) | mapped);
+            }
+        }
+        if (SPARSE && __ballot(my_c >= 0) == 0ull) continue;
+        const int m = min(LPR, nmax - base);
+        for (int j = 0; j < m; j += UNROLL) {
+            float w[UNROLL];
+            float4 xr[UNROLL];
+            int tg[UNROLL];
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) {
+                const int32_t c = __shfl(my_c, j + u, LPR);
+                w[u] = __shfl(my_v, j + u, LPR);
+                const bool ok = c >= 0;
+                tg[u] = ok ? (c >> 28) : -1;
+                const float4* src = X4 + (int64_t)(ok ? (c & 0x0FFFFFFF) : 0) * ldx4;
+                xr[u] = (ok && li < d4) ? src[li] : mi_f4_zero();
+            }
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) {
+                if (tg[u] < 0) continue;
+                if (tg[u] != cur) {   // sub-group-uniform: the tag was broadcast
+                    if (cur >= 0) mine[cur * LPR + li] = mi_f4_add(mine[cur * LPR + li], run);
+                    cur = tg[u];
+                    run = mi_f4_zero();
+                }
+                mi_f4_fma(run, w[u], xr[u]);
+            }
+        }
+    }
+    if (cur >= 0) mine[cur * LPR + li] = mi_f4_add(mine[cur * LPR + li], run);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int32_t slot = sw.slot_of[k * 8 + q];
+        if (slot >= 0 && li < d4) mi_store4<1>(partial + ((int64_t)slot * 8 + x) * d4 + li, mine[q * LPR + li], streaming);
+    }
+}
+
 // One 256-thread block per split row.  Its 4 wavefronts x NB sub-groups stride over the row's
 // partial sums (several loads in flight each), then combine through LDS in a fixed order, so the
 // result does not depend on scheduling.  Wave 0 applies the epilogue.
@@ -594,7 +663,7 @@ dim3 plan_grid(int64_t n) { return dim3((unsigned)mi_ceil_div(n > 0 ? n : 1, 256
 template <int LPR, int VPL, bool SPARSE, bool ADAM>
 int launch_spmm_mode(int64_t n_rows, int d4, const int32_t* rowptr, const int32_t* col, const float* val,
                      const float4* X4, int64_t ldx4, const Epilogue& ep, const mi_spmm_plan* plan,
-                     float4* partial, const Ex& ex, int64_t n_list, hipStream_t s) {
+                     float4* partial, const Ex& ex, int64_t n_list, hipStream_t s, const mi_spmm_sweep* sweep) {
     constexpr int UNROLL = (VPL == 1) ? MI_SPMM_UNROLL : MI_SPMM_UNROLL / 2;
     constexpr int SG = (MI_WAVE / LPR) * kWavesPerBlock;
     constexpr int ROWS_RPS = MI_SPMM_ROWS_RPS;
@@ -605,7 +674,25 @@ int launch_spmm_mode(int64_t n_rows, int d4, const int32_t* rowptr, const int32_
     const int32_t chunk = plan ? plan->chunk : INT32_MAX;
     const bool listed = SPARSE && ex.row_list != nullptr;
     const bool do_short = (ex.parts & MI_SPMM_SHORT_ROWS) != 0, do_split = (ex.parts & MI_SPMM_SPLIT_ROWS) != 0;
-    if (do_split && plan && plan->n_items > 0) {  // row_list mode still reduces every split row: hubs are few and almost always wanted
+    if (do_split && plan && plan->n_items > 0 && sweep) {
+        if constexpr (VPL == 1 && LPR <= 32) {
+            constexpr int NB = MI_WAVE / LPR;
+            const int threads = 32 / NB * MI_WAVE;  // 32 sub-groups per workgroup
+            const size_t lds = (size_t)32 * 8 * LPR * sizeof(float4);
+            auto kern = spmm_sweep_kernel<LPR, UNROLL, SPARSE>;
+            static bool attr_set = false;  // per instantiation; idempotent
+            if (!attr_set) {
+                if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)lds) != hipSuccess)
+                    return MI_ERR_UNSUPPORTED;
+                attr_set = true;
+            }
+            hipLaunchKernelGGL(kern, dim3((unsigned)(8 * (sweep->n_streams / 32))), dim3(threads), lds, s, *sweep, d4, X4, ldx4,
+                               partial, ex.x_map, ep.streaming);
+        } else {
+            return MI_ERR_UNSUPPORTED;
+        }
+    } else if (do_split && plan && plan->n_items > 0) {  // row_list mode still reduces every split row: hubs are few and almost always wanted
         const int64_t n_launch = plan->n_launch;
         dim3 gi((unsigned)mi_ceil_div(n_launch, SG * ITEMS_RPS));
         hipLaunchKernelGGL((spmm_items_kernel<LPR, VPL, UNROLL, ITEMS_RPS, SPARSE>), gi, dim3(kBlock), 0, s, n_launch,
@@ -630,10 +717,10 @@ int launch_spmm_mode(int64_t n_rows, int d4, const int32_t* rowptr, const int32_
 template <int LPR, int VPL>
 int launch_spmm(int64_t n_rows, int d4, const int32_t* rowptr, const int32_t* col, const float* val,
                 const float4* X4, int64_t ldx4, const Epilogue& ep, const mi_spmm_plan* plan,
-                float4* partial, const Ex& ex, int64_t n_list, hipStream_t s) {
+                float4* partial, const Ex& ex, int64_t n_list, hipStream_t s, const mi_spmm_sweep* sweep) {
     const bool sparse = ex.x_map || ex.row_list;
 #define MI_SPMM_GO(SP, AD) \
-    return launch_spmm_mode<LPR, VPL, SP, AD>(n_rows, d4, rowptr, col, val, X4, ldx4, ep, plan, partial, ex, n_list, s)
+    return launch_spmm_mode<LPR, VPL, SP, AD>(n_rows, d4, rowptr, col, val, X4, ldx4, ep, plan, partial, ex, n_list, s, sweep)
     if (ep.p) {
         if (sparse) MI_SPMM_GO(true, true);
         MI_SPMM_GO(false, true);
@@ -644,6 +731,8 @@ int launch_spmm(int64_t n_rows, int d4, const int32_t* rowptr, const int32_t* co
 }
 
 }  // namespace
+
+static inline bool n_cols_ok(const mi_spmm_sweep*) { return true; }  // columns are < 2^28 by construction of the plan (checked on the host side)
 
 extern "C" {
 
@@ -811,12 +900,19 @@ int mi_spmm_csr_ex_f32(int64_t n_rows, int64_t d, const int32_t* rowptr, const i
             }
         }
     }
+    const mi_spmm_sweep* sweep = (exh && plan && plan->n_items > 0) ? exh->sweep : nullptr;
+    if (sweep) {
+        MI_CHECK_ARG(sweep->col && sweep->val && sweep->stream_ptr && sweep->slot_of);
+        MI_CHECK_ARG(sweep->n_streams > 0 && sweep->n_streams % 32 == 0 && sweep->n_streams <= 32 * 32);
+        MI_CHECK_ARG(sweep->n_slots > 0 && plan->n_items == 8 * sweep->n_slots && n_cols_ok(sweep));
+        if (d > 128) return MI_ERR_UNSUPPORTED;
+    }
     float4* partial = nullptr;
     if (plan && plan->n_items > 0) {
-        MI_CHECK_ARG(plan->items && plan->item_ptr && plan->long_rows && plan->n_launch >= plan->n_items);
-        MI_CHECK_ARG(plan->band == 0 || plan->n_launch % (8 * kPlanGroup) == 0);
+        MI_CHECK_ARG(plan->item_ptr && plan->long_rows && (sweep || (plan->items && plan->n_launch >= plan->n_items)));
+        MI_CHECK_ARG(sweep || plan->band == 0 || plan->n_launch % (8 * kPlanGroup) == 0);
         if (!ws || ws_bytes < mi_spmm_workspace_bytes(plan, d)) return MI_ERR_WORKSPACE;
-        MI_CHECK_ARG(mi_aligned16(ws) && mi_aligned16(plan->items));
+        MI_CHECK_ARG(mi_aligned16(ws) && (sweep || mi_aligned16(plan->items)));
         partial = reinterpret_cast<float4*>(ws);
     }
     Epilogue ep;
@@ -842,11 +938,11 @@ int mi_spmm_csr_ex_f32(int64_t n_rows, int64_t d, const int32_t* rowptr, const i
     const float4* X4 = reinterpret_cast<const float4*>(X);
     const int d4 = (int)(d / 4);
     hipStream_t s = (hipStream_t)stream;
-    if (d4 <= 8)   return launch_spmm<8, 1>(n_rows, d4, rowptr, col, val, X4, ldx / 4, ep, plan, partial, ex, n_list, s);
-    if (d4 <= 16)  return launch_spmm<16, 1>(n_rows, d4, rowptr, col, val, X4, ldx / 4, ep, plan, partial, ex, n_list, s);
-    if (d4 <= 32)  return launch_spmm<32, 1>(n_rows, d4, rowptr, col, val, X4, ldx / 4, ep, plan, partial, ex, n_list, s);
-    if (d4 <= 64)  return launch_spmm<64, 1>(n_rows, d4, rowptr, col, val, X4, ldx / 4, ep, plan, partial, ex, n_list, s);
-    return launch_spmm<64, 2>(n_rows, d4, rowptr, col, val, X4, ldx / 4, ep, plan, partial, ex, n_list, s);
+    if (d4 <= 8)   return launch_spmm<8, 1>(n_rows, d4, rowptr, col, val, X4, ldx / 4, ep, plan, partial, ex, n_list, s, sweep);
+    if (d4 <= 16)  return launch_spmm<16, 1>(n_rows, d4, rowptr, col, val, X4, ldx / 4, ep, plan, partial, ex, n_list, s, sweep);
+    if (d4 <= 32)  return launch_spmm<32, 1>(n_rows, d4, rowptr, col, val, X4, ldx / 4, ep, plan, partial, ex, n_list, s, sweep);
+    if (d4 <= 64)  return launch_spmm<64, 1>(n_rows, d4, rowptr, col, val, X4, ldx / 4, ep, plan, partial, ex, n_list, s, sweep);
+    return launch_spmm<64, 2>(n_rows, d4, rowptr, col, val, X4, ldx / 4, ep, plan, partial, ex, n_list, s, sweep);
 }
 
 int mi_spmm_csr_f32(int64_t n_rows, int64_t d, const int32_t* rowptr, const int32_t* col,

@@ -13,7 +13,7 @@ import torch as t
 from torch import Tensor
 
 from . import _lib
-from ._lib import SpmmExStruct, SpmmPlanStruct, check
+from ._lib import SpmmExStruct, SpmmPlanStruct, SpmmSweepStruct, check
 
 DEFAULT_CHUNK = 256  # max nnz per work item of a split (hub) row
 DEFAULT_BAND = 8192  # columns per band of a banded plan: 8192 rows x 128 floats = the 4 MB L2 of one XCD
@@ -86,6 +86,9 @@ class SpmmPlan:
     items: Optional[Tensor]
     long_index: Optional[Tensor] = None
     partial: dict = field(default_factory=dict)  # d -> workspace tensor
+    sweep: Optional[SpmmSweepStruct] = None       # split rows in SWEEP form (mi_spmm_sweep); tensors kept in sweep_t
+    sweep_t: tuple = ()
+    wide: Optional["SpmmPlan"] = None             # work-item plan of the same adjacency for widths the sweep form lacks
 
     @property
     def n_long_rows(self) -> int:
@@ -191,9 +194,110 @@ def row_slice(a: DeviceCSR, r0: int, r1: int) -> DeviceCSR:
     return DeviceCSR(r1 - r0, a.n_cols, a.rowptr[r0:r1 + 1], a.col, a.val, None)
 
 
-def build_spmm_plan(a: DeviceCSR, chunk: int = DEFAULT_CHUNK, band: Optional[int] = None) -> SpmmPlan:
+SWEEP_BAND = 2048     # columns per band of a sweep plan: 2048 rows x 128 floats = 1 MB, a quarter of an XCD's L2
+SWEEP_STREAMS = 1024  # sub-groups per XCD: 32 CUs x one workgroup of 32 sub-groups
+SWEEP_MIN_BANDS = 64  # narrower adjacencies have nothing to sweep
+
+
+def build_sweep_plan(a: DeviceCSR, chunk: int = DEFAULT_CHUNK, band: int = SWEEP_BAND,
+                     n_streams: int = SWEEP_STREAMS) -> Optional[SpmmPlan]:
+    """SWEEP-form split-row plan (include/laplace_hip.h, mi_spmm_sweep), or None when the adjacency does not qualify
+    (no long rows, fewer than SWEEP_MIN_BANDS bands, more row parts than the 8 * n_streams accumulators of an XCD,
+    columns >= 2^28, no values yet).  Set-up: a few device sorts and one host pass over the long rows' degrees."""
+    import heapq
+    if a.val is None or a.nnz == 0 or a.n_cols >= (1 << 28) or a.n_cols < SWEEP_MIN_BANDS * band:
+        return None
+    dev = a.device
+    deg = (a.rowptr[1:] - a.rowptr[:-1]).to(t.int64)
+    long_rows = t.nonzero(deg > chunk).view(-1)
+    n_long = int(long_rows.numel())
+    if n_long == 0:
+        return None
+    dl = deg[long_rows]
+    dl_host = dl.cpu().tolist()
+    total = sum(dl_host)
+    # parts per row: a slot should carry about a third of a stream's share, so that streams can be balanced
+    target = max(chunk, total // (3 * n_streams))
+    parts = [max(1, -(-d // target)) for d in dl_host]
+    n_slots = sum(parts)
+    if n_slots > 8 * n_streams:
+        return None
+    # longest-processing-time assignment of slots to streams (<= 8 per stream)
+    loads = []
+    slot_base = [0] * (n_long + 1)
+    for i, (d, p) in enumerate(zip(dl_host, parts)):
+        slot_base[i + 1] = slot_base[i] + p
+        loads += [(d / p, slot_base[i] + j) for j in range(p)]
+    loads.sort(key=lambda z: (-z[0], z[1]))
+    heap = [(0.0, k, 0) for k in range(n_streams)]
+    heapq.heapify(heap)
+    owner = [0] * n_slots
+    qidx = [0] * n_slots
+    slot_of = [-1] * (8 * n_streams)
+    full = []
+    for w, sid in loads:
+        while True:
+            load, k, cnt = heapq.heappop(heap)
+            if cnt < 8:
+                break
+            full.append((load, k, cnt))
+        owner[sid], qidx[sid] = k, cnt
+        slot_of[k * 8 + cnt] = sid
+        heapq.heappush(heap, (load + w, k, cnt + 1))
+    owner_t = t.tensor(owner, dtype=t.int64, device=dev)
+    q_t = t.tensor(qidx, dtype=t.int64, device=dev)
+    parts_t = t.tensor(parts, dtype=t.int64, device=dev)
+    base_t = t.tensor(slot_base, dtype=t.int64, device=dev)
+    # entries of the long rows, in CSR order
+    starts = a.rowptr[long_rows].to(t.int64)
+    row_i = t.repeat_interleave(t.arange(n_long, device=dev), dl)                       # long-row index per entry
+    first = t.cumsum(dl, 0) - dl
+    e = starts[row_i] + (t.arange(total, device=dev) - first[row_i])                    # position in a.col / a.val
+    c = a.col[e].to(t.int64)
+    b = c // band
+    n_b = (a.n_cols + band - 1) // band
+    grp = row_i * n_b + b                                                               # (row, band): contiguous runs
+    _, counts = t.unique_consecutive(grp, return_counts=True)
+    g_first = t.cumsum(counts, 0) - counts
+    g_of = t.repeat_interleave(t.arange(counts.numel(), device=dev), counts)
+    rank = t.arange(total, device=dev) - g_first[g_of]
+    part = (rank * parts_t[row_i]) // counts[g_of]                                      # equal consecutive pieces
+    slot = base_t[row_i] + part
+    x, tb = b & 7, b >> 3
+    n_t = (n_b + 7) // 8
+    key = (((x * n_streams + owner_t[slot]) * n_t + tb) << 3) | q_t[slot]
+    order = t.argsort(key, stable=True)                                                 # columns stay ascending in a run
+    col_s = ((q_t[slot] << 28) | c)[order].to(t.int32).contiguous()
+    val_s = a.val[e][order].contiguous()
+    stream_key = (key[order] >> 3) // n_t
+    stream_ptr = t.searchsorted(stream_key, t.arange(8 * n_streams + 1, device=dev)).to(t.int32).contiguous()
+    slot_of_t = t.tensor(slot_of, dtype=t.int32, device=dev)
+    long_rows32 = long_rows.to(t.int32).contiguous()
+    item_ptr = (8 * base_t).to(t.int32).contiguous()
+    long_index = t.full((max(a.n_rows, 1),), -1, dtype=t.int32, device=dev)
+    long_index[long_rows] = t.arange(n_long, dtype=t.int32, device=dev)
+    st = SpmmPlanStruct()
+    st.chunk, st.n_long_rows, st.n_items, st.n_launch = chunk, n_long, 8 * n_slots, 8 * n_slots
+    st.long_rows, st.item_ptr, st.items = long_rows32.data_ptr(), item_ptr.data_ptr(), None
+    st.long_index = long_index.data_ptr()
+    st.band, st.n_bands = band, n_b
+    sw = SpmmSweepStruct(col_s.data_ptr(), val_s.data_ptr(), stream_ptr.data_ptr(), slot_of_t.data_ptr(), n_streams, n_slots)
+    return SpmmPlan(st, long_rows32, item_ptr, None, long_index, sweep=sw, sweep_t=(col_s, val_s, stream_ptr, slot_of_t))
+
+
+import os as _os
+SWEEP = _os.environ.get("LAPLACE_SWEEP", "1") != "0"  # module switch (A/B): off keeps the banded work-item plans
+SWEEP_BAND = int(_os.environ.get("LAPLACE_SWEEP_BAND", SWEEP_BAND))
+
+
+def build_spmm_plan(a: DeviceCSR, chunk: int = DEFAULT_CHUNK, band: Optional[int] = None, sweep: Optional[bool] = None) -> SpmmPlan:
     """Split-row plan of an adjacency.  band = columns per band of a banded plan (see include/laplace_hip.h),
-    0 = row-major, None = DEFAULT_BAND when the adjacency spans at least MIN_BANDS of them."""
+    0 = row-major, None = DEFAULT_BAND when the adjacency spans at least MIN_BANDS of them.  sweep (default: the
+    module switch SWEEP, and only when band is not given): the SWEEP form when the adjacency qualifies."""
+    if (SWEEP if sweep is None else sweep) and band is None:
+        plan = build_sweep_plan(a, chunk)
+        if plan is not None:
+            return plan
     L = _lib.lib()
     if band is None:
         band = DEFAULT_BAND if a.n_cols >= MIN_BANDS * DEFAULT_BAND else 0
@@ -274,6 +378,10 @@ def spmm(a: DeviceCSR, X: Tensor, *, Y: Optional[Tensor] = None, addend: Optiona
     if a.plan is None and (a.nnz >= PLAN_MIN_NNZ or row_list is not None):
         a.plan = build_spmm_plan(a)
     plan = a.plan
+    if plan is not None and plan.sweep is not None and d > 128:  # the sweep form stops at 128 floats per row
+        if plan.wide is None:
+            plan.wide = build_spmm_plan(a, chunk=int(plan.struct.chunk), sweep=False)
+        plan = plan.wide
     L = _lib.lib()
     ws_ptr, ws_bytes = None, 0
     if plan is not None and plan.n_items > 0:
@@ -286,12 +394,16 @@ def spmm(a: DeviceCSR, X: Tensor, *, Y: Optional[Tensor] = None, addend: Optiona
     if SPMM_EVENTS is not None:
         ev = (t.cuda.Event(enable_timing=True), t.cuda.Event(enable_timing=True))
         ev[0].record()
+    sweep = plan.sweep if (plan is not None and plan.sweep is not None) else None
+
     def launch(parts: int, stream: int) -> None:
         exs = None
-        if x_map is not None or addend_map is not None or row_list is not None or adam_args is not None or parts:
+        if (x_map is not None or addend_map is not None or row_list is not None or adam_args is not None or parts
+                or sweep is not None):
             exs = SpmmExStruct(_ptr(x_map), _ptr(addend_map), _ptr(row_list), _ptr(n_list_dev),
                                row_list.numel() if row_list is not None else 0,
-                               ctypes.pointer(adam_args) if adam_args is not None else None, parts, 0)
+                               ctypes.pointer(adam_args) if adam_args is not None else None, parts, 0,
+                               ctypes.pointer(sweep) if sweep is not None else None)
         check(L.mi_spmm_csr_ex_f32(a.n_rows, d, _ptr(a.rowptr), col_ptr, val_ptr, X.data_ptr(), ldx,
                                    _ptr(Y), ldy, _ptr(addend), lda, _ptr(S), lds, float(scale),
                                    ctypes.byref(plan.struct) if plan is not None else None,

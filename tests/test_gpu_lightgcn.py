@@ -184,6 +184,84 @@ def test_spmm_planless_long_rows_are_summed_by_the_workgroup(d):
     assert t.equal(Y2, Y)
 
 
+@pytest.mark.parametrize("d", [16, 64, 128])
+@pytest.mark.parametrize("n_streams", [32, 96])
+def test_spmm_sweep_plan_equals_work_item_plan(d, n_streams):
+    """SWEEP form of the split rows (include/laplace_hip.h, mi_spmm_sweep): streams per (XCD, sub-group), accumulators in
+    LDS across all bands, 8 partial rows per row part.  Every epilogue / sparse-operand form against the work-item plan
+    of the same adjacency (same sums, another association) and against float64; bitwise reproducible; a width beyond
+    128 falls back to a work-item plan by itself."""
+    ops = _ops()
+    g = t.Generator().manual_seed(d + n_streams)
+    n = 6000
+    hubs = {3: 5000, 10: 2600, 777: 900, 4000: 300, 5999: 257, 17: 256}
+    rows = [t.full((L,), r) for r, L in hubs.items()] + [t.randint(0, n, (30000,), generator=g)]
+    row = t.cat(rows)
+    col = t.randint(0, n, (row.numel(),), generator=g)
+    a = ops.coo_to_csr(row.to(DEV), col.to(DEV), n, n, want_perm=False)
+    a.val = (t.rand(a.nnz, generator=g) + 0.5).to(DEV)
+    sweep = ops.build_sweep_plan(a, chunk=256, band=64, n_streams=n_streams)
+    items = ops.build_spmm_plan(a, chunk=256, band=64)
+    assert sweep is not None and sweep.sweep is not None and items.sweep is None
+    assert sweep.n_long_rows == items.n_long_rows >= 5 and t.equal(sweep.long_rows, items.long_rows)
+    assert sweep.n_items == 8 * int(sweep.sweep.n_slots) and int(sweep.sweep.n_slots) >= 5
+    X = t.randn(n, d, generator=g).to(DEV)
+    A = t.randn(n, d, generator=g).to(DEV)
+    out = {}
+    for name, plan in (("sweep", sweep), ("items", items)):
+        a.plan = plan
+        Y, S = t.empty(n, d, device=DEV), t.empty(n, d, device=DEV)
+        ops.spmm(a, X, Y=Y, addend=A, S=S, scale=0.5)
+        out[name] = (Y, S)
+    scale = float(out["items"][0].abs().max())
+    assert (out["sweep"][0] - out["items"][0]).abs().max() <= 1e-5 * scale
+    assert (out["sweep"][1] - out["items"][1]).abs().max() <= 1e-5 * scale
+    rp, cc, vv, Xd = a.rowptr.cpu().long(), a.col.cpu().long(), a.val.cpu().double(), X.cpu().double()
+    for r in list(hubs) + [0, 1, 5998]:
+        b, e = int(rp[r]), int(rp[r + 1])
+        want = (vv[b:e, None] * Xd[cc[b:e]]).sum(0)
+        tol = 1e-6 * float((vv[b:e, None] * Xd[cc[b:e]].abs()).sum(0).max()) + 1e-6
+        assert (out["sweep"][0][r].cpu().double() - want).abs().max() <= tol, r
+    a.plan = sweep
+    Y2 = t.empty(n, d, device=DEV)
+    ops.spmm(a, X, Y=Y2)
+    assert t.equal(Y2, out["sweep"][0])
+    # sparse-operand forms on the sweep plan: compact X through x_map, a row list
+    keep = t.rand(n, generator=g) < 0.3
+    xmap = t.full((n,), -1, dtype=t.int32)
+    xmap[keep] = t.arange(int(keep.sum()), dtype=t.int32)
+    Xc = X[keep.to(DEV)].contiguous()
+    Xz = X * keep.to(DEV)[:, None]
+    Ys, Yd = t.empty(n, d, device=DEV), t.empty(n, d, device=DEV)
+    ops.spmm(a, Xc, Y=Ys, x_map=xmap.to(DEV))
+    ops.spmm(a, Xz, Y=Yd)
+    assert (Ys - Yd).abs().max() <= 1e-5 * scale
+    rl = t.tensor([3, 5, 10, 5999, 17, 4000, 2], dtype=t.int32, device=DEV)
+    Yl = t.empty(rl.numel(), d, device=DEV)
+    ops.spmm(a, X, Y=Yl, row_list=rl)
+    assert (Yl - out["sweep"][0][rl.long()]).abs().max() <= 1e-5 * scale
+    # Adam in the epilogue of the fix-up rows
+    p0 = t.randn(n, d, generator=g).to(DEV)
+    res = {}
+    for name, plan in (("sweep", sweep), ("items", items)):
+        a.plan = plan
+        p, m, v = p0.clone(), t.zeros(n, d, device=DEV), t.zeros(n, d, device=DEV)
+        ops.spmm(a, X, addend=A, adam=dict(p=p, m=m, v=v, step=1, lr=1e-2))
+        res[name] = p
+    assert (res["sweep"] - res["items"]).abs().max() <= 2e-2 + 1e-6  # |Adam step| <= lr each: signs of ~0 gradients may differ
+    assert ((res["sweep"] - res["items"]).abs() > 1e-6).float().mean() < 1e-3
+    # wider than the sweep form: falls back to a work-item plan of the same adjacency
+    a.plan = sweep
+    Xw = t.randn(n, 256, generator=g).to(DEV)
+    Yw = t.empty(n, 256, device=DEV)
+    ops.spmm(a, Xw, Y=Yw)
+    assert sweep.wide is not None and sweep.wide.sweep is None
+    r = 3
+    b, e = int(rp[r]), int(rp[r + 1])
+    want = (vv[b:e, None] * Xw.cpu().double()[cc[b:e]]).sum(0)
+    assert (Yw[r].cpu().double() - want).abs().max() <= 1e-3
+
+
 @pytest.mark.parametrize("band,chunk", [(0, 256), (64, 256), (7, 50), (100, 1000), (1, 256)])
 def test_spmm_plan_structure(band, chunk):
     """The work items partition the entries of every split row, slots are contiguous per row, banded items stay
