@@ -203,12 +203,17 @@ typedef struct mi_adam_args {
  * Feature widths up to 128 (one float4 per lane); wider products use the work-item form. */
 typedef struct mi_spmm_sweep {
     const int32_t* col;         /* int32[nnz_long], stream order: bits 28..30 = accumulator of the owning sub-group (0..7),
-                                   bits 0..27 = column                                                                  */
+                                   bit 27 = first entry of a new band in this stream, bits 0..26 = column                */
     const float*   val;         /* float[nnz_long], stream order                                                        */
     const int32_t* stream_ptr;  /* int32[8 * n_streams + 1]: stream (x, k) = entries [ptr[x*n_streams+k], ptr[..+1])    */
     const int32_t* slot_of;     /* int32[n_streams * 8]: slot held in accumulator q of sub-group k; < 0 = unused        */
     int32_t        n_streams;   /* sub-groups per XCD: a multiple of 32, at most 32 * 32                                */
     int32_t        n_slots;
+    int32_t*       progress;    /* reserved (null)                                                                          */
+    int32_t        epoch;       /* reserved (0)                                                                             */
+    int32_t        slack;       /* pacing: ticks of the 100 MHz device clock per band; wavefronts do not start band t before
+                                   t * slack ticks after their start (a late wavefront never waits).  0 = no pacing.  For the
+                                   L2 hit rate only: results do not depend on it                                          */
 } mi_spmm_sweep;
 
 typedef struct mi_spmm_ex {

@@ -37,7 +37,7 @@ class AdamArgs(Structure):
 
 class SpmmSweepStruct(Structure):
     _fields_ = [("col", c_void_p), ("val", c_void_p), ("stream_ptr", c_void_p), ("slot_of", c_void_p),
-                ("n_streams", c_int32), ("n_slots", c_int32)]
+                ("n_streams", c_int32), ("n_slots", c_int32), ("progress", c_void_p), ("epoch", c_int32), ("slack", c_int32)]
 
 
 class SpmmExStruct(Structure):

@@ -347,22 +347,37 @@ __global__ __launch_bounds__(kBlock) void spmm_items_kernel(int64_t n_launch, in
 // time — adding each product into the accumulator its column's tag names.  A run of entries with the same tag is summed
 // in registers and meets its LDS accumulator once.  Streams are sorted by band, so the XCD's sub-groups gather from
 // the same band of X at about the same time without any synchronisation (nothing depends on it but the L2 hit rate).
+#ifndef MI_SWEEP_MAX_POLLS
+#define MI_SWEEP_MAX_POLLS 64
+#endif
 template <int LPR, int UNROLL, bool SPARSE>
 __global__ __launch_bounds__(1024) void spmm_sweep_kernel(mi_spmm_sweep sw, int d4, const float4* __restrict__ X4, int64_t ldx4,
-                                  float4* __restrict__ partial, const int32_t* __restrict__ x_map, bool streaming) {
+                                                          float4* __restrict__ partial, const int32_t* __restrict__ x_map,
+                                                          bool streaming) {
     extern __shared__ float4 sweep_acc[];  // [32 sub-groups][8 accumulators][LPR]
     constexpr int NB = MI_WAVE / LPR;
+    constexpr int kColMask = 0x07FFFFFF;
     const int lane = mi_lane();
     const int li = lane % LPR;
     const int sg = (threadIdx.x / MI_WAVE) * NB + lane / LPR;  // 0..31
-    const int x = blockIdx.x & 7;
-    const int k = (blockIdx.x >> 3) * 32 + sg;
+    const int x = blockIdx.x & 7, wg = blockIdx.x >> 3;
+    const int k = wg * 32 + sg;
     float4* mine = sweep_acc + sg * 8 * LPR;
 #pragma unroll
     for (int q = 0; q < 8; ++q) mine[q * LPR + li] = mi_f4_zero();
     const int32_t beg = sw.stream_ptr[x * sw.n_streams + k];
     const int n = sw.stream_ptr[x * sw.n_streams + k + 1] - beg;
     const int nmax = wave_max_over_subgroups<LPR>(n);
+    // Pacing (performance only, never correctness).  Streams are sorted by band and balanced per band, but wavefronts
+    // run at their own speed and nothing pulls a slow one back: measured without pacing every row of X is fetched 3.1
+    // times although an XCD's L2 keeps a whole 4 MB region under 32 concurrent readers (tools/probes/l2_merge.hip).
+    // Communication between 512 wavefronts per XCD costs more than it saves (progress counters + polling: 2.7 ms).
+    // So every wavefront follows the same TIME TABLE instead: band t is not started before t0 + t * pace ticks of the
+    // device-wide constant-rate clock (s_memrealtime, 100 MHz); a wavefront that is late simply does not wait.
+    const uint64_t t0 = wall_clock64();
+    const uint64_t pace = (uint64_t)sw.slack;  // ticks per band; 0 = off
+    int my_band = 0;
+    __syncthreads();
     int cur = -1;                 // tag of the run being summed in registers
     float4 run = mi_f4_zero();
     for (int base = 0; base < nmax; base += LPR) {
@@ -371,35 +386,49 @@ __global__ __launch_bounds__(1024) void spmm_sweep_kernel(mi_spmm_sweep sw, int 
         if (base + li < n) {
             my_c = sw.col[beg + base + li];
             my_v = sw.val[beg + base + li];
-            if (SPARSE && x_map) {
-                const int32_t mapped = x_map[my_c & 0x0FFFFFFF];
-                my_c = mapped < 0 ? -1 : ((my_c & 0x70000000) | mapped);
-            }
         }
-        if (SPARSE && __ballot(my_c >= 0) == 0ull) continue;
-        const int m = min(LPR, nmax - base);
-        for (int j = 0; j < m; j += UNROLL) {
-            float w[UNROLL];
-            float4 xr[UNROLL];
-            int tg[UNROLL];
-#pragma unroll
-            for (int u = 0; u < UNROLL; ++u) {
-                const int32_t c = __shfl(my_c, j + u, LPR);
-                w[u] = __shfl(my_v, j + u, LPR);
-                const bool ok = c >= 0;
-                tg[u] = ok ? (c >> 28) : -1;
-                const float4* src = X4 + (int64_t)(ok ? (c & 0x0FFFFFFF) : 0) * ldx4;
-                xr[u] = (ok && li < d4) ? src[li] : mi_f4_zero();
-            }
-#pragma unroll
-            for (int u = 0; u < UNROLL; ++u) {
-                if (tg[u] < 0) continue;
-                if (tg[u] != cur) {   // sub-group-uniform: the tag was broadcast
-                    if (cur >= 0) mine[cur * LPR + li] = mi_f4_add(mine[cur * LPR + li], run);
-                    cur = tg[u];
-                    run = mi_f4_zero();
+        unsigned long long band_starts = 0ull;  // bit j: entry j of this batch opens a band (first sub-group's stream)
+        if (pace) {
+            const unsigned long long fl = __ballot(my_c >= 0 && (my_c & 0x08000000));
+            band_starts = (LPR == MI_WAVE) ? fl : (fl & ((1ull << LPR) - 1));
+        }
+        if (SPARSE && x_map && my_c >= 0) {
+            const int32_t mapped = x_map[my_c & kColMask];
+            my_c = mapped < 0 ? -1 : ((my_c & 0x70000000) | mapped);
+        }
+        if (!(SPARSE && __ballot(my_c >= 0) == 0ull)) {
+            const int m = min(LPR, nmax - base);
+            for (int j = 0; j < m; j += UNROLL) {
+                if (pace) {  // wave-uniform: a group of UNROLL entries that opens a band waits for that band's slot
+                    const int opens = __popcll((band_starts >> j) & ((1ull << UNROLL) - 1));
+                    if (opens) {
+                        my_band += opens;  // EXACT band count of the wavefront's first sub-group; the others ride along
+                        const uint64_t due = t0 + (uint64_t)(my_band - 1) * pace;
+                        while (wall_clock64() < due) __builtin_amdgcn_s_sleep(2);
+                    }
                 }
-                mi_f4_fma(run, w[u], xr[u]);
+                float w[UNROLL];
+                float4 xr[UNROLL];
+                int tg[UNROLL];
+#pragma unroll
+                for (int u = 0; u < UNROLL; ++u) {
+                    const int32_t c = __shfl(my_c, j + u, LPR);
+                    w[u] = __shfl(my_v, j + u, LPR);
+                    const bool ok = c >= 0;
+                    tg[u] = ok ? (c >> 28) : -1;
+                    const float4* src = X4 + (int64_t)(ok ? (c & kColMask) : 0) * ldx4;
+                    xr[u] = (ok && li < d4) ? src[li] : mi_f4_zero();
+                }
+#pragma unroll
+                for (int u = 0; u < UNROLL; ++u) {
+                    if (tg[u] < 0) continue;
+                    if (tg[u] != cur) {   // sub-group-uniform: the tag was broadcast
+                        if (cur >= 0) mine[cur * LPR + li] = mi_f4_add(mine[cur * LPR + li], run);
+                        cur = tg[u];
+                        run = mi_f4_zero();
+                    }
+                    mi_f4_fma(run, w[u], xr[u]);
+                }
             }
         }
     }
@@ -905,6 +934,7 @@ int mi_spmm_csr_ex_f32(int64_t n_rows, int64_t d, const int32_t* rowptr, const i
         MI_CHECK_ARG(sweep->col && sweep->val && sweep->stream_ptr && sweep->slot_of);
         MI_CHECK_ARG(sweep->n_streams > 0 && sweep->n_streams % 32 == 0 && sweep->n_streams <= 32 * 32);
         MI_CHECK_ARG(sweep->n_slots > 0 && plan->n_items == 8 * sweep->n_slots && n_cols_ok(sweep));
+        MI_CHECK_ARG(sweep->slack >= 0);
         if (d > 128) return MI_ERR_UNSUPPORTED;
     }
     float4* partial = nullptr;

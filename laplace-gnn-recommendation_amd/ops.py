@@ -197,6 +197,7 @@ def row_slice(a: DeviceCSR, r0: int, r1: int) -> DeviceCSR:
 SWEEP_BAND = 2048     # columns per band of a sweep plan: 2048 rows x 128 floats = 1 MB, a quarter of an XCD's L2
 SWEEP_STREAMS = 1024  # sub-groups per XCD: 32 CUs x one workgroup of 32 sub-groups
 SWEEP_MIN_BANDS = 64  # narrower adjacencies have nothing to sweep
+SWEEP_PACE = 0        # pacing of the sweep: ticks (10 ns) per band of the time table; 0 = none
 
 
 def build_sweep_plan(a: DeviceCSR, chunk: int = DEFAULT_CHUNK, band: int = SWEEP_BAND,
@@ -205,7 +206,7 @@ def build_sweep_plan(a: DeviceCSR, chunk: int = DEFAULT_CHUNK, band: int = SWEEP
     (no long rows, fewer than SWEEP_MIN_BANDS bands, more row parts than the 8 * n_streams accumulators of an XCD,
     columns >= 2^28, no values yet).  Set-up: a few device sorts and one host pass over the long rows' degrees."""
     import heapq
-    if a.val is None or a.nnz == 0 or a.n_cols >= (1 << 28) or a.n_cols < SWEEP_MIN_BANDS * band:
+    if a.val is None or a.nnz == 0 or a.n_cols >= (1 << 27) or a.n_cols < SWEEP_MIN_BANDS * band:
         return None
     dev = a.device
     deg = (a.rowptr[1:] - a.rowptr[:-1]).to(t.int64)
@@ -267,9 +268,13 @@ def build_sweep_plan(a: DeviceCSR, chunk: int = DEFAULT_CHUNK, band: int = SWEEP
     n_t = (n_b + 7) // 8
     key = (((x * n_streams + owner_t[slot]) * n_t + tb) << 3) | q_t[slot]
     order = t.argsort(key, stable=True)                                                 # columns stay ascending in a run
-    col_s = ((q_t[slot] << 28) | c)[order].to(t.int32).contiguous()
+    skey = key[order]
+    stream_key = (skey >> 3) // n_t
+    band_key = skey >> 3                                                                # (stream, band)
+    new_band = t.ones_like(band_key, dtype=t.bool)
+    new_band[1:] = band_key[1:] != band_key[:-1]                                        # first entry of a band in its stream
+    col_s = (((q_t[slot] << 28) | c)[order] | (new_band.to(t.int64) << 27)).to(t.int32).contiguous()
     val_s = a.val[e][order].contiguous()
-    stream_key = (key[order] >> 3) // n_t
     stream_ptr = t.searchsorted(stream_key, t.arange(8 * n_streams + 1, device=dev)).to(t.int32).contiguous()
     slot_of_t = t.tensor(slot_of, dtype=t.int32, device=dev)
     long_rows32 = long_rows.to(t.int32).contiguous()
@@ -281,13 +286,15 @@ def build_sweep_plan(a: DeviceCSR, chunk: int = DEFAULT_CHUNK, band: int = SWEEP
     st.long_rows, st.item_ptr, st.items = long_rows32.data_ptr(), item_ptr.data_ptr(), None
     st.long_index = long_index.data_ptr()
     st.band, st.n_bands = band, n_b
-    sw = SpmmSweepStruct(col_s.data_ptr(), val_s.data_ptr(), stream_ptr.data_ptr(), slot_of_t.data_ptr(), n_streams, n_slots)
+    sw = SpmmSweepStruct(col_s.data_ptr(), val_s.data_ptr(), stream_ptr.data_ptr(), slot_of_t.data_ptr(), n_streams, n_slots,
+                         None, 0, max(SWEEP_PACE, 0))
     return SpmmPlan(st, long_rows32, item_ptr, None, long_index, sweep=sw, sweep_t=(col_s, val_s, stream_ptr, slot_of_t))
 
 
 import os as _os
 SWEEP = _os.environ.get("LAPLACE_SWEEP", "1") != "0"  # module switch (A/B): off keeps the banded work-item plans
 SWEEP_BAND = int(_os.environ.get("LAPLACE_SWEEP_BAND", SWEEP_BAND))
+SWEEP_PACE = int(_os.environ.get("LAPLACE_SWEEP_PACE", SWEEP_PACE))
 
 
 def build_spmm_plan(a: DeviceCSR, chunk: int = DEFAULT_CHUNK, band: Optional[int] = None, sweep: Optional[bool] = None) -> SpmmPlan:
@@ -295,7 +302,7 @@ def build_spmm_plan(a: DeviceCSR, chunk: int = DEFAULT_CHUNK, band: Optional[int
     0 = row-major, None = DEFAULT_BAND when the adjacency spans at least MIN_BANDS of them.  sweep (default: the
     module switch SWEEP, and only when band is not given): the SWEEP form when the adjacency qualifies."""
     if (SWEEP if sweep is None else sweep) and band is None:
-        plan = build_sweep_plan(a, chunk)
+        plan = build_sweep_plan(a, chunk, band=SWEEP_BAND)
         if plan is not None:
             return plan
     L = _lib.lib()
