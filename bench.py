@@ -51,7 +51,7 @@ def parse_args():
                     help="A/B: time the straightforward step (full final, dense gradient buffer) as the headline instead of the byte-saving one")
     ap.add_argument("--no-plain-leg", action="store_true", help="skip the extra plain-step timing (plain_step_ms)")
     ap.add_argument("--no-map", action="store_true", help="skip the MAP@12 leg")
-    ap.add_argument("--map-steps", type=int, default=300, help="extra train steps before MAP@12 is scored")
+    ap.add_argument("--map-steps", type=int, default=1000, help="extra train steps before MAP@12 is scored")
     ap.add_argument("--map-users", type=int, default=20000)
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--no-cpu-faithful", action="store_true", help="skip timing the reference's per-iteration sampler on the host")
@@ -164,11 +164,20 @@ def map_at_12(model, trainer, inter, held, n_steps: int) -> dict:
     from laplace_amd.utils.metrics_lightgcn import topk_for_users
     for _ in range(n_steps):
         trainer.step()
-    trainer.to_original_order()
     users, truth = held[0], held[1]
+    rank = t.arange(1, 13, device=users.device, dtype=t.float32)
+    # LightGCN's own predictor for comparison: the PROPAGATED embeddings mean_k(A^k E0) (the reference scores with layer 0, F8)
+    fin = trainer.forward()
+    if getattr(trainer, "order", None) is not None:
+        fin = fin[trainer.order.node_new_of_old()]
+    U = model.num_users
+    top_f = topk_for_users(fin[:U].contiguous(), fin[U:].contiguous(), users, inter.edge_index, 12)
+    hit_f = top_f == truth[:, None]
+    ap_f = (hit_f.to(t.float32) / rank).sum(dim=1)
+    del fin
+    trainer.to_original_order()
     top = topk_for_users(model.users_emb.weight.detach(), model.items_emb.weight.detach(), users, inter.edge_index, 12)
     hit = top == truth[:, None]
-    rank = t.arange(1, 13, device=top.device, dtype=t.float32)
     ap = (hit.to(t.float32) / rank).sum(dim=1)
     # yardstick on the same users: the popularity predictor (the synthetic graph has no structure beyond popularity)
     I = model.num_items
@@ -181,7 +190,8 @@ def map_at_12(model, trainer, inter, held, n_steps: int) -> dict:
     place = t.cumsum(free.to(t.int64), dim=1)                                     # 1-based position in the user's list
     hit_pop = free & (pop[None, :] == truth[:, None]) & (place <= 12)
     ap_pop = (hit_pop.to(t.float32) / place.clamp(min=1).to(t.float32)).sum(dim=1)
-    return {"value": float(ap.mean()), "popularity_predictor_map_at_12": float(ap_pop.mean()), "k": 12, "users": int(users.numel()), "heldout_per_user": 1,
+    return {"value": float(ap.mean()), "propagated_embeddings_map_at_12": float(ap_f.mean()),
+            "popularity_predictor_map_at_12": float(ap_pop.mean()), "k": 12, "users": int(users.numel()), "heldout_per_user": 1,
             "train_steps_before_scoring": int(trainer.step_count), "hit_rate_at_12": float(hit.any(dim=1).float().mean()),
             "predictor": "layer-0 embeddings, train items excluded (utils/metrics_lightgcn.py:125-142)"}
 

@@ -39,10 +39,13 @@ from .model.lightgcn import LightGCN
 class ShardedLightGCNTrainer:
     def __init__(self, model: LightGCN, train: Interactions, *, lr: float, Lambda: float, batch_size: int,
                  betas: Tuple[float, float] = (0.9, 0.999), eps: float = 1e-8, seed: int = 0,
-                 neg_range: Optional[int] = None, group=None, ops_impl=None, sparse_batch: bool = True):
+                 neg_range: Optional[int] = None, group=None, ops_impl=None, sparse_batch: bool = True,
+                 reorder: Optional[bool] = None):
         """model: LightGCN(num_users = this rank's users, num_items = all items).  `train` holds this
         rank's edges with LOCAL user ids.  ops_impl: the kernel provider (default: the HIP ops;
-        the CPU gloo tests inject an oracle-backed one — the product never does)."""
+        the CPU gloo tests inject an oracle-backed one — the product never does).
+        reorder (default: on from 1M local edges): train under the locality order of trainer.LightGCNTrainer — the
+        replicated items are ranked by their GLOBAL degree, so every rank numbers them alike; users are local anyway."""
         self.ops = ops_impl if ops_impl is not None else hip_ops
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -59,6 +62,22 @@ class ShardedLightGCNTrainer:
 
         # item replicas start identical: rank 0's rows win
         self._bcast(self.table[U:])
+
+        can_reorder = self.neg_range == I
+        if reorder is None:
+            reorder = can_reorder and train.num_edges >= (1 << 20)
+        elif reorder and not can_reorder:
+            raise ValueError("reorder=True needs neg_range == num_items")
+        self.order, self.in_training_order = None, True
+        if reorder:
+            gdeg = t.bincount(train.edge_index[1], minlength=I)
+            self._allreduce(gdeg)                       # the same ranking of the items on every rank
+            self.order = train.locality_order(item_degree=gdeg)
+            self._new_of_old, self._old_of_new = self.order.node_new_of_old(), self.order.node_old_of_new()
+            train = train.permuted(self.order)
+            self.train = train
+            self.in_training_order = False
+            self.to_training_order()
 
         # local symmetric bipartite CSR, globally-normalised edge weights
         u, i = train.edge_index[0], train.edge_index[1]
@@ -104,6 +123,25 @@ class ShardedLightGCNTrainer:
                                                                              want_perm=False)
         self._row_of_edge = self.ops.expand_rows(self._r)
 
+    # -- locality order (see trainer.LightGCNTrainer) -------------------------------------------------
+    def to_training_order(self) -> None:
+        if self.order is not None and not self.in_training_order:
+            self.table.copy_(self.table[self._old_of_new])
+            self.in_training_order = True
+
+    def to_original_order(self) -> None:
+        if self.order is not None and self.in_training_order:
+            self.table.copy_(self.table[self._new_of_old])
+            self.in_training_order = False
+
+    finish = to_original_order
+
+    def _ids_to_training(self, batch):
+        if self.order is None or batch is None:
+            return batch
+        users, pos, neg = batch
+        return self.order.user_new_of_old[users], self.order.item_new_of_old[pos], self.order.item_new_of_old[neg]
+
     # -- collectives ---------------------------------------------------------------------------
     def _allreduce(self, x: Tensor, async_op: bool = False):
         if self.world == 1:
@@ -129,7 +167,8 @@ class ShardedLightGCNTrainer:
             work.wait()
 
     def forward(self) -> Tensor:
-        """final = mean_k(A^k E0) on the local node space (model/lightgcn.py:46-80, sharded)."""
+        """final = mean_k(A^k E0) on the local node space (model/lightgcn.py:46-80, sharded); rows in training order."""
+        self.to_training_order()
         U, K = self.U, self.K
         S, tab = self.final, self.table
         if K == 0:
@@ -151,20 +190,29 @@ class ShardedLightGCNTrainer:
             x = out
         return S
 
-    def sample(self):
+    def _sample(self):
         return self.ops.sample_bpr_batch(self._r, self._row_of_edge, self.batch_size, self.neg_range, self.seed,
                                          self.step_count, out=self.batch_idx)
+
+    def sample(self):
+        """(users, pos, neg) of the next step's batch, ORIGINAL (local) ids."""
+        users, pos, neg = self._sample()
+        if self.order is None:
+            return users, pos, neg
+        return self.order.user_old_of_new[users], self.order.item_old_of_new[pos], self.order.item_old_of_new[neg]
 
     def step(self, batch=None) -> Tensor:
         """One training iteration over the GLOBAL batch (world * batch_size positive edges); returns this
         rank's local loss term as a 1-element tensor."""
+        self.to_training_order()
+        batch = self._ids_to_training(batch)
         if self.sparse_batch and self.K >= 1:
             return self._step_sparse(batch)
         if self.gc is None:
             self.gc = t.zeros_like(self.table)
         U, K, P = self.U, self.K, self.world
         self.forward()
-        users, pos, neg = batch if batch is not None else self.sample()
+        users, pos, neg = batch if batch is not None else self._sample()
         self.gc.zero_()
         self.reg_w.zero_()
         # global loss = mean over P*B slots => each rank's share of the softplus term carries 1/P
@@ -190,7 +238,7 @@ class ShardedLightGCNTrainer:
         sum of every rank's batch."""
         U, I, K, P, ops = self.U, self.I, self.K, self.world, self.ops
         tab, c = self.table, 1.0 / (self.K + 1)
-        users, pos, neg = batch if batch is not None else self.sample()
+        users, pos, neg = batch if batch is not None else self._sample()
         gmap, nodes, cnt2 = ops.batch_nodes(users, pos, neg, U, tab.shape[0], gmap=self.gmap, nodes=self.nodes,
                                             count=self.n_nodes)
         cnt, cnt_u = cnt2[0:1], cnt2[1:2]

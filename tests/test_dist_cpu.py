@@ -37,7 +37,7 @@ def _batches(step):
     return out
 
 
-def _worker(rank, world, port, ret, sparse_batch):
+def _worker(rank, world, port, ret, sparse_batch, reorder=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -57,12 +57,17 @@ def _worker(rank, world, port, ret, sparse_batch):
         # rank 1 starts with garbage item rows: the constructor's broadcast must fix them
         model.items_emb.weight.copy_(ti if rank == 0 else t.zeros_like(ti))
     tr = ShardedLightGCNTrainer(model, Interactions(ei, U, I), lr=1e-2, Lambda=1e-4, batch_size=B, seed=3,
-                                ops_impl=cpu_ops, sparse_batch=sparse_batch)
+                                ops_impl=cpu_ops, sparse_batch=sparse_batch, reorder=reorder)
     losses = []
     for s in range(STEPS):
         losses.append(float(tr.step(_batches(s)[rank])))
     fin = tr.forward().clone()
-    ret[rank] = {"table": tr.table.clone(), "final": fin, "losses": losses}
+    item_order = None
+    if reorder:  # rows back under their original ids; every rank must have numbered the items alike
+        fin = fin[tr.order.node_new_of_old()]
+        item_order = tr.order.item_new_of_old.clone()
+        tr.finish()
+    ret[rank] = {"table": tr.table.clone(), "final": fin, "losses": losses, "item_order": item_order}
     dist.barrier()
     dist.destroy_process_group()
 
@@ -73,12 +78,16 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("sparse_batch", [False, True])
-def test_two_rank_sharded_training_equals_single_process_reference(sparse_batch):
+@pytest.mark.parametrize("sparse_batch,reorder", [(False, False), (True, False), (True, True)])
+def test_two_rank_sharded_training_equals_single_process_reference(sparse_batch, reorder):
+    """reorder=True: each rank trains under the locality order (items ranked by their all-reduced GLOBAL degree, so
+    the replicas agree on the numbering; users relabelled locally) and still reproduces the reference loop."""
     from oracle import lightgcn_ref as R
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(2, _free_port(), ret, sparse_batch), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, _free_port(), ret, sparse_batch, reorder), nprocs=2, join=True)
+    if reorder:
+        assert t.equal(ret[0]["item_order"], ret[1]["item_order"])
 
     # single-process reference on the union graph: users of rank 1 follow those of rank 0
     e0, e1 = _shards()
