@@ -61,16 +61,16 @@ def main():
             traffic[k] = b
             lines.append(f"| `{k}` | {f:.0f} | {w:.0f} | {b/1e9:.3f} GB |")
     def dense(k):  # the plain dense launch: SPARSE=false and (rows / fix-up kernels) ADAM=false instantiations
-        m = re.match(r"spmm_(rows|items|fixup)_kernel<([^>]*)>", k)
+        m = re.match(r"spmm_(rows|items|fixup|sweep)_kernel<([^>]*)>", k)
         if not m:
             return False
         a = [x.strip() for x in m.group(2).split(",")]
-        flags = {"rows": a[4:6], "items": a[4:5], "fixup": a[2:4]}[m.group(1)]
+        flags = {"rows": a[4:6], "items": a[4:5], "fixup": a[2:4], "sweep": a[2:3]}[m.group(1)]
         return all(f == "false" for f in flags)
     spmm = sum(v for k, v in traffic.items() if dense(k))
     spmm_us = sum(v for k, v in per_kernel.items() if dense(k))
     if spmm:
-        lines.append(f"\nOne plain DENSE propagate launch (items + rows + fixup kernels; SPARSE=false, no optimizer epilogue): {spmm/1e9:.3f} GB of L2-miss traffic"
+        lines.append(f"\nOne plain DENSE propagate launch (sweep or items + rows + fixup kernels; SPARSE=false, no optimizer epilogue): {spmm/1e9:.3f} GB of L2-miss traffic"
                      + (f", {spmm_us:.1f} us summed kernel time => {spmm/spmm_us/1e6:.2f} TB/s" if spmm_us else ""))
     with open(out + ".md", "w") as fh:
         fh.write(f"# {os.path.basename(out)}\n\n" + "\n".join(lines) + "\n")
