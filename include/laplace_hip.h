@@ -476,6 +476,15 @@ int mi_batchnorm_bwd_f32(int64_t n, int64_t c, const float* X, int64_t ldx,
                          void* ws, size_t ws_bytes, mi_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
+ * b9  the ranker's objective and its gradient in one launch.
+ * replaces: torch.nn.BCEWithLogitsLoss()(logits, edge_label.float()) at training.py:26-31 and the backward of it.
+ * loss[0] = mean(max(x,0) - x*y + log1p(exp(-|x|))); dlogits (nullable) = (sigmoid(x) - y) / n.  One workgroup,
+ * double sums in a fixed tree.
+ * ---------------------------------------------------------------------------------- */
+int mi_bce_logits_f32(int64_t n, const float* logits, const float* labels, float* loss, float* dlogits,
+                      mi_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
  * b7  decoder input: z = cat(z_user[row], z_item[col], dim=-1) over the label edges.
  * replaces: EdgeDecoder.forward's two index_selects + cat at model/encoder_decoder.py:57-63
  *           and their backward (index_add into the two node tables).

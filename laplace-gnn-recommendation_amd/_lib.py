@@ -113,6 +113,7 @@ _PROTOTYPES = {
     "mi_batchnorm_fwd_f32": (c_int32, [c_int64, c_int64, P, c_int64, P, P, P, P, c_float, c_float, c_int32, P, P, P, c_int64,
                                        P, c_size_t, P]),
     "mi_batchnorm_bwd_f32": (c_int32, [c_int64, c_int64, P, c_int64, P, c_int64, P, P, P, P, c_int64, P, P, P, c_size_t, P]),
+    "mi_bce_logits_f32": (c_int32, [c_int64, P, P, P, P, P]),
     "mi_gather_cat_f32": (c_int32, [c_int64, c_int64, c_int64, P, P, P, c_int64, P, c_int64, P, c_int64, P]),
     "mi_gather_cat_bwd_max_edges": (c_int64, []),
     "mi_gather_cat_bwd_f32": (c_int32, [c_int64, c_int64, c_int64, P, P, c_int64, P, c_int64, P]),

@@ -208,9 +208,36 @@ __global__ __launch_bounds__(kBlock) void gather_cat_bwd_kernel(int64_t n_e, int
     }
 }
 
+// BCEWithLogitsLoss(reduction="mean") and its gradient in one launch, one workgroup: loss = mean(max(x, 0) - x*y +
+// log1p(exp(-|x|))) (torch's formulation), dx = (sigmoid(x) - y) / n.  Sums in double, fixed tree: reproducible.
+__global__ __launch_bounds__(1024) void bce_logits_kernel(int64_t n, const float* __restrict__ x, const float* __restrict__ y,
+                                                          float* __restrict__ loss, float* __restrict__ dx) {
+    __shared__ double red[1024];
+    double acc = 0.0;
+    const float inv_n = 1.0f / (float)n;
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
+        const float xi = x[i], yi = y[i];
+        acc += (double)(fmaxf(xi, 0.f) - xi * yi + log1pf(expf(-fabsf(xi))));
+        if (dx) dx[i] = (1.0f / (1.0f + expf(-xi)) - yi) * inv_n;
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = blockDim.x / 2; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) loss[0] = (float)(red[0] / (double)n);
+}
+
 }  // namespace
 
 extern "C" {
+
+int mi_bce_logits_f32(int64_t n, const float* logits, const float* labels, float* loss, float* dlogits, mi_stream_t stream) {
+    MI_CHECK_ARG(n > 0 && logits && labels && loss);
+    hipLaunchKernelGGL(bce_logits_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, n, logits, labels, loss, dlogits);
+    return mi_launch_status();
+}
 
 size_t mi_batchnorm_workspace_bytes(int64_t c) { return (size_t)kBnParts * 2 * (size_t)(c > 0 ? c : 1) * sizeof(double); }
 

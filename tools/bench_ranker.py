@@ -58,8 +58,15 @@ def main():
     crit = t.nn.BCEWithLogitsLoss()
     model.train()
 
-    def step(batch):
+    from laplace_amd.ranker_step import FusedRankerStep
+    fused = None if os.environ.get("LAPLACE_RANKER_AUTOGRAD") == "1" else FusedRankerStep(model, opt)
+
+    def step(batch):  # = one iteration of training.train_with_dataloader
         x, ei, eli, y = select_properties(batch)
+        if fused is not None:
+            loss = fused.step(x, ei, eli, y)
+            if loss is not None:
+                return loss
         opt.zero_grad()
         loss = crit(model(x, ei, eli).view(-1), y)
         loss.backward()

@@ -22,8 +22,14 @@ model.initialize_encoder_input_size(first.to(dev))
 opt = t.optim.Adam(model.parameters(), lr=0.01, fused=True)  # one multi-tensor launch, same update
 crit = t.nn.BCEWithLogitsLoss()
 model.train()
+from laplace_amd.ranker_step import FusedRankerStep
+fused = None if os.environ.get("LAPLACE_RANKER_AUTOGRAD") == "1" else FusedRankerStep(model, opt)
 def step(batch):
     x, ei, eli, y = select_properties(batch)
+    if fused is not None:
+        loss = fused.step(x, ei, eli, y)
+        if loss is not None:
+            return loss
     opt.zero_grad()
     loss = crit(model(x, ei, eli).view(-1), y)
     loss.backward()
