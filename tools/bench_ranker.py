@@ -25,6 +25,8 @@ def main():
     ap.add_argument("--fanout", type=int, default=64)
     ap.add_argument("--cpu", action="store_true", help="also time the torch-only oracle twin on the host cores")
     ap.add_argument("--device-sampler", action="store_true", help="sample batches on the GPU (N1) instead of on the host")
+    ap.add_argument("--bench-line", action="store_true",
+                    help="print ONE line in bench.py's schema (metric / value / roofline / cpu_baseline) for the overlapped training loop")
     ap.add_argument("--pipelined", action="store_true",
                     help="with --device-sampler: time the plain training loop (sampling of batch i+1 overlaps step i)")
     args = ap.parse_args()
@@ -74,6 +76,68 @@ def main():
         return loss
 
     t.autograd.set_multithreading_enabled(False)  # as training.train_with_dataloader does
+    if args.bench_line:
+        assert args.device_sampler
+        n_c = n_a = n_lab = pos = 0
+        for i in range(args.warmup + args.steps):
+            if i == args.warmup:
+                t.cuda.synchronize()
+                t0 = time.perf_counter()
+            batch = next(it)
+            loss = step(batch)
+            if i >= args.warmup:
+                store = batch[("customer", "buys", "article")]
+                n_c += batch["customer"].x.shape[0]; n_a += batch["article"].x.shape[0]
+                n_lab += store.edge_label.numel()
+        t.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        # positives counted after the timed region (a device->host read)
+        # (same iterator: a sampler's workspace and side stream belong to ONE live epoch iterator at a time)
+        pos_per_batch = float(sum(int(next(it)[("customer", "buys", "article")].edge_label.sum()) for _ in range(20))) / 20
+        n = args.steps
+        n_c, n_a, n_lab = n_c / n, n_a / n, n_lab / n
+        cw = sum(tb.shape[1] for tb in model.embedding_layers["customer"]); aw = sum(tb.shape[1] for tb in model.embedding_layers["article"])
+        H, O = 128, 64
+        fwd = (2 * n_c * H * (aw + cw) + 2 * n_a * H * (cw + aw)          # layer 1: lin_l(agg of the other type) + lin_r(own)
+               + 2 * n_c * O * 2 * H + 2 * n_a * O * 2 * H                  # layer 2
+               + 2 * n_lab * (2 * O * H + H))                               # decoder 128 -> 128 -> 1
+        flops = 3 * fwd - 2 * (n_c * H * (aw + cw) + n_a * H * (cw + aw))   # backward = dX + dW; layer 1 has no dX
+        ms = 1e3 * dt / n
+        achieved = flops / (ms * 1e-3) / 1e12
+        out = {"metric": "positive-edges/sec (ranker train iteration)", "value": pos_per_batch * n / dt, "unit": "positive-edges/s",
+               "n_gpus": 1, "steps": n, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": f"encoder-decoder ranker training loop (training.train_with_dataloader's iteration), H&M-shaped "
+                                      f"synthetic {args.users}x{args.items}, {args.edges} edges, {args.batch} users/batch, {args.hops}-hop "
+                                      f"on-device sampling with fan-out {args.fanout} overlapped on a side stream; BASELINE.json configs[2]",
+                          "parallelism": "1 GPU"},
+               "roofline": {"bound": "mfma", "achieved": achieved, "peak": 157.0, "unit": "TFLOP/s", "frac": achieved / 157.0,
+                            "traffic": None, "flops_per_iteration": flops,
+                            "note": "a 24-user batch is ~3*10^4 nodes: the iteration is launch- and host-bound (~95 launches, "
+                                    "~1 ms), nowhere near the f32 MFMA roof; the figure is reported because the schema asks for one",
+                            "avg_customers_articles_label_edges_per_batch": [n_c, n_a, n_lab]},
+               "loss": float(loss)}
+        if args.cpu:
+            from oracle import ranker_ref as RR
+            ref = RR.ref_from_product(model, first.x_dict)
+            ref.train()
+            opt_r = t.optim.Adam(ref.parameters(), lr=0.01)
+            batches = [next(it) for _ in range(6)]
+            for j, b in enumerate(batches):
+                if j == 1:
+                    t1 = time.perf_counter()
+                x, ei, eli, y = select_properties(b.to("cpu"))
+                opt_r.zero_grad()
+                l = crit(ref({k: v.clone() for k, v in x.items()}, ei, eli), y)
+                l.backward()
+                opt_r.step()
+            cdt = (time.perf_counter() - t1) / (len(batches) - 1)
+            out["cpu_baseline"] = {"value": pos_per_batch / cdt, "unit": "positive-edges/s", "cores": t.get_num_threads(), "kind": "port",
+                                   "sample": f"5 model-only training iterations of the torch-only twin (oracle/ranker_ref.py) on batches "
+                                             f"sampled by the device sampler, {1e3 * cdt:.0f} ms/iteration; the reference's own sampler "
+                                             f"(python sets / lists per user) is not in this figure"}
+        print(json.dumps(out))
+        return
     if args.pipelined:
         assert args.device_sampler
         labels = []
