@@ -488,6 +488,97 @@ __global__ __launch_bounds__(256, 2) void topk_scores_filter_kernel(FusedArgs a)
     }
 }
 
+// Round 2: the same fused kernel with the query panel's MFMA fragments kept in REGISTERS and the item panels
+// double-buffered.  The query panel is fixed for the whole launch: each lane's K/2 A-fragment values (its row, its k
+// half) are read from LDS once into NM VGPRs, so an MFMA needs ONE ds_read_b32 (the item fragment) instead of two,
+// and the LDS the query panel occupied becomes the second item buffer — the next panel is committed into the buffer
+// nobody reads while the current one is consumed, which leaves ONE barrier per item panel instead of two.
+// (round 1: 64 TF/s = 0.41 of the f32 MFMA peak, two reads + two barriers per panel; profiles/r01_topk_v3.md.)
+// NM = MFMAs per panel = ceil(d / 2): instantiated for d = 128 and d = 64; other widths use the kernel above.
+#ifndef MI_TOPK_REGA
+#define MI_TOPK_REGA 1
+#endif
+template <int NM>
+__global__ __launch_bounds__(256, 2) void topk_scores_filter_rega_kernel(FusedArgs a) {
+    __shared__ float P0[FM][FKPAD];   // the query panel first, then item buffer 1
+    __shared__ float P1[FN][FKPAD];   // item buffer 0
+    __shared__ unsigned long long st_val[kStage];
+    __shared__ unsigned char st_row[kStage];
+    __shared__ int st_cnt;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int64_t m0 = (int64_t)blockIdx.y * FM;
+    const int64_t n_tiles = (a.n_items + FN - 1) / FN;
+    const int64_t t0 = (int64_t)blockIdx.x * a.tiles_per_slice;
+    const int64_t t1 = min(n_tiles, t0 + a.tiles_per_slice);
+    if (t0 >= t1) return;
+    float4 va[8], vb[8];
+    fpanel_issue(va, a.U, a.ldu, a.uid, m0, a.n_q, a.d, tid);
+    fpanel_issue(vb, a.I, a.ldi, nullptr, t0 * FN, a.n_items, a.d, tid);
+    fpanel_commit(P0, va, tid);
+    fpanel_commit(P1, vb, tid);
+    if (tid == 0) st_cnt = 0;
+    uint32_t thr[16];
+    const int row_base = wm * 32 + 4 * (lane >> 5);
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const int64_t gm = m0 + row_base + (reg & 3) + 8 * (reg >> 2);
+        thr[reg] = gm < a.n_q ? a.thr[gm] : 0xFFFFFFFFu;
+    }
+    const int rows_here = (int)min((int64_t)FM, a.n_q - m0);
+    __syncthreads();
+    float areg[NM];
+    {
+        const float* ap = &P0[wm * 32 + (lane & 31)][lane >> 5];
+#pragma unroll
+        for (int s = 0; s < NM; ++s) areg[s] = ap[2 * s];
+    }
+    __syncthreads();  // P0 is free: it becomes item buffer 1
+    const int boff = (wn * 32 + (lane & 31)) * FKPAD + (lane >> 5);
+    for (int64_t t = t0; t < t1; ++t) {
+        const bool more = t + 1 < t1;
+        const bool odd = ((t - t0) & 1) != 0;
+        float (*cur)[FKPAD] = odd ? P0 : P1;
+        float (*nxt)[FKPAD] = odd ? P1 : P0;
+        if (more) fpanel_issue(vb, a.I, a.ldi, nullptr, (t + 1) * FN, a.n_items, a.d, tid);  // in flight under the MFMAs
+        const float* bp = &cur[0][0] + boff;
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+        for (int s = 0; s < NM; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[s], bp[2 * s], acc, 0, 0, 0);
+        const int64_t gn = t * FN + wn * 32 + (lane & 31);
+        if (gn < a.n_items) {
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const uint32_t key = score_key(acc[reg]);
+                const int rl = row_base + (reg & 3) + 8 * (reg >> 2);
+                if (key >= thr[reg] && rl < rows_here) {
+                    const unsigned long long c = composite(key, (uint32_t)gn);
+                    const int slot = atomicAdd(&st_cnt, 1);
+                    if (slot < kStage) {
+                        st_val[slot] = c;
+                        st_row[slot] = (unsigned char)rl;
+                    } else if (!((a.bitmap[(m0 + rl) * a.words + (gn >> 5)] >> (gn & 31)) & 1u)) {
+                        const int gs = atomicAdd(&a.cnt[m0 + rl], 1);
+                        if (gs < kCap) a.cand[(m0 + rl) * kCap + gs] = c;
+                    }
+                }
+            }
+        }
+        if (more) fpanel_commit(nxt, vb, tid);  // nobody reads nxt: it was `cur` before the last barrier
+        __syncthreads();                        // commits and staged candidates visible; everybody is done with `cur`
+        const int staged = min(st_cnt, kStage);
+        if (staged >= kStage / 2 || !more) {    // block-uniform
+            flush_stage(a, m0, st_val, st_row, staged);
+            __syncthreads();
+            if (tid == 0) st_cnt = 0;
+            __syncthreads();
+        }
+    }
+}
+
 __global__ __launch_bounds__(kBlock) void topk_finalize_kernel(FusedArgs a, int k, int kpow2, float* __restrict__ scores,
                                                                int64_t* __restrict__ out_idx,
                                                                float* __restrict__ out_score) {
@@ -588,7 +679,12 @@ int mi_topk_excl_f32(int64_t n_q, int64_t n_items, int64_t d, int64_t k, const i
         if (slices > n_tiles) slices = n_tiles;
         a.tiles_per_slice = mi_ceil_div(n_tiles, slices);
         slices = mi_ceil_div(n_tiles, a.tiles_per_slice);
-        hipLaunchKernelGGL(topk_scores_filter_kernel, dim3((unsigned)slices, (unsigned)strips), dim3(256), 0, s, a);
+        if (MI_TOPK_REGA && d == 128)
+            hipLaunchKernelGGL(topk_scores_filter_rega_kernel<64>, dim3((unsigned)slices, (unsigned)strips), dim3(256), 0, s, a);
+        else if (MI_TOPK_REGA && d == 64)
+            hipLaunchKernelGGL(topk_scores_filter_rega_kernel<32>, dim3((unsigned)slices, (unsigned)strips), dim3(256), 0, s, a);
+        else
+            hipLaunchKernelGGL(topk_scores_filter_kernel, dim3((unsigned)slices, (unsigned)strips), dim3(256), 0, s, a);
         hipLaunchKernelGGL(topk_finalize_kernel, dim3((unsigned)n_q), dim3(kBlock), 0, s, a, (int)k, kpow2, scores, out_idx,
                            out_score);
         return mi_launch_status();
