@@ -498,6 +498,9 @@ __global__ __launch_bounds__(256, 2) void topk_scores_filter_kernel(FusedArgs a)
 #ifndef MI_TOPK_REGA
 #define MI_TOPK_REGA 1
 #endif
+#ifndef MI_TOPK_STAGE
+#define MI_TOPK_STAGE 0   // stage timing only (wrong results): 1 = no threshold epilogue, 2 = also no panel loads / commits
+#endif
 template <int NM>
 __global__ __launch_bounds__(256, 2) void topk_scores_filter_rega_kernel(FusedArgs a) {
     __shared__ float P0[FM][FKPAD];   // the query panel first, then item buffer 1
@@ -519,14 +522,21 @@ __global__ __launch_bounds__(256, 2) void topk_scores_filter_rega_kernel(FusedAr
     fpanel_commit(P0, va, tid);
     fpanel_commit(P1, vb, tid);
     if (tid == 0) st_cnt = 0;
-    uint32_t thr[16];
+    // thresholds as FLOATS: the test is one unordered compare per score, `!(score < thr)`, voted per accumulator register
+    // with a ballot.  It is a superset of `key(score) >= key(thr)` (equal for ordinary numbers, also true for NaNs):
+    // an extra candidate sorts below the threshold in the final per-row sort and cannot displace a winner.  Stage timing
+    // of the per-lane key-compare epilogue it replaces (tools/topk_stage.sh): 206 of 883 us per chunk.
+    float thr_f[16];
     const int row_base = wm * 32 + 4 * (lane >> 5);
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
         const int64_t gm = m0 + row_base + (reg & 3) + 8 * (reg >> 2);
-        thr[reg] = gm < a.n_q ? a.thr[gm] : 0xFFFFFFFFu;
+        thr_f[reg] = gm < a.n_q ? key_score(a.thr[gm]) : INFINITY;
     }
     const int rows_here = (int)min((int64_t)FM, a.n_q - m0);
+    unsigned long long row_ok[16];  // lanes whose accumulator row `reg` is a real query (wave-uniform: SGPRs)
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) row_ok[reg] = __ballot(row_base + (reg & 3) + 8 * (reg >> 2) < rows_here);
     __syncthreads();
     float areg[NM];
     {
@@ -541,7 +551,7 @@ __global__ __launch_bounds__(256, 2) void topk_scores_filter_rega_kernel(FusedAr
         const bool odd = ((t - t0) & 1) != 0;
         float (*cur)[FKPAD] = odd ? P0 : P1;
         float (*nxt)[FKPAD] = odd ? P1 : P0;
-        if (more) fpanel_issue(vb, a.I, a.ldi, nullptr, (t + 1) * FN, a.n_items, a.d, tid);  // in flight under the MFMAs
+        if (more && MI_TOPK_STAGE < 2) fpanel_issue(vb, a.I, a.ldi, nullptr, (t + 1) * FN, a.n_items, a.d, tid);  // in flight under the MFMAs
         const float* bp = &cur[0][0] + boff;
         f32x16 acc;
 #pragma unroll
@@ -549,25 +559,43 @@ __global__ __launch_bounds__(256, 2) void topk_scores_filter_rega_kernel(FusedAr
 #pragma unroll
         for (int s = 0; s < NM; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[s], bp[2 * s], acc, 0, 0, 0);
         const int64_t gn = t * FN + wn * 32 + (lane & 31);
-        if (gn < a.n_items) {
+        if (MI_TOPK_STAGE >= 1) {
+            if (acc[0] == 12345.678f && acc[7] == 3.f) st_cnt = 1;  // keeps the chain alive
+        } else {
+            // 16 votes, all scalar: hit[reg] = lanes whose score is not below its row's threshold (rows / columns beyond
+            // the operands masked out); one LDS atomic per wavefront and panel reserves the staging slots of all of them
+            const unsigned long long col_ok = __ballot(gn < a.n_items);
+            unsigned long long hit[16];
+            int total = 0;
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
-                const uint32_t key = score_key(acc[reg]);
-                const int rl = row_base + (reg & 3) + 8 * (reg >> 2);
-                if (key >= thr[reg] && rl < rows_here) {
-                    const unsigned long long c = composite(key, (uint32_t)gn);
-                    const int slot = atomicAdd(&st_cnt, 1);
-                    if (slot < kStage) {
-                        st_val[slot] = c;
-                        st_row[slot] = (unsigned char)rl;
-                    } else if (!((a.bitmap[(m0 + rl) * a.words + (gn >> 5)] >> (gn & 31)) & 1u)) {
-                        const int gs = atomicAdd(&a.cnt[m0 + rl], 1);
-                        if (gs < kCap) a.cand[(m0 + rl) * kCap + gs] = c;
+                hit[reg] = __ballot(!(acc[reg] < thr_f[reg])) & col_ok & row_ok[reg];
+                total += __popcll(hit[reg]);
+            }
+            if (total) {  // wave-uniform
+                int base = 0;
+                if (lane == 0) base = atomicAdd(&st_cnt, total);
+                base = __shfl(base, 0, 64);
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    if (hit[reg] == 0ull) continue;
+                    if ((hit[reg] >> lane) & 1ull) {
+                        const int slot = base + __popcll(hit[reg] & ((1ull << lane) - 1ull));
+                        const int rl = row_base + (reg & 3) + 8 * (reg >> 2);
+                        const unsigned long long c = composite(score_key(acc[reg]), (uint32_t)gn);
+                        if (slot < kStage) {
+                            st_val[slot] = c;
+                            st_row[slot] = (unsigned char)rl;
+                        } else if (!((a.bitmap[(m0 + rl) * a.words + (gn >> 5)] >> (gn & 31)) & 1u)) {  // staging full
+                            const int gs = atomicAdd(&a.cnt[m0 + rl], 1);
+                            if (gs < kCap) a.cand[(m0 + rl) * kCap + gs] = c;
+                        }
                     }
+                    base += __popcll(hit[reg]);
                 }
             }
         }
-        if (more) fpanel_commit(nxt, vb, tid);  // nobody reads nxt: it was `cur` before the last barrier
+        if (more && MI_TOPK_STAGE < 2) fpanel_commit(nxt, vb, tid);  // nobody reads nxt: it was `cur` before the last barrier
         __syncthreads();                        // commits and staged candidates visible; everybody is done with `cur`
         const int staged = min(st_cnt, kStage);
         if (staged >= kStage / 2 || !more) {    // block-uniform
