@@ -232,7 +232,19 @@ __global__ __launch_bounds__(kBlock) void spmm_rows_kernel(int64_t n_out, int d4
     const bool listed = SPARSE && ex.row_list != nullptr;
     int64_t n_valid = n_out;
     if (listed && ex.n_list_dev) n_valid = min(n_out, (int64_t)*ex.n_list_dev);
-    const int64_t base = (int64_t)blockIdx.x * (SG * RPS);
+#ifndef MI_SPMM_XCD_RANGES
+#define MI_SPMM_XCD_RANGES 0
+#endif
+    // MI_SPMM_XCD_RANGES: workgroup w (XCD w & 7) takes the (w >> 3)-th block of the XCD's CONTIGUOUS eighth of the rows
+    // instead of block w: under the locality order neighbouring rows share their cold gathers, which then meet in one L2.
+    // A/B on C2, round 2 (tools/exp_locality.py --reorder cold): traffic 4.27 -> 4.16 GB but 808 -> 1 491 us — the eighths
+    // are unequal work (the item rows and the high-degree users sit at the end of the order).  Off.
+    int64_t blk = blockIdx.x;
+    if (MI_SPMM_XCD_RANGES && !listed) {
+        const int64_t per = gridDim.x / 8;  // the launcher rounds the grid up to a multiple of 8
+        blk = (int64_t)(blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    }
+    const int64_t base = blk * (SG * RPS);
     if (kCoop && coop) {
         if (threadIdx.x == 0) coop_n = 0;
         __syncthreads();
@@ -731,6 +743,7 @@ int launch_spmm_mode(int64_t n_rows, int d4, const int32_t* rowptr, const int32_
     const int64_t n_out = listed ? n_list : n_rows;
     if (do_short && n_out > 0) {
         dim3 gr((unsigned)mi_ceil_div(n_out, SG * ROWS_RPS));
+        if (MI_SPMM_XCD_RANGES && !listed) gr.x = (gr.x + 7u) / 8u * 8u;
         hipLaunchKernelGGL((spmm_rows_kernel<LPR, VPL, UNROLL, ROWS_RPS, SPARSE, ADAM>), gr, dim3(kBlock), 0, s, n_out, d4,
                            rowptr, col, val, X4, ldx4, ep, chunk, ex, plan ? 0 : 1);
     }
