@@ -45,6 +45,12 @@ def allreduce_gradients(params: Iterable[nn.Parameter], group=None) -> None:
         off += n
 
 
+def fused_step(model: nn.Module, optimizer: t.optim.Optimizer, group=None):
+    """ranker_step.FusedRankerStep with the gradient all-reduce between the backward and the optimizer step."""
+    from .ranker_step import FusedRankerStep
+    return FusedRankerStep(model, optimizer, before_step=lambda: allreduce_gradients(model.parameters(), group))
+
+
 def train_step(model: nn.Module, optimizer: t.optim.Optimizer, batch, group=None) -> Tensor:
     """training.py:19-34 with the gradient all-reduce between backward and step."""
     from .utils.get_info import select_properties

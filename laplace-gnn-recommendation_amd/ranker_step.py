@@ -40,10 +40,12 @@ def _dropout_bwd(dy: Tensor, mask: Optional[Tensor], p: Optional[float]) -> Tens
 
 
 class FusedRankerStep:
-    def __init__(self, model: Encoder_Decoder_Model, optimizer: t.optim.Optimizer):
+    def __init__(self, model: Encoder_Decoder_Model, optimizer: t.optim.Optimizer, before_step=None):
+        """before_step: called with no arguments once every gradient is in place, before optimizer.step() — the data-parallel
+        ranker passes `lambda: dist_ranker.allreduce_gradients(model.parameters())`."""
         if not self.supports(model):
             raise ValueError("model is not of the shape FusedRankerStep supports")
-        self.model, self.optimizer = model, optimizer
+        self.model, self.optimizer, self.before_step = model, optimizer, before_step
 
     @staticmethod
     def supports(model) -> bool:
@@ -186,5 +188,7 @@ class FusedRankerStep:
                 conv.lin_r.weight.grad = gw[3 * i + 2]
             if need_x:
                 dxs = [None if d is None else _dropout_bwd(d, m, p) for d, m in zip(dxl, masks)]
+        if self.before_step is not None:
+            self.before_step()
         self.optimizer.step()
         return loss

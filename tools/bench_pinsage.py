@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
-"""PinSAGE path (BASELINE configs[4]) at H&M scale on one MI355X: item-item batches from on-device
-random walks (csrc/pinsage.hip) + the weighted SAGE model, training loop timing.  Prints one JSON line."""
+"""PinSAGE path (BASELINE configs[4]) at H&M scale: item-item batches from on-device random walks
+(csrc/pinsage.hip) + the weighted SAGE model, training loop timing.  Prints one JSON line.
+--gpus N (BASELINE configs[4] names 4): data parallel — the graph is replicated, every rank draws its own batches
+(its own Philox stream), the gradients (item-id embedding table + the dense layers) are averaged with one flat
+all-reduce per iteration (dist_ranker.allreduce_gradients); the parent starts the N workers itself."""
 import argparse
 import json
 import os
@@ -24,9 +27,16 @@ def main():
     ap.add_argument("--layers", type=int, default=2)
     ap.add_argument("--hidden", type=int, default=64)
     ap.add_argument("--iters", type=int, default=200)
+    ap.add_argument("--gpus", type=int, default=1)
     args = ap.parse_args()
+    from laplace_amd import launch
+    if args.gpus > 1 and not launch.launched():
+        sys.exit(launch.self_launch(__file__, sys.argv[1:], args.gpus, result_marker='"workload"'))
     import numpy as np
     import torch as t
+    import torch.distributed as dist
+    rank, world, dev = launch.init_distributed()
+    from laplace_amd.dist_ranker import allreduce_gradients, broadcast_parameters
     from laplace_amd import synthetic as S
     from laplace_amd.data.dataset import AdjList
     from laplace_amd.pinsage.model import PinSAGEModel
@@ -37,9 +47,10 @@ def main():
     users, items = AdjList.from_edges(u, a, args.users), AdjList.from_edges(a, u, args.items)
     smp = PinSAGESampler(users, items, args.users, args.items, batch_size=args.batch, random_walk_length=args.walk_length,
                          random_walk_restart_prob=args.restart, num_random_walks=args.walks, num_neighbors=args.neighbors,
-                         num_layers=args.layers, seed=1)
+                         num_layers=args.layers, seed=1 + 7919 * rank)
     t.manual_seed(0)
-    model = PinSAGEModel(args.items, args.hidden, args.layers).to("cuda")
+    model = PinSAGEModel(args.items, args.hidden, args.layers).to(dev)
+    broadcast_parameters(model)
     opt = t.optim.Adam(model.parameters(), lr=3e-3)
     model.train()
 
@@ -48,6 +59,7 @@ def main():
         loss = model(b["seeds"], b["pos"], b["neg"], b["blocks"]).mean()
         opt.zero_grad()
         loss.backward()
+        allreduce_gradients(model.parameters())
         opt.step()
         return loss, b
 
@@ -60,18 +72,32 @@ def main():
         loss, b = one()
         pairs += int(b["pos"][0].numel())
     t.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
     dt = time.perf_counter() - t0
+    if world > 1:
+        tot = t.tensor([float(pairs), dt], device=dev, dtype=t.float64)
+        dist.all_reduce(tot[:1])
+        dist.all_reduce(tot[1:], op=dist.ReduceOp.MAX)
+        pairs, dt = float(tot[0]), float(tot[1])
     # sampler alone
     t0 = time.perf_counter()
     for _ in range(50):
         smp.sample_batch()
     t.cuda.synchronize()
     ds = (time.perf_counter() - t0) / 50
-    print(json.dumps({"workload": f"PinSAGE item-item training, H&M-shaped synthetic {args.users}x{args.items}, {args.edges} edges; "
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+    print(json.dumps({"n_gpus": world, "backend": os.environ.get("LAPLACE_BENCH_BACKEND", "nccl") if world > 1 else None,
+                      "workload": f"PinSAGE item-item training, H&M-shaped synthetic {args.users}x{args.items}, {args.edges} edges; "
                                   f"batch {args.batch} pairs, walks {args.walks} x length {args.walk_length}, restart {args.restart}, "
                                   f"T={args.neighbors}, {args.layers} layers, hidden {args.hidden}",
                       "ms_per_iteration": round(1e3 * dt / args.iters, 3), "positive_pairs_per_s": round(pairs / dt),
                       "sampler_ms_per_batch": round(1e3 * ds, 3), "loss": round(float(loss.detach()), 4)}))
+    if world > 1:
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":
