@@ -38,7 +38,7 @@ def _batches(step):
             for U in (U0, U1)]
 
 
-def _worker(rank, world, port, ret, sparse_batch):
+def _worker(rank, world, port, ret, sparse_batch, reorder=False):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -57,13 +57,18 @@ def _worker(rank, world, port, ret, sparse_batch):
         model.items_emb.weight.copy_(ti if rank == 0 else t.zeros_like(ti))  # the constructor's broadcast must fix rank 1
     model.to("cuda")
     tr = ShardedLightGCNTrainer(model, Interactions(ei.cuda(), U, I), lr=1e-2, Lambda=1e-4, batch_size=B, seed=3,
-                                sparse_batch=sparse_batch)
+                                sparse_batch=sparse_batch, reorder=reorder)
     assert tr.a_items.plan.n_long_rows > 0
     losses = []
     for s in range(STEPS):
         losses.append(float(tr.step(tuple(x.cuda() for x in _batches(s)[rank]))))
     fin = tr.forward().clone()
-    ret[rank] = {"table": tr.table.cpu(), "final": fin.cpu(), "losses": losses}
+    item_order = None
+    if reorder:  # rows back under their original (local) ids; the replicated items must be numbered alike on both ranks
+        fin = fin[tr.order.node_new_of_old()]
+        item_order = tr.order.item_new_of_old.cpu()
+        tr.finish()
+    ret[rank] = {"table": tr.table.cpu(), "final": fin.cpu(), "losses": losses, "item_order": item_order}
     dist.barrier()
     dist.destroy_process_group()
 
@@ -74,12 +79,14 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("sparse_batch", [True, False])
-def test_two_ranks_on_one_gpu_equal_the_single_process_reference(sparse_batch):
+@pytest.mark.parametrize("sparse_batch,reorder", [(True, False), (False, False), (True, True)])
+def test_two_ranks_on_one_gpu_equal_the_single_process_reference(sparse_batch, reorder):
     from oracle import lightgcn_ref as R
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(2, _free_port(), ret, sparse_batch), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, _free_port(), ret, sparse_batch, reorder), nprocs=2, join=True)
+    if reorder:
+        assert t.equal(ret[0]["item_order"], ret[1]["item_order"])
     e0, e1 = _shards()
     eu, ei = t.cat([e0[0], e1[0] + U0]), t.cat([e0[1], e1[1]])
     row, col = R.bipartite_edges(eu, ei, U0 + U1)
