@@ -210,19 +210,28 @@ def build_sweep_plan(a: DeviceCSR, chunk: int = DEFAULT_CHUNK, band: int = SWEEP
         return None
     dev = a.device
     deg = (a.rowptr[1:] - a.rowptr[:-1]).to(t.int64)
-    long_rows = t.nonzero(deg > chunk).view(-1)
-    n_long = int(long_rows.numel())
-    if n_long == 0:
+
+    def slots_for(ch: int):
+        rows = t.nonzero(deg > ch).view(-1)
+        if rows.numel() == 0:
+            return rows, [], 0, [], 0
+        host = deg[rows].cpu().tolist()
+        tot = sum(host)
+        # parts per row: a slot should carry about a third of a stream's share, so that streams can be balanced
+        target = max(ch, tot // (3 * n_streams))
+        pp = [max(1, -(-d // target)) for d in host]
+        return rows, host, tot, pp, sum(pp)
+
+    long_rows, dl_host, total, parts, n_slots = slots_for(chunk)
+    if long_rows.numel() == 0:
         return None
-    dl = deg[long_rows]
-    dl_host = dl.cpu().tolist()
-    total = sum(dl_host)
-    # parts per row: a slot should carry about a third of a stream's share, so that streams can be balanced
-    target = max(chunk, total // (3 * n_streams))
-    parts = [max(1, -(-d // target)) for d in dl_host]
-    n_slots = sum(parts)
     if n_slots > 8 * n_streams:
+        # More long rows than an XCD has accumulators (a graph whose typical row is long, e.g. C4's item rows).  Raising the
+        # threshold until the longest rows fit was measured on C4 (round 2): dense launch 10.1 -> 10.7 ms against the banded
+        # work items, so such adjacencies keep those.
         return None
+    n_long = int(long_rows.numel())
+    dl = deg[long_rows]
     # longest-processing-time assignment of slots to streams (<= 8 per stream)
     loads = []
     slot_base = [0] * (n_long + 1)
