@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MI_ABI_VERSION 6
+#define MI_ABI_VERSION 7
 
 #define MI_ERR_BAD_ARG      (-1)  /* null pointer, negative size, misaligned buffer   */
 #define MI_ERR_TOO_LARGE    (-2)  /* a size does not fit int32 indexing                */
@@ -537,6 +537,13 @@ int mi_match_common_items_i32(int64_t n_queries, const int64_t* query_users,
  *                     within each sample), edge_index int64[2, tot2], edge_label_index
  *                     int64[2, tot3] (batch-local ids), edge_label int64[tot3],
  *                     user_ptr / article_ptr int64[batch+1] (node offsets per sample).
+ *   mi_sampler_emit_csr  (optional, after mi_sampler_count*, same ws) writes the SAME message-passing edges as the
+ *                     two CSRs mi_coo_to_csr_i32 would build from edge_index — customers x articles
+ *                     (customer_rowptr int32[tot0+1], customer_col int32[tot2]) and articles x customers
+ *                     (article_rowptr int32[tot1+1], article_col int32[tot2]), both sorted by (row, column),
+ *                     batch-local ids — so the encoder needs no sort per batch (model/layers.py BipartiteGraph;
+ *                     replaces the SparseTensor construction inside PyG's SAGEConv propagate).  article_cursor:
+ *                     int32[tot1] scratch.  MI_ERR_UNSUPPORTED when n_hops*num_neighbors > 512.
  * Frontier: when the queued articles' user lists total more than reject_min_entries, the
  * uniform num_neighbors-subset of their distinct unexplored users is drawn by rejection (position of
  * the concatenated lists, acceptance 1/multiplicity) instead of materialising the set — hub
@@ -568,6 +575,9 @@ int    mi_sampler_emit(const mi_sampler_desc* d, const int64_t* seed_users, void
                        const int64_t* totals_host, int64_t* user_ids, int64_t* article_ids,
                        int64_t* edge_index, int64_t* edge_label_index, int64_t* edge_label,
                        int64_t* user_ptr, int64_t* article_ptr, mi_stream_t stream);
+int    mi_sampler_emit_csr(const mi_sampler_desc* d, void* ws, size_t ws_bytes, const int64_t* totals_host,
+                           int32_t* customer_rowptr, int32_t* customer_col, int32_t* article_rowptr,
+                           int32_t* article_col, int32_t* article_cursor, mi_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * N5  PinSAGE samplers (reference: pinsage/sampler.py:16-106 over DGL's random_walk and

@@ -8,7 +8,7 @@ from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int32, c_i
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG_DIR, "liblaplace_hip.so")
 
-MI_ABI_VERSION = 6
+MI_ABI_VERSION = 7
 MI_SPMM_GROUP = 32
 
 
@@ -122,6 +122,7 @@ _PROTOTYPES = {
     "mi_sampler_count": (c_int32, [POINTER(SamplerDesc), P, c_uint64, c_uint64, P, c_size_t, POINTER(c_int64), P]),
     "mi_sampler_count_async": (c_int32, [POINTER(SamplerDesc), P, c_uint64, c_uint64, P, c_size_t, P, P]),
     "mi_sampler_emit": (c_int32, [POINTER(SamplerDesc), P, P, c_size_t, POINTER(c_int64), P, P, P, P, P, P, P, P]),
+    "mi_sampler_emit_csr": (c_int32, [POINTER(SamplerDesc), P, c_size_t, POINTER(c_int64), P, P, P, P, P, P]),
     "mi_pinsage_item_pairs": (c_int32, [c_int64, c_int64, P, P, P, P, c_uint64, c_uint64, P, P, P, P]),
     "mi_pinsage_neighbors_workspace_bytes": (c_size_t, [c_int64, c_int32, c_int32]),
     "mi_pinsage_neighbors": (c_int32, [c_int64, P, P, P, P, P, c_int32, c_double, c_int32, c_int32, c_int32,

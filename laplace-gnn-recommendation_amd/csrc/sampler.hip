@@ -39,12 +39,13 @@ struct Smp {
     uint32_t* bm_art;   int32_t WA;
     int32_t* pre_a;
     int32_t* uq; int32_t* uq_n; int32_t* uq_local; int32_t* uq_estart;
+    int32_t* uq_rstart;  // edge start of a user's row when the sample's users are laid out in RANK order (CSR emit)
     int32_t* aq; int32_t* aq_n;
     int64_t* aq_L;      // [B] total length of the queued articles' user lists
     int64_t reject_min; // above this the next frontier is drawn by rejection instead of being materialised
     int32_t* pos_items; int32_t* neg_items; int32_t* n_pos; int32_t* n_neg;
     int32_t* cnt;   // [B][4]
-    int32_t* off;   // [4][B+1]
+    int32_t* off;   // [4][B+1], then the four totals again, contiguous (one copy to the host)
 };
 
 __device__ __forceinline__ uint64_t rand_below(uint64_t m, uint32_t purpose, uint32_t seed_user, uint32_t i,
@@ -497,10 +498,15 @@ __global__ __launch_bounds__(kSelThreads) void smp_count_kernel(Smp p) {
         const int h = e / p.n, q = e % p.n;
         if (q >= uq_n[h]) continue;
         const int32_t v = uq[e];
-        int r = 0;
+        int r = 0, before = 0;
         for (int h2 = 0; h2 < p.H; ++h2)
-            for (int q2 = 0; q2 < uq_n[h2]; ++q2) r += (uq[h2 * p.n + q2] < v);
+            for (int q2 = 0; q2 < uq_n[h2]; ++q2) {
+                const int32_t w = uq[h2 * p.n + q2];
+                r += (w < v);
+                before += (w < v) ? p.uptr[w + 1] - p.uptr[w] : 0;
+            }
         ul[e] = r;
+        p.uq_rstart[(int64_t)s * p.H * p.n + e] = before;
     }
     if (tid == 0) {
         int32_t* es = p.uq_estart + (int64_t)s * p.H * p.n;
@@ -529,6 +535,7 @@ __global__ void smp_offsets_kernel(Smp p) {  // B is small: one thread per count
         run += p.cnt[(int64_t)s * 4 + c];
     }
     p.off[c * (p.B + 1) + p.B] = run;
+    p.off[4 * (p.B + 1) + c] = run;
 }
 
 struct SmpOut {
@@ -593,6 +600,152 @@ __global__ __launch_bounds__(256) void smp_emit_articles_kernel(Smp p, SmpOut o)
     }
 }
 
+// ---- phase 6b: the batch's message-passing edges as two sorted CSRs ---------------------------------
+// The encoder reads every relation as a CSR sorted by (row, column) in both directions (model/layers.py
+// BipartiteGraph).  The samples of a batch are disjoint graphs with their nodes numbered in id order, so both CSRs
+// can be written straight from the walk's tables: customer rows are the explored users in rank order with their
+// article lists relabelled and sorted; article rows are the transpose, at most one sample's users long.
+struct SmpCsr {
+    int32_t* u_rowptr; int32_t* u_col;   // customers x articles
+    int32_t* a_rowptr; int32_t* a_col;   // articles x customers
+    int32_t* a_cur;                      // [total articles] fill cursors
+    int32_t n_users, n_articles, n_edges;
+};
+constexpr int kCsrSortCap = 8192;  // keys one workgroup sorts in LDS; longer lists take the quadratic path
+constexpr int kCsrRowRegs = 8;     // article rows up to 64 * kCsrRowRegs customers (guarded on the host)
+
+__global__ __launch_bounds__(256) void smp_csr_users_kernel(Smp p, SmpCsr o) {
+    __shared__ int32_t key[kCsrSortCap];
+    const int s = blockIdx.y, e = blockIdx.x, h = e / p.n, q = e % p.n;
+    const int tid = threadIdx.x;
+    const int32_t off_u = p.off[0 * (p.B + 1) + s], off_a = p.off[1 * (p.B + 1) + s], off_e = p.off[2 * (p.B + 1) + s];
+    if (s == p.B - 1 && e == 0 && tid == 0) o.u_rowptr[o.n_users] = o.n_edges;
+    if (h >= p.H || q >= p.uq_n[(int64_t)s * p.H + h]) return;
+    const int64_t slot = ((int64_t)s * p.H + h) * p.n + q;
+    const int32_t usr = p.uq[slot], ul = p.uq_local[slot];
+    const int32_t base = off_e + p.uq_rstart[slot];
+    if (tid == 0) o.u_rowptr[off_u + ul] = base;
+    const int32_t beg = p.uptr[usr], deg = p.uptr[usr + 1] - beg;
+    if (deg <= 0) return;
+    if (deg > kCsrSortCap) {  // rank by counting over the list itself: correct for any length, slow, rare
+        for (int x = tid; x < deg; x += blockDim.x) {
+            const int32_t r = article_rank(p, s, p.uidx[beg + x]);
+            int pos = 0;
+            for (int y = 0; y < deg; ++y) {
+                const int32_t r2 = article_rank(p, s, p.uidx[beg + y]);
+                pos += (r2 < r) || (r2 == r && y < x);
+            }
+            o.u_col[base + pos] = off_a + r;
+            atomicAdd(o.a_rowptr + off_a + r + 1, 1);
+        }
+        return;
+    }
+    for (int x = tid; x < deg; x += blockDim.x) key[x] = article_rank(p, s, p.uidx[beg + x]);
+    __syncthreads();
+    if (deg <= 256) {  // one key per thread: position = keys below it (ties by list position)
+        if (tid < deg) {
+            const int32_t r = key[tid];
+            int pos = 0;
+            for (int y = 0; y < deg; ++y) pos += (key[y] < r) || (key[y] == r && y < tid);
+            o.u_col[base + pos] = off_a + r;
+            atomicAdd(o.a_rowptr + off_a + r + 1, 1);
+        }
+        return;
+    }
+    int n2 = 512;
+    while (n2 < deg) n2 <<= 1;
+    for (int x = deg + tid; x < n2; x += blockDim.x) key[x] = INT32_MAX;
+    __syncthreads();
+    for (int k = 2; k <= n2; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int x = tid; x < n2; x += blockDim.x) {
+                const int y = x ^ j;
+                if (y > x) {
+                    const int32_t a = key[x], b = key[y];
+                    const bool up = (x & k) == 0;
+                    if ((a > b) == up) { key[x] = b; key[y] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    for (int x = tid; x < deg; x += blockDim.x) {
+        o.u_col[base + x] = off_a + key[x];
+        atomicAdd(o.a_rowptr + off_a + key[x] + 1, 1);
+    }
+}
+
+// per sample: counts (left in a_rowptr[off_a + 1 + i] by the kernel above) -> row ends, row starts -> cursors
+__global__ __launch_bounds__(kSelThreads) void smp_csr_scan_kernel(Smp p, SmpCsr o) {
+    __shared__ int32_t scan[kSelThreads + 1];
+    const int s = blockIdx.x, tid = threadIdx.x;
+    const int32_t off_a = p.off[1 * (p.B + 1) + s], off_e = p.off[2 * (p.B + 1) + s];
+    const int na = p.cnt[(int64_t)s * 4 + 1];
+    const int per = (na + kSelThreads - 1) / kSelThreads;
+    const int i0 = min(tid * per, na), i1 = min(i0 + per, na);
+    int32_t* cntp = o.a_rowptr + off_a + 1;
+    int c = 0;
+    for (int i = i0; i < i1; ++i) c += cntp[i];
+    scan[tid + 1] = c;
+    if (tid == 0) scan[0] = 0;
+    __syncthreads();
+    for (int off = 1; off < kSelThreads; off <<= 1) {
+        int v = (tid + 1 > off) ? scan[tid + 1 - off] : 0;
+        __syncthreads();
+        scan[tid + 1] += (tid + 1 > off) ? v : 0;
+        __syncthreads();
+    }
+    int run = off_e + scan[tid];
+    for (int i = i0; i < i1; ++i) {
+        o.a_cur[off_a + i] = run;
+        run += cntp[i];
+        cntp[i] = run;
+    }
+}
+
+__global__ __launch_bounds__(256) void smp_csr_fill_kernel(Smp p, SmpCsr o) {
+    const int s = blockIdx.y, e = blockIdx.x, h = e / p.n, q = e % p.n;
+    if (h >= p.H || q >= p.uq_n[(int64_t)s * p.H + h]) return;
+    const int32_t off_u = p.off[0 * (p.B + 1) + s], off_a = p.off[1 * (p.B + 1) + s];
+    const int64_t slot = ((int64_t)s * p.H + h) * p.n + q;
+    const int32_t usr = p.uq[slot], ul = p.uq_local[slot];
+    for (int32_t x = p.uptr[usr] + threadIdx.x; x < p.uptr[usr + 1]; x += blockDim.x) {
+        const int32_t pos = atomicAdd(o.a_cur + off_a + article_rank(p, s, p.uidx[x]), 1);
+        o.a_col[pos] = off_u + ul;
+    }
+}
+
+// one wave per article row: the cursors filled it in arrival order; put it in customer order.  Every lane ranks
+// its own entries against the whole row (reads), then writes them — the wave runs in lockstep, so all reads of
+// the row have returned before the first store is issued.
+__global__ __launch_bounds__(256) void smp_csr_sort_rows_kernel(SmpCsr o) {
+    const int row = blockIdx.x * (blockDim.x / MI_WAVE) + threadIdx.x / MI_WAVE, lane = threadIdx.x % MI_WAVE;
+    if (row >= o.n_articles) return;
+    const int32_t b = o.a_rowptr[row], len = o.a_rowptr[row + 1] - b;
+    if (len <= 1) return;
+    int32_t* r = o.a_col + b;
+    int32_t mine[kCsrRowRegs], pos[kCsrRowRegs];
+#pragma unroll
+    for (int k = 0; k < kCsrRowRegs; ++k) {
+        const int i = lane + MI_WAVE * k;
+        mine[k] = i < len ? r[i] : 0;
+        pos[k] = 0;
+    }
+    for (int y = 0; y < len; ++y) {
+        const int32_t v = r[y];
+#pragma unroll
+        for (int k = 0; k < kCsrRowRegs; ++k) {
+            const int i = lane + MI_WAVE * k;
+            pos[k] += (v < mine[k]) || (v == mine[k] && y < i);
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int k = 0; k < kCsrRowRegs; ++k)
+        if (lane + MI_WAVE * k < len) r[pos[k]] = mine[k];
+}
+
+
 size_t smp_scratch_layout(const Smp& p, Smp* out, char* base) {
     size_t off = 0;
     auto take = [&](size_t bytes) {
@@ -608,6 +761,7 @@ size_t smp_scratch_layout(const Smp& p, Smp* out, char* base) {
     char* a4 = take(B * H * 4);
     char* a5 = take(B * H * n * 4);
     char* a6 = take(B * H * n * 4);
+    char* a6b = take(B * H * n * 4);
     char* a7 = take(B * n * 4);
     char* a8 = take(B * 4);
     char* a8b = take(B * 8);
@@ -616,10 +770,10 @@ size_t smp_scratch_layout(const Smp& p, Smp* out, char* base) {
     char* a11 = take(B * 4);
     char* a12 = take(B * 4);
     char* a13 = take(B * 4 * 4);
-    char* a14 = take(4 * (B + 1) * 4);
+    char* a14 = take((4 * (B + 1) + 4) * 4);
     if (out) {
         out->bm_users = (uint32_t*)a0; out->bm_art = (uint32_t*)a1; out->pre_a = (int32_t*)a2;
-        out->uq = (int32_t*)a3; out->uq_n = (int32_t*)a4; out->uq_local = (int32_t*)a5; out->uq_estart = (int32_t*)a6;
+        out->uq = (int32_t*)a3; out->uq_n = (int32_t*)a4; out->uq_local = (int32_t*)a5; out->uq_estart = (int32_t*)a6; out->uq_rstart = (int32_t*)a6b;
         out->aq = (int32_t*)a7; out->aq_n = (int32_t*)a8; out->aq_L = (int64_t*)a8b; out->pos_items = (int32_t*)a9; out->neg_items = (int32_t*)a10;
         out->n_pos = (int32_t*)a11; out->n_neg = (int32_t*)a12; out->cnt = (int32_t*)a13; out->off = (int32_t*)a14;
     }
@@ -680,8 +834,7 @@ int mi_sampler_count_async(const mi_sampler_desc* d, const int64_t* seed_users, 
     hipLaunchKernelGGL(smp_mark_articles_kernel, dim3(1 + p.H * p.n, p.B), dim3(256), 0, s, p);
     hipLaunchKernelGGL(smp_count_kernel, dim3(p.B), dim3(kSelThreads), 0, s, p);
     hipLaunchKernelGGL(smp_offsets_kernel, dim3(1), dim3(64), 0, s, p);
-    for (int c = 0; c < 4; ++c)
-        MI_HIP(hipMemcpyAsync(&totals_pinned[c], p.off + c * (p.B + 1) + p.B, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    MI_HIP(hipMemcpyAsync(totals_pinned, p.off + 4 * (p.B + 1), 4 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     return mi_launch_status();
 }
 
@@ -717,6 +870,34 @@ int mi_sampler_emit(const mi_sampler_desc* d, const int64_t* seed_users, void* w
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(smp_emit_edges_kernel, dim3(1 + p.H * p.n, p.B), dim3(256), 0, s, p, o);
     hipLaunchKernelGGL(smp_emit_articles_kernel, dim3((p.WA + 255) / 256, p.B), dim3(256), 0, s, p, o);
+    return mi_launch_status();
+}
+
+// Phase B': the same edges as the two sorted CSRs the encoder consumes (after phase A, before or after mi_sampler_emit).
+int mi_sampler_emit_csr(const mi_sampler_desc* d, void* ws, size_t ws_bytes, const int64_t* totals_host,
+                        int32_t* customer_rowptr, int32_t* customer_col, int32_t* article_rowptr, int32_t* article_col,
+                        int32_t* article_cursor, mi_stream_t stream) {
+    Smp p;
+    int rc = fill_params(p, d);
+    if (rc) return rc;
+    MI_CHECK_ARG(ws && totals_host && customer_rowptr && article_rowptr);
+    MI_CHECK_ARG(totals_host[2] == 0 || (customer_col && article_col));
+    MI_CHECK_ARG(totals_host[1] == 0 || article_cursor);
+    if ((int64_t)p.H * p.n > (int64_t)MI_WAVE * kCsrRowRegs) return MI_ERR_UNSUPPORTED;  // bound on an article row
+    if (ws_bytes < smp_scratch_layout(p, nullptr, nullptr)) return MI_ERR_WORKSPACE;
+    smp_scratch_layout(p, &p, static_cast<char*>(ws));
+    SmpCsr o;
+    o.u_rowptr = customer_rowptr; o.u_col = customer_col; o.a_rowptr = article_rowptr; o.a_col = article_col;
+    o.a_cur = article_cursor;
+    o.n_users = (int32_t)totals_host[0]; o.n_articles = (int32_t)totals_host[1]; o.n_edges = (int32_t)totals_host[2];
+    hipStream_t s = (hipStream_t)stream;
+    MI_HIP(hipMemsetAsync(article_rowptr, 0, ((size_t)o.n_articles + 1) * 4, s));
+    hipLaunchKernelGGL(smp_csr_users_kernel, dim3(p.H * p.n, p.B), dim3(256), 0, s, p, o);
+    hipLaunchKernelGGL(smp_csr_scan_kernel, dim3(p.B), dim3(kSelThreads), 0, s, p, o);
+    if (o.n_edges > 0) {
+        hipLaunchKernelGGL(smp_csr_fill_kernel, dim3(p.H * p.n, p.B), dim3(256), 0, s, p, o);
+        hipLaunchKernelGGL(smp_csr_sort_rows_kernel, dim3((o.n_articles + 3) / 4), dim3(256), 0, s, o);
+    }
     return mi_launch_status();
 }
 

@@ -66,12 +66,15 @@ def candidate_csr_device(matchers, num_users: int, device):
 class DeviceGraphSampler:
     def __init__(self, config, graph: HeteroData, users_adj_list, articles_adj_list, batch_size: Optional[int] = None,
                  randomization: bool = True, device: str = "cuda", seed: int = 0, prefetch: bool = True,
-                 train: bool = True, matchers=None, shuffle: bool = True):
-        """train=False: evaluation samples as GraphDataset(train=False) builds them — the label-0 edges are the
+                 train: bool = True, matchers=None, shuffle: bool = True, emit_csr: bool = True):
+        """emit_csr: also write each batch's edges as the two sorted CSRs the encoder consumes (mi_sampler_emit_csr),
+        attached to edge_index as `_sorted_csr`; the encoder then builds no CSR of its own for the batch.
+        train=False: evaluation samples as GraphDataset(train=False) builds them — the label-0 edges are the
         matchers' candidates (minus purchases, plus purchases no matcher proposed; data/dataset.py:94-105)."""
         self.config, self.device, self.seed = config, t.device(device), int(seed)
-        self.prefetch, self._side = bool(prefetch), None
+        self.prefetch, self._side = ("thread" if prefetch == "thread" else bool(prefetch)), None
         self.train, self.shuffle = bool(train), bool(shuffle)
+        self.emit_csr = bool(emit_csr) and int(config.n_hop_neighbors) * int(config.num_neighbors) <= 512
         self.batch_size = int(batch_size if batch_size is not None else config.batch_size)
         self.randomization = randomization
         ux, ax = graph[Constants.node_user].x, graph[Constants.node_item].x
@@ -154,14 +157,31 @@ class DeviceGraphSampler:
                                 user_ids.data_ptr(), article_ids.data_ptr(), edge_index.data_ptr() if ne else None,
                                 label_index.data_ptr(), labels.data_ptr(), user_ptr.data_ptr(), article_ptr.data_ptr(),
                                 stream), "mi_sampler_emit")
+        csr = None
+        if getattr(self, "emit_csr", False):
+            from .. import ops
+            u_rowptr = t.empty(nu + 1, dtype=t.int32, device=dev)
+            a_rowptr = t.empty(na + 1, dtype=t.int32, device=dev)
+            u_col, a_col = t.empty(ne, dtype=t.int32, device=dev), t.empty(ne, dtype=t.int32, device=dev)
+            cursor = t.empty(max(na, 1), dtype=t.int32, device=dev)
+            check(L.mi_sampler_emit_csr(ctypes.byref(desc), self._ws.data_ptr(), self._ws.numel(), tot, u_rowptr.data_ptr(),
+                                        u_col.data_ptr() if ne else None, a_rowptr.data_ptr(), a_col.data_ptr() if ne else None,
+                                        cursor.data_ptr(), stream), "mi_sampler_emit_csr")
+            # (rows = customers, rows = articles): by-source and by-destination forms of the customer -> article relation
+            csr = (ops.DeviceCSR(nu, na, u_rowptr, u_col), ops.DeviceCSR(na, nu, a_rowptr, a_col))
         if raw:
-            return {"user_ids": user_ids, "article_ids": article_ids, "edge_index": edge_index,
+            out = {"user_ids": user_ids, "article_ids": article_ids, "edge_index": edge_index,
                     "edge_label_index": label_index, "edge_label": labels, "user_ptr": user_ptr, "article_ptr": article_ptr}
+            if csr is not None:
+                out["csr_by_customer"], out["csr_by_article"] = csr
+            return out
         data = HeteroData()
         data[Constants.node_user].x = self.user_x[user_ids]
         data[Constants.node_item].x = self.article_x[article_ids]
         data[Constants.node_user].n_id = user_ids
         data[Constants.node_item].n_id = article_ids
+        if csr is not None:
+            edge_index._sorted_csr = csr  # (by source, by destination), read by model/layers.py BipartiteGraph.of
         data[Constants.edge_key].edge_index = edge_index
         data[Constants.edge_key].edge_label_index = label_index
         data[Constants.edge_key].edge_label = labels
@@ -174,8 +194,8 @@ class DeviceGraphSampler:
 
     def __iter__(self) -> Iterator[HeteroData]:
         """One epoch: every user once, shuffled (DataLoader(shuffle=True) semantics).  With `prefetch` (default)
-        the walk of batch i+1 runs on a side stream while the consumer trains on batch i: only the short emit
-        phase sits between two steps.  Same batches, same order, same Philox steps as the serial loop."""
+        sampling runs two batches ahead on a side stream while the consumer trains on batch i: nothing of the
+        sampler sits between two steps.  Same batches, same order, same Philox steps as the serial loop."""
         g = t.Generator(device="cpu").manual_seed(self.seed + self.step)
         order = t.randperm(self.num_users, generator=g) if self.shuffle else t.arange(self.num_users)
         batches = [order[b:b + self.batch_size] for b in range(0, self.num_users, self.batch_size)]
@@ -202,9 +222,7 @@ class DeviceGraphSampler:
                 ev.record(side)
             return seeds, desc, ev
 
-        side.wait_stream(main)
-        pend = start(0)
-        for i in range(len(batches)):
+        def finish(i: int, pend):  # phase B of batch i on the side stream, once its four totals have landed
             seeds, desc, ev = pend
             ev.synchronize()
             totals = self._pinned[i % 2].tolist()
@@ -212,13 +230,76 @@ class DeviceGraphSampler:
                 data = self._emit(seeds, desc, totals, side.cuda_stream)
                 ready = t.cuda.Event()
                 ready.record(side)
-            self.step = step0 + i + 1
-            if i + 1 < len(batches):  # the workspace is free again once emit(i) has run: same stream, in order
-                pend = start(i + 1)
+            return data, ready
+
+        def hand_out(data, ready):
             main.wait_event(ready)
             for store in (data[Constants.node_user], data[Constants.node_item], data[Constants.edge_key],
                           data[Constants.rev_edge_key]):
                 for v in store.values():
                     if isinstance(v, Tensor):
                         v.record_stream(main)
-            yield data
+            for c in getattr(data[Constants.edge_key].edge_index, "_sorted_csr", ()):
+                c.rowptr.record_stream(main)
+                c.col.record_stream(main)
+            return data
+
+        # Two batches ahead: while the consumer trains on batch i, batch i+1 is complete (or being emitted) and the walk
+        # of batch i+2 is running; the wait in finish(i+1) is on work enqueued a whole training step earlier.  One
+        # workspace serves all of it because the side stream runs count(i+1), emit(i+1), count(i+2), ... in order.
+        side.wait_stream(main)
+        nb = len(batches)
+        if getattr(self, "prefetch", True) == "thread":
+            # the sampler's host side (a dozen launches and allocations per batch) on a thread of its own: the training
+            # step is bound by its own launches, so this takes the sampler's share off the loop's critical path
+            import queue
+            import threading
+            out: "queue.Queue" = queue.Queue(maxsize=2)
+            dev_index = self.device.index if self.device.index is not None else t.cuda.current_device()
+            stop = threading.Event()
+
+            def produce():
+                try:
+                    t.cuda.set_device(dev_index)
+                    pend = start(0)
+                    for i in range(nb):
+                        item = finish(i, pend)
+                        pend = start(i + 1) if i + 1 < nb else None
+                        while not stop.is_set():
+                            try:
+                                out.put(item, timeout=0.05)
+                                break
+                            except queue.Full:
+                                continue
+                        if stop.is_set():
+                            return
+                except BaseException as exc:  # surfaces in the consumer
+                    out.put(exc)
+
+            import sys
+            interval = sys.getswitchinterval()
+            sys.setswitchinterval(min(interval, 1e-4))  # neither thread may sit on the interpreter lock for 5 ms
+            worker = threading.Thread(target=produce, name="laplace-sampler", daemon=True)
+            worker.start()
+            try:
+                for i in range(nb):
+                    item = out.get()
+                    if isinstance(item, BaseException):
+                        raise item
+                    self.step = step0 + i + 1
+                    yield hand_out(*item)
+            finally:
+                stop.set()
+                worker.join()
+                sys.setswitchinterval(interval)
+                t.cuda.current_stream(self.device).wait_stream(side)
+            return
+        cur = finish(0, start(0))
+        pend = start(1) if nb > 1 else None
+        for i in range(nb):
+            data, ready = cur
+            if i + 1 < nb:
+                cur = finish(i + 1, pend)
+                pend = start(i + 2) if i + 2 < nb else None
+            self.step = step0 + i + 1
+            yield hand_out(data, ready)

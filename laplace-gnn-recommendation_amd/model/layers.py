@@ -97,6 +97,17 @@ class BipartiteGraph:
         self.by_dst = ops.coo_to_csr(dst, src, self.n_dst, self.n_src, want_perm=False)
         self.by_src = ops.coo_to_csr(src, dst, self.n_src, self.n_dst, want_perm=False)
 
+    @classmethod
+    def of(cls, edge_index: Tensor, n_src: int, n_dst: int) -> "BipartiteGraph":
+        """The relation of `edge_index`; when its producer already holds the two sorted CSRs (the device sampler
+        attaches them as `_sorted_csr` = (by source, by destination)) they are taken as they are."""
+        pre = getattr(edge_index, "_sorted_csr", None)
+        if pre is None or pre[0].n_rows != int(n_src) or pre[1].n_rows != int(n_dst):
+            return cls(edge_index, n_src, n_dst)
+        g = cls(None, n_src, n_dst)
+        g.by_src, g.by_dst = pre
+        return g
+
     def reversed(self) -> "BipartiteGraph":
         """The relation with every edge turned round (the reference's `rev_*` relation is `edge_index.flip(0)`,
         data/dataset.py:176-182): the same two CSRs with their roles swapped — no second pair of sorts."""

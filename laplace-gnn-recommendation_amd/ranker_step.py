@@ -78,7 +78,7 @@ class FusedRankerStep:
                 elif fwd is not None and id(fwd) in built:
                     graphs[et] = built[id(fwd)].reversed()
                 else:
-                    graphs[et] = BipartiteGraph(ei, x_dict[et[0]].shape[0], x_dict[et[2]].shape[0])
+                    graphs[et] = BipartiteGraph.of(ei, x_dict[et[0]].shape[0], x_dict[et[2]].shape[0])
                     built[id(ei)] = graphs[et]
         # ---- encoder forward
         n_layers = len(enc.layers)

@@ -18,6 +18,25 @@ def _graph(seed, U, A, E, zipf=1.0):
     return S.generate_hetero(spec, customer_cards=(50, 2, 84), article_cards=(40, 9))
 
 
+def _np_csr(rows, cols, n_rows):
+    """(rowptr, col) sorted by (row, col) — what mi_coo_to_csr_i32 builds from the same edges."""
+    order = np.lexsort((cols, rows))
+    ptr = np.zeros(n_rows + 1, dtype=np.int64)
+    np.cumsum(np.bincount(rows, minlength=n_rows), out=ptr[1:])
+    return ptr, cols[order]
+
+
+def _check_emitted_csrs(got, want):
+    """The CSRs the sampler writes itself are the sorted CSRs of the mirror's edge_index, both ways round."""
+    nu, na = len(want["user_ids"]), len(want["article_ids"])
+    src, dst = want["edge_index"][0], want["edge_index"][1]
+    for key, (r, c, n) in (("csr_by_customer", (src, dst, nu)), ("csr_by_article", (dst, src, na))):
+        ptr, col = _np_csr(r, c, n)
+        assert got[key].n_rows == n
+        assert np.array_equal(got[key].rowptr.cpu().numpy(), ptr), key
+        assert np.array_equal(got[key].col.cpu().numpy(), col), key
+
+
 def _cfg(**kw):
     base = dict(k=12, num_neighbors=8, n_hop_neighbors=2, positive_edges_ratio=0.5, negative_edges_ratio=3.0, batch_size=16)
     base.update(kw)
@@ -46,6 +65,9 @@ def test_device_sampler_bit_exact_vs_mirror(hops, fan, E, rand, rmin):
             assert np.array_equal(got[key].cpu().numpy(), want[key]), (key, step)
         assert np.array_equal(got["user_ptr"].cpu().numpy(), want["user_ptr"])
         assert np.array_equal(got["article_ptr"].cpu().numpy(), want["article_ptr"])
+        assert ("csr_by_customer" in got) == (hops * fan <= 512)
+        if "csr_by_customer" in got:
+            _check_emitted_csrs(got, want)
     # a short last batch reuses the scratch with a smaller descriptor
     got = smp.sample(t.tensor([5, 9, 200]), step=3, raw=True)
     want = SR.sample_batch([5, 9, 200], ucsr, acsr, int(ei.shape[1]), int(ei[1].max()), cfg, 1234, 3, rand)
@@ -67,14 +89,46 @@ def test_device_sampler_hub_graph_and_collated_heterodata():
     want = SR.sample_batch(seeds.tolist(), ucsr, acsr, int(ei.shape[1]), int(ei[1].max()), cfg, 5, 9, True)
     for key in ("user_ids", "article_ids", "edge_index", "edge_label_index", "edge_label"):
         assert np.array_equal(got[key].cpu().numpy(), want[key]), key
+    _check_emitted_csrs(got, want)
     batch = smp.sample(seeds, step=9)
     s, r = batch[Constants.edge_key], batch[Constants.rev_edge_key]
+    by_customer, by_article = s.edge_index._sorted_csr
+    assert t.equal(by_customer.col, got["csr_by_customer"].col) and t.equal(by_article.rowptr, got["csr_by_article"].rowptr)
     assert t.equal(batch[Constants.node_user].x.cpu(), graph[Constants.node_user].x[t.from_numpy(want["user_ids"])])
     assert t.equal(batch[Constants.node_item].x.cpu(), graph[Constants.node_item].x[t.from_numpy(want["article_ids"])])
     assert t.equal(r.edge_index, s.edge_index.flip(0)) and t.equal(r.edge_label, s.edge_label)
     assert int(s.edge_index[0].max()) < batch[Constants.node_user].x.shape[0]
     assert int(s.edge_index[1].max()) < batch[Constants.node_item].x.shape[0]
     assert batch.metadata() == ([Constants.node_user, Constants.node_item], [Constants.edge_key, Constants.rev_edge_key])
+
+
+def test_emitted_csrs_with_repeated_purchases_and_a_list_longer_than_the_lds_sort():
+    """Multi-edges (a customer buying an article twice is two edges, data/dataset.py keeps both) and one customer
+    with 9000 purchases — past the 8192 keys a workgroup sorts in LDS — against the mirror's edge_index."""
+    from laplace_amd.data.dataset import AdjList
+    from laplace_amd.data.device_sampler import DeviceGraphSampler
+    from laplace_amd.hetero import HeteroData
+    from laplace_amd.utils.constants import Constants
+    rng = np.random.default_rng(11)
+    U, A = 200, 3000
+    deg = rng.integers(1, 40, size=U)
+    deg[7], deg[8] = 9000, 700
+    u = np.repeat(np.arange(U), deg)
+    a = rng.integers(0, A, size=u.size)           # with replacement: repeated (customer, article) pairs
+    a[: U] = rng.integers(0, 5, size=U)            # a few articles nearly everybody bought: long article rows
+    g = HeteroData()
+    g[Constants.node_user].x = t.from_numpy(rng.integers(0, 5, size=(U, 3)))
+    g[Constants.node_item].x = t.from_numpy(rng.integers(0, 5, size=(A, 2)))
+    g[Constants.edge_key].edge_index = t.from_numpy(np.stack([u, a]))
+    users, articles = AdjList.from_edges(u, a, U), AdjList.from_edges(a, u, A)
+    cfg = _cfg(n_hop_neighbors=3, num_neighbors=32, batch_size=8)
+    smp = DeviceGraphSampler(cfg, g, users, articles, randomization=True, device=DEV, seed=2)
+    ucsr, acsr = SR.CsrAdj(users.ptr, users.idx), SR.CsrAdj(articles.ptr, articles.idx)
+    for step, seeds in ((0, [7, 8, 1, 2, 3, 4, 5, 6]), (1, [100, 7, 150])):
+        got = smp.sample(t.tensor(seeds), step=step, raw=True)
+        want = SR.sample_batch(seeds, ucsr, acsr, int(u.size), int(a.max()), cfg, 2, step, True)
+        assert np.array_equal(got["edge_index"].cpu().numpy(), want["edge_index"])
+        _check_emitted_csrs(got, want)
 
 
 def test_ranker_trains_from_device_sampled_batches():
@@ -98,15 +152,17 @@ def test_ranker_trains_from_device_sampled_batches():
     assert np.isfinite(losses).all() and np.mean(losses) < np.mean(first_epoch)
 
 
-def test_prefetching_epoch_equals_the_serial_epoch():
-    """Iterating the sampler with the walk of batch i+1 on a side stream gives, batch for batch, the tensors of
-    the serial loop (same order, same Philox steps), also while another stream keeps the GPU busy."""
+@pytest.mark.parametrize("mode", [True, "thread"])
+def test_prefetching_epoch_equals_the_serial_epoch(mode):
+    """Iterating the sampler two batches ahead on a side stream (from the calling thread, or from a thread of its own)
+    gives, batch for batch, the tensors of the serial loop (same order, same Philox steps), also while another stream
+    keeps the GPU busy."""
     from laplace_amd.data.device_sampler import DeviceGraphSampler
     from laplace_amd.utils.constants import Constants
     graph, users, articles = _graph(seed=31, U=210, A=90, E=4000)
     cfg = _cfg(n_hop_neighbors=3, num_neighbors=6)
     serial = DeviceGraphSampler(cfg, graph, users, articles, batch_size=16, device=DEV, seed=77, prefetch=False)
-    ahead = DeviceGraphSampler(cfg, graph, users, articles, batch_size=16, device=DEV, seed=77, prefetch=True)
+    ahead = DeviceGraphSampler(cfg, graph, users, articles, batch_size=16, device=DEV, seed=77, prefetch=mode)
     busy = t.randn(2048, 2048, device=DEV)
     n = 0
     for epoch in range(2):
@@ -117,6 +173,8 @@ def test_prefetching_epoch_equals_the_serial_epoch():
             for key in ("edge_index", "edge_label_index", "edge_label"):
                 assert t.equal(a[Constants.edge_key][key], b[Constants.edge_key][key])
                 assert t.equal(a[Constants.rev_edge_key][key], b[Constants.rev_edge_key][key])
+            for ca, cb in zip(a[Constants.edge_key].edge_index._sorted_csr, b[Constants.edge_key].edge_index._sorted_csr):
+                assert t.equal(ca.rowptr, cb.rowptr) and t.equal(ca.col, cb.col)
             n += 1
     assert n == 2 * len(serial) and serial.step == ahead.step == n
 

@@ -46,7 +46,8 @@ def main():
                           negative_edges_ratio=3.0, batch_size=args.batch)
     if args.device_sampler:
         from laplace_amd.data.device_sampler import DeviceGraphSampler
-        loader = DeviceGraphSampler(cfg, graph, users, articles, device=dev, seed=0)
+        loader = DeviceGraphSampler(cfg, graph, users, articles, device=dev, seed=0,
+                                    prefetch=os.environ.get("LAPLACE_SAMPLER_PREFETCH", "1") if os.environ.get("LAPLACE_SAMPLER_PREFETCH") != "0" else False)
     else:
         ds = GraphDataset(cfg, graph, users, articles, train=True, randomization=True, seed=0)
         loader = DataLoader(ds, batch_size=args.batch, shuffle=True, generator=t.Generator().manual_seed(0))
