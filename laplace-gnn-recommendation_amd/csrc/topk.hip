@@ -488,44 +488,196 @@ __global__ __launch_bounds__(256, 2) void topk_scores_filter_kernel(FusedArgs a)
     }
 }
 
-// Round 2: the same fused kernel with the query panel's MFMA fragments kept in REGISTERS and the item panels
-// double-buffered.  The query panel is fixed for the whole launch: each lane's K/2 A-fragment values (its row, its k
-// half) are read from LDS once into NM VGPRs, so an MFMA needs ONE ds_read_b32 (the item fragment) instead of two,
-// and the LDS the query panel occupied becomes the second item buffer — the next panel is committed into the buffer
-// nobody reads while the current one is consumed, which leaves ONE barrier per item panel instead of two.
-// (round 1: 64 TF/s = 0.41 of the f32 MFMA peak, two reads + two barriers per panel; profiles/r01_topk_v3.md.)
-// NM = MFMAs per panel = ceil(d / 2): instantiated for d = 128 and d = 64; other widths use the kernel above.
-#ifndef MI_TOPK_REGA
-#define MI_TOPK_REGA 1
-#endif
+// Round 2: the fused kernel rebuilt in three steps (each measured with tools/topk_stage.sh; what was removed is noted
+// where it taught something).
+// Step 1 — the query panel's MFMA fragments live in REGISTERS (64 VGPRs per lane for the whole launch: one LDS read per
+// MFMA instead of two) and the LDS it occupied becomes a second item buffer: one barrier per panel instead of two.
+// 0.41 -> 0.49 of the f32 MFMA peak.  Also here: the grid rule (rounds x panels, see the launcher) — the old rule made
+// 1 025 workgroups for a 2 621-query chunk, one more than two rounds of the chip.
 #ifndef MI_TOPK_STAGE
-#define MI_TOPK_STAGE 0   // stage timing only (wrong results): 1 = no threshold epilogue, 2 = also no panel loads / commits
+#define MI_TOPK_STAGE 0   // stage timing only (wrong results): 1 = no threshold epilogue, 2 = also no item-panel DMA, 3 = also no barrier,
+#endif                    // 4 = also no flush check, 5 = also no DMA wait + device printf of cycles, 6 = votes but no staging
+
+// Step 2 — the work on panel t-1's scores is issued INSIDE the MFMA chain of panel t.  An MFMA of this shape holds
+// the matrix pipe for 64 cycles and each one waits for the one before it (one accumulator), so whatever the wavefront
+// issues in between is free: with two accumulators that take turns, the 16 votes of the previous panel, one LDS atomic
+// reserving the staging slots of all its hits, and the hits of one accumulator register per MFMA slot (a few per panel
+// and wavefront pass: this path runs on most panels, not rarely) all go into that shadow instead of after the chain
+// has drained.  0.49 -> 0.53.  Measured since: the votes cost nothing; the 16 wave-uniform branches of the staging
+// steps cost 110 us (k = 12) to 190 us (k = 256) of a 730-810 us chunk, taken or not.
+struct PipeState {
+    unsigned long long hit[16];
+    unsigned long long col_ok_prev;
+    int64_t gn_prev;
+    int base, total;
+};
+
+template <int NM, bool PIN_READS>
+__device__ __forceinline__ void pipe_panel(const FusedArgs& a, f32x16& acc, const f32x16& prev, const float (&areg)[NM],
+                                           const float* bp, const float (&thr_f)[16], const unsigned long long (&row_ok)[16],
+                                           PipeState& st, int lane, int row_base, int64_t m0, int* st_cnt, unsigned long long* st_val,
+                                           unsigned char* st_row) {
+    constexpr int q = NM / 32;  // MFMAs per vote pair
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    st.total = 0;
+    st.base = 0;
+    // PIN_READS: the B operands of MFMAs 8g..8g+7 are read while group g-1 runs, and scheduling barriers keep them
+    // there — left alone the compiler sinks every read to just in front of its MFMA (one in flight) whatever registers
+    // it has.  (Measured: it makes no difference to the chain's rate — see the note at the DMA kernel — but the waits
+    // become counted ones.)
+    float bq[2][8];
+    if (PIN_READS) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) bq[0][u] = bp[2 * u];
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int s = 0; s < NM; ++s) {
+        if (PIN_READS && s % 8 == 0) {
+            if (s + 8 < NM) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) bq[((s >> 3) + 1) & 1][u] = bp[2 * (s + 8 + u)];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[s], PIN_READS ? bq[(s >> 3) & 1][s & 7] : bp[2 * s], acc, 0, 0, 0);
+        if (MI_TOPK_STAGE >= 1 && MI_TOPK_STAGE < 6) {
+        } else if (s < 8 * q) {  // votes: one register per MFMA (d = 128) or two (d = 64)
+#pragma unroll
+            for (int reg = (2 * s) / q; reg < (2 * s + 2) / q; ++reg) {
+                st.hit[reg] = __ballot(!(prev[reg] < thr_f[reg])) & st.col_ok_prev & row_ok[reg];
+                st.total += __popcll(st.hit[reg]);
+            }
+        } else if (MI_TOPK_STAGE == 6) {  // votes only
+            if (s == NM - 1 && st.total == 12345) *st_cnt = 1;
+        } else if (s == 8 * q) {
+            if (st.total) {  // wave-uniform
+                if (lane == 0) st.base = atomicAdd(st_cnt, st.total);
+                st.base = __shfl(st.base, 0, 64);
+            }
+        } else if (s <= 8 * q + 16 * q && (s - 8 * q - 1) % q == 0) {
+            const int reg = (s - 8 * q - 1) / q;
+            if (st.hit[reg] != 0ull) {  // wave-uniform
+                if ((st.hit[reg] >> lane) & 1ull) {
+                    const int slot = st.base + __popcll(st.hit[reg] & ((1ull << lane) - 1ull));
+                    const int rl = row_base + (reg & 3) + 8 * (reg >> 2);
+                    const unsigned long long c = composite(score_key(prev[reg]), (uint32_t)st.gn_prev);
+                    if (slot < kStage) {
+                        st_val[slot] = c;
+                        st_row[slot] = (unsigned char)rl;
+                    } else if (!((a.bitmap[(m0 + rl) * a.words + (st.gn_prev >> 5)] >> (st.gn_prev & 31)) & 1u)) {  // staging full
+                        const int gs = atomicAdd(&a.cnt[m0 + rl], 1);
+                        if (gs < kCap) a.cand[(m0 + rl) * kCap + gs] = c;
+                    }
+                }
+                st.base += __popcll(st.hit[reg]);
+            }
+        }
+    }
+}
+// (A/B: a second copy of MFMAs 8q..NM-1 without the staging steps, taken when no score of the previous panel passed —
+// about half of a wavefront's panels at k = 12 — cost registers (132 B of scratch) and ran slower: 731 -> 753 us.)
+
+// the scores of `acc` that passed (hit[reg] = lanes) -> staging slots; one LDS atomic per wavefront (last panel only)
+__device__ __forceinline__ void stage_hits(const FusedArgs& a, const f32x16& acc, const unsigned long long (&hit)[16], int total,
+                                           int64_t gn, int row_base, int64_t m0, int lane, int* st_cnt,
+                                           unsigned long long* st_val, unsigned char* st_row) {
+    int base = 0;
+    if (lane == 0) base = atomicAdd(st_cnt, total);
+    base = __shfl(base, 0, 64);
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        if (hit[reg] == 0ull) continue;
+        if ((hit[reg] >> lane) & 1ull) {
+            const int slot = base + __popcll(hit[reg] & ((1ull << lane) - 1ull));
+            const int rl = row_base + (reg & 3) + 8 * (reg >> 2);
+            const unsigned long long c = composite(score_key(acc[reg]), (uint32_t)gn);
+            if (slot < kStage) {
+                st_val[slot] = c;
+                st_row[slot] = (unsigned char)rl;
+            } else if (m0 + rl < a.n_q && !((a.bitmap[(m0 + rl) * a.words + (gn >> 5)] >> (gn & 31)) & 1u)) {  // staging full
+                const int gs = atomicAdd(&a.cnt[m0 + rl], 1);
+                if (gs < kCap) a.cand[(m0 + rl) * kCap + gs] = c;
+            }
+        }
+        base += __popcll(hit[reg]);
+    }
+}
+
+// Step 3 — item panels by LDS-DMA, so that the MFMA chain gets its registers back.
+// What the chain can do was measured in isolation (tools/probes/mfma_peak.hip, 2 waves per SIMD, 64 A fragments in
+// registers, B operand from LDS, nothing else): register-only 0.98 of the 157 TF/s peak; one conflict-free ds_read_b32
+// per MFMA from 129-float rows, compiler free to read ahead 0.975; ds_read_b128 chunks 0.93; any VALU instruction
+// producing the B operand (a v_cndmask picking the half-wave's component of a b128 chunk) 0.83-0.87 — the MFMA issue
+// slips behind the dependent VALU op every time.  The kernel above uses the good form of read but, at its 256-VGPR
+// cap (64 A fragments, two accumulators, EIGHT float4 of the register-staged next panel, thresholds), leaves the
+// compiler two registers for B: one read in flight, its latency exposed every second MFMA — 0.79 for its bare chain.
+// So the next panel no longer passes through registers: `global_load_lds_dword` pieces of 64 floats (half a row; the
+// LDS destination of a wave-instruction is contiguous, so dword pieces are what lets rows keep their 129-float pitch)
+// go straight into the padded image, 32 per wavefront and panel, issued in front of the chain and waited for at its
+// end.  (A 16-byte DMA needs an unpadded, XOR-swizzled image: its reads are b128 + select or 4-way conflicted b32,
+// and 32 swizzled read addresses per buffer pinned 64 VGPRs — built and measured, no gain, removed.)
+#ifndef MI_TOPK_DMA
+#define MI_TOPK_DMA 1
 #endif
+#ifndef MI_TOPK_PIN
+#define MI_TOPK_PIN 1   // B reads pinned a group of 8 MFMAs ahead (A/B)
+#endif
+
+__device__ __forceinline__ uint32_t lds_addr(const void* p) {
+    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
+}
+__device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// Item panel rows [row0, row0 + 64) x D floats (all inside the table) -> the padded panel.  Inline asm on purpose: for
+// the builtin the compiler drains the DMA (vmcnt(0)) in front of the next LDS read, i.e. before the MFMA chain it is
+// supposed to run under; the caller waits itself (dma_wait) before its barrier.
+template <int D>
+__device__ __forceinline__ void dma_item_panel(const float* __restrict__ T, int64_t ld, int64_t row0,
+                                               float (*panel)[FKPAD], int wave, uint32_t lane_off) {
+    constexpr int PIECES = D / 64, PER_WAVE = 64 * PIECES / 4;
+    const char* base = reinterpret_cast<const char*>(T + row0 * ld);
+    const uint32_t l0 = lds_addr(&panel[0][0]);
+#pragma unroll
+    for (int i = 0; i < PER_WAVE; ++i) {
+        const int idx = wave * PER_WAVE + i;
+        const int row = idx / PIECES, piece = idx % PIECES;
+        const char* gb = base + ((int64_t)row * ld + piece * 64) * 4;
+        const uint32_t l = l0 + (uint32_t)(row * FKPAD + piece * 64) * 4u;
+        uint32_t keep;  // m0 is the compiler's: saved and put back (naming it as a clobber is not honoured)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %2, %3\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "s"(l), "v"(lane_off), "s"(gb) : "memory");
+    }
+}
+
 template <int NM>
-__global__ __launch_bounds__(256, 2) void topk_scores_filter_rega_kernel(FusedArgs a) {
+__global__ __launch_bounds__(256, 2) void topk_scores_filter_dma_kernel(FusedArgs a) {
+    constexpr int D = 2 * NM;
     __shared__ float P0[FM][FKPAD];   // the query panel first, then item buffer 1
     __shared__ float P1[FN][FKPAD];   // item buffer 0
     __shared__ unsigned long long st_val[kStage];
     __shared__ unsigned char st_row[kStage];
     __shared__ int st_cnt;
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave & 1, wn = wave >> 1;
     const int64_t m0 = (int64_t)blockIdx.y * FM;
     const int64_t n_tiles = (a.n_items + FN - 1) / FN;
     const int64_t t0 = (int64_t)blockIdx.x * a.tiles_per_slice;
     const int64_t t1 = min(n_tiles, t0 + a.tiles_per_slice);
     if (t0 >= t1) return;
-    float4 va[8], vb[8];
-    fpanel_issue(va, a.U, a.ldu, a.uid, m0, a.n_q, a.d, tid);
-    fpanel_issue(vb, a.I, a.ldi, nullptr, t0 * FN, a.n_items, a.d, tid);
-    fpanel_commit(P0, va, tid);
-    fpanel_commit(P1, vb, tid);
+    // a panel is always 64 rows inside the table: the last one is shifted back and its rows below t * 64 (already
+    // scored by the panel before it) are masked out of the votes
+    const int64_t last_row0 = a.n_items - FN;
+    const uint32_t lane_off = (uint32_t)lane * 4u;
+    dma_item_panel<D>(a.I, a.ldi, min(t0 * FN, last_row0), P1, wave, lane_off);
+    {
+        float4 va[8];
+        fpanel_issue(va, a.U, a.ldu, a.uid, m0, a.n_q, a.d, tid);
+        fpanel_commit(P0, va, tid);
+    }
     if (tid == 0) st_cnt = 0;
-    // thresholds as FLOATS: the test is one unordered compare per score, `!(score < thr)`, voted per accumulator register
-    // with a ballot.  It is a superset of `key(score) >= key(thr)` (equal for ordinary numbers, also true for NaNs):
-    // an extra candidate sorts below the threshold in the final per-row sort and cannot displace a winner.  Stage timing
-    // of the per-lane key-compare epilogue it replaces (tools/topk_stage.sh): 206 of 883 us per chunk.
     float thr_f[16];
     const int row_base = wm * 32 + 4 * (lane >> 5);
 #pragma unroll
@@ -534,9 +686,10 @@ __global__ __launch_bounds__(256, 2) void topk_scores_filter_rega_kernel(FusedAr
         thr_f[reg] = gm < a.n_q ? key_score(a.thr[gm]) : INFINITY;
     }
     const int rows_here = (int)min((int64_t)FM, a.n_q - m0);
-    unsigned long long row_ok[16];  // lanes whose accumulator row `reg` is a real query (wave-uniform: SGPRs)
+    unsigned long long row_ok[16];
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) row_ok[reg] = __ballot(row_base + (reg & 3) + 8 * (reg >> 2) < rows_here);
+    dma_wait();
     __syncthreads();
     float areg[NM];
     {
@@ -546,65 +699,69 @@ __global__ __launch_bounds__(256, 2) void topk_scores_filter_rega_kernel(FusedAr
     }
     __syncthreads();  // P0 is free: it becomes item buffer 1
     const int boff = (wn * 32 + (lane & 31)) * FKPAD + (lane >> 5);
-    for (int64_t t = t0; t < t1; ++t) {
-        const bool more = t + 1 < t1;
-        const bool odd = ((t - t0) & 1) != 0;
-        float (*cur)[FKPAD] = odd ? P0 : P1;
-        float (*nxt)[FKPAD] = odd ? P1 : P0;
-        if (more && MI_TOPK_STAGE < 2) fpanel_issue(vb, a.I, a.ldi, nullptr, (t + 1) * FN, a.n_items, a.d, tid);  // in flight under the MFMAs
-        const float* bp = &cur[0][0] + boff;
-        f32x16 acc;
+    const int col = wn * 32 + (lane & 31);
+    f32x16 acc0, acc1;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    for (int i = 0; i < 16; ++i) acc1[i] = 0.f;
+    PipeState st;
 #pragma unroll
-        for (int s = 0; s < NM; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[s], bp[2 * s], acc, 0, 0, 0);
-        const int64_t gn = t * FN + wn * 32 + (lane & 31);
-        if (MI_TOPK_STAGE >= 1) {
-            if (acc[0] == 12345.678f && acc[7] == 3.f) st_cnt = 1;  // keeps the chain alive
-        } else {
-            // 16 votes, all scalar: hit[reg] = lanes whose score is not below its row's threshold (rows / columns beyond
-            // the operands masked out); one LDS atomic per wavefront and panel reserves the staging slots of all of them
-            const unsigned long long col_ok = __ballot(gn < a.n_items);
-            unsigned long long hit[16];
-            int total = 0;
+    for (int reg = 0; reg < 16; ++reg) st.hit[reg] = 0ull;
+    st.col_ok_prev = 0ull;   // no previous panel yet: every vote comes out empty
+    st.gn_prev = 0;
+
+#define MI_TOPK_PANEL(acc, prev, t, cur, nxt)                                                                          \
+    {                                                                                                                  \
+        if ((MI_TOPK_STAGE < 2 || MI_TOPK_STAGE == 6) && (t) + 1 < t1)  /* block-uniform */                              \
+            dma_item_panel<D>(a.I, a.ldi, min(((t) + 1) * FN, last_row0), nxt, wave, lane_off);                        \
+        pipe_panel<NM, MI_TOPK_PIN != 0>(a, acc, prev, areg, &cur[0][0] + boff, thr_f, row_ok, st, lane, row_base, m0,   \
+                                         &st_cnt, st_val, st_row);                                                     \
+        st.gn_prev = min((t) * FN, last_row0) + col;                                                                   \
+        st.col_ok_prev = __ballot(st.gn_prev >= (t) * FN);                                                             \
+        if (MI_TOPK_STAGE >= 1 && MI_TOPK_STAGE < 6 && prev[0] == 12345.678f && prev[7] == 3.f) st_cnt = 1; /* keeps the chain alive */ \
+        if (MI_TOPK_STAGE < 5 || MI_TOPK_STAGE == 6) dma_wait();                                                       \
+        if (MI_TOPK_STAGE < 3 || MI_TOPK_STAGE == 6) __syncthreads(); /* next panel landed and everybody is done with cur */                 \
+        if ((MI_TOPK_STAGE < 4 || MI_TOPK_STAGE == 6) && min(st_cnt, kStage) >= kStage / 2) {  /* block-uniform */                             \
+            flush_stage(a, m0, st_val, st_row, min(st_cnt, kStage));                                                   \
+            __syncthreads();                                                                                           \
+            if (tid == 0) st_cnt = 0;                                                                                  \
+            __syncthreads();                                                                                           \
+        }                                                                                                              \
+    }
+#if MI_TOPK_STAGE == 5
+    const unsigned long long dbg_c0 = clock64(), dbg_w0 = wall_clock64();
+#endif
+    int64_t t = t0;
+    for (; t + 1 < t1; t += 2) {
+        MI_TOPK_PANEL(acc0, acc1, t, P1, P0)
+        MI_TOPK_PANEL(acc1, acc0, t + 1, P0, P1)
+    }
+    bool last_in_acc0 = false;
+    if (t < t1) {
+        MI_TOPK_PANEL(acc0, acc1, t, P1, P0)
+        last_in_acc0 = true;
+    }
+#undef MI_TOPK_PANEL
+#if MI_TOPK_STAGE == 5
+    if ((blockIdx.x == 0 || blockIdx.x == 7) && (blockIdx.y == 0 || blockIdx.y == 30) && tid == 0)
+        printf("[stage5] wg (%d,%d): %llu shader cycles, %llu ticks of 10 ns for %lld panels\n", (int)blockIdx.x, (int)blockIdx.y,
+               (unsigned long long)(clock64() - dbg_c0), (unsigned long long)(wall_clock64() - dbg_w0), (long long)(t1 - t0));
+#endif
+    {   // the last panel's scores have not been voted on yet
+        unsigned long long hit[16];
+        int total = 0;
 #pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                hit[reg] = __ballot(!(acc[reg] < thr_f[reg])) & col_ok & row_ok[reg];
-                total += __popcll(hit[reg]);
-            }
-            if (total) {  // wave-uniform
-                int base = 0;
-                if (lane == 0) base = atomicAdd(&st_cnt, total);
-                base = __shfl(base, 0, 64);
-#pragma unroll
-                for (int reg = 0; reg < 16; ++reg) {
-                    if (hit[reg] == 0ull) continue;
-                    if ((hit[reg] >> lane) & 1ull) {
-                        const int slot = base + __popcll(hit[reg] & ((1ull << lane) - 1ull));
-                        const int rl = row_base + (reg & 3) + 8 * (reg >> 2);
-                        const unsigned long long c = composite(score_key(acc[reg]), (uint32_t)gn);
-                        if (slot < kStage) {
-                            st_val[slot] = c;
-                            st_row[slot] = (unsigned char)rl;
-                        } else if (!((a.bitmap[(m0 + rl) * a.words + (gn >> 5)] >> (gn & 31)) & 1u)) {  // staging full
-                            const int gs = atomicAdd(&a.cnt[m0 + rl], 1);
-                            if (gs < kCap) a.cand[(m0 + rl) * kCap + gs] = c;
-                        }
-                    }
-                    base += __popcll(hit[reg]);
-                }
-            }
+        for (int reg = 0; reg < 16; ++reg) {
+            const float sc = last_in_acc0 ? acc0[reg] : acc1[reg];
+            hit[reg] = __ballot(!(sc < thr_f[reg])) & st.col_ok_prev & row_ok[reg];
+            total += __popcll(hit[reg]);
         }
-        if (more && MI_TOPK_STAGE < 2) fpanel_commit(nxt, vb, tid);  // nobody reads nxt: it was `cur` before the last barrier
-        __syncthreads();                        // commits and staged candidates visible; everybody is done with `cur`
-        const int staged = min(st_cnt, kStage);
-        if (staged >= kStage / 2 || !more) {    // block-uniform
-            flush_stage(a, m0, st_val, st_row, staged);
-            __syncthreads();
-            if (tid == 0) st_cnt = 0;
-            __syncthreads();
+        if (total) {
+            if (last_in_acc0) stage_hits(a, acc0, hit, total, st.gn_prev, row_base, m0, lane, &st_cnt, st_val, st_row);
+            else stage_hits(a, acc1, hit, total, st.gn_prev, row_base, m0, lane, &st_cnt, st_val, st_row);
         }
     }
+    __syncthreads();
+    flush_stage(a, m0, st_val, st_row, min(st_cnt, kStage));
 }
 
 __global__ __launch_bounds__(kBlock) void topk_finalize_kernel(FusedArgs a, int k, int kpow2, float* __restrict__ scores,
@@ -703,14 +860,28 @@ int mi_topk_excl_f32(int64_t n_q, int64_t n_items, int64_t d, int64_t k, const i
         a.U = user_emb; a.ldu = ldu; a.I = item_emb; a.ldi = ldi;
         a.thr = thr; a.bitmap = bitmap; a.words = words; a.cand = cand; a.cnt = cnt;
         const int64_t strips = mi_ceil_div(n_q, FM), n_tiles = mi_ceil_div(n_items, FN);
-        int64_t slices = mi_ceil_div(4 * 256, strips);  // >= 4 workgroups per CU in the grid
-        if (slices > n_tiles) slices = n_tiles;
+        // Every workgroup does the same work and two fit on a CU, so the launch runs in ceil(grid / (2 * CUs)) rounds of
+        // tiles_per_slice panels each: a grid one workgroup over a multiple of the chip's capacity (the old rule,
+        // >= 4 workgroups per CU, made 1 025 of them for a 2 621-query chunk) pays a whole extra round for it.  Pick the
+        // split of the item axis that minimises rounds x (panels + the query-panel prologue, ~2 panels' worth).
+        static int n_cu = 0;
+        if (n_cu == 0) {
+            int dev = 0, v = 0;
+            if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n_cu = v;
+            else n_cu = 256;
+        }
+        const int64_t capacity = 2 * (int64_t)n_cu;
+        int64_t slices = 1, best = INT64_MAX;
+        for (int64_t l = 1; l <= n_tiles && l <= 4096; ++l) {
+            const int64_t cost = mi_ceil_div(strips * l, capacity) * (mi_ceil_div(n_tiles, l) + 2);
+            if (cost < best) { best = cost; slices = l; }
+        }
         a.tiles_per_slice = mi_ceil_div(n_tiles, slices);
         slices = mi_ceil_div(n_tiles, a.tiles_per_slice);
-        if (MI_TOPK_REGA && d == 128)
-            hipLaunchKernelGGL(topk_scores_filter_rega_kernel<64>, dim3((unsigned)slices, (unsigned)strips), dim3(256), 0, s, a);
-        else if (MI_TOPK_REGA && d == 64)
-            hipLaunchKernelGGL(topk_scores_filter_rega_kernel<32>, dim3((unsigned)slices, (unsigned)strips), dim3(256), 0, s, a);
+        if (MI_TOPK_DMA && d == 128)
+            hipLaunchKernelGGL(topk_scores_filter_dma_kernel<64>, dim3((unsigned)slices, (unsigned)strips), dim3(256), 0, s, a);
+        else if (MI_TOPK_DMA && d == 64)
+            hipLaunchKernelGGL(topk_scores_filter_dma_kernel<32>, dim3((unsigned)slices, (unsigned)strips), dim3(256), 0, s, a);
         else
             hipLaunchKernelGGL(topk_scores_filter_kernel, dim3((unsigned)slices, (unsigned)strips), dim3(256), 0, s, a);
         hipLaunchKernelGGL(topk_finalize_kernel, dim3((unsigned)n_q), dim3(kBlock), 0, s, a, (int)k, kpow2, scores, out_idx,

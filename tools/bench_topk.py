@@ -23,7 +23,7 @@ def main():
     ue = t.randn(spec.num_users, 128, device=dev, generator=g) * 0.1
     ie = t.randn(spec.num_items, 128, device=dev, generator=g) * 0.1
     out = {"workload": f"top-K with exclusion, {spec.num_items} items, D=128, users' own edges excluded"}
-    n_q = 16384
+    n_q = int(sys.argv[sys.argv.index("--users") + 1]) if "--users" in sys.argv else 16384
     uid = t.arange(n_q, device=dev)
     excl = ops.row_slice(r, 0, n_q)
     for k in (12, 256):
