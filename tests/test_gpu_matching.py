@@ -85,4 +85,7 @@ def test_evaluation_sampler_with_device_candidates_equals_host_candidates():
     seeds = t.arange(32, 48)
     ra, rb = a.sample(seeds, step=0, raw=True), b.sample(seeds, step=0, raw=True)
     for key in ra:
-        assert t.equal(ra[key], rb[key]), key
+        if key.startswith("csr_"):  # the emitted CSRs (DeviceCSR)
+            assert t.equal(ra[key].rowptr, rb[key].rowptr) and t.equal(ra[key].col, rb[key].col), key
+        else:
+            assert t.equal(ra[key], rb[key]), key
