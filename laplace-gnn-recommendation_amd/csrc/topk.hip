@@ -154,7 +154,10 @@ __device__ __forceinline__ uint32_t sample_threshold(const uint32_t* skey, int m
 }
 
 // rank in the sample such that, with p = kk / n_items the chance of an item to be a winner, more than m of the
-// sample being winners is a > 6-sigma event: then at least kk items of the row are >= the m-th sample key
+// sample being winners is a > 6-sigma event: then at least kk items of the row are >= the m-th sample key.
+// (A/B round 2: mu + 3.5 sqrt(mu) + 3 halves the candidates per row (270 -> 122 at k = 12) and does not change the
+// fused kernel's time at all, while the rows that then end short of k candidates — exclusions eat into the margin — and
+// are recomputed exactly take the whole call from 2.7 to 1.5 M users/s.  The margin stays.)
 __device__ __forceinline__ int sample_rank(int kk, int64_t n_items) {
     const float mu = (float)kSample * (float)kk / (float)n_items;
     return (int)(mu + 4.f * sqrtf(mu) + 8.f);
@@ -496,7 +499,7 @@ __global__ __launch_bounds__(256, 2) void topk_scores_filter_kernel(FusedArgs a)
 // 1 025 workgroups for a 2 621-query chunk, one more than two rounds of the chip.
 #ifndef MI_TOPK_STAGE
 #define MI_TOPK_STAGE 0   // stage timing only (wrong results): 1 = no threshold epilogue, 2 = also no item-panel DMA, 3 = also no barrier,
-#endif                    // 4 = also no flush check, 5 = also no DMA wait + device printf of cycles, 6 = votes but no staging
+#endif                    // 5 = also no DMA wait + device printf of cycles, 6 = votes but no staging, 8 = everything, thresholds at +inf
 
 // Step 2 — the work on panel t-1's scores is issued INSIDE the MFMA chain of panel t.  An MFMA of this shape holds
 // the matrix pipe for 64 cycles and each one waits for the one before it (one accumulator), so whatever the wavefront
@@ -510,65 +513,49 @@ struct PipeState {
     unsigned long long col_ok_prev;
     int64_t gn_prev;
     int base, total;
+    int mine;   // entries in this wavefront's own staging region (wave-uniform; may run past kStageW: overflow)
 };
+constexpr int kStageW = kStage / 4;  // staging slots per wavefront
 
+// one MFMA of the chain with its B operand.  PIN_READS: the operands of MFMAs 8g..8g+7 are read while group g-1 runs,
+// and scheduling barriers keep them there — left alone the compiler sinks every read to just in front of its MFMA
+// (one in flight) whatever registers it has
 template <int NM, bool PIN_READS>
-__device__ __forceinline__ void pipe_panel(const FusedArgs& a, f32x16& acc, const f32x16& prev, const float (&areg)[NM],
-                                           const float* bp, const float (&thr_f)[16], const unsigned long long (&row_ok)[16],
-                                           PipeState& st, int lane, int row_base, int64_t m0, int* st_cnt, unsigned long long* st_val,
-                                           unsigned char* st_row) {
-    constexpr int q = NM / 32;  // MFMAs per vote pair
+__device__ __forceinline__ void pipe_mfma(int s, f32x16& acc, const float (&areg)[NM], const float* bp, float (&bq)[2][8]) {
+    if (PIN_READS && s % 8 == 0) {
+        if (s + 8 < NM) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-    st.total = 0;
-    st.base = 0;
-    // PIN_READS: the B operands of MFMAs 8g..8g+7 are read while group g-1 runs, and scheduling barriers keep them
-    // there — left alone the compiler sinks every read to just in front of its MFMA (one in flight) whatever registers
-    // it has.  (Measured: it makes no difference to the chain's rate — see the note at the DMA kernel — but the waits
-    // become counted ones.)
-    float bq[2][8];
-    if (PIN_READS) {
-#pragma unroll
-        for (int u = 0; u < 8; ++u) bq[0][u] = bp[2 * u];
+            for (int u = 0; u < 8; ++u) bq[((s >> 3) + 1) & 1][u] = bp[2 * (s + 8 + u)];
+        }
         __builtin_amdgcn_sched_barrier(0);
     }
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[s], PIN_READS ? bq[(s >> 3) & 1][s & 7] : bp[2 * s], acc, 0, 0, 0);
+}
+
+// MFMAs 8q..NM-1 of a panel; STAGING: with the previous panel's hits woven in (one accumulator register per MFMA slot)
+template <int NM, bool PIN_READS, bool STAGING>
+__device__ __forceinline__ void pipe_tail(f32x16& acc, const f32x16& prev, const float (&areg)[NM], const float* bp,
+                                          float (&bq)[2][8], PipeState& st, int lane, int row_base,
+                                          unsigned long long* st_val, unsigned char* st_row, unsigned char* st_over) {
+    constexpr int q = NM / 32;
 #pragma unroll
-    for (int s = 0; s < NM; ++s) {
-        if (PIN_READS && s % 8 == 0) {
-            if (s + 8 < NM) {
-#pragma unroll
-                for (int u = 0; u < 8; ++u) bq[((s >> 3) + 1) & 1][u] = bp[2 * (s + 8 + u)];
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[s], PIN_READS ? bq[(s >> 3) & 1][s & 7] : bp[2 * s], acc, 0, 0, 0);
-        if (MI_TOPK_STAGE >= 1 && MI_TOPK_STAGE < 6) {
-        } else if (s < 8 * q) {  // votes: one register per MFMA (d = 128) or two (d = 64)
-#pragma unroll
-            for (int reg = (2 * s) / q; reg < (2 * s + 2) / q; ++reg) {
-                st.hit[reg] = __ballot(!(prev[reg] < thr_f[reg])) & st.col_ok_prev & row_ok[reg];
-                st.total += __popcll(st.hit[reg]);
-            }
-        } else if (MI_TOPK_STAGE == 6) {  // votes only
-            if (s == NM - 1 && st.total == 12345) *st_cnt = 1;
-        } else if (s == 8 * q) {
-            if (st.total) {  // wave-uniform
-                if (lane == 0) st.base = atomicAdd(st_cnt, st.total);
-                st.base = __shfl(st.base, 0, 64);
-            }
-        } else if (s <= 8 * q + 16 * q && (s - 8 * q - 1) % q == 0) {
+    for (int s = 8 * q; s < NM; ++s) {
+        pipe_mfma<NM, PIN_READS>(s, acc, areg, bp, bq);
+        if (STAGING && s == 8 * q) {
+            st.base = st.mine;   // the region is this wavefront's own: reserving slots is scalar arithmetic
+            st.mine += st.total;
+        } else if (STAGING && s <= 8 * q + 16 * q && (s - 8 * q - 1) % q == 0) {
             const int reg = (s - 8 * q - 1) / q;
             if (st.hit[reg] != 0ull) {  // wave-uniform
                 if ((st.hit[reg] >> lane) & 1ull) {
                     const int slot = st.base + __popcll(st.hit[reg] & ((1ull << lane) - 1ull));
                     const int rl = row_base + (reg & 3) + 8 * (reg >> 2);
                     const unsigned long long c = composite(score_key(prev[reg]), (uint32_t)st.gn_prev);
-                    if (slot < kStage) {
+                    if (slot < kStageW) {
                         st_val[slot] = c;
                         st_row[slot] = (unsigned char)rl;
-                    } else if (!((a.bitmap[(m0 + rl) * a.words + (st.gn_prev >> 5)] >> (st.gn_prev & 31)) & 1u)) {  // staging full
-                        const int gs = atomicAdd(&a.cnt[m0 + rl], 1);
-                        if (gs < kCap) a.cand[(m0 + rl) * kCap + gs] = c;
+                    } else {
+                        st_over[rl] = 1;  // region full: the row takes the exact path (see wave_flush)
                     }
                 }
                 st.base += __popcll(st.hit[reg]);
@@ -576,16 +563,51 @@ __device__ __forceinline__ void pipe_panel(const FusedArgs& a, f32x16& acc, cons
         }
     }
 }
+
+template <int NM, bool PIN_READS>
+__device__ __forceinline__ void pipe_panel(const FusedArgs& a, f32x16& acc, const f32x16& prev, const float (&areg)[NM],
+                                           const float* bp, const float (&thr_f)[16], const unsigned long long (&row_ok)[16],
+                                           PipeState& st, int lane, int row_base, unsigned long long* st_val, unsigned char* st_row,
+                                           unsigned char* st_over) {
+    constexpr int q = NM / 32;  // MFMAs per vote pair
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    st.total = 0;
+    st.base = 0;
+    float bq[2][8];
+    if (PIN_READS) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) bq[0][u] = bp[2 * u];
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int s = 0; s < 8 * q; ++s) {  // votes: one register per MFMA (d = 128) or two (d = 64)
+        pipe_mfma<NM, PIN_READS>(s, acc, areg, bp, bq);
+        if (MI_TOPK_STAGE == 0 || MI_TOPK_STAGE == 6 || MI_TOPK_STAGE == 8) {
+#pragma unroll
+            for (int reg = (2 * s) / q; reg < (2 * s + 2) / q; ++reg) {
+                st.hit[reg] = __ballot(!(prev[reg] < thr_f[reg])) & st.col_ok_prev & row_ok[reg];
+                st.total += __popcll(st.hit[reg]);
+            }
+        }
+    }
+    // Nothing passed (about half of a wavefront's panels at k = 12): the rest of the chain as one straight run;
+    // otherwise the copy with the staging steps and their 16 wave-uniform branches
+    if (MI_TOPK_STAGE == 6 && st.total == 12345) st_over[0] = 1;
+    if ((MI_TOPK_STAGE == 0 || MI_TOPK_STAGE == 8) && st.total != 0)
+        pipe_tail<NM, PIN_READS, true>(acc, prev, areg, bp, bq, st, lane, row_base, st_val, st_row, st_over);
+    else
+        pipe_tail<NM, PIN_READS, false>(acc, prev, areg, bp, bq, st, lane, row_base, st_val, st_row, st_over);
+}
 // (A/B: a second copy of MFMAs 8q..NM-1 without the staging steps, taken when no score of the previous panel passed —
 // about half of a wavefront's panels at k = 12 — cost registers (132 B of scratch) and ran slower: 731 -> 753 us.)
 
-// the scores of `acc` that passed (hit[reg] = lanes) -> staging slots; one LDS atomic per wavefront (last panel only)
-__device__ __forceinline__ void stage_hits(const FusedArgs& a, const f32x16& acc, const unsigned long long (&hit)[16], int total,
-                                           int64_t gn, int row_base, int64_t m0, int lane, int* st_cnt,
-                                           unsigned long long* st_val, unsigned char* st_row) {
-    int base = 0;
-    if (lane == 0) base = atomicAdd(st_cnt, total);
-    base = __shfl(base, 0, 64);
+// the scores of `acc` that passed (hit[reg] = lanes) -> this wavefront's staging region (the last panel's, after the loop)
+__device__ __forceinline__ void stage_hits(const f32x16& acc, const unsigned long long (&hit)[16], int total, int64_t gn,
+                                           int row_base, int lane, PipeState& st, unsigned long long* st_val,
+                                           unsigned char* st_row, unsigned char* st_over) {
+    int base = st.mine;
+    st.mine += total;
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
         if (hit[reg] == 0ull) continue;
@@ -593,15 +615,36 @@ __device__ __forceinline__ void stage_hits(const FusedArgs& a, const f32x16& acc
             const int slot = base + __popcll(hit[reg] & ((1ull << lane) - 1ull));
             const int rl = row_base + (reg & 3) + 8 * (reg >> 2);
             const unsigned long long c = composite(score_key(acc[reg]), (uint32_t)gn);
-            if (slot < kStage) {
+            if (slot < kStageW) {
                 st_val[slot] = c;
                 st_row[slot] = (unsigned char)rl;
-            } else if (m0 + rl < a.n_q && !((a.bitmap[(m0 + rl) * a.words + (gn >> 5)] >> (gn & 31)) & 1u)) {  // staging full
-                const int gs = atomicAdd(&a.cnt[m0 + rl], 1);
-                if (gs < kCap) a.cand[(m0 + rl) * kCap + gs] = c;
+            } else {
+                st_over[rl] = 1;
             }
         }
         base += __popcll(hit[reg]);
+    }
+}
+
+// One wavefront empties its own staging region into its rows' candidate lists (exclusion bitmap tested here, off the
+// MFMA path) — no barrier, no shared counter: the other three wavefronts of the workgroup are not involved.  Rows whose
+// hits did not fit the region (more than kStageW / 2 scores of ONE panel passed in one wavefront: ties by the thousand,
+// thresholds that cut nothing) are declared overflowed, so topk_finalize_kernel recomputes them exactly.  (Round 1
+// appended such hits straight to global memory from inside the MFMA loop; the 16 per-register row pointers that path
+// kept live cost ~90 VGPRs for something that happens on adversarial inputs only.)
+__device__ __forceinline__ void wave_flush(const FusedArgs& a, int64_t m0, const unsigned long long* st_val,
+                                           const unsigned char* st_row, unsigned char* st_over, int n, int lane, int wm) {
+    for (int e = lane; e < n; e += 64) {
+        const unsigned long long c = st_val[e];
+        const int64_t q = m0 + st_row[e];
+        const uint32_t item = 0xFFFFFFFFu - (uint32_t)c;
+        if ((a.bitmap[q * a.words + (item >> 5)] >> (item & 31)) & 1u) continue;
+        const int slot = atomicAdd(&a.cnt[q], 1);
+        if (slot < kCap) a.cand[q * kCap + slot] = c;
+    }
+    if (n >= kStageW && lane < 32) {  // the region ran full: push the marked rows of this wavefront's 32 queries past kCap.  Marks are
+        const int r = wm * 32 + lane;  // never cleared (the twin wavefront shares them: clearing could lose its mark); adding twice is harmless
+        if (st_over[r] && m0 + r < a.n_q) atomicAdd(&a.cnt[m0 + r], kCap + 1);
     }
 }
 
@@ -620,6 +663,9 @@ __device__ __forceinline__ void stage_hits(const FusedArgs& a, const f32x16& acc
 // and 32 swizzled read addresses per buffer pinned 64 VGPRs — built and measured, no gain, removed.)
 #ifndef MI_TOPK_DMA
 #define MI_TOPK_DMA 1
+#endif
+#ifndef MI_TOPK_ONE_COPY
+#define MI_TOPK_ONE_COPY 0   // A/B: one copy of the panel body instead of three (37 -> 20 KB of code): 741 -> 757 us, so it is not the instruction cache
 #endif
 #ifndef MI_TOPK_PIN
 #define MI_TOPK_PIN 1   // B reads pinned a group of 8 MFMAs ahead (A/B)
@@ -658,7 +704,7 @@ __global__ __launch_bounds__(256, 2) void topk_scores_filter_dma_kernel(FusedArg
     __shared__ float P1[FN][FKPAD];   // item buffer 0
     __shared__ unsigned long long st_val[kStage];
     __shared__ unsigned char st_row[kStage];
-    __shared__ int st_cnt;
+    __shared__ unsigned char st_over[FM];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave & 1, wn = wave >> 1;
@@ -677,13 +723,13 @@ __global__ __launch_bounds__(256, 2) void topk_scores_filter_dma_kernel(FusedArg
         fpanel_issue(va, a.U, a.ldu, a.uid, m0, a.n_q, a.d, tid);
         fpanel_commit(P0, va, tid);
     }
-    if (tid == 0) st_cnt = 0;
+    if (tid < FM) st_over[tid] = 0;
     float thr_f[16];
     const int row_base = wm * 32 + 4 * (lane >> 5);
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
         const int64_t gm = m0 + row_base + (reg & 3) + 8 * (reg >> 2);
-        thr_f[reg] = gm < a.n_q ? key_score(a.thr[gm]) : INFINITY;
+        thr_f[reg] = (gm < a.n_q && MI_TOPK_STAGE != 8) ? key_score(a.thr[gm]) : INFINITY;  // (stage 8: nothing ever passes)
     }
     const int rows_here = (int)min((int64_t)FM, a.n_q - m0);
     unsigned long long row_ok[16];
@@ -708,28 +754,40 @@ __global__ __launch_bounds__(256, 2) void topk_scores_filter_dma_kernel(FusedArg
     for (int reg = 0; reg < 16; ++reg) st.hit[reg] = 0ull;
     st.col_ok_prev = 0ull;   // no previous panel yet: every vote comes out empty
     st.gn_prev = 0;
+    st.mine = 0;
+    unsigned long long* my_val = st_val + wave * kStageW;   // this wavefront's staging region
+    unsigned char* my_row = st_row + wave * kStageW;
 
 #define MI_TOPK_PANEL(acc, prev, t, cur, nxt)                                                                          \
     {                                                                                                                  \
-        if ((MI_TOPK_STAGE < 2 || MI_TOPK_STAGE == 6) && (t) + 1 < t1)  /* block-uniform */                              \
+        if ((MI_TOPK_STAGE < 2 || MI_TOPK_STAGE == 6 || MI_TOPK_STAGE == 8) && (t) + 1 < t1)  /* block-uniform */                              \
             dma_item_panel<D>(a.I, a.ldi, min(((t) + 1) * FN, last_row0), nxt, wave, lane_off);                        \
-        pipe_panel<NM, MI_TOPK_PIN != 0>(a, acc, prev, areg, &cur[0][0] + boff, thr_f, row_ok, st, lane, row_base, m0,   \
-                                         &st_cnt, st_val, st_row);                                                     \
+        pipe_panel<NM, MI_TOPK_PIN != 0>(a, acc, prev, areg, &cur[0][0] + boff, thr_f, row_ok, st, lane, row_base,       \
+                                         my_val, my_row, st_over);                                                     \
         st.gn_prev = min((t) * FN, last_row0) + col;                                                                   \
         st.col_ok_prev = __ballot(st.gn_prev >= (t) * FN);                                                             \
-        if (MI_TOPK_STAGE >= 1 && MI_TOPK_STAGE < 6 && prev[0] == 12345.678f && prev[7] == 3.f) st_cnt = 1; /* keeps the chain alive */ \
-        if (MI_TOPK_STAGE < 5 || MI_TOPK_STAGE == 6) dma_wait();                                                       \
-        if (MI_TOPK_STAGE < 3 || MI_TOPK_STAGE == 6) __syncthreads(); /* next panel landed and everybody is done with cur */                 \
-        if ((MI_TOPK_STAGE < 4 || MI_TOPK_STAGE == 6) && min(st_cnt, kStage) >= kStage / 2) {  /* block-uniform */                             \
-            flush_stage(a, m0, st_val, st_row, min(st_cnt, kStage));                                                   \
-            __syncthreads();                                                                                           \
-            if (tid == 0) st_cnt = 0;                                                                                  \
-            __syncthreads();                                                                                           \
+        if (MI_TOPK_STAGE >= 1 && MI_TOPK_STAGE < 6 && prev[0] == 12345.678f && prev[7] == 3.f) st_over[0] = 1; /* keeps the chain alive */ \
+        if (st.mine >= kStageW / 2) {  /* wave-uniform: this wavefront's region is half full */                        \
+            wave_flush(a, m0, my_val, my_row, st_over, min(st.mine, kStageW), lane, wm);                               \
+            st.mine = 0;                                                                                               \
         }                                                                                                              \
+        if (MI_TOPK_STAGE < 5 || MI_TOPK_STAGE == 6 || MI_TOPK_STAGE == 8) dma_wait();                                                       \
+        if (MI_TOPK_STAGE < 3 || MI_TOPK_STAGE == 6 || MI_TOPK_STAGE == 8) __syncthreads(); /* next panel landed and everybody is done with cur */ \
     }
 #if MI_TOPK_STAGE == 5
     const unsigned long long dbg_c0 = clock64(), dbg_w0 = wall_clock64();
 #endif
+#if MI_TOPK_ONE_COPY
+    // one copy of the panel body (the accumulator handed over by 16 moves per panel): a third of the code
+    for (int64_t t = t0; t < t1; ++t) {
+        const bool odd = ((t - t0) & 1) != 0;
+        float (*cur)[FKPAD] = odd ? P0 : P1;
+        float (*nxt)[FKPAD] = odd ? P1 : P0;
+        MI_TOPK_PANEL(acc0, acc1, t, cur, nxt)
+        acc1 = acc0;
+    }
+    const bool last_in_acc0 = false;
+#else
     int64_t t = t0;
     for (; t + 1 < t1; t += 2) {
         MI_TOPK_PANEL(acc0, acc1, t, P1, P0)
@@ -740,6 +798,7 @@ __global__ __launch_bounds__(256, 2) void topk_scores_filter_dma_kernel(FusedArg
         MI_TOPK_PANEL(acc0, acc1, t, P1, P0)
         last_in_acc0 = true;
     }
+#endif
 #undef MI_TOPK_PANEL
 #if MI_TOPK_STAGE == 5
     if ((blockIdx.x == 0 || blockIdx.x == 7) && (blockIdx.y == 0 || blockIdx.y == 30) && tid == 0)
@@ -756,12 +815,11 @@ __global__ __launch_bounds__(256, 2) void topk_scores_filter_dma_kernel(FusedArg
             total += __popcll(hit[reg]);
         }
         if (total) {
-            if (last_in_acc0) stage_hits(a, acc0, hit, total, st.gn_prev, row_base, m0, lane, &st_cnt, st_val, st_row);
-            else stage_hits(a, acc1, hit, total, st.gn_prev, row_base, m0, lane, &st_cnt, st_val, st_row);
+            if (last_in_acc0) stage_hits(acc0, hit, total, st.gn_prev, row_base, lane, st, my_val, my_row, st_over);
+            else stage_hits(acc1, hit, total, st.gn_prev, row_base, lane, st, my_val, my_row, st_over);
         }
     }
-    __syncthreads();
-    flush_stage(a, m0, st_val, st_row, min(st_cnt, kStage));
+    wave_flush(a, m0, my_val, my_row, st_over, min(st.mine, kStageW), lane, wm);
 }
 
 __global__ __launch_bounds__(kBlock) void topk_finalize_kernel(FusedArgs a, int k, int kpow2, float* __restrict__ scores,

@@ -2,7 +2,7 @@
 # per-dispatch durations of the fused top-K kernel (grid size tells the chunk: strips x slices)
 export TMPDIR=/tmp
 rm -rf /tmp/tkc
-rocprofv3 --kernel-trace -d /tmp/tkc --output-format csv -- python3 tools/bench_topk.py --full $TOPK_ARGS > /dev/null 2>&1
+timeout -k 10 150 rocprofv3 --kernel-trace -d /tmp/tkc --output-format csv -- python3 tools/bench_topk.py --full $TOPK_ARGS > /dev/null 2>&1
 python3 - <<EOF2
 import csv, glob
 f = glob.glob("/tmp/tkc/**/*kernel_trace.csv", recursive=True)[0]

@@ -8,7 +8,7 @@ cp $P/liblaplace_hip.so $P/liblaplace_hip_full.so
 for v in full "$@"; do
   cp $P/liblaplace_hip_$v.so $P/liblaplace_hip.so
   rm -rf /tmp/tk_$v
-  rocprofv3 --kernel-trace -d /tmp/tk_$v --output-format csv -- python3 tools/bench_topk.py --full --users 131072 > /dev/null 2>&1
+  timeout -k 10 150 rocprofv3 --kernel-trace -d /tmp/tk_$v --output-format csv -- python3 tools/bench_topk.py --full --users 131072 > /dev/null 2>&1
   python3 - <<EOF2
 import csv, glob
 f = glob.glob("/tmp/tk_$v/**/*kernel_trace.csv", recursive=True)[0]
