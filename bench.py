@@ -37,7 +37,7 @@ def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", choices=("c2", "c4"), default="c2")
     ap.add_argument("--users", type=int, default=None)
     ap.add_argument("--items", type=int, default=None)
