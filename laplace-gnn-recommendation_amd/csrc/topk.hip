@@ -503,11 +503,12 @@ __global__ __launch_bounds__(256, 2) void topk_scores_filter_kernel(FusedArgs a)
 
 // Step 2 — the work on panel t-1's scores is issued INSIDE the MFMA chain of panel t.  An MFMA of this shape holds
 // the matrix pipe for 64 cycles and each one waits for the one before it (one accumulator), so whatever the wavefront
-// issues in between is free: with two accumulators that take turns, the 16 votes of the previous panel, one LDS atomic
-// reserving the staging slots of all its hits, and the hits of one accumulator register per MFMA slot (a few per panel
-// and wavefront pass: this path runs on most panels, not rarely) all go into that shadow instead of after the chain
-// has drained.  0.49 -> 0.53.  Measured since: the votes cost nothing; the 16 wave-uniform branches of the staging
-// steps cost 110 us (k = 12) to 190 us (k = 256) of a 730-810 us chunk, taken or not.
+// issues in between is free: with two accumulators that take turns, the 16 votes of the previous panel, the reservation
+// of staging slots for all its hits (scalar arithmetic: each wavefront owns a quarter of the staging area) and the hits
+// of one accumulator register per MFMA slot (a few per panel and wavefront pass: this path runs on most panels, not
+// rarely) all go into that shadow instead of after the chain has drained.  0.49 -> 0.53.  Measured since: the votes
+// cost nothing; having the staging code in the loop costs 120 us (k = 12) to 200 us (k = 256) of a 730-810 us chunk
+// whether a score ever passes or not (thresholds at +inf: 752 us) — profiles/r02_topk.md lists what did not move it.
 struct PipeState {
     unsigned long long hit[16];
     unsigned long long col_ok_prev;
@@ -599,8 +600,8 @@ __device__ __forceinline__ void pipe_panel(const FusedArgs& a, f32x16& acc, cons
     else
         pipe_tail<NM, PIN_READS, false>(acc, prev, areg, bp, bq, st, lane, row_base, st_val, st_row, st_over);
 }
-// (A/B: a second copy of MFMAs 8q..NM-1 without the staging steps, taken when no score of the previous panel passed —
-// about half of a wavefront's panels at k = 12 — cost registers (132 B of scratch) and ran slower: 731 -> 753 us.)
+// (The two copies of the tail are an A/B outcome: equal speed to one copy with the branches woven in, kept because the
+// common no-hit path is then branch-free.)
 
 // the scores of `acc` that passed (hit[reg] = lanes) -> this wavefront's staging region (the last panel's, after the loop)
 __device__ __forceinline__ void stage_hits(const f32x16& acc, const unsigned long long (&hit)[16], int total, int64_t gn,
