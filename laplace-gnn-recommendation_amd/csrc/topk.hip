@@ -123,6 +123,33 @@ __device__ __forceinline__ void write_row(const unsigned long long* cand, int go
     }
 }
 
+// The bin of a 256-bin histogram (one bin per thread, kBlock = 256) that holds the need-th largest key: the highest b with
+// hist[b..255] >= need.  Suffix sums by wavefront shuffles + one LDS hop across the four wavefronts; the thread that owns
+// the bin publishes (prefix | b << shift, need - hist(b+1..255)).  (Round 1 let thread 0 walk the bins: up to 255 dependent
+// LDS reads per pass, 4 passes — most of threshold_kernel's 97 us per 2 684-row chunk.)
+__device__ __forceinline__ void radix_pick_bin(SelectShared& sh, uint32_t prefix, int shift) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = sh.hist[tid];
+    int suf = h;  // inclusive suffix sum inside the wavefront: lanes lane..63
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_down(suf, d, 64);
+        if (lane + d < 64) suf += o;
+    }
+    if (lane == 0) sh.scan_sh[wave] = suf;  // the wavefront's total
+    __syncthreads();
+    int above = 0;                          // bins of the wavefronts above this one
+    for (int w = wave + 1; w < kBlock / 64; ++w) above += sh.scan_sh[w];
+    const int incl = suf + above, excl = incl - h;  // keys in bins >= tid / > tid
+    const int need = sh.need;
+    __syncthreads();                        // everybody has read need / scan_sh before they are rewritten
+    if (incl >= need && excl < need) {      // exactly one bin (need <= total by construction)
+        sh.prefix = prefix | ((uint32_t)tid << shift);
+        sh.need = need - excl;
+    }
+    __syncthreads();
+}
+
 // m-th largest of kSample keys held in LDS (4-pass radix select); every thread returns it.
 __device__ __forceinline__ uint32_t sample_threshold(const uint32_t* skey, int m, SelectShared& sh) {
     const int tid = threadIdx.x;
@@ -139,16 +166,7 @@ __device__ __forceinline__ uint32_t sample_threshold(const uint32_t* skey, int m
             if ((key & hi_mask) == prefix) atomicAdd(&sh.hist[(key >> shift) & 255u], 1);
         }
         __syncthreads();
-        if (tid == 0) {
-            int need = sh.need, b = 255;
-            for (; b > 0; --b) {
-                if (sh.hist[b] >= need) break;
-                need -= sh.hist[b];
-            }
-            sh.prefix = prefix | ((uint32_t)b << shift);
-            sh.need = need;
-        }
-        __syncthreads();
+        radix_pick_bin(sh, prefix, shift);
     }
     return sh.prefix;
 }
