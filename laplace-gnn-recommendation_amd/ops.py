@@ -53,6 +53,11 @@ def _ptr(x: Optional[Tensor]) -> Optional[int]:
 
 
 def _need(x: Tensor, dtype: t.dtype, name: str, contiguous: bool = True) -> None:
+    try:  # the valid case in three attribute reads; the messages below are for everything else
+        if x.dtype is dtype and x.is_cuda and (not contiguous or x.is_contiguous()):
+            return
+    except AttributeError:
+        pass
     if not isinstance(x, Tensor):
         raise TypeError(f"{name}: expected a tensor, got {type(x)}")
     if not x.is_cuda:
@@ -65,6 +70,13 @@ def _need(x: Tensor, dtype: t.dtype, name: str, contiguous: bool = True) -> None
 
 def _rows_ok(x: Tensor, name: str) -> int:
     """Checks a 2-D fp32 row-major matrix with unit inner stride; returns its leading dimension."""
+    try:  # the valid case first and in one frame: this runs ~130 times per ranker iteration
+        if x.dtype is t.float32 and x.is_cuda and x.dim() == 2:
+            (r, c), (s0, s1) = x.shape, x.stride()
+            if c <= 1 or s1 == 1:
+                return s0 if r > 1 else max(c, s0)
+    except AttributeError:
+        pass
     _need(x, t.float32, name, contiguous=False)
     if x.dim() != 2 or (x.shape[1] > 1 and x.stride(1) != 1):
         raise ValueError(f"{name}: expected a row-major 2-D matrix, got shape {tuple(x.shape)} strides {x.stride()}")
@@ -73,6 +85,22 @@ def _rows_ok(x: Tensor, name: str) -> int:
 
 def _ws(nbytes: int, device) -> Tensor:
     return t.empty(max(int(nbytes), 256), dtype=t.uint8, device=device)
+
+
+_WS_CACHE = {}
+
+
+def _ws_reused(nbytes: int, device) -> Tensor:
+    """Scratch for launches that consume it before they return control to the stream's next launch (the GEMM split-K
+    partials): one buffer per (device, stream), grown on demand, instead of an allocation per call — the ranker issues
+    ~10 such launches per iteration.  Launches on one stream run in order, so the next user cannot overtake the last."""
+    dev = t.device(device) if not isinstance(device, int) else t.device("cuda", device)
+    key = (dev.index if dev.index is not None else t.cuda.current_device(), _stream())
+    cur = _WS_CACHE.get(key)
+    if cur is None or cur.numel() < nbytes:
+        cur = t.empty(max(int(nbytes) * 2, 1 << 20), dtype=t.uint8, device=dev)
+        _WS_CACHE[key] = cur
+    return cur
 
 
 # --------------------------------------------------------------------------------------
@@ -534,7 +562,7 @@ def gemm(A: Tensor, B: Tensor, *, trans_a: bool = False, trans_b: bool = True, b
         raise ValueError(f"out must be [{m}, {n}]")
     L = _lib.lib()
     ws_bytes = L.mi_gemm_workspace_bytes(m, n, k)
-    ws = _ws(ws_bytes, A.device) if ws_bytes else None
+    ws = _ws_reused(ws_bytes, A.device) if ws_bytes else None
     check(L.mi_gemm_f32(1 if trans_a else 0, 1 if trans_b else 0, m, n, k, _ptr(A), lda, _ptr(B), ldb,
                         _ptr(bias), out.data_ptr(), ldc, 1 if accumulate else 0, 1 if relu else 0,
                         ws.data_ptr() if ws is not None else None, ws_bytes, _stream()), "mi_gemm_f32")
@@ -575,7 +603,7 @@ def gemm_group(problems) -> bool:
     arr = (_lib.GemmProblem * n)(*[p[0] for p in problems])  # p[1] keeps the operands alive across the allocation below
     L = _lib.lib()
     ws_bytes = L.mi_gemm_group_workspace_bytes(arr, n)
-    ws = _ws(ws_bytes, t.cuda.current_device()) if ws_bytes else None
+    ws = _ws_reused(ws_bytes, t.cuda.current_device()) if ws_bytes else None
     rc = L.mi_gemm_group_f32(arr, n, ws.data_ptr() if ws is not None else None, ws_bytes, _stream())
     if rc == _lib.MI_ERR_UNSUPPORTED:
         return False
