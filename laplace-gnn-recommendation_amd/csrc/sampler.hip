@@ -46,6 +46,8 @@ struct Smp {
     int32_t* pos_items; int32_t* neg_items; int32_t* n_pos; int32_t* n_neg;
     int32_t* cnt;   // [B][4]
     int32_t* off;   // [4][B+1], then the four totals again, contiguous (one copy to the host)
+    int32_t* banned;    // [B][max_pos] exact negative path: the sorted distinct sampled positives
+    int32_t* csr_long;  // [B] CSR emit: the sample has an article row too long for the one-wavefront row sort
 };
 
 __device__ __forceinline__ uint64_t rand_below(uint64_t m, uint32_t purpose, uint32_t seed_user, uint32_t i,
@@ -205,8 +207,7 @@ __global__ __launch_bounds__(256) void smp_seed_kernel(Smp p) {
         int nn = nneg;
         if (p.randomization && !sh_fast) {
             // exact path (tiny graphs): uniform subset of {0..id_max} minus the distinct sampled positives.
-            // banned = sorted distinct sampled positives, kept in neg_items' tail as scratch.
-            int32_t* banned = neg_items + (p.max_neg - npos > 0 ? p.max_neg - npos : 0);
+            int32_t* banned = p.banned + (int64_t)s * p.max_pos;  // sorted distinct sampled positives
             int nb = 0;
             for (int i = 0; i < npos; ++i) {
                 const int32_t v = pos_items[i];
@@ -219,15 +220,48 @@ __global__ __launch_bounds__(256) void smp_seed_kernel(Smp p) {
                 ++nb;
             }
             const int64_t M = p.id_max + 1 - nb;
-            const int want = nneg < kMaxFan ? nneg : kMaxFan;
-            nn = floyd_subset(M, want, P_NEG_EXACT, (uint32_t)u, 0, p.seed, p.step, sel);
-            for (int q = 0; q < nn; ++q) {
-                int32_t id = sel[q];
-                for (int b = 0; b < nb; ++b)
-                    if (banned[b] <= id) ++id;
-                sel[q] = id;
+            if (nneg <= kMaxFan) {
+                nn = floyd_subset(M, nneg, P_NEG_EXACT, (uint32_t)u, 0, p.seed, p.step, sel);
+                for (int q = 0; q < nn; ++q) {
+                    int32_t id = sel[q];
+                    for (int b = 0; b < nb; ++b)
+                        if (banned[b] <= id) ++id;
+                    neg_items[q] = id;
+                }
+            } else {
+                // more negatives than the LDS list holds (a heavy user of a tiny graph): the same Floyd draws with the
+                // sample's article bitmap (all zero at this point, M <= id_max + 1 bits) as the "seen" set, read back in
+                // ascending order and mapped past the banned ids by a two-pointer walk
+                uint32_t* bm = p.bm_art + (int64_t)s * p.WA;
+                if (M <= nneg) {
+                    nn = (int)M;
+                    int b = 0;
+                    for (int32_t r = 0; r < (int32_t)M; ++r) {
+                        while (b < nb && banned[b] <= r + b) ++b;
+                        neg_items[r] = r + b;
+                    }
+                } else {
+                    for (int64_t j = M - nneg; j < M; ++j) {
+                        const int32_t tdraw = (int32_t)rand_below((uint64_t)(j + 1), P_NEG_EXACT, (uint32_t)u, 0, (uint32_t)j, p.seed, p.step);
+                        const bool seen = (bm[tdraw >> 5] >> (tdraw & 31)) & 1u;
+                        const int32_t pick = seen ? (int32_t)j : tdraw;
+                        bm[pick >> 5] |= 1u << (pick & 31);
+                    }
+                    nn = 0;
+                    int b = 0;
+                    const int words = (int)((M + 31) / 32);
+                    for (int w = 0; w < words; ++w) {
+                        uint32_t word = bm[w];
+                        bm[w] = 0u;
+                        while (word) {
+                            const int32_t r = w * 32 + (__ffs(word) - 1);
+                            word &= word - 1;
+                            while (b < nb && banned[b] <= r + b) ++b;
+                            neg_items[nn++] = r + b;
+                        }
+                    }
+                }
             }
-            for (int q = 0; q < nn; ++q) neg_items[q] = sel[q];
         }
         p.n_neg[s] = nn;
         if (p.H >= 2 && deg > 0) cut_articles(p, &u, 1, (uint32_t)u, 0, sel, p.aq + (int64_t)s * p.n, p.aq_n + s);
@@ -683,11 +717,19 @@ __global__ __launch_bounds__(kSelThreads) void smp_csr_scan_kernel(Smp p, SmpCsr
     const int per = (na + kSelThreads - 1) / kSelThreads;
     const int i0 = min(tid * per, na), i1 = min(i0 + per, na);
     int32_t* cntp = o.a_rowptr + off_a + 1;
-    int c = 0;
-    for (int i = i0; i < i1; ++i) c += cntp[i];
+    __shared__ int longest;
+    if (tid == 0) longest = 0;
+    __syncthreads();
+    int c = 0, mx = 0;
+    for (int i = i0; i < i1; ++i) {
+        c += cntp[i];
+        mx = max(mx, cntp[i]);
+    }
+    if (mx > MI_WAVE * kCsrRowRegs) atomicMax(&longest, mx);
     scan[tid + 1] = c;
     if (tid == 0) scan[0] = 0;
     __syncthreads();
+    if (tid == 0) p.csr_long[s] = longest > MI_WAVE * kCsrRowRegs;  // (a customer may hold an article many times: rows are not bounded by the sample's users)
     for (int off = 1; off < kSelThreads; off <<= 1) {
         int v = (tid + 1 > off) ? scan[tid + 1 - off] : 0;
         __syncthreads();
@@ -721,7 +763,7 @@ __global__ __launch_bounds__(256) void smp_csr_sort_rows_kernel(SmpCsr o) {
     const int row = blockIdx.x * (blockDim.x / MI_WAVE) + threadIdx.x / MI_WAVE, lane = threadIdx.x % MI_WAVE;
     if (row >= o.n_articles) return;
     const int32_t b = o.a_rowptr[row], len = o.a_rowptr[row + 1] - b;
-    if (len <= 1) return;
+    if (len <= 1 || len > MI_WAVE * kCsrRowRegs) return;  // longer rows: their whole sample is refilled in order (smp_csr_refill_kernel)
     int32_t* r = o.a_col + b;
     int32_t mine[kCsrRowRegs], pos[kCsrRowRegs];
 #pragma unroll
@@ -745,6 +787,32 @@ __global__ __launch_bounds__(256) void smp_csr_sort_rows_kernel(SmpCsr o) {
         if (lane + MI_WAVE * k < len) r[pos[k]] = mine[k];
 }
 
+
+// Samples with an article row longer than the row sort handles (a customer holding one article hundreds of times): the
+// sample's article rows are filled again, this time customer by customer in rank order with a barrier in between, so
+// every row comes out sorted without a sort.  Slow (one barrier per customer) and rare; all other samples return at once.
+__global__ __launch_bounds__(kSelThreads) void smp_csr_refill_kernel(Smp p, SmpCsr o) {
+    __shared__ int32_t by_rank[MI_WAVE * kCsrRowRegs];
+    const int s = blockIdx.x, tid = threadIdx.x;
+    if (!p.csr_long[s]) return;
+    const int32_t off_u = p.off[0 * (p.B + 1) + s], off_a = p.off[1 * (p.B + 1) + s];
+    const int na = p.cnt[(int64_t)s * 4 + 1], nu = p.cnt[(int64_t)s * 4 + 0];
+    for (int i = tid; i < na; i += blockDim.x) o.a_cur[off_a + i] = o.a_rowptr[off_a + i];  // row starts
+    const int32_t* uq_n = p.uq_n + (int64_t)s * p.H;
+    for (int e = tid; e < p.H * p.n; e += blockDim.x) {
+        const int h = e / p.n, q = e % p.n;
+        if (q < uq_n[h]) by_rank[p.uq_local[(int64_t)s * p.H * p.n + e]] = e;
+    }
+    __syncthreads();
+    for (int r = 0; r < nu; ++r) {
+        const int32_t usr = p.uq[(int64_t)s * p.H * p.n + by_rank[r]];
+        for (int32_t x = p.uptr[usr] + tid; x < p.uptr[usr + 1]; x += blockDim.x) {
+            const int32_t pos = atomicAdd(o.a_cur + off_a + article_rank(p, s, p.uidx[x]), 1);
+            o.a_col[pos] = off_u + r;
+        }
+        __syncthreads();  // the next customer's entries go behind this one's (the atomics have returned)
+    }
+}
 
 size_t smp_scratch_layout(const Smp& p, Smp* out, char* base) {
     size_t off = 0;
@@ -771,11 +839,13 @@ size_t smp_scratch_layout(const Smp& p, Smp* out, char* base) {
     char* a12 = take(B * 4);
     char* a13 = take(B * 4 * 4);
     char* a14 = take((4 * (B + 1) + 4) * 4);
+    char* a15 = take(B * 4);
+    char* a16 = take(B * (size_t)p.max_pos * 4);
     if (out) {
         out->bm_users = (uint32_t*)a0; out->bm_art = (uint32_t*)a1; out->pre_a = (int32_t*)a2;
         out->uq = (int32_t*)a3; out->uq_n = (int32_t*)a4; out->uq_local = (int32_t*)a5; out->uq_estart = (int32_t*)a6; out->uq_rstart = (int32_t*)a6b;
         out->aq = (int32_t*)a7; out->aq_n = (int32_t*)a8; out->aq_L = (int64_t*)a8b; out->pos_items = (int32_t*)a9; out->neg_items = (int32_t*)a10;
-        out->n_pos = (int32_t*)a11; out->n_neg = (int32_t*)a12; out->cnt = (int32_t*)a13; out->off = (int32_t*)a14;
+        out->n_pos = (int32_t*)a11; out->n_neg = (int32_t*)a12; out->cnt = (int32_t*)a13; out->off = (int32_t*)a14; out->csr_long = (int32_t*)a15; out->banned = (int32_t*)a16;
     }
     return off;
 }
@@ -897,6 +967,7 @@ int mi_sampler_emit_csr(const mi_sampler_desc* d, void* ws, size_t ws_bytes, con
     if (o.n_edges > 0) {
         hipLaunchKernelGGL(smp_csr_fill_kernel, dim3(p.H * p.n, p.B), dim3(256), 0, s, p, o);
         hipLaunchKernelGGL(smp_csr_sort_rows_kernel, dim3((o.n_articles + 3) / 4), dim3(256), 0, s, o);
+        hipLaunchKernelGGL(smp_csr_refill_kernel, dim3(p.B), dim3(kSelThreads), 0, s, p, o);
     }
     return mi_launch_status();
 }

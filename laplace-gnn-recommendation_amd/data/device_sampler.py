@@ -5,6 +5,7 @@ PyG collate; draws come from a counter-based Philox stream (oracle/sampler_ref.p
 from __future__ import annotations
 
 import ctypes
+import os
 import math
 from typing import Iterator, Optional
 
@@ -278,7 +279,7 @@ class DeviceGraphSampler:
 
             import sys
             interval = sys.getswitchinterval()
-            sys.setswitchinterval(min(interval, 1e-4))  # neither thread may sit on the interpreter lock for 5 ms
+            sys.setswitchinterval(min(interval, float(os.environ.get("LAPLACE_SAMPLER_SWITCH", "1e-4"))))  # neither thread may sit on the interpreter lock for 5 ms
             worker = threading.Thread(target=produce, name="laplace-sampler", daemon=True)
             worker.start()
             try:

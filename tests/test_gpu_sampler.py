@@ -113,9 +113,12 @@ def test_emitted_csrs_with_repeated_purchases_and_a_list_longer_than_the_lds_sor
     U, A = 200, 3000
     deg = rng.integers(1, 40, size=U)
     deg[7], deg[8] = 9000, 700
+    deg[20:23] = 300
     u = np.repeat(np.arange(U), deg)
     a = rng.integers(0, A, size=u.size)           # with replacement: repeated (customer, article) pairs
     a[: U] = rng.integers(0, 5, size=U)            # a few articles nearly everybody bought: long article rows
+    a[(u >= 20) & (u < 23)] = 5                    # three customers holding ONE article 300 times each: an article row of
+                                                   # 900+ entries, past what one wavefront sorts (the ordered refill path)
     g = HeteroData()
     g[Constants.node_user].x = t.from_numpy(rng.integers(0, 5, size=(U, 3)))
     g[Constants.node_item].x = t.from_numpy(rng.integers(0, 5, size=(A, 2)))
@@ -124,11 +127,13 @@ def test_emitted_csrs_with_repeated_purchases_and_a_list_longer_than_the_lds_sor
     cfg = _cfg(n_hop_neighbors=3, num_neighbors=32, batch_size=8)
     smp = DeviceGraphSampler(cfg, g, users, articles, randomization=True, device=DEV, seed=2)
     ucsr, acsr = SR.CsrAdj(users.ptr, users.idx), SR.CsrAdj(articles.ptr, articles.idx)
-    for step, seeds in ((0, [7, 8, 1, 2, 3, 4, 5, 6]), (1, [100, 7, 150])):
+    for step, seeds in ((0, [7, 8, 1, 2, 3, 4, 5, 6]), (1, [100, 7, 150]), (2, [20, 9, 21])):
         got = smp.sample(t.tensor(seeds), step=step, raw=True)
         want = SR.sample_batch(seeds, ucsr, acsr, int(u.size), int(a.max()), cfg, 2, step, True)
         assert np.array_equal(got["edge_index"].cpu().numpy(), want["edge_index"])
         _check_emitted_csrs(got, want)
+        if step == 2:
+            assert int(np.diff(got["csr_by_article"].rowptr.cpu().numpy()).max()) > 512
 
 
 def test_ranker_trains_from_device_sampled_batches():
