@@ -134,6 +134,15 @@ def test_emitted_csrs_with_repeated_purchases_and_a_list_longer_than_the_lds_sor
         _check_emitted_csrs(got, want)
         if step == 2:
             assert int(np.diff(got["csr_by_article"].rowptr.cpu().numpy()).max()) > 512
+    # the same multi-edge graph with the frontier drawn by rejection (threshold at its lower bound n*(n*(hops+1)+1))
+    cfg2 = _cfg(n_hop_neighbors=3, num_neighbors=8, batch_size=8, reject_min_entries=264)
+    smp2 = DeviceGraphSampler(cfg2, g, users, articles, randomization=True, device=DEV, seed=4)
+    for step, seeds in ((0, [7, 8, 20, 1, 2, 3, 4, 5]), (5, [21, 100, 150])):
+        got = smp2.sample(t.tensor(seeds), step=step, raw=True)
+        want = SR.sample_batch(seeds, ucsr, acsr, int(u.size), int(a.max()), cfg2, 4, step, True)
+        for key in ("user_ids", "article_ids", "edge_index", "edge_label_index", "edge_label"):
+            assert np.array_equal(got[key].cpu().numpy(), want[key]), (key, step)
+        _check_emitted_csrs(got, want)
 
 
 def test_ranker_trains_from_device_sampled_batches():
