@@ -75,10 +75,11 @@ def test_topk_matches_reference_golden(golden_dir):
                                        # one-pass path (sample threshold + single collect pass): rows >= 32 768 items, also
                                        # rows that are not 16-byte aligned, k = 1 and the largest k
                                        (40_000, 1), (50_001, 12), (33_333, 256), (100_000, 1024)])
-def test_topk_exact_vs_oracle(n_items, k):
+@pytest.mark.parametrize("D", [64, 128])
+def test_topk_exact_vs_oracle(n_items, k, D):
     from laplace_amd import ops
     g = t.Generator().manual_seed(n_items + k)
-    U, D, n_q = 300, 64, 41
+    U, n_q = 300, 41
     ue, ie = t.randn(U, D, generator=g) * 0.1, t.randn(n_items, D, generator=g) * 0.1
     uid = t.randint(0, U, (n_q,), generator=g)
     excl = [t.randperm(n_items, generator=g)[: int(t.randint(0, min(n_items, 400), (1,), generator=g))] for _ in range(n_q)]
@@ -108,12 +109,13 @@ def test_topk_ties_resolved_by_item_id():
     assert t.equal(zeros.cpu(), t.arange(k).repeat(7, 1))
 
 
-def test_topk_large_rows_with_massive_ties_and_exclusions_fall_back_exactly():
+@pytest.mark.parametrize("D", [32, 64, 128])  # 32: the generic fused kernel; 64 / 128: the LDS-DMA kernel and its overflow marks
+def test_topk_large_rows_with_massive_ties_and_exclusions_fall_back_exactly(D):
     """Rows where the sampled threshold cannot work — thousands of equal scores at the cut, all scores equal,
     almost everything excluded — take the multi-pass path and still return the exact lists."""
     from laplace_amd import ops
     g = t.Generator().manual_seed(9)
-    D, n_items, k = 32, 50_000, 100
+    n_items, k = 50_000, 100
     base = t.randn(25, D, generator=g)
     ie = base[t.randint(0, 25, (n_items,), generator=g)]  # 25 distinct rows: ~2 000-way ties
     ue = t.randn(5, D, generator=g)
@@ -123,6 +125,10 @@ def test_topk_large_rows_with_massive_ties_and_exclusions_fall_back_exactly():
     assert t.equal(ids.cpu(), R.topk_excl_exact(R.scores_fma(ue, ie), none, k))
     zeros = ops.topk_excl(uid.to(DEV), t.zeros(5, D, device=DEV), ie.to(DEV), k, None)
     assert t.equal(zeros.cpu(), t.arange(k).repeat(5, 1))
+    # 70 such queries: every score of every panel passes in every wavefront — far more than a staging region holds,
+    # so the rows are marked overflowed from inside the fused kernel and recomputed exactly
+    many = ops.topk_excl(t.arange(70, device=DEV), t.zeros(70, D, device=DEV), ie.to(DEV), k, None)
+    assert t.equal(many.cpu(), t.arange(k).repeat(70, 1))
     # all but 60 items excluded for user 0, all but 3 000 for user 1: padded with -1 / exact
     ie2 = t.randn(n_items, D, generator=g)
     keep0, keep1 = t.randperm(n_items, generator=g)[:60], t.randperm(n_items, generator=g)[:3000]
