@@ -841,6 +841,67 @@ __global__ __launch_bounds__(256, 2) void topk_scores_filter_dma_kernel(FusedArg
     wave_flush(a, m0, my_val, my_row, st_over, min(st.mine, kStageW), lane, wm);
 }
 
+// The sampled scores the thresholds come from (n_q x kSample against the gathered sample rows `Is`, ld = d): the same
+// tile machinery — query fragments in registers, sample panels by LDS-DMA, pinned B reads — with a plain store of the
+// accumulator instead of the votes.  Same MFMA, same k order as mi_gemm_launch's kernel: the scores are bitwise the
+// ones it wrote (76 us per 2 684-query chunk there, one panel per workgroup and no overlap of loads and MFMAs).
+template <int NM>
+__global__ __launch_bounds__(256, 2) void topk_sample_scores_kernel(FusedArgs a, const float* __restrict__ Is,
+                                                                    float* __restrict__ out, int tiles_per_slice) {
+    constexpr int D = 2 * NM;
+    __shared__ float P0[FM][FKPAD];   // the query panel first, then sample buffer 1
+    __shared__ float P1[FN][FKPAD];   // sample buffer 0
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave & 1, wn = wave >> 1;
+    const int64_t m0 = (int64_t)blockIdx.y * FM;
+    const int t0 = (int)blockIdx.x * tiles_per_slice;
+    const int t1 = min(kSample / FN, t0 + tiles_per_slice);
+    if (t0 >= t1) return;
+    const uint32_t lane_off = (uint32_t)lane * 4u;
+    dma_item_panel<D>(Is, D, (int64_t)t0 * FN, P1, wave, lane_off);
+    {
+        float4 va[8];
+        fpanel_issue(va, a.U, a.ldu, a.uid, m0, a.n_q, a.d, tid);
+        fpanel_commit(P0, va, tid);
+    }
+    dma_wait();
+    __syncthreads();
+    float areg[NM];
+    {
+        const float* ap = &P0[wm * 32 + (lane & 31)][lane >> 5];
+#pragma unroll
+        for (int s = 0; s < NM; ++s) areg[s] = ap[2 * s];
+    }
+    __syncthreads();  // P0 is free: it becomes sample buffer 1
+    const int boff = (wn * 32 + (lane & 31)) * FKPAD + (lane >> 5);
+    const int col = wn * 32 + (lane & 31);
+    const int row_base = wm * 32 + 4 * (lane >> 5);
+    for (int t = t0; t < t1; ++t) {
+        const bool odd = ((t - t0) & 1) != 0;
+        float (*cur)[FKPAD] = odd ? P0 : P1;
+        float (*nxt)[FKPAD] = odd ? P1 : P0;
+        if (t + 1 < t1) dma_item_panel<D>(Is, D, (int64_t)(t + 1) * FN, nxt, wave, lane_off);  // block-uniform
+        const float* bp = &cur[0][0] + boff;
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        float bq[2][8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) bq[0][u] = bp[2 * u];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < NM; ++s) pipe_mfma<NM, true>(s, acc, areg, bp, bq);
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int64_t gm = m0 + row_base + (reg & 3) + 8 * (reg >> 2);
+            if (gm < a.n_q) out[gm * kSample + t * FN + col] = acc[reg];
+        }
+        dma_wait();
+        __syncthreads();  // next panel landed and everybody is done with cur
+    }
+}
+
 __global__ __launch_bounds__(kBlock) void topk_finalize_kernel(FusedArgs a, int k, int kpow2, float* __restrict__ scores,
                                                                int64_t* __restrict__ out_idx,
                                                                float* __restrict__ out_score) {
@@ -871,6 +932,16 @@ __global__ __launch_bounds__(kBlock) void topk_finalize_kernel(FusedArgs a, int 
 }
 
 }  // namespace
+
+static int mi_cu_count() {
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n_cu = v;
+        else n_cu = 256;
+    }
+    return n_cu;
+}
 
 extern "C" {
 
@@ -918,13 +989,32 @@ int mi_topk_excl_f32(int64_t n_q, int64_t n_items, int64_t d, int64_t k, const i
         unsigned long long* cand = ar.take<unsigned long long>((size_t)n_q * kCap);
         if (!Is || !sample_scores || !bitmap || !thr || !cnt || !cand) return MI_ERR_WORKSPACE;
         hipLaunchKernelGGL(gather_sample_rows_kernel, dim3(kSample), dim3(64), 0, s, n_items, (int)d, item_emb, ldi, Is);
-        MiGemmArgs g;
-        g.M = n_q; g.N = kSample; g.K = d;
-        g.A = user_emb; g.sa_m = ldu; g.sa_k = 1; g.a_rows = uid;
-        g.B = Is; g.sb_n = d; g.sb_k = 1;
-        g.bias = nullptr; g.C = sample_scores; g.ldc = kSample; g.accumulate = 0; g.act = 0;
-        int rc = mi_gemm_launch(g, nullptr, 0, s);
-        if (rc) return rc;
+        FusedArgs a;
+        a.n_q = n_q; a.n_items = n_items; a.d = (int)d; a.uid = uid;
+        a.U = user_emb; a.ldu = ldu; a.I = item_emb; a.ldi = ldi;
+        const int64_t strips = mi_ceil_div(n_q, FM);
+        const int64_t capacity = 2 * (int64_t)mi_cu_count();
+        if (MI_TOPK_DMA && (d == 128 || d == 64)) {
+            int64_t sl = 1, best = INT64_MAX;  // split of the 64 sample panels: rounds x (panels + prologue), as below
+            for (int64_t l = 1; l <= kSample / FN; ++l) {
+                const int64_t cost = mi_ceil_div(strips * l, capacity) * (mi_ceil_div(kSample / FN, l) + 2);
+                if (cost < best) { best = cost; sl = l; }
+            }
+            const int tps = (int)mi_ceil_div(kSample / FN, sl);
+            sl = mi_ceil_div(kSample / FN, tps);
+            if (d == 128)
+                hipLaunchKernelGGL(topk_sample_scores_kernel<64>, dim3((unsigned)sl, (unsigned)strips), dim3(256), 0, s, a, Is, sample_scores, tps);
+            else
+                hipLaunchKernelGGL(topk_sample_scores_kernel<32>, dim3((unsigned)sl, (unsigned)strips), dim3(256), 0, s, a, Is, sample_scores, tps);
+        } else {
+            MiGemmArgs g;
+            g.M = n_q; g.N = kSample; g.K = d;
+            g.A = user_emb; g.sa_m = ldu; g.sa_k = 1; g.a_rows = uid;
+            g.B = Is; g.sb_n = d; g.sb_k = 1;
+            g.bias = nullptr; g.C = sample_scores; g.ldc = kSample; g.accumulate = 0; g.act = 0;
+            int rc = mi_gemm_launch(g, nullptr, 0, s);
+            if (rc) return rc;
+        }
         MI_HIP(hipMemsetAsync(bitmap, 0, (size_t)n_q * words * sizeof(uint32_t), s));
         MI_HIP(hipMemsetAsync(cnt, 0, (size_t)n_q * sizeof(int), s));
         if (excl_ptr)
@@ -932,22 +1022,12 @@ int mi_topk_excl_f32(int64_t n_q, int64_t n_items, int64_t d, int64_t k, const i
                                excl_idx, bitmap, words, sample_scores);
         hipLaunchKernelGGL(threshold_kernel, dim3((unsigned)n_q), dim3(kBlock), 0, s, n_q, n_items, (int)k, sample_scores,
                            thr);
-        FusedArgs a;
-        a.n_q = n_q; a.n_items = n_items; a.d = (int)d; a.uid = uid;
-        a.U = user_emb; a.ldu = ldu; a.I = item_emb; a.ldi = ldi;
         a.thr = thr; a.bitmap = bitmap; a.words = words; a.cand = cand; a.cnt = cnt;
-        const int64_t strips = mi_ceil_div(n_q, FM), n_tiles = mi_ceil_div(n_items, FN);
+        const int64_t n_tiles = mi_ceil_div(n_items, FN);
         // Every workgroup does the same work and two fit on a CU, so the launch runs in ceil(grid / (2 * CUs)) rounds of
         // tiles_per_slice panels each: a grid one workgroup over a multiple of the chip's capacity (the old rule,
         // >= 4 workgroups per CU, made 1 025 of them for a 2 621-query chunk) pays a whole extra round for it.  Pick the
         // split of the item axis that minimises rounds x (panels + the query-panel prologue, ~2 panels' worth).
-        static int n_cu = 0;
-        if (n_cu == 0) {
-            int dev = 0, v = 0;
-            if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n_cu = v;
-            else n_cu = 256;
-        }
-        const int64_t capacity = 2 * (int64_t)n_cu;
         int64_t slices = 1, best = INT64_MAX;
         for (int64_t l = 1; l <= n_tiles && l <= 4096; ++l) {
             const int64_t cost = mi_ceil_div(strips * l, capacity) * (mi_ceil_div(n_tiles, l) + 2);
