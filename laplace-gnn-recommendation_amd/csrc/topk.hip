@@ -524,9 +524,7 @@ __global__ __launch_bounds__(256, 2) void topk_scores_filter_kernel(FusedArgs a)
 // issues in between is free: with two accumulators that take turns, the 16 votes of the previous panel, the reservation
 // of staging slots for all its hits (scalar arithmetic: each wavefront owns a quarter of the staging area) and the hits
 // of one accumulator register per MFMA slot (a few per panel and wavefront pass: this path runs on most panels, not
-// rarely) all go into that shadow instead of after the chain has drained.  0.49 -> 0.53.  Measured since: the votes
-// cost nothing; having the staging code in the loop costs 120 us (k = 12) to 200 us (k = 256) of a 730-810 us chunk
-// whether a score ever passes or not (thresholds at +inf: 752 us) — profiles/r02_topk.md lists what did not move it.
+// rarely) all go into that shadow instead of after the chain has drained.  0.49 -> 0.53 of peak.
 struct PipeState {
     unsigned long long hit[16];
     unsigned long long col_ok_prev;
@@ -585,8 +583,7 @@ __device__ __forceinline__ void pipe_tail(f32x16& acc, const f32x16& prev, const
 
 template <int NM, bool PIN_READS>
 __device__ __forceinline__ void pipe_panel(const FusedArgs& a, f32x16& acc, const f32x16& prev, const float (&areg)[NM],
-                                           const float* bp, const float (&thr_f)[16], const unsigned long long (&row_ok)[16],
-                                           PipeState& st, int lane, int row_base, unsigned long long* st_val, unsigned char* st_row,
+                                           const float* bp, const float (&thr_f)[16], PipeState& st, int lane, int row_base, unsigned long long* st_val, unsigned char* st_row,
                                            unsigned char* st_over) {
     constexpr int q = NM / 32;  // MFMAs per vote pair
 #pragma unroll
@@ -605,21 +602,20 @@ __device__ __forceinline__ void pipe_panel(const FusedArgs& a, f32x16& acc, cons
         if (MI_TOPK_STAGE == 0 || MI_TOPK_STAGE == 6 || MI_TOPK_STAGE == 8) {
 #pragma unroll
             for (int reg = (2 * s) / q; reg < (2 * s + 2) / q; ++reg) {
-                st.hit[reg] = __ballot(!(prev[reg] < thr_f[reg])) & st.col_ok_prev & row_ok[reg];
+                st.hit[reg] = __ballot(!(prev[reg] < thr_f[reg])) & st.col_ok_prev;
                 st.total += __popcll(st.hit[reg]);
             }
         }
     }
     // Nothing passed (about half of a wavefront's panels at k = 12): the rest of the chain as one straight run;
-    // otherwise the copy with the staging steps and their 16 wave-uniform branches
+    // otherwise the copy with the staging steps and their 16 wave-uniform branches (A/B: equal speed to one copy)
     if (MI_TOPK_STAGE == 6 && st.total == 12345) st_over[0] = 1;
     if ((MI_TOPK_STAGE == 0 || MI_TOPK_STAGE == 8) && st.total != 0)
         pipe_tail<NM, PIN_READS, true>(acc, prev, areg, bp, bq, st, lane, row_base, st_val, st_row, st_over);
     else
         pipe_tail<NM, PIN_READS, false>(acc, prev, areg, bp, bq, st, lane, row_base, st_val, st_row, st_over);
 }
-// (The two copies of the tail are an A/B outcome: equal speed to one copy with the branches woven in, kept because the
-// common no-hit path is then branch-free.)
+
 
 // the scores of `acc` that passed (hit[reg] = lanes) -> this wavefront's staging region (the last panel's, after the loop)
 __device__ __forceinline__ void stage_hits(const f32x16& acc, const unsigned long long (&hit)[16], int total, int64_t gn,
@@ -656,6 +652,7 @@ __device__ __forceinline__ void wave_flush(const FusedArgs& a, int64_t m0, const
     for (int e = lane; e < n; e += 64) {
         const unsigned long long c = st_val[e];
         const int64_t q = m0 + st_row[e];
+        if (q >= a.n_q) continue;  // a padding row (see the thresholds)
         const uint32_t item = 0xFFFFFFFFu - (uint32_t)c;
         if ((a.bitmap[q * a.words + (item >> 5)] >> (item & 31)) & 1u) continue;
         const int slot = atomicAdd(&a.cnt[q], 1);
@@ -684,7 +681,7 @@ __device__ __forceinline__ void wave_flush(const FusedArgs& a, int64_t m0, const
 #define MI_TOPK_DMA 1
 #endif
 #ifndef MI_TOPK_ONE_COPY
-#define MI_TOPK_ONE_COPY 0   // A/B: one copy of the panel body instead of three (37 -> 20 KB of code): 741 -> 757 us, so it is not the instruction cache
+#define MI_TOPK_ONE_COPY 0   // A/B: one copy of the panel body instead of three (37 -> 20 KB of code): no faster (it is not the instruction cache)
 #endif
 #ifndef MI_TOPK_PIN
 #define MI_TOPK_PIN 1   // B reads pinned a group of 8 MFMAs ahead (A/B)
@@ -701,18 +698,28 @@ __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" :
 template <int D>
 __device__ __forceinline__ void dma_item_panel(const float* __restrict__ T, int64_t ld, int64_t row0,
                                                float (*panel)[FKPAD], int wave, uint32_t lane_off) {
-    constexpr int PIECES = D / 64, PER_WAVE = 64 * PIECES / 4;
-    const char* base = reinterpret_cast<const char*>(T + row0 * ld);
-    const uint32_t l0 = lds_addr(&panel[0][0]);
+    constexpr int PIECES = D / 64;  // 256-byte pieces per row: the second one rides on the instruction offset, which moves
+                                    // the global and the LDS address alike
+    const char* gb = reinterpret_cast<const char*>(T + (row0 + wave * 16) * ld);
+    uint32_t l = lds_addr(&panel[wave * 16][0]);
+    const int64_t row_bytes = ld * 4;
+    // opaque to the optimiser: otherwise the addresses of the unrolled loop are hoisted out of the panel loop as loop
+    // invariants — ~100 SGPRs, spilled to VGPR lanes and read back (v_readlane) in front of every MFMA chain.  That, not
+    // anything in the vector code, was 120 us of a 741 us chunk (profiles/r02_topk.md): 741 -> 716 with the addresses
+    // opaque, -> 621 with two scalar adds per row and no spill left
+    asm volatile("" : "+s"(l), "+s"(gb));
 #pragma unroll
-    for (int i = 0; i < PER_WAVE; ++i) {
-        const int idx = wave * PER_WAVE + i;
-        const int row = idx / PIECES, piece = idx % PIECES;
-        const char* gb = base + ((int64_t)row * ld + piece * 64) * 4;
-        const uint32_t l = l0 + (uint32_t)(row * FKPAD + piece * 64) * 4u;
+    for (int r = 0; r < 16; ++r) {  // a wavefront moves 16 of the panel's 64 rows
         uint32_t keep;  // m0 is the compiler's: saved and put back (naming it as a clobber is not honoured)
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %2, %3\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep) : "s"(l), "v"(lane_off), "s"(gb) : "memory");
+        if (PIECES == 2)
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %2, %3\n\t"
+                         "global_load_lds_dword %2, %3 offset:256\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "s"(l), "v"(lane_off), "s"(gb) : "memory");
+        else
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %2, %3\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "s"(l), "v"(lane_off), "s"(gb) : "memory");
+        l += FKPAD * 4;
+        gb += row_bytes;
     }
 }
 
@@ -750,10 +757,8 @@ __global__ __launch_bounds__(256, 2) void topk_scores_filter_dma_kernel(FusedArg
         const int64_t gm = m0 + row_base + (reg & 3) + 8 * (reg >> 2);
         thr_f[reg] = (gm < a.n_q && MI_TOPK_STAGE != 8) ? key_score(a.thr[gm]) : INFINITY;  // (stage 8: nothing ever passes)
     }
-    const int rows_here = (int)min((int64_t)FM, a.n_q - m0);
-    unsigned long long row_ok[16];
-#pragma unroll
-    for (int reg = 0; reg < 16; ++reg) row_ok[reg] = __ballot(row_base + (reg & 3) + 8 * (reg >> 2) < rows_here);
+    // (padding rows — queries beyond n_q, copies of row 0 of the panel's zero fill — have threshold +inf: only a NaN score
+    // passes there, and wave_flush drops entries of rows >= n_q)
     dma_wait();
     __syncthreads();
     float areg[NM];
@@ -781,7 +786,7 @@ __global__ __launch_bounds__(256, 2) void topk_scores_filter_dma_kernel(FusedArg
     {                                                                                                                  \
         if ((MI_TOPK_STAGE < 2 || MI_TOPK_STAGE == 6 || MI_TOPK_STAGE == 8) && (t) + 1 < t1)  /* block-uniform */                              \
             dma_item_panel<D>(a.I, a.ldi, min(((t) + 1) * FN, last_row0), nxt, wave, lane_off);                        \
-        pipe_panel<NM, MI_TOPK_PIN != 0>(a, acc, prev, areg, &cur[0][0] + boff, thr_f, row_ok, st, lane, row_base,       \
+        pipe_panel<NM, MI_TOPK_PIN != 0>(a, acc, prev, areg, &cur[0][0] + boff, thr_f, st, lane, row_base,       \
                                          my_val, my_row, st_over);                                                     \
         st.gn_prev = min((t) * FN, last_row0) + col;                                                                   \
         st.col_ok_prev = __ballot(st.gn_prev >= (t) * FN);                                                             \
@@ -830,7 +835,7 @@ __global__ __launch_bounds__(256, 2) void topk_scores_filter_dma_kernel(FusedArg
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
             const float sc = last_in_acc0 ? acc0[reg] : acc1[reg];
-            hit[reg] = __ballot(!(sc < thr_f[reg])) & st.col_ok_prev & row_ok[reg];
+            hit[reg] = __ballot(!(sc < thr_f[reg])) & st.col_ok_prev;
             total += __popcll(hit[reg]);
         }
         if (total) {
