@@ -648,15 +648,43 @@ __device__ __forceinline__ void stage_hits(const f32x16& acc, const unsigned lon
 // appended such hits straight to global memory from inside the MFMA loop; the 16 per-register row pointers that path
 // kept live cost ~90 VGPRs for something that happens on adversarial inputs only.)
 __device__ __forceinline__ void wave_flush(const FusedArgs& a, int64_t m0, const unsigned long long* st_val,
-                                           const unsigned char* st_row, unsigned char* st_over, int n, int lane, int wm) {
-    for (int e = lane; e < n; e += 64) {
-        const unsigned long long c = st_val[e];
-        const int64_t q = m0 + st_row[e];
-        if (q >= a.n_q) continue;  // a padding row (see the thresholds)
-        const uint32_t item = 0xFFFFFFFFu - (uint32_t)c;
-        if ((a.bitmap[q * a.words + (item >> 5)] >> (item & 31)) & 1u) continue;
-        const int slot = atomicAdd(&a.cnt[q], 1);
-        if (slot < kCap) a.cand[q * kCap + slot] = c;
+                                           const unsigned char* st_row, unsigned char* st_over, int n, int lane, int wm,
+                                           int* fl_cnt /* [32] of this wavefront */) {
+    // One global atomic per (row, flush) instead of one per candidate: the region's entries are counted per query row in
+    // LDS first (a wavefront's hits fall on its 32 rows), each row's count reserves its slots with a single add, then the
+    // candidates go to base + rank.  (k = 256: ~760 candidates per row, 2 M per chunk.)
+    constexpr int kPer = kStageW / 64;  // entries per lane
+    if (lane < 32) fl_cnt[lane] = 0;
+    unsigned long long c[kPer];
+    int pos[kPer], rl[kPer];
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) {
+        const int e = lane + 64 * j;
+        pos[j] = -1;
+        rl[j] = 0;
+        c[j] = 0ull;
+        if (e < n) {
+            c[j] = st_val[e];
+            rl[j] = st_row[e] - wm * 32;
+            const int64_t q = m0 + wm * 32 + rl[j];
+            const uint32_t item = 0xFFFFFFFFu - (uint32_t)c[j];
+            if (q < a.n_q && !((a.bitmap[q * a.words + (item >> 5)] >> (item & 31)) & 1u))  // (q >= n_q: a padding row, see the thresholds)
+                pos[j] = atomicAdd(&fl_cnt[rl[j]], 1);
+        }
+    }
+    int base = 0;
+    if (lane < 32) {
+        const int cnt = fl_cnt[lane];
+        if (cnt) base = atomicAdd(&a.cnt[m0 + wm * 32 + lane], cnt);
+    }
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) {
+        const int b = __shfl(base, rl[j], 64);
+        if (pos[j] >= 0) {
+            const int64_t q = m0 + wm * 32 + rl[j];
+            const int slot = b + pos[j];
+            if (slot < kCap) a.cand[q * kCap + slot] = c[j];
+        }
     }
     if (n >= kStageW && lane < 32) {  // the region ran full: push the marked rows of this wavefront's 32 queries past kCap.  Marks are
         const int r = wm * 32 + lane;  // never cleared (the twin wavefront shares them: clearing could lose its mark); adding twice is harmless
@@ -731,6 +759,7 @@ __global__ __launch_bounds__(256, 2) void topk_scores_filter_dma_kernel(FusedArg
     __shared__ unsigned long long st_val[kStage];
     __shared__ unsigned char st_row[kStage];
     __shared__ unsigned char st_over[FM];
+    __shared__ int fl_cnt[4][32];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave & 1, wn = wave >> 1;
@@ -792,7 +821,7 @@ __global__ __launch_bounds__(256, 2) void topk_scores_filter_dma_kernel(FusedArg
         st.col_ok_prev = __ballot(st.gn_prev >= (t) * FN);                                                             \
         if (MI_TOPK_STAGE >= 1 && MI_TOPK_STAGE < 6 && prev[0] == 12345.678f && prev[7] == 3.f) st_over[0] = 1; /* keeps the chain alive */ \
         if (st.mine >= kStageW / 2) {  /* wave-uniform: this wavefront's region is half full */                        \
-            wave_flush(a, m0, my_val, my_row, st_over, min(st.mine, kStageW), lane, wm);                               \
+            wave_flush(a, m0, my_val, my_row, st_over, min(st.mine, kStageW), lane, wm, fl_cnt[wave]);                 \
             st.mine = 0;                                                                                               \
         }                                                                                                              \
         if (MI_TOPK_STAGE < 5 || MI_TOPK_STAGE == 6 || MI_TOPK_STAGE == 8) dma_wait();                                                       \
@@ -843,7 +872,7 @@ __global__ __launch_bounds__(256, 2) void topk_scores_filter_dma_kernel(FusedArg
             else stage_hits(acc1, hit, total, st.gn_prev, row_base, lane, st, my_val, my_row, st_over);
         }
     }
-    wave_flush(a, m0, my_val, my_row, st_over, min(st.mine, kStageW), lane, wm);
+    wave_flush(a, m0, my_val, my_row, st_over, min(st.mine, kStageW), lane, wm, fl_cnt[wave]);
 }
 
 // The sampled scores the thresholds come from (n_q x kSample against the gathered sample rows `Is`, ld = d): the same
