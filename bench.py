@@ -20,8 +20,6 @@ import argparse
 import hashlib
 import json
 import os
-import socket
-import subprocess
 import sys
 import time
 
@@ -74,46 +72,6 @@ def kernel_source_hash() -> str:
         with open(os.path.join(ROOT, "laplace-gnn-recommendation_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
-
-
-def self_launch(args) -> int:
-    """N>1 without a launcher: start N workers (one per GPU) BEFORE this process touches the GPU, hand rank 0's JSON
-    line through, fail if any worker fails.  The parent never initialises HIP and never re-execs itself."""
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    procs = []
-    for r in range(args.gpus):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0 = procs[0].stdout
-    line = None
-    rc = 0
-    try:
-        for raw in out0:
-            txt = raw.decode(errors="replace").rstrip("\n")
-            if txt.startswith("{") and '"metric"' in txt:
-                line = txt
-            elif txt:
-                print(txt, file=sys.stderr, flush=True)
-        deadline = time.time() + 600
-        for p in procs:
-            try:
-                p.wait(timeout=max(1.0, deadline - time.time()))
-            except subprocess.TimeoutExpired:
-                rc = rc or 124
-            rc = rc or (p.returncode or 0)
-    finally:
-        for p in procs:
-            if p.poll() is None:
-                p.kill()
-    if line is None:
-        print("bench.py: rank 0 produced no result line", file=sys.stderr)
-        return rc or 1
-    print(line, flush=True)
-    return rc
 
 
 def cpu_baseline(ei, U, I, args, B, table0):
@@ -198,31 +156,22 @@ def map_at_12(model, trainer, inter, held, n_steps: int) -> dict:
 
 def main():
     args = parse_args()
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        sys.exit(self_launch(args))
+    from laplace_amd import launch
+    if args.gpus > 1 and not launch.launched():
+        # the parent never touches the GPU; one deadline from launch, every worker watched (laplace_amd/launch.py)
+        sys.exit(launch.self_launch(__file__, sys.argv[1:], args.gpus, timeout_s=float(os.environ.get("LAPLACE_BENCH_DEADLINE_S", 900))))
     import torch as t
     import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not t.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
     # LAPLACE_BENCH_BACKEND=gloo + LAPLACE_BENCH_ONE_GPU=1 rehearse the N>1 path on a 1-GPU box
     # (ranks share the card, collectives staged through the host); never used for a reported number.
-    backend = os.environ.get("LAPLACE_BENCH_BACKEND", "nccl")
-    if os.environ.get("LAPLACE_BENCH_ONE_GPU") == "1":
-        local_rank = 0
-    t.cuda.set_device(local_rank)
-    dev = t.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend)
+    backend = launch.backend_name()
+    rank, world, dev = launch.init_distributed()   # rendezvous + collectives time out instead of hanging
 
     from laplace_amd import ops, synthetic as S
     from laplace_amd.interactions import Interactions
@@ -264,7 +213,7 @@ def main():
     else:
         from laplace_amd.dist import ShardedLightGCNTrainer
         trainer = ShardedLightGCNTrainer(model, inter, lr=1e-3, Lambda=1e-6, batch_size=B, seed=7 + rank,
-                                         sparse_batch=not args.plain_step)
+                                         sparse_batch=not args.plain_step, reorder=False if args.no_reorder else None)
     nnz, n_rows = trainer.adj_fwd.nnz, trainer.adj_fwd.n_rows
     t.cuda.synchronize()
 
@@ -358,7 +307,7 @@ def main():
                                     f"{K}-layer D={D}, batch {B} positive edges per GPU, on-device sampling, "
                                     f"BPR + dense Adam; BASELINE.json configs[1]"),
                        "parallelism": "1 GPU" if world == 1 else f"user-sharded x{world}, items replicated, "
-                                                                 f"RCCL all-reduce of item rows per layer"},
+                                                                 f"{'RCCL' if backend == 'nccl' else backend} all-reduce of item rows per layer"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "basis": basis, "traffic_source": traffic_src,
                          "kernel": "mi_spmm_csr_f32 dense launch (spmm_items_kernel + spmm_rows_kernel + spmm_fixup_kernel, SPARSE=false)",

@@ -6,7 +6,9 @@ import os
 from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int32, c_int64, c_size_t, c_uint64, c_void_p
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG_DIR, "liblaplace_hip.so")
+# LAPLACE_HIP_LIB names a VARIANT build of the same library (A/B and timing probes under tools/): the product library in
+# the package directory is never overwritten by an experiment.  It is still this library or nothing — no fallback.
+LIB_PATH = os.environ.get("LAPLACE_HIP_LIB") or os.path.join(PKG_DIR, "liblaplace_hip.so")
 
 MI_ABI_VERSION = 7
 MI_SPMM_GROUP = 32

@@ -36,6 +36,9 @@ from .interactions import Interactions
 from .model.lightgcn import LightGCN
 
 
+REORDER_MIN_EDGES_PER_RANK = 1 << 20   # default locality order: on when the JOB holds this many edges per rank
+
+
 class ShardedLightGCNTrainer:
     def __init__(self, model: LightGCN, train: Interactions, *, lr: float, Lambda: float, batch_size: int,
                  betas: Tuple[float, float] = (0.9, 0.999), eps: float = 1e-8, seed: int = 0,
@@ -44,7 +47,7 @@ class ShardedLightGCNTrainer:
         """model: LightGCN(num_users = this rank's users, num_items = all items).  `train` holds this
         rank's edges with LOCAL user ids.  ops_impl: the kernel provider (default: the HIP ops;
         the CPU gloo tests inject an oracle-backed one — the product never does).
-        reorder (default: on from 1M local edges): train under the locality order of trainer.LightGCNTrainer — the
+        reorder (default: on from 1M edges per rank, decided on the all-reduced total): train under the locality order of trainer.LightGCNTrainer — the
         replicated items are ranked by their GLOBAL degree, so every rank numbers them alike; users are local anyway."""
         self.ops = ops_impl if ops_impl is not None else hip_ops
         self.group = group
@@ -63,11 +66,24 @@ class ShardedLightGCNTrainer:
         # item replicas start identical: rank 0's rows win
         self._bcast(self.table[U:])
 
+        # The decision is COLLECTIVE: a reordering rank all-reduces the item degrees and renumbers the replicated item
+        # rows, so every rank must take the same branch (a rank-local threshold on uneven shards would mismatch the
+        # collective sequence and sum rows of different items).  Default: on when the job's edges / world reach
+        # REORDER_MIN_EDGES_PER_RANK.
         can_reorder = self.neg_range == I
-        if reorder is None:
-            reorder = can_reorder and train.num_edges >= (1 << 20)
-        elif reorder and not can_reorder:
+        if reorder and not can_reorder:
             raise ValueError("reorder=True needs neg_range == num_items")
+        votes = t.tensor([train.num_edges, -1 if reorder is None else int(bool(reorder)), int(can_reorder)],
+                         dtype=t.int64, device=dev)
+        lo, hi = votes.clone(), votes.clone()
+        if self.world > 1:
+            self._allreduce(votes)                                            # total edges (and sums of the flags)
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=self.group)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=self.group)
+        if int(lo[1]) != int(hi[1]):
+            raise ValueError("ShardedLightGCNTrainer: the `reorder` argument differs across ranks")
+        if reorder is None:
+            reorder = bool(int(lo[2])) and int(votes[0]) >= REORDER_MIN_EDGES_PER_RANK * self.world
         self.order, self.in_training_order = None, True
         if reorder:
             gdeg = t.bincount(train.edge_index[1], minlength=I)

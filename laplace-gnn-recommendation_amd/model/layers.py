@@ -356,6 +356,7 @@ def hetero_layer_backward(rels, xs, wts, aggs, args, outs, dys, need):
     dx = [None] * n_x
     d_aggs = [None] * n_rel
     specs = []
+    dst_bufs = {}
     for i, (si, di, graph, aggr) in enumerate(rels):
         dy = dys[i]
         if dy is None:
@@ -367,8 +368,13 @@ def hetero_layer_backward(rels, xs, wts, aggs, args, outs, dys, need):
         if need[di]:
             buf = t.empty(graph.n_dst, w_r.shape[1], device=dev)
             specs.append(dict(A=dy, B=w_r, out=buf, trans_b=False, mask=outs[i]))
-            dx[di] = buf if dx[di] is None else dx[di] + buf
+            dst_bufs.setdefault(di, []).append(buf)
     _run_products(specs)
+    for di, bufs in dst_bufs.items():   # summed only now: the buffers are filled by the launch above
+        acc = bufs[0]
+        for b in bufs[1:]:
+            acc = acc + b
+        dx[di] = acc
     for i, (si, di, graph, aggr) in enumerate(rels):
         if d_aggs[i] is None:
             continue

@@ -782,13 +782,22 @@ def gather_cat(zu: Tensor, zi: Tensor, row: Tensor, col: Tensor) -> Tensor:
 
 
 def gather_cat_bwd(d_out: Tensor, idx: Tensor, n_rows: int, c: int, off: int) -> Tensor:
-    """dZ [n_rows, c]: rows of d_out[:, off:off+c] summed per idx value, in edge order (deterministic)."""
+    """dZ [n_rows, c]: rows of d_out[:, off:off+c] summed per idx value, in edge order (deterministic: no float
+    atomics on either path)."""
     _need(idx, t.int64, "idx")
     ldo = _rows_ok(d_out, "d_out")
-    dz = t.zeros(n_rows, c, dtype=t.float32, device=d_out.device)
     ne = idx.numel()
-    if ne > int(_lib.lib().mi_gather_cat_bwd_max_edges()):  # beyond the all-pairs kernel's range: torch's sorted index_add
-        return dz.index_add_(0, idx, d_out[:, off:off + c])
+    if ne > int(_lib.lib().mi_gather_cat_bwd_max_edges()):
+        # beyond the all-pairs kernel's range: the same sum as a product with the [n_rows, ne] incidence matrix — a sorted
+        # CSR (columns = edge positions, ascending) through the SpMM kernel, i.e. still summed in edge order
+        if c % 4 or off % 4 or ldo % 4:
+            raise ValueError("gather_cat_bwd beyond mi_gather_cat_bwd_max_edges needs widths / offsets that are multiples of 4")
+        inc = coo_to_csr(idx.contiguous(), t.arange(ne, dtype=t.int64, device=idx.device), n_rows, ne, want_perm=False)
+        inc.val = t.ones(ne, dtype=t.float32, device=idx.device)
+        dz = t.empty(n_rows, c, dtype=t.float32, device=d_out.device)
+        spmm(inc, d_out[:, off:off + c], Y=dz)
+        return dz
+    dz = t.zeros(n_rows, c, dtype=t.float32, device=d_out.device)
     check(_lib.lib().mi_gather_cat_bwd_f32(ne, c, off, _ptr(idx), _ptr(d_out), ldo, _ptr(dz), c, _stream()),
           "mi_gather_cat_bwd_f32")
     return dz

@@ -60,23 +60,25 @@ def train(config: LightGCNConfig = lightgcn_config, *, edge_index: Tensor, num_u
                               reference_sampler_quirks=(compat == "reference"))
     train_loss = t.zeros(1, device=device)
     recall = precision = 0.0
-    for it in range(config.epochs):
-        train_loss = trainer.step()
-        if it % config.eval_every == 0:
-            model.eval()
-            trainer.to_original_order()  # evaluation reads the model's tables by original id; step() re-enters the training order
-            val_loss, recall, precision, ndcg = evaluation(model, val_edges, val_sparse, [train_edges], config.k,
-                                                           config.Lambda, seed)
-            if verbose:
-                print(f"[Iter {it}/{config.epochs}] train_loss: {round(float(train_loss), 5)}, val_loss: "
-                      f"{round(val_loss, 5)}, val_recall@{config.k}: {round(recall, 6)}, val_precision@{config.k}: "
-                      f"{round(precision, 6)}, val_ndcg@{config.k}: {round(ndcg, 6)}")
-            model.train()
-        if it % config.lr_decay_every == 0 and it != 0:
-            trainer.decay_lr(0.95)
+    try:   # the trainer permutes the model's rows in place: whatever happens, hand them back under their original ids
+        for it in range(config.epochs):
+            train_loss = trainer.step()
+            if it % config.eval_every == 0:
+                model.eval()
+                trainer.to_original_order()  # evaluation reads the model's tables by original id; step() re-enters the training order
+                val_loss, recall, precision, ndcg = evaluation(model, val_edges, val_sparse, [train_edges], config.k,
+                                                               config.Lambda, seed)
+                if verbose:
+                    print(f"[Iter {it}/{config.epochs}] train_loss: {round(float(train_loss), 5)}, val_loss: "
+                          f"{round(val_loss, 5)}, val_recall@{config.k}: {round(recall, 6)}, val_precision@{config.k}: "
+                          f"{round(precision, 6)}, val_ndcg@{config.k}: {round(ndcg, 6)}")
+                model.train()
+            if it % config.lr_decay_every == 0 and it != 0:
+                trainer.decay_lr(0.95)
+    finally:
+        trainer.finish()
 
     model.eval()
-    trainer.finish()
     test_loss, test_recall, test_precision, test_ndcg = evaluation(
         model, test_edges, test_sparse, [train_edges, val_edges], config.k, config.Lambda, seed)
     if verbose:

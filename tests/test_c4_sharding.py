@@ -105,3 +105,66 @@ def test_c4_two_rank_shards_use_global_degrees_and_match_the_whole_graph_forward
         assert t.allclose(f[:per], wu[r * per:(r + 1) * per], atol=2e-6)
         assert t.allclose(f[per:], wi, atol=2e-6)
     assert t.equal(ret[0]["final"][per:], ret[1]["final"][per:])  # item replicas bitwise identical
+
+
+# ---- the launcher behind `bench.py --gpus N` (laplace_amd/launch.py): no child may leave the parent waiting -----------------
+
+def _py(code):
+    return [sys.executable, "-c", code]
+
+
+def test_launcher_returns_at_once_when_a_worker_dies_before_the_rendezvous():
+    """Rank 1 exits 3 straight away; rank 0 would wait for ten minutes (as in init_process_group without its peer).
+    The parent must kill rank 0 and return rank 1's code within seconds, printing no result line."""
+    import io
+    import time
+    from contextlib import redirect_stdout
+    from laplace_amd import launch
+    env = dict(os.environ)
+    buf = io.StringIO()
+    t0 = time.time()
+    with redirect_stdout(buf):
+        rc = launch.supervise([_py("import time; time.sleep(600)"), _py("import sys; sys.exit(3)")], [env, env], timeout_s=120)
+    assert rc == 3
+    assert time.time() - t0 < 20
+    assert buf.getvalue() == ""
+
+
+def test_launcher_deadline_counts_from_launch_and_kills_silent_workers():
+    import time
+    from laplace_amd import launch
+    env = dict(os.environ)
+    t0 = time.time()
+    rc = launch.supervise([_py("import time; time.sleep(600)"), _py("import time; time.sleep(600)")], [env, env], timeout_s=2)
+    assert rc == 124 and time.time() - t0 < 20
+
+
+def test_launcher_hands_rank0s_result_line_through_when_all_workers_succeed(capfd):
+    from laplace_amd import launch
+    env = dict(os.environ)
+    rc = launch.supervise([_py("print('noise'); print('{\"metric\": \"m\", \"value\": 1}')"), _py("pass")], [env, env], timeout_s=60)
+    out, err = capfd.readouterr()
+    assert rc == 0 and out.strip() == '{"metric": "m", "value": 1}' and "noise" in err
+
+
+def test_launcher_fails_when_rank0_succeeds_without_a_result_line():
+    from laplace_amd import launch
+    env = dict(os.environ)
+    assert launch.supervise([_py("print('hello')"), _py("pass")], [env, env], timeout_s=60) == 1
+
+
+def test_bench_parent_uses_the_launcher_and_fails_fast_without_gpus():
+    """python bench.py --gpus 2 here (no GPU): both workers exit non-zero at once ('needs a GPU'); the parent must
+    return non-zero promptly and print no result line."""
+    import subprocess
+    import time
+    if t.cuda.is_available():
+        import pytest
+        pytest.skip("CPU-only check of the launcher's failure path")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0 and r.stdout.strip() == ""
+    assert "needs a GPU" in r.stderr and "stopping the other workers" in r.stderr
+    assert time.time() - t0 < 120

@@ -37,15 +37,28 @@ def _batches(step):
     return out
 
 
-def _worker(rank, world, port, ret, sparse_batch, reorder=False):
+def _worker(rank, world, port, ret, sparse_batch, reorder=False, min_edges=None):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import datetime
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
     t.set_num_threads(2)
     import cpu_ops
+    import laplace_amd.dist as D_
     from laplace_amd.dist import ShardedLightGCNTrainer
+    if min_edges is not None:
+        D_.REORDER_MIN_EDGES_PER_RANK = min_edges
+    if reorder == "disagree":   # ranks passing different explicit values must be told so, not left to hang
+        try:
+            ShardedLightGCNTrainer(LightGCN_(rank), Interactions_(rank), lr=1e-2, Lambda=1e-4, batch_size=B, seed=3,
+                                   ops_impl=cpu_ops, reorder=bool(rank))
+            ret[rank] = "no error"
+        except ValueError as e:
+            ret[rank] = str(e)
+        dist.destroy_process_group()
+        return
     from laplace_amd.interactions import Interactions
     from laplace_amd.model.lightgcn import LightGCN
     ei = _shards()[rank]
@@ -63,6 +76,8 @@ def _worker(rank, world, port, ret, sparse_batch, reorder=False):
         losses.append(float(tr.step(_batches(s)[rank])))
     fin = tr.forward().clone()
     item_order = None
+    if reorder is None:
+        reorder = tr.order is not None
     if reorder:  # rows back under their original ids; every rank must have numbered the items alike
         fin = fin[tr.order.node_new_of_old()]
         item_order = tr.order.item_new_of_old.clone()
@@ -72,20 +87,44 @@ def _worker(rank, world, port, ret, sparse_batch, reorder=False):
     dist.destroy_process_group()
 
 
+def LightGCN_(rank):
+    from laplace_amd.model.lightgcn import LightGCN
+    return LightGCN((U0, U1)[rank], I, D, K)
+
+
+def Interactions_(rank):
+    from laplace_amd.interactions import Interactions
+    return Interactions(_shards()[rank], (U0, U1)[rank], I)
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("sparse_batch,reorder", [(False, False), (True, False), (True, True)])
-def test_two_rank_sharded_training_equals_single_process_reference(sparse_batch, reorder):
+def test_explicit_reorder_arguments_that_differ_across_ranks_raise_on_every_rank():
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(2, _free_port(), ret, True, "disagree"), nprocs=2, join=True)
+    assert "differs across ranks" in ret[0] and "differs across ranks" in ret[1]
+
+
+@pytest.mark.parametrize("sparse_batch,reorder,min_edges", [(False, False, None), (True, False, None), (True, True, None),
+                                                            (True, None, 440), (True, None, 441)])
+def test_two_rank_sharded_training_equals_single_process_reference(sparse_batch, reorder, min_edges):
     """reorder=True: each rank trains under the locality order (items ranked by their all-reduced GLOBAL degree, so
-    the replicas agree on the numbering; users relabelled locally) and still reproduces the reference loop."""
+    the replicas agree on the numbering; users relabelled locally) and still reproduces the reference loop.
+    reorder=None with the threshold BETWEEN the two shards' edge counts (500 and 380 edges): the default is decided on
+    the all-reduced total (880 >= 2 x 440: both ranks reorder; < 2 x 441: neither does) — a rank-local rule would put
+    rank 0 into an all-reduce rank 1 never joins."""
     from oracle import lightgcn_ref as R
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(2, _free_port(), ret, sparse_batch, reorder), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, _free_port(), ret, sparse_batch, reorder, min_edges), nprocs=2, join=True)
+    if reorder is None:
+        assert (ret[0]["item_order"] is not None) == (min_edges == 440) == (ret[1]["item_order"] is not None)
+        reorder = min_edges == 440
     if reorder:
         assert t.equal(ret[0]["item_order"], ret[1]["item_order"])
 

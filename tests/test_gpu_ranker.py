@@ -322,6 +322,23 @@ def test_gather_cat_forward_and_deterministic_backward():
         assert t.equal(ag.grad, first)
 
 
+def test_gather_cat_backward_beyond_the_all_pairs_range_is_deterministic_too():
+    """More label edges than mi_gather_cat_bwd_max_edges: the sum runs as a product with the sorted incidence CSR
+    (edge order inside a node's row), not through torch's atomic index_add_."""
+    from laplace_amd import _lib, ops
+    ne = int(_lib.lib().mi_gather_cat_bwd_max_edges()) + 1234
+    g = t.Generator().manual_seed(9)
+    n, cu, ci = 700, 64, 64
+    idx = t.randint(0, n, (ne,), generator=g)
+    idx[: ne // 3] = 3                                   # one node named by a third of the edges
+    d_out = t.randn(ne, cu + ci, generator=g)
+    want = t.zeros(n, ci, dtype=t.float64).index_add_(0, idx, d_out[:, cu:].double())
+    a = ops.gather_cat_bwd(d_out.to(DEV), idx.to(DEV), n, ci, cu)
+    assert (a.cpu().double() - want).abs().max() <= 1e-5 * float(want.abs().max())
+    for _ in range(2):
+        assert t.equal(ops.gather_cat_bwd(d_out.to(DEV), idx.to(DEV), n, ci, cu), a)
+
+
 @pytest.mark.parametrize("aggr,embedding", [("add", True), ("mean", True), ("max", False)])
 def test_fused_ranker_step_equals_the_autograd_iteration(aggr, embedding):
     """ranker_step.FusedRankerStep: the training iteration as straight-line code (no autograd engine) gives the loss,

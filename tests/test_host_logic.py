@@ -148,5 +148,5 @@ def test_bench_self_launch_parent_never_needs_a_gpu_and_reports_worker_failure()
     r = subprocess.run([_sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
                        capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode != 0
-    assert "needs a GPU" in r.stderr and "no result line" in r.stderr
+    assert "needs a GPU" in r.stderr and "exited with code" in r.stderr
     assert r.stdout.strip() == ""

@@ -4,9 +4,9 @@
 # the shader clock needs ~15 ms of load to settle after an idle start (809 -> 727 us per chunk), medians are of the settled half.
 export TMPDIR=/tmp
 P=laplace-gnn-recommendation_amd
-cp $P/liblaplace_hip.so $P/liblaplace_hip_full.so
+# the variant is selected through LAPLACE_HIP_LIB (laplace_amd/_lib.py): the product library is never overwritten
 for v in full "$@"; do
-  cp $P/liblaplace_hip_$v.so $P/liblaplace_hip.so
+  if [ "$v" = full ]; then export LAPLACE_HIP_LIB=$PWD/$P/liblaplace_hip.so; else export LAPLACE_HIP_LIB=$PWD/$P/liblaplace_hip_$v.so; fi
   rm -rf /tmp/tk_$v
   timeout -k 10 150 rocprofv3 --kernel-trace -d /tmp/tk_$v --output-format csv -- python3 tools/bench_topk.py --full --users 131072 > /dev/null 2>&1
   python3 - <<EOF2
@@ -19,4 +19,3 @@ h = len(d) // 2   # first half: k = 12, second half: k = 256; the clock takes ~2
 print("$v", f"full chunks, settled: k=12 median {st.median(d[h // 2:h]):.0f} us, k=256 median {st.median(d[h + h // 2:]):.0f} us; first chunk {d[0]:.0f} us")
 EOF2
 done
-cp $P/liblaplace_hip_full.so $P/liblaplace_hip.so
