@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MI_ABI_VERSION 7
+#define MI_ABI_VERSION 8
 
 #define MI_ERR_BAD_ARG      (-1)  /* null pointer, negative size, misaligned buffer   */
 #define MI_ERR_TOO_LARGE    (-2)  /* a size does not fit int32 indexing                */
@@ -514,6 +514,16 @@ int mi_match_common_items_i32(int64_t n_queries, const int64_t* query_users,
                               const int32_t* users_ptr, const int32_t* users_idx,
                               const int32_t* articles_ptr, const int32_t* articles_idx,
                               int32_t k, int32_t* out, int32_t* out_count, mi_stream_t stream);
+
+/* N3  candidate matcher: items bought by the customers at the query user's location.
+ * replaces: UsersSameLocationMatcher.get_matches at data/matching/fashion/users_same_location.py:15-25
+ *           (t.cat of the article lists of customers_per_location[location_for_user[u]], [:k]).
+ * location_of_user int32[num_users] (negative = unknown: no proposals); loc_ptr/loc_idx: customers per location in
+ * list order; users_ptr/users_idx as above.  Output as mi_match_common_items_i32. */
+int mi_match_same_location_i32(int64_t n_queries, const int64_t* query_users, const int32_t* location_of_user,
+                               const int32_t* loc_ptr, const int32_t* loc_idx,
+                               const int32_t* users_ptr, const int32_t* users_idx,
+                               int32_t k, int32_t* out, int32_t* out_count, mi_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * N1  on-device N-hop subgraph sampler for the ranker.

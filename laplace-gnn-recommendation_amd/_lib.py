@@ -10,7 +10,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 # the package directory is never overwritten by an experiment.  It is still this library or nothing — no fallback.
 LIB_PATH = os.environ.get("LAPLACE_HIP_LIB") or os.path.join(PKG_DIR, "liblaplace_hip.so")
 
-MI_ABI_VERSION = 7
+MI_ABI_VERSION = 8
 MI_SPMM_GROUP = 32
 
 
@@ -120,6 +120,7 @@ _PROTOTYPES = {
     "mi_gather_cat_bwd_max_edges": (c_int64, []),
     "mi_gather_cat_bwd_f32": (c_int32, [c_int64, c_int64, c_int64, P, P, c_int64, P, c_int64, P]),
     "mi_match_common_items_i32": (c_int32, [c_int64, P, P, P, P, P, c_int32, P, P, P]),
+    "mi_match_same_location_i32": (c_int32, [c_int64, P, P, P, P, P, P, c_int32, P, P, P]),
     "mi_sampler_workspace_bytes": (c_size_t, [POINTER(SamplerDesc)]),
     "mi_sampler_count": (c_int32, [POINTER(SamplerDesc), P, c_uint64, c_uint64, P, c_size_t, POINTER(c_int64), P]),
     "mi_sampler_count_async": (c_int32, [POINTER(SamplerDesc), P, c_uint64, c_uint64, P, c_size_t, P, P]),

@@ -9,6 +9,13 @@ the reference materialises every article of every co-purchasing user and then ke
                                user of that article (list order, the user itself included), all their
                                articles (data/matching/users_with_common_purchases.py:14-26)
 
+  UsersSameLocationMatcher     first k entries of: for each customer at the user's location (list order, the user
+                               itself included), all their articles (data/matching/fashion/users_same_location.py:8-25;
+                               commented out of the reference's get_matchers, kept here the same way)
+
+All four are pinned against the reference's own classes: tests/golden/matchers.pt (tests/make_golden.py runs them on
+small dict-of-list files) — host forms in tests/test_oracle_golden.py, device forms in tests/test_gpu_matching.py.
+
 Device forms: every matcher also answers for ALL users at once as a device tensor [U, k] (int64, -1 = no
 proposal) through `matches_for_all_device(num_users, device)` — the common-purchase expansion is the HIP kernel
 mi_match_common_items_i32, popularity is a device argsort of the degrees, the LightGCN rows are a slice of the top-K
@@ -101,6 +108,47 @@ class UsersWithCommonItemsMatcher(Matcher):
                 if have >= self.k:
                     return t.from_numpy(np.concatenate(out)[: self.k].astype(np.int64))
         return t.from_numpy(np.concatenate(out).astype(np.int64)) if out else t.empty(0, dtype=t.long)
+
+
+class UsersSameLocationMatcher(Matcher):
+    def __init__(self, customers_per_location, location_for_user, users_adj, k: int):
+        """customers_per_location: dict location -> [customer ids] (customers_per_location.pt); location_for_user: dict
+        or array customer -> location (location_for_user.pt); users_adj: edges_<split>.pt."""
+        self.users = users_adj if isinstance(users_adj, AdjList) else AdjList(users_adj)
+        n_users = len(self.users)
+        if isinstance(location_for_user, dict):
+            loc = np.full(n_users, -1, dtype=np.int64)
+            for u, l in location_for_user.items():
+                if 0 <= int(u) < n_users:
+                    loc[int(u)] = int(l)
+        else:
+            loc = np.asarray(location_for_user, dtype=np.int64)
+        self.location_for_user = loc
+        n_loc = max([int(loc.max()) + 1 if loc.size else 0] + [int(l) + 1 for l in customers_per_location])
+        self.customers = AdjList({int(l): list(v) for l, v in customers_per_location.items()}, n_loc)
+        self.k = int(k)
+
+    def get_matches(self, user_id: int) -> Tensor:
+        loc = int(self.location_for_user[user_id])
+        out: List[np.ndarray] = []
+        have = 0
+        if loc >= 0:
+            for v in self.customers[loc]:
+                lst = self.users[int(v)]
+                out.append(lst)
+                have += len(lst)
+                if have >= self.k:
+                    break
+        return t.from_numpy(np.concatenate(out)[: self.k].astype(np.int64)) if out else t.empty(0, dtype=t.long)
+
+    def matches_for_all_device(self, num_users: int, device) -> Tensor:
+        from .. import ops
+        if getattr(self, "_dev", None) is None or self._dev[0].device != t.device(device):
+            to32 = lambda a: t.from_numpy(np.ascontiguousarray(np.asarray(a).astype(np.int32))).to(device)
+            self._dev = (to32(self.location_for_user), to32(self.customers.ptr), to32(self.customers.idx),
+                         to32(self.users.ptr), to32(self.users.idx))
+        out, _ = ops.match_same_location(*self._dev, self.k, n_queries=num_users)
+        return out.to(t.int64)
 
 
 def get_matchers(dataset_type: str, users_adj, articles_adj, candidate_pool_size: int) -> List[Matcher]:

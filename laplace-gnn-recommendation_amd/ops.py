@@ -715,6 +715,29 @@ def match_common_items(users_ptr: Tensor, users_idx: Tensor, articles_ptr: Tenso
     return out, cnt
 
 
+def match_same_location(location_of_user: Tensor, loc_ptr: Tensor, loc_idx: Tensor, users_ptr: Tensor, users_idx: Tensor,
+                        k: int, query_users: Optional[Tensor] = None, n_queries: Optional[int] = None):
+    """N3 — UsersSameLocationMatcher for many users at once: (out int32[n, k] with -1 pads, counts int32[n])."""
+    for n, x in (("location_of_user", location_of_user), ("loc_ptr", loc_ptr), ("loc_idx", loc_idx),
+                 ("users_ptr", users_ptr), ("users_idx", users_idx)):
+        _need(x, t.int32, n)
+    if query_users is not None:
+        _need(query_users, t.int64, "query_users")
+        n_queries = query_users.numel()
+    elif n_queries is None:
+        n_queries = location_of_user.numel()
+    if location_of_user.numel() != users_ptr.numel() - 1:
+        raise ValueError("location_of_user must have one entry per user")
+    dev = users_ptr.device
+    out = t.empty(n_queries, int(k), dtype=t.int32, device=dev)
+    cnt = t.empty(n_queries, dtype=t.int32, device=dev)
+    check(_lib.lib().mi_match_same_location_i32(n_queries, _ptr(query_users), location_of_user.data_ptr(), loc_ptr.data_ptr(),
+                                                loc_idx.data_ptr() if loc_idx.numel() else loc_ptr.data_ptr(),
+                                                users_ptr.data_ptr(), users_idx.data_ptr() if users_idx.numel() else users_ptr.data_ptr(),
+                                                int(k), _ptr(out), _ptr(cnt), _stream()), "mi_match_same_location_i32")
+    return out, cnt
+
+
 _BN_WS = {}
 
 

@@ -142,6 +142,67 @@ def time_split_golden() -> None:
             "rev_edges_train": extract_reverse_edges(tr)}, os.path.join(OUT, "time_split.pt"))
 
 
+def matchers_golden() -> None:
+    """tests/golden/matchers.pt: the reference's OWN matcher classes (data/matching/*.py) run on small dict-of-list
+    files written into a temporary cwd in the layout their constructors read (data/derived/edges_<split>.pt, ...).
+    Stored: the inputs (plain dicts / lists) and get_matches(user) for every user that has purchases, several k."""
+    import tempfile
+    import numpy as np
+    sys.path.insert(0, REF)
+    from data.matching import LightGCNMatcher, PopularItemsMatcher, UsersSameLocationMatcher, UsersWithCommonItemsMatcher
+    rng = np.random.default_rng(5)
+    U, A, E, L = 70, 45, 420, 9
+    cu, ca = rng.integers(0, U, E), rng.integers(0, A, E)
+    cu[cu == 11] = 12                                  # user 11 buys nothing; duplicates (repeat purchases) are kept
+    ca[:40] = 3                                        # a hub article
+    edges, rev = {}, {}
+    for u, a in zip(cu.tolist(), ca.tolist()):         # list order = transaction order (utils/preprocessing.py:84-89)
+        edges.setdefault(u, []).append(a)
+        rev.setdefault(a, []).append(u)
+    popular = [int(x) for x in np.argsort(-np.bincount(ca, minlength=A), kind="stable")]
+    g = t.Generator().manual_seed(3)
+    top = t.stack([t.randperm(A, generator=g)[:20] for _ in range(U)])
+    location_for_user = {u: int(rng.integers(0, L)) for u in range(U)}
+    customers_per_location = {}
+    for u in range(U):
+        customers_per_location.setdefault(location_for_user[u], []).append(u)
+    cwd = os.getcwd()
+    out = {"edges": edges, "rev_edges": rev, "popular": popular, "lightgcn_top": top, "location_for_user": location_for_user,
+           "customers_per_location": customers_per_location, "num_users": U, "num_articles": A, "matches": {}}
+    with tempfile.TemporaryDirectory() as tmp:
+        os.makedirs(os.path.join(tmp, "data", "derived"))
+        d = os.path.join(tmp, "data", "derived")
+        t.save(edges, os.path.join(d, "edges_train.pt"))
+        t.save(rev, os.path.join(d, "rev_edges_train.pt"))
+        t.save(popular, os.path.join(d, "most_popular_products.pt"))
+        t.save(top, os.path.join(d, "lightgcn_output.pt"))
+        t.save(location_for_user, os.path.join(d, "location_for_user.pt"))
+        t.save(customers_per_location, os.path.join(d, "customers_per_location.pt"))
+        os.chdir(tmp)
+        try:
+            for k in (1, 7, 50, 300):
+                common = UsersWithCommonItemsMatcher(k, "train")
+                loc = UsersSameLocationMatcher(k, "train")
+                pop = PopularItemsMatcher(k)
+                lg = LightGCNMatcher(k)
+                res = {"common": {}, "location": {}, "popular": pop.get_matches(0).clone(), "lightgcn": {}}
+                for u in range(U):
+                    res["lightgcn"][u] = lg.get_matches(u).clone()
+                    if u in edges:                      # the reference raises KeyError for a user without purchases
+                        res["common"][u] = common.get_matches(u).clone()
+                    # same-location: every customer at the location must have purchases or the reference raises
+                    if all(v in edges for v in customers_per_location[location_for_user[u]]):
+                        res["location"][u] = loc.get_matches(u).clone()
+                out["matches"][k] = res
+        finally:
+            os.chdir(cwd)
+    t.save(out, os.path.join(OUT, "matchers.pt"))
+    n_loc = len(out["matches"][7]["location"])
+    print(f"  matchers.pt: {os.path.getsize(os.path.join(OUT, 'matchers.pt'))} bytes ({len(out['matches'][7]['common'])} common-item users, {n_loc} same-location users)")
+
+
 if __name__ == "__main__":
-    main()
-    time_split_golden()
+    if "--only-matchers" not in sys.argv:
+        main()
+        time_split_golden()
+    matchers_golden()

@@ -39,6 +39,51 @@ def test_common_items_matcher_device_equals_host(k):
     assert int((got[0] >= 0).sum()) == 0             # a user without purchases proposes nothing
 
 
+def test_device_matchers_equal_the_reference_classes(golden_dir):
+    """The DEVICE forms against get_matches of the reference's own classes (tests/golden/matchers.pt): common
+    purchases (mi_match_common_items_i32), same location (mi_match_same_location_i32), popularity, LightGCN rows."""
+    import os
+    from laplace_amd.data.dataset import AdjList
+    from laplace_amd.data.matching import (LightGCNMatcher, PopularItemsMatcher, UsersSameLocationMatcher,
+                                           UsersWithCommonItemsMatcher)
+    fx = t.load(os.path.join(golden_dir, "matchers.pt"), weights_only=False)
+    U, A = fx["num_users"], fx["num_articles"]
+    users, articles = AdjList(fx["edges"], U), AdjList(fx["rev_edges"], A)
+    deg = t.from_numpy(np.diff(articles.ptr)).to(DEV)
+    for k, res in fx["matches"].items():
+        got_c = UsersWithCommonItemsMatcher(users, articles, k).matches_for_all_device(U, DEV).cpu()
+        got_l = UsersSameLocationMatcher(fx["customers_per_location"], fx["location_for_user"], users, k).matches_for_all_device(U, DEV).cpu()
+        got_g = LightGCNMatcher(fx["lightgcn_top"].to(DEV), k).matches_for_all_device(U, DEV).cpu()
+        got_p = PopularItemsMatcher.from_degrees_device(deg, k).matches_for_all_device(U, DEV).cpu()
+        assert got_c.shape == (U, k) and got_l.shape == (U, k)
+        for name, got, table in (("common", got_c, res["common"]), ("location", got_l, res["location"]), ("lightgcn", got_g, res["lightgcn"])):
+            for u, want in table.items():
+                n = want.numel()
+                assert t.equal(got[u, :n], want), (name, k, u)
+                assert bool((got[u, n:] == -1).all()), (name, k, u)
+        assert t.equal(got_p[0], res["popular"]) and t.equal(got_p[U - 1], res["popular"])
+        assert int((got_c[11] >= 0).sum()) == 0          # user 11 has no purchases: the reference raises, the device proposes nothing
+
+
+@pytest.mark.parametrize("k", [3, 64, 200])
+def test_same_location_matcher_device_equals_host(k):
+    from laplace_amd.data.matching import UsersSameLocationMatcher
+    users, articles, U, A = _adj(20 + k)
+    g = np.random.default_rng(k)
+    loc = g.integers(0, 12, U)
+    loc[5] = -1                                           # unknown location: no proposals
+    per = {}
+    for u in g.permutation(U).tolist():                   # list order is not id order
+        if loc[u] >= 0:
+            per.setdefault(int(loc[u]), []).append(u)
+    m = UsersSameLocationMatcher(per, loc, users, k)
+    got = m.matches_for_all_device(U, DEV).cpu()
+    for u in range(U):
+        want = m.get_matches(u)
+        assert t.equal(got[u, : want.numel()], want) and bool((got[u, want.numel():] == -1).all()), u
+    assert int((got[5] >= 0).sum()) == 0
+
+
 def test_popular_and_lightgcn_matchers_device_and_candidate_csr():
     from laplace_amd.data.device_sampler import candidate_csr, candidate_csr_device
     from laplace_amd.data.matching import LightGCNMatcher, PopularItemsMatcher, UsersWithCommonItemsMatcher

@@ -220,3 +220,37 @@ if _HAVE_HYPOTHESIS:
         assert (got_c.double() - want).abs().max() <= tol
         assert (got_t.double() - want).abs().max() <= tol
         assert (got_sp.double() - want).abs().max() <= tol
+
+
+# ---- N3: the host matchers against the reference's OWN classes (tests/golden/matchers.pt <- tests/make_golden.py) ----------
+
+def _matcher_fixture(golden_dir):
+    import os
+    return t.load(os.path.join(golden_dir, "matchers.pt"), weights_only=False)
+
+
+def test_matchers_equal_the_reference_classes(golden_dir):
+    """data/matching/{users_with_common_purchases,lightgcn}.py, fashion/{popular_items,users_same_location}.py:
+    get_matches(user) of the reference's classes on the same dict-of-list inputs, for every user the reference
+    answers for (it raises KeyError on a user without purchases), k in {1, 7, 50, 300}."""
+    from laplace_amd.data.dataset import AdjList
+    from laplace_amd.data.matching import (LightGCNMatcher, PopularItemsMatcher, UsersSameLocationMatcher,
+                                           UsersWithCommonItemsMatcher)
+    fx = _matcher_fixture(golden_dir)
+    U, A = fx["num_users"], fx["num_articles"]
+    users, articles = AdjList(fx["edges"], U), AdjList(fx["rev_edges"], A)
+    for k, res in fx["matches"].items():
+        common = UsersWithCommonItemsMatcher(users, articles, k)
+        loc = UsersSameLocationMatcher(fx["customers_per_location"], fx["location_for_user"], users, k)
+        pop = PopularItemsMatcher(fx["popular"], k)
+        lg = LightGCNMatcher(fx["lightgcn_top"], k)
+        assert len(res["common"]) >= 60 and len(res["location"]) >= 50
+        for u, want in res["common"].items():
+            assert t.equal(common.get_matches(u), want), (k, u)
+        for u, want in res["location"].items():
+            assert t.equal(loc.get_matches(u), want), (k, u)
+        for u, want in res["lightgcn"].items():
+            assert t.equal(lg.get_matches(u), want), (k, u)
+        assert t.equal(pop.get_matches(0), res["popular"]) and pop.get_matches(0).dtype == t.int64
+    # the popularity order the fixture was built with is the one from_adjacency derives from the reverse lists
+    assert PopularItemsMatcher.from_adjacency(articles, 300).popular_items.tolist() == fx["popular"]
