@@ -44,8 +44,8 @@ class SpmmSweepStruct(Structure):
 
 class SpmmExStruct(Structure):
     _fields_ = [("x_map", c_void_p), ("addend_map", c_void_p), ("row_list", c_void_p), ("n_list_dev", c_void_p),
-                ("n_list", c_int64), ("adam", POINTER(AdamArgs)), ("parts", c_int32), ("reserved", c_int32),
-                ("sweep", POINTER(SpmmSweepStruct))]
+                ("n_list", c_int64), ("adam", POINTER(AdamArgs)), ("parts", c_int32), ("hot_rows", c_int32),
+                ("sweep", POINTER(SpmmSweepStruct)), ("hot_base", c_int32), ("hot_threads", c_int32)]
 
 
 MI_SPMM_SHORT_ROWS, MI_SPMM_SPLIT_ROWS = 1, 2

@@ -109,6 +109,8 @@ class ShardedLightGCNTrainer:
         self.adj_fwd = raw  # kept whole for bookkeeping (bench reads nnz / n_rows)
         self.a_users = self.ops.row_slice(raw, 0, U)
         self.a_items = self.ops.row_slice(raw, U, n)
+        if self.order is not None and self.ops is hip_ops:
+            self.a_users.hot = hip_ops.hot_item_rows(U, I)   # popular items first: LDS hot-row cache of the user-row products
         self.a_users.plan = self.ops.build_spmm_plan(self.a_users)
         self.a_items.plan = self.ops.build_spmm_plan(self.a_items)
 

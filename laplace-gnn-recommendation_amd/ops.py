@@ -6,6 +6,7 @@ function requires GPU tensors and raises otherwise — there is no CPU path in t
 from __future__ import annotations
 
 import ctypes
+from os import environ as _os_environ
 from dataclasses import dataclass, field
 from typing import Optional, Tuple
 
@@ -137,6 +138,7 @@ class DeviceCSR:
     val: Optional[Tensor] = None
     perm: Optional[Tensor] = None
     plan: Optional[SpmmPlan] = None
+    hot: Optional[Tuple[int, int]] = None   # (first row, rows) of X worth an LDS cache in dense launches: see spmm()
 
     @property
     def nnz(self) -> int:
@@ -219,7 +221,27 @@ def scale_csr(a: DeviceCSR, val_in: Optional[Tensor] = None, row_scale: Optional
 
 def row_slice(a: DeviceCSR, r0: int, r1: int) -> DeviceCSR:
     """Rows [r0, r1) of `a` as a CSR that shares col/val storage (rowptr keeps absolute offsets)."""
-    return DeviceCSR(r1 - r0, a.n_cols, a.rowptr[r0:r1 + 1], a.col, a.val, None)
+    return DeviceCSR(r1 - r0, a.n_cols, a.rowptr[r0:r1 + 1], a.col, a.val, None, None, a.hot)
+
+
+# LDS hot-row cache of the dense short-row launches (include/laplace_hip.h, mi_spmm_ex.hot_rows): module switches for A/B
+# Persistent, software-pipelined short-row launch (+ optional LDS hot-row cache).  OFF by default: measured on C2 (round 3,
+# profiles/r03_spmm_rows_persistent.md) it is 5-15 % SLOWER than the plain launch — the propagate runs at the chip's
+# random-row gather ceiling for the bytes that miss L2 (5.0-5.5 TB/s of fabric traffic against the 5.5-5.8 TB/s the
+# guide measures for random whole rows), rows the LDS cache serves were L2 hits already, and fewer resident wavefronts
+# (86-105 VGPRs against 78) cost more than the shorter dependency chain returns.  Kept as a bitwise-equal alternative
+# (tests/test_gpu_lightgcn.py) for graphs / parts whose balance differs.
+PERSISTENT_ROWS = _os_environ.get("LAPLACE_PERSISTENT_ROWS", "0") == "1"
+HOT_ROWS = int(_os_environ.get("LAPLACE_HOT_ROWS", 304))        # rows offered to the cache (the kernel clips to its LDS share); 0 = off
+HOT_THREADS = int(_os_environ.get("LAPLACE_HOT_THREADS", 0))    # workgroup size of the persistent launch; 0 = the library's default
+
+
+def hot_item_rows(num_users: int, num_items: int) -> Optional[Tuple[int, int]]:
+    """The `hot` hint of a [users; items] adjacency whose items are numbered by popularity (interactions.LocalityOrder):
+    the first item rows are the ones most gathers go to."""
+    if HOT_ROWS <= 0 or num_items <= 0:
+        return None
+    return (int(num_users), int(min(HOT_ROWS, num_items)))
 
 
 SWEEP_BAND = 2048     # columns per band of a sweep plan: 2048 rows x 128 floats = 1 MB, a quarter of an XCD's L2
@@ -372,6 +394,10 @@ def spmm(a: DeviceCSR, X: Tensor, *, Y: Optional[Tensor] = None, addend: Optiona
     adam = dict(p=, m=, v=, step=, lr=, beta1=, beta2=, eps=, reg_w=): S's value is the gradient of parameter
     table p and is consumed in registers by the Adam update (adam_step's arithmetic); S itself may be None.
 
+    a.hot = (first row, rows): a speed hint for dense launches (no x_map / row_list) of a planned adjacency — those rows
+    of X are cached in LDS by a persistent short-row launch.  Same values, same summation order: the result is bitwise
+    the one without the hint.
+
     Sparse-operand forms (mi_spmm_csr_ex_f32): x_map int32[n_cols] — X is compact, column c reads
     X[x_map[c]], negative = an all-zero row; addend_map int32[n_rows] — addend is compact; row_list
     int32[n] (+ n_list_dev, device int32[1]) — compute only these rows, Y/S/addend compact by list position."""
@@ -439,15 +465,21 @@ def spmm(a: DeviceCSR, X: Tensor, *, Y: Optional[Tensor] = None, addend: Optiona
         ev = (t.cuda.Event(enable_timing=True), t.cuda.Event(enable_timing=True))
         ev[0].record()
     sweep = plan.sweep if (plan is not None and plan.sweep is not None) else None
+    hot_base, hot_rows = 0, (0 if PERSISTENT_ROWS else -1)
+    if (a.hot is not None and plan is not None and x_map is None and row_list is None and d <= 256 and HOT_ROWS > 0
+            and PERSISTENT_ROWS):
+        hot_base, hot_rows = int(a.hot[0]), int(a.hot[1])
+        if hot_base < 0 or hot_rows < 0 or hot_base + hot_rows > X.shape[0]:
+            raise ValueError(f"hot rows [{hot_base}, {hot_base + hot_rows}) lie outside X ({X.shape[0]} rows)")
 
     def launch(parts: int, stream: int) -> None:
         exs = None
         if (x_map is not None or addend_map is not None or row_list is not None or adam_args is not None or parts
-                or sweep is not None):
+                or sweep is not None or hot_rows != 0 or HOT_THREADS):
             exs = SpmmExStruct(_ptr(x_map), _ptr(addend_map), _ptr(row_list), _ptr(n_list_dev),
                                row_list.numel() if row_list is not None else 0,
-                               ctypes.pointer(adam_args) if adam_args is not None else None, parts, 0,
-                               ctypes.pointer(sweep) if sweep is not None else None)
+                               ctypes.pointer(adam_args) if adam_args is not None else None, parts, hot_rows,
+                               ctypes.pointer(sweep) if sweep is not None else None, hot_base, HOT_THREADS)
         check(L.mi_spmm_csr_ex_f32(a.n_rows, d, _ptr(a.rowptr), col_ptr, val_ptr, X.data_ptr(), ldx,
                                    _ptr(Y), ldy, _ptr(addend), lda, _ptr(S), lds, float(scale),
                                    ctypes.byref(plan.struct) if plan is not None else None,

@@ -89,6 +89,10 @@ class LightGCNTrainer:
             self.in_training_order = False
             self.to_training_order()
         self.adj_fwd, self.adj_bwd = adj.gcn_normalized(model.add_self_loops)
+        if self.order is not None:
+            # items are numbered by popularity: their first rows take half of all user-row gathers — dense launches keep
+            # them in LDS (ops.spmm, `hot`; a speed hint, results unchanged)
+            self.adj_fwd.hot = self.adj_bwd.hot = ops.hot_item_rows(model.num_users, model.num_items)
         self.train = train
         n, d = self.table.shape
         dev = self.table.device

@@ -375,6 +375,61 @@ def test_spmm_adam_epilogue_equals_spmm_then_adam(d, band):
             assert t.equal(G3, G) and t.equal(p3, p4) and t.equal(v3, v4)
 
 
+@pytest.mark.parametrize("d", [32, 64, 96, 128, 256])
+@pytest.mark.parametrize("threads", [0, 256, 1024])
+def test_spmm_hot_row_cache_is_bitwise_the_plain_launch(d, threads, monkeypatch):
+    """mi_spmm_ex.hot_rows: rows of X served from LDS by the persistent short-row launch — same entries, same order, same
+    bits as the plain launch: Y / S / addend_map / Adam epilogue forms, a cached range in the middle of X, at its end,
+    larger than the LDS share (clipped) and one row; split rows, empty rows and columns below the range alongside."""
+    ops = _ops()
+    monkeypatch.setattr(ops, "HOT_THREADS", threads)
+    n_u, n_i = 1500, 700
+    n = n_u + n_i
+    g = t.Generator().manual_seed(d + threads)
+    # bipartite-like: user rows gather item rows (popular ones first, Zipf-ish), item rows gather user rows
+    e = 30000
+    u = t.randint(0, n_u, (e,), generator=g)
+    i = (t.rand(e, generator=g).pow(3) * n_i).long().clamp(max=n_i - 1) + n_u
+    rows, cols = t.cat([u, i]), t.cat([i, u])
+    rows[rows == 9] = 10                                   # an empty row
+    a = _csr_with_vals(rows, cols, n, n, seed=3)
+    a.plan = ops.build_spmm_plan(a, chunk=64, band=0)      # the popular item rows are split rows
+    assert a.plan.n_long_rows > 10
+    X, A = t.randn(n, d, generator=g).to(DEV), t.randn(n, d, generator=g).to(DEV)
+    nz = t.unique(t.randint(0, n, (400,), generator=g))
+    gmap = t.full((n,), -1, dtype=t.int32)
+    gmap[nz] = t.arange(nz.numel(), dtype=t.int32)
+    gmap = gmap.to(DEV)
+    Ac = t.randn(nz.numel(), d, generator=g).to(DEV)
+    hyp = dict(lr=1e-2, beta1=0.9, beta2=0.999, eps=1e-8, step=3)
+
+    def run(hot, persistent=True):
+        a.hot = hot
+        monkeypatch.setattr(ops, "PERSISTENT_ROWS", persistent)
+        out = []
+        Y, S = t.empty(n, d, device=DEV), t.empty(n, d, device=DEV)
+        ops.spmm(a, X, Y=Y)
+        out.append(Y.clone())
+        ops.spmm(a, X, Y=Y, addend=A, S=S, scale=0.25)
+        out += [Y.clone(), S.clone()]
+        ops.spmm(a, X, addend=Ac, addend_map=gmap, S=S, scale=1.0)
+        out.append(S.clone())
+        p, m, v = A.clone(), t.zeros(n, d, device=DEV), t.zeros(n, d, device=DEV)
+        ops.spmm(a, X, addend=Ac, addend_map=gmap, adam=dict(p=p, m=m, v=v, **hyp))
+        out += [p, m, v]
+        return out
+
+    want = run(None, persistent=False)                     # the plain one-workgroup-per-8-rows launch
+    assert t.allclose(want[0].cpu(), _oracle_spmm(a, X), atol=2e-4, rtol=1e-4)
+    for hot in (None, (n_u, 64), (n_u, n_i), (n_u + n_i - 5, 5), (n_u + 17, 1), (0, 300), (n_u - 8, 40)):
+        got = run(hot)
+        for w, h in zip(want, got):
+            assert t.equal(w, h), hot
+    a.hot = (n - 2, 3)                                     # past the end of X: refused by the wrapper
+    with pytest.raises(ValueError):
+        ops.spmm(a, X, Y=t.empty(n, d, device=DEV))
+
+
 def test_spmm_halves_on_two_streams_equal_the_whole_product():
     """mi_spmm_ex.parts: short rows and split rows write disjoint output rows; enqueued on two streams (ops.SPMM_TWO_STREAMS)
     they give the bits of the single call."""
@@ -808,6 +863,9 @@ def c2_graph():
     return ei, inter, adj
 
 
+S_C2_USERS = 1_000_000
+
+
 def test_full_size_propagate_properties(c2_graph):
     """Size-independent properties at the benchmark's full size, D=128:
     linearity, the D^1/2 eigenvector of the normalised adjacency, run-to-run bit stability, and a
@@ -828,6 +886,17 @@ def test_full_size_propagate_properties(c2_graph):
     y2 = t.empty(n, d, device=DEV)
     ops.spmm(adj, X, Y=y2)
     assert t.equal(y2, yx)  # bitwise reproducible (no float atomics anywhere in the propagate)
+    # the plain short-row launch and the persistent one with an LDS hot-row cache (ops.spmm `hot`) give the same bits,
+    # whatever the cached range — first item rows, or user rows
+    was = ops.PERSISTENT_ROWS
+    try:
+        for persistent, hot in ((False, None), (True, None), (True, (S_C2_USERS, 304)), (True, (1234, 100))):
+            ops.PERSISTENT_ROWS, adj.hot = persistent, hot
+            y2.fill_(float("nan"))
+            ops.spmm(adj, X, Y=y2)
+            assert t.equal(y2, yx), (persistent, hot)
+    finally:
+        ops.PERSISTENT_ROWS, adj.hot = was, None
     # A~ (D^1/2 1) = D^-1/2 A 1 = D^1/2 1 on rows with deg > 0
     deg = (adj.rowptr[1:] - adj.rowptr[:-1]).float()
     v = deg.sqrt()[:, None].expand(n, 4).contiguous()
