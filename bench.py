@@ -12,23 +12,45 @@ dense Adam over the whole table (run_pipeline_lightgcn.py:117-159).
                          by user_id // ceil(U/N) over the N ranks (items replicated, one RCCL all-reduce of the item
                          rows per layer), global batch 131072: total work fixed, "scaling": "strong".
 
+The default N=1 run carries, after the timed region, the metric's other configurations as blocks of the same JSON line:
+  "c4_n1"      BASELINE configs[3] on one GPU (ms/step, positive-edges/s, roofline with live PMC traffic, cpu_baseline
+               from ONE CPU step)                                                            [--no-c4 to skip]
+  "ranker_c3"  BASELINE configs[2]: the encoder-decoder ranker's training loop at the full H&M shape, 24 users per
+               batch, on-device 2-hop sampling (tools/bench_ranker.py's bench line)          [--no-ranker to skip]
+  "map_at_12"  ranking quality on a PLANTED-structure graph (synthetic.SyntheticSpec.communities), layer-0 predictor vs
+               propagated embeddings vs popularity                                           [--no-map to skip]
+
+roofline.traffic is measured in THIS invocation: before the parent touches the GPU it runs itself twice per
+configuration as a short child under `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes, no trace
+domains) and reads the per-dispatch counters of the propagate kernels.                       [--no-pmc to skip]
+
 Launch: python bench.py --gpus N --steps K --warmup W      (N>1: the parent starts N worker processes itself, before
         touching the GPU) or, equivalently, python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 Prints ONE JSON line (rank 0).
 """
 import argparse
+import collections
+import csv
+import glob
 import hashlib
 import json
 import os
+import re
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured achievable rate
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); the guide's measured rates: 6.0-6.1 TB/s for an in-order
+                       # sweep, 5.5-5.8 TB/s for random whole rows gathered from beyond the caches
 C4_GLOBAL_BATCH = 131072
+# the planted-structure graph of the MAP@12 leg: small enough that 100 steps are a few epochs
+MAP_SPEC = dict(num_users=50_000, num_items=5_000, num_edges=1_000_000, seed=5, communities=32, community_mix=0.9, deg_max=2000)
 
 
 def parse_args():
@@ -44,13 +66,19 @@ def parse_args():
     ap.add_argument("--layers", type=int, default=3)
     ap.add_argument("--batch", type=int, default=None, help="positive edges per GPU (c2) / per job (c4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-baseline", action="store_true", help="time the CPU port on --config c4 too (minutes of host work)")
+    ap.add_argument("--cpu-baseline", action="store_true", help="time the CPU port when --config c4 is the headline too")
     ap.add_argument("--plain-step", action="store_true",
                     help="A/B: time the straightforward step (full final, dense gradient buffer) as the headline instead of the byte-saving one")
     ap.add_argument("--no-plain-leg", action="store_true", help="skip the extra plain-step timing (plain_step_ms)")
     ap.add_argument("--no-map", action="store_true", help="skip the MAP@12 leg")
-    ap.add_argument("--map-steps", type=int, default=1000, help="extra train steps before MAP@12 is scored")
+    ap.add_argument("--map-steps", type=int, default=100, help="train steps on the planted-structure graph before MAP@12 is scored")
     ap.add_argument("--map-users", type=int, default=20000)
+    ap.add_argument("--no-c4", action="store_true", help="skip the c4_n1 block (BASELINE configs[3] on one GPU)")
+    ap.add_argument("--c4-steps", type=int, default=10)
+    ap.add_argument("--no-ranker", action="store_true", help="skip the ranker_c3 block (BASELINE configs[2])")
+    ap.add_argument("--ranker-steps", type=int, default=400)
+    ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 --pmc passes (roofline.traffic falls back to profiles/traffic.json)")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)  # the short run the PMC passes profile
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--no-cpu-faithful", action="store_true", help="skip timing the reference's per-iteration sampler on the host")
     ap.add_argument("--no-reorder", action="store_true", help="A/B: train under the generator's ids instead of the locality order")
@@ -66,15 +94,210 @@ def spmm_bytes(nnz: int, n_rows: int, d: int) -> int:
 
 
 def kernel_source_hash() -> str:
-    """Identifies the propagate kernels a PMC traffic figure was collected on (profiles/traffic.json)."""
+    """Identifies the code a PMC traffic figure was collected on: the propagate kernels AND the host code that decides
+    their plans, launch forms and the node order (all of which move the traffic)."""
     h = hashlib.sha256()
-    for f in ("spmm.hip", "common.hpp"):
-        with open(os.path.join(ROOT, "laplace-gnn-recommendation_amd", "csrc", f), "rb") as fh:
+    pkg = os.path.join(ROOT, "laplace-gnn-recommendation_amd")
+    for f in ("csrc/spmm.hip", "csrc/common.hpp", "ops.py", "interactions.py", "trainer.py", "sparse.py"):
+        with open(os.path.join(pkg, f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
 
 
-def cpu_baseline(ei, U, I, args, B, table0):
+# ---- live PMC traffic ---------------------------------------------------------------------------------------------------
+
+def _short_kernel(name: str) -> str:
+    name = re.sub(r"\(anonymous namespace\)::", "", name)
+    name = re.sub(r"^void ", "", name)
+    m = re.match(r"([A-Za-z0-9_:]+(<[^(]*>)?)", name)
+    return (m.group(1) if m else name)[:80]
+
+
+def is_dense_spmm_kernel(k: str) -> bool:
+    """A kernel of the plain DENSE propagate launch: SPARSE=false and no optimizer epilogue."""
+    m = re.match(r"spmm_(rows_hot|rows|items|fixup|sweep)_kernel<([^>]*)>", k)
+    if not m:
+        return False
+    a = [x.strip() for x in m.group(2).split(",")]
+    flags = {"rows": a[4:6], "items": a[4:5], "fixup": a[2:4], "sweep": a[2:3], "rows_hot": a[2:3]}[m.group(1)]
+    return all(f == "false" for f in flags)
+
+
+def pmc_traffic(config: str, passthrough: list, timeout_s: float = 240.0):
+    """L2-miss (fabric) bytes per dense propagate launch of `config`, measured NOW: this script run as a short child
+    (3 steps) under rocprofv3 --pmc FETCH_SIZE and again under --pmc WRITE_SIZE (counters only: no trace domain beside
+    them), per-dispatch counters averaged per kernel, bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (MI355X_MICROARCH.md:
+    counters in KiB, FETCH_SIZE tallies 128-B requests at 64 B on gfx950).  Must be called BEFORE this process touches
+    the GPU (the children are ordinary fresh processes).  Returns (bytes, per_kernel dict, note) or (None, None, why)."""
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(prof):
+        return None, None, "rocprofv3 not found"
+    per = {}
+    t0 = time.time()
+    with tempfile.TemporaryDirectory(dir="/tmp", prefix="laplace_pmc_") as tmp:
+        env = dict(os.environ, TMPDIR="/tmp")
+        for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE"):
+            env.pop(k, None)
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, counter)
+            cmd = [prof, "--pmc", counter, "-d", out, "--output-format", "csv", "--", sys.executable, os.path.abspath(__file__),
+                   "--pmc-child", "--config", config, "--steps", "3", "--warmup", "1"] + passthrough
+            try:
+                r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                return None, None, f"rocprofv3 --pmc {counter} pass timed out"
+            if r.returncode != 0:
+                return None, None, f"rocprofv3 --pmc {counter} pass failed (rc {r.returncode}): {r.stderr.decode(errors='replace')[-300:]}"
+            files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
+            if not files:
+                return None, None, f"rocprofv3 --pmc {counter} wrote no counter file"
+            agg = collections.defaultdict(list)
+            for row in csv.DictReader(open(files[0])):
+                if row.get("Counter_Name", counter) == counter:
+                    agg[_short_kernel(row["Kernel_Name"])].append(float(row["Counter_Value"]))
+            per[counter] = {k: sum(v) / len(v) for k, v in agg.items()}
+    kernels = {}
+    for k in set(per["FETCH_SIZE"]) | set(per["WRITE_SIZE"]):
+        if k.startswith("spmm_") or "adam" in k:
+            kernels[k] = (2.0 * per["FETCH_SIZE"].get(k, 0.0) + per["WRITE_SIZE"].get(k, 0.0)) * 1024.0
+    dense = sum(v for k, v in kernels.items() if is_dense_spmm_kernel(k))
+    if dense <= 0:
+        return None, None, "no dense propagate kernel in the counter file"
+    note = (f"live: this invocation ran itself as a 3-step child under rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate "
+            f"passes, {time.time() - t0:.0f} s) before the timed region; (2*FETCH_SIZE+WRITE_SIZE)*1024 per dispatch, averaged, "
+            f"summed over the dense launch's kernels; counts L2 misses incl. Infinity-Cache hits, i.e. an upper bound on HBM bytes")
+    return dense, kernels, note
+
+
+# ---- workload construction (shared by the headline, the PMC child and the c4_n1 block) -------------------------------------
+
+def build_workload(config: str, args, world: int, rank: int, dev, plain: bool = False, want_table0: bool = False):
+    import torch as t
+    from laplace_amd import synthetic as S
+    from laplace_amd.interactions import Interactions
+    from laplace_amd.model.lightgcn import LightGCN
+    from laplace_amd.trainer import LightGCNTrainer
+    base = S.C4 if config == "c4" else S.C2
+    custom = config == args.config   # size overrides belong to the headline configuration only
+    spec = S.SyntheticSpec((args.users if custom else None) or base.num_users, (args.items if custom else None) or base.num_items,
+                           (args.edges if custom else None) or base.num_edges, seed=base.seed, uniform=args.uniform and custom)
+    strong = config == "c4"
+    t_gen = time.perf_counter()
+    if strong:
+        b0, b1 = S.shard_blocks(S.C4_BLOCKS, world, rank)
+        ei = S.generate_blocks(spec, S.C4_BLOCKS, b0, b1)
+        U = spec.num_users // world
+        B = ((args.batch if custom else None) or C4_GLOBAL_BATCH) // world
+    else:
+        ei = S.generate(S.shard_spec(spec, rank) if world > 1 else spec)
+        U = spec.num_users
+        B = (args.batch if custom else None) or 16384
+    t_gen = time.perf_counter() - t_gen
+    I, D, K = spec.num_items, args.dim, args.layers
+    t.manual_seed(1234 + rank)
+    model = LightGCN(U, I, embedding_dim=D, num_iterations=K)
+    table0 = model.table().clone() if want_table0 else None
+    model.to(dev)
+    inter = Interactions(ei.to(dev), U, I)
+    adj = None
+    if world == 1:
+        adj = inter.adjacency("bipartite")
+        trainer = LightGCNTrainer(model, adj, inter, lr=1e-3, Lambda=1e-6, batch_size=B, seed=7,
+                                  sparse_batch=not plain, reorder=False if args.no_reorder else None)
+    else:
+        from laplace_amd.dist import ShardedLightGCNTrainer
+        trainer = ShardedLightGCNTrainer(model, inter, lr=1e-3, Lambda=1e-6, batch_size=B, seed=7 + rank,
+                                         sparse_batch=not plain, reorder=False if args.no_reorder else None)
+    return dict(spec=spec, ei=ei, U=U, I=I, D=D, K=K, B=B, model=model, inter=inter, adj=adj, trainer=trainer,
+                table0=table0, t_gen=t_gen, strong=strong)
+
+
+def timed_steps(trainer, steps: int, warmup: int, sync):
+    """W untimed + K timed steps bracketed by sync(); returns (elapsed s, per-step ms sorted, spmm events, last loss)."""
+    import torch as t
+    from laplace_amd import ops
+    for _ in range(warmup):
+        trainer.step()
+    sync()
+    ops.SPMM_EVENTS = []  # (start, end) HIP events around every propagate launch, on the launch stream
+    marks = [t.cuda.Event(enable_timing=True) for _ in range(steps + 1)]  # per-step spread; no sync inside the loop
+    t0 = time.perf_counter()
+    marks[0].record()
+    loss = None
+    for i in range(steps):
+        loss = trainer.step()
+        marks[i + 1].record()
+    sync()
+    elapsed = time.perf_counter() - t0
+    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(steps))
+    events, ops.SPMM_EVENTS = ops.SPMM_EVENTS, None
+    return elapsed, per_step, events, loss
+
+
+def roofline_block(events, nnz: int, n_rows: int, D: int, steps: int, traffic, traffic_src) -> dict:
+    """The roofline is quoted on the DENSE propagate (every entry of the adjacency slice gathered): kernels
+    spmm_*_kernel<..., false>.  The sparse-operand launches of the byte-saving step (last forward layer at the batch
+    rows, first backward layer over the non-zero gradient rows) gather a data-dependent subset and are reported beside
+    it, not mixed in; the last backward product carries the Adam update in its epilogue (+6 table streams): timed apart."""
+    dense = [(s.elapsed_time(e), a) for s, e, kind, _, _, a in events if kind == "dense"]
+    sparse_ms = [s.elapsed_time(e) for s, e, kind, _, _, _ in events if kind == "sparse"]
+    fused_ms = [s.elapsed_time(e) for s, e, kind, _, _, _ in events if kind == "dense_adam"]
+    nnz_of = {}
+    for _, a in dense:
+        if id(a) not in nnz_of:  # entries of a row slice = rowptr[last] - rowptr[first]
+            nnz_of[id(a)] = int(a.rowptr[-1]) - int(a.rowptr[0])
+    spmm_ms = [ms for ms, _ in dense]
+    algo_total = sum(spmm_bytes(nnz_of[id(a)], a.n_rows, D) for _, a in dense)
+    avg_ms = sum(spmm_ms) / max(len(spmm_ms), 1)
+    algo = algo_total / max(len(dense), 1)
+    algo_gbs = algo_total / (sum(spmm_ms) * 1e-3) / 1e9 if spmm_ms else 0.0
+    compulsory = nnz * 8 + (n_rows + 1) * 4 + 2 * n_rows * D * 4  # every operand read once / written once
+    comp_gbs = compulsory / (avg_ms * 1e-3) / 1e9 if spmm_ms else 0.0
+    if traffic:
+        achieved = traffic / (avg_ms * 1e-3) / 1e9
+        basis = "measured L2-miss traffic (PMC) / HIP-event launch time"
+    else:  # no counter figure for this workload: the compulsory bytes are the only physically meaningful numerator
+        achieved = comp_gbs
+        basis = "compulsory bytes (every operand once) / HIP-event launch time; no PMC traffic figure for this workload"
+    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "basis": basis, "traffic_source": traffic_src,
+            "frac_of_measured_random_gather_ceiling": achieved / 5650.0,
+            "ceiling_note": "MI355X_MICROARCH.md measures 5.5-5.8 TB/s for random whole rows gathered from beyond the caches (6.0-6.1 "
+                            "TB/s for an in-order HBM sweep): the denominator of this extra fraction is 5.65 TB/s",
+            "kernel": "mi_spmm_csr_f32 dense launch (spmm_sweep_kernel or spmm_items_kernel + spmm_rows_kernel + spmm_fixup_kernel, SPARSE=false)",
+            "avg_launch_ms": avg_ms,
+            "compulsory": {"bytes_per_launch": compulsory, "GBps": comp_gbs, "frac_of_peak": comp_gbs / HBM_PEAK_GBS,
+                           "note": "every operand read once, every output written once (SURVEY 8d lower bound)"},
+            "algorithmic": {"bytes_per_launch": algo, "GBps": algo_gbs, "frac_of_peak": algo_gbs / HBM_PEAK_GBS,
+                            "note": "SURVEY 8d byte model: one gathered row per entry, NO cache-reuse credit; "
+                                    "a work rate, not a bound (exceeds the HBM peak when rows are served by L2)"},
+            "launches_timed": len(spmm_ms),
+            "dense_launches_per_step": len(dense) / steps,
+            "sparse_launches_per_step": len(sparse_ms) / steps,
+            "sparse_launch_avg_ms": (sum(sparse_ms) / len(sparse_ms)) if sparse_ms else None,
+            "dense_launches_with_adam_epilogue_per_step": len(fused_ms) / steps,
+            "dense_with_adam_epilogue_avg_ms": (sum(fused_ms) / len(fused_ms)) if fused_ms else None}
+
+
+def offline_traffic(default_workload: bool):
+    """profiles/traffic.json (tools/prof_bench.sh): used only when the live passes are off or failed; refused when the
+    kernels or the host code that shapes their launches changed since it was collected."""
+    tf = os.path.join(ROOT, "profiles", "traffic.json")
+    if not (os.path.exists(tf) and default_workload):
+        return None, None
+    try:
+        tj = json.load(open(tf))
+        if tj.get("kernel_source_hash") == kernel_source_hash():
+            return tj.get("spmm_hbm_bytes_per_launch"), (
+                f"profiles/traffic.json <- {tj.get('source')}: offline rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on "
+                f"the code with hash {tj.get('kernel_source_hash')} (matches this build); (2*FETCH_SIZE+WRITE_SIZE)*1024 per "
+                f"MI355X_MICROARCH.md; counts L2 misses incl. Infinity-Cache hits, i.e. an upper bound on HBM bytes")
+        return None, "profiles/traffic.json is stale (kernel or launch code changed since it was collected): not used"
+    except Exception:
+        return None, None
+
+
+def cpu_baseline(ei, U, I, K, B, table0, steps: int, warm: bool, faithful: bool):
     """The oracle's CPU port of the same step, timed on this box's host cores (rank 0, N=1 only)."""
     import torch as t
     from oracle import lightgcn_ref as R
@@ -83,7 +306,8 @@ def cpu_baseline(ei, U, I, args, B, table0):
     r, c = R.bipartite_edges(ei[0], ei[1], U)
     rowptr, cs, _ = R.sparse_tensor_csr(r, c, U + I, U + I)
     val = R.gcn_norm_csr(rowptr, cs)
-    port = R.CpuTrainPort(table0, rowptr, cs, val, U, args.layers, 1e-3, 1e-6)
+    del r, c
+    port = R.CpuTrainPort(table0, rowptr, cs, val, U, K, 1e-3, 1e-6)
     g = t.Generator().manual_seed(1)
     E = ei.shape[1]
 
@@ -91,13 +315,14 @@ def cpu_baseline(ei, U, I, args, B, table0):
         e = t.randint(0, E, (B,), generator=g)
         return ei[0][e], ei[1][e], t.randint(0, I, (B,), generator=g)  # negatives pre-drawn
 
-    port.step(batch())  # warm-up (page-faults the buffers)
+    if warm:
+        port.step(batch())  # warm-up (page-faults the buffers)
     t0 = time.perf_counter()
-    for _ in range(args.cpu_steps):
+    for _ in range(steps):
         port.step(batch())
-    dt = (time.perf_counter() - t0) / args.cpu_steps
-    faithful = None
-    if not args.no_cpu_faithful and args.config == "c2":
+    dt = (time.perf_counter() - t0) / steps
+    extra = None
+    if faithful:
         # informational: the reference draws a negative for EVERY train edge every iteration
         # (data/lightgcn_loader.py:95-112, np.isin rejection) before picking the batch; one draw is timed
         import random
@@ -105,10 +330,10 @@ def cpu_baseline(ei, U, I, args, B, table0):
         t1 = time.perf_counter()
         R.sample_mini_batch(B, ei, np.random.default_rng(0), random.Random(0))
         ts = time.perf_counter() - t1
-        faithful = {"sampler_s_per_step": round(ts, 2), "value": B / (dt + ts), "unit": "positive-edges/s",
-                    "note": "model-only step + the reference's per-iteration O(E) negative sampling; not the denominator of any claim"}
-    return {"value": B / dt, "unit": "positive-edges/s", "cores": int(cores), "kind": "port", "faithful_step": faithful,
-            "sample": f"{args.cpu_steps} full model-only train steps (fwd+BPR+bwd+Adam, negatives pre-drawn) of the "
+        extra = {"sampler_s_per_step": round(ts, 2), "value": B / (dt + ts), "unit": "positive-edges/s",
+                 "note": "model-only step + the reference's per-iteration O(E) negative sampling; not the denominator of any claim"}
+    return {"value": B / dt, "unit": "positive-edges/s", "cores": int(cores), "kind": "port", "faithful_step": extra,
+            "sample": f"{steps} full model-only train step(s) (fwd+BPR+bwd+Adam, negatives pre-drawn{'' if warm else ', no warm-up step'}) of the "
                       f"same graph and batch size with oracle/ (C/OpenMP restatement of torch_sparse spmm_cpu + "
                       f"torch CPU ops), {dt:.2f} s/step"}
 
@@ -137,7 +362,7 @@ def map_at_12(model, trainer, inter, held, n_steps: int) -> dict:
     top = topk_for_users(model.users_emb.weight.detach(), model.items_emb.weight.detach(), users, inter.edge_index, 12)
     hit = top == truth[:, None]
     ap = (hit.to(t.float32) / rank).sum(dim=1)
-    # yardstick on the same users: the popularity predictor (the synthetic graph has no structure beyond popularity)
+    # yardstick on the same users: the popularity predictor
     I = model.num_items
     deg = t.bincount(inter.edge_index[1], minlength=I)
     pop = t.argsort(deg, descending=True, stable=True)[:256]                       # more than 12 + any realistic overlap
@@ -154,18 +379,97 @@ def map_at_12(model, trainer, inter, held, n_steps: int) -> dict:
             "predictor": "layer-0 embeddings, train items excluded (utils/metrics_lightgcn.py:125-142)"}
 
 
+def map_leg(args, dev) -> dict:
+    """MAP@12 on a graph with PLANTED structure: on the plain benchmark graph popularity is all there is to learn, so
+    no predictor can beat the popularity baseline and the figure says nothing about the trainer.  Here users and items
+    belong to latent groups (synthetic.SyntheticSpec.communities); a trainer that works lifts the reference's layer-0
+    predictor above the popularity predictor within ~100 steps (tests/test_gpu_acceptance.py asserts the ordering)."""
+    import torch as t
+    from laplace_amd import synthetic as S
+    from laplace_amd.interactions import Interactions
+    from laplace_amd.model.lightgcn import LightGCN
+    from laplace_amd.trainer import LightGCNTrainer
+    spec = S.SyntheticSpec(**MAP_SPEC)
+    ei = S.generate(spec)
+    held = S.heldout_edges(spec, ei, args.map_users).to(dev)
+    t.manual_seed(0)
+    model = LightGCN(spec.num_users, spec.num_items, args.dim, args.layers).to(dev)
+    inter = Interactions(ei.to(dev), spec.num_users, spec.num_items)
+    tr = LightGCNTrainer(model, inter.adjacency("bipartite"), inter, lr=0.05, Lambda=1e-6, batch_size=16384, seed=7)
+    out = map_at_12(model, tr, inter, held, args.map_steps)
+    out["workload"] = (f"planted-structure synthetic {spec.num_users}x{spec.num_items}, {spec.num_edges} edges, {spec.communities} latent "
+                       f"groups (own-group draw with p={spec.community_mix}), LightGCN {args.layers}-layer D={args.dim}, batch 16384, lr 0.05, "
+                       f"{args.map_steps} steps; one held-out positive per scored user drawn from the same law")
+    return out
+
+
+def c4_block(args, dev, traffic, traffic_src) -> dict:
+    """BASELINE configs[3] on ONE GPU: the 8M x 100K, 100M-edge graph, global batch 131072."""
+    import torch as t
+    w = build_workload("c4", args, 1, 0, dev, want_table0=not args.no_cpu_baseline)
+    trainer = w["trainer"]
+    sync = t.cuda.synchronize
+    sync()
+    elapsed, per_step, events, loss = timed_steps(trainer, args.c4_steps, 3, sync)
+    nnz, n_rows = trainer.adj_fwd.nnz, trainer.adj_fwd.n_rows
+    spec, B = w["spec"], w["B"]
+    block = {"metric": "positive-edges/sec (train step)", "value": B * args.c4_steps / elapsed, "unit": "positive-edges/s",
+             "n_gpus": 1, "steps": args.c4_steps, "warmup": 3, "ms_per_step": 1e3 * elapsed / args.c4_steps,
+             "ms_per_step_p10_p50_p90": [round(per_step[min(len(per_step) - 1, int(q * len(per_step)))], 4) for q in (0.1, 0.5, 0.9)],
+             "workload": (f"LightGCN train step, ONE synthetic bipartite graph {spec.num_users}x{w['I']} users x items, {spec.num_edges} edges "
+                          f"(seed {spec.seed}), all of it on one GPU (symmetric adjacency nnz={nnz}), {w['K']}-layer D={w['D']}, batch {B} "
+                          f"positive edges, on-device sampling, BPR + dense Adam; BASELINE.json configs[3] at N=1"),
+             "roofline": roofline_block(events, nnz, n_rows, w["D"], args.c4_steps, traffic, traffic_src),
+             "loss": float(loss), "graph_gen_s": round(w["t_gen"], 1)}
+    trainer.finish()
+    ei, U, I, K, table0 = w["ei"], w["U"], w["I"], w["K"], w["table0"]
+    del trainer, w, events
+    t.cuda.empty_cache()
+    if table0 is not None:
+        block["cpu_baseline"] = cpu_baseline(ei, U, I, K, B, table0, steps=1, warm=False, faithful=False)
+    return block
+
+
+def ranker_block(args) -> dict:
+    """BASELINE configs[2]: the ranker's training loop at the full H&M shape (tools/bench_ranker.py, bench-line mode)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_ranker", os.path.join(ROOT, "tools", "bench_ranker.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.bench_line(users=1_371_980, items=105_542, edges=31_800_000, batch=24, steps=args.ranker_steps, warmup=50,
+                          hops=2, fanout=64, cpu=not args.no_cpu_baseline)
+
+
 def main():
     args = parse_args()
     from laplace_amd import launch
     if args.gpus > 1 and not launch.launched():
         # the parent never touches the GPU; one deadline from launch, every worker watched (laplace_amd/launch.py)
         sys.exit(launch.self_launch(__file__, sys.argv[1:], args.gpus, timeout_s=float(os.environ.get("LAPLACE_BENCH_DEADLINE_S", 900))))
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+
+    # ---- live PMC passes: children first, while this process has not touched the GPU ----------------------------------
+    pmc = {}
+    want_c4_leg = world_env == 1 and args.config == "c2" and not args.no_c4 and not args.pmc_child
+    if world_env == 1 and not args.no_pmc and not args.pmc_child and not args.plain_step:
+        passthrough = []
+        for flag, val in (("--users", args.users), ("--items", args.items), ("--edges", args.edges), ("--batch", args.batch)):
+            if val is not None:
+                passthrough += [flag, str(val)]
+        passthrough += ["--dim", str(args.dim), "--layers", str(args.layers)]
+        if args.no_reorder:
+            passthrough.append("--no-reorder")
+        if args.uniform:
+            passthrough.append("--uniform")
+        pmc[args.config] = pmc_traffic(args.config, passthrough)
+        if want_c4_leg:
+            pmc["c4"] = pmc_traffic("c4", ["--dim", str(args.dim), "--layers", str(args.layers)] + (["--no-reorder"] if args.no_reorder else []))
+
     import torch as t
     import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world_env != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world_env}")
     if not t.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
     # LAPLACE_BENCH_BACKEND=gloo + LAPLACE_BENCH_ONE_GPU=1 rehearse the N>1 path on a 1-GPU box
@@ -174,46 +478,16 @@ def main():
     rank, world, dev = launch.init_distributed()   # rendezvous + collectives time out instead of hanging
 
     from laplace_amd import ops, synthetic as S
-    from laplace_amd.interactions import Interactions
-    from laplace_amd.model.lightgcn import LightGCN
     from laplace_amd.trainer import LightGCNTrainer
 
     if os.environ.get("LAPLACE_SPMM_TWO_STREAMS") is not None:  # A/B switch
         ops.SPMM_TWO_STREAMS = os.environ["LAPLACE_SPMM_TWO_STREAMS"] == "1"
-    base = S.C4 if args.config == "c4" else S.C2
-    spec = S.SyntheticSpec(args.users or base.num_users, args.items or base.num_items, args.edges or base.num_edges,
-                           seed=base.seed, uniform=args.uniform)
-    strong = args.config == "c4"
-    t_gen = time.perf_counter()
-    if strong:
-        b0, b1 = S.shard_blocks(S.C4_BLOCKS, world, rank)
-        ei = S.generate_blocks(spec, S.C4_BLOCKS, b0, b1)
-        U_local = spec.num_users // world
-        B = (args.batch or C4_GLOBAL_BATCH) // world
-    else:
-        lspec = S.shard_spec(spec, rank) if world > 1 else spec
-        ei = S.generate(lspec)
-        U_local = spec.num_users
-        B = args.batch or 16384
-    t_gen = time.perf_counter() - t_gen
-    U, I, D, K = U_local, spec.num_items, args.dim, args.layers
+    want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline and not args.pmc_child and (args.config == "c2" or args.cpu_baseline)
+    w = build_workload(args.config, args, world, rank, dev, plain=args.plain_step, want_table0=want_cpu)
+    spec, ei, U, I, D, K, B = w["spec"], w["ei"], w["U"], w["I"], w["D"], w["K"], w["B"]
+    model, inter, adj, trainer, strong = w["model"], w["inter"], w["adj"], w["trainer"], w["strong"]
     default_workload = (args.config == "c2" and (spec.num_users, I, spec.num_edges, D, K) == (1_000_000, 100_000, 10_000_000, 128, 3)
                         and not args.uniform)
-
-    t.manual_seed(1234 + rank)
-    model = LightGCN(U, I, embedding_dim=D, num_iterations=K)
-    want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline and (args.config == "c2" or args.cpu_baseline)
-    table0 = model.table().clone() if want_cpu else None
-    model.to(dev)
-    inter = Interactions(ei.to(dev), U, I)
-    if world == 1:
-        adj = inter.adjacency("bipartite")
-        trainer = LightGCNTrainer(model, adj, inter, lr=1e-3, Lambda=1e-6, batch_size=B, seed=7,
-                                  sparse_batch=not args.plain_step, reorder=False if args.no_reorder else None)
-    else:
-        from laplace_amd.dist import ShardedLightGCNTrainer
-        trainer = ShardedLightGCNTrainer(model, inter, lr=1e-3, Lambda=1e-6, batch_size=B, seed=7 + rank,
-                                         sparse_batch=not args.plain_step, reorder=False if args.no_reorder else None)
     nnz, n_rows = trainer.adj_fwd.nnz, trainer.adj_fwd.n_rows
     t.cuda.synchronize()
 
@@ -222,21 +496,10 @@ def main():
             dist.barrier()
         t.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        trainer.step()
-    sync()
-    ops.SPMM_EVENTS = []  # (start, end) HIP events around every propagate launch, on the launch stream
-    marks = [t.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]  # per-step spread; no sync inside the loop
-    t0 = time.perf_counter()
-    marks[0].record()
-    for i in range(args.steps):
-        loss = trainer.step()
-        marks[i + 1].record()
-    sync()
-    elapsed = time.perf_counter() - t0
-    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    elapsed, per_step, events, loss = timed_steps(trainer, args.steps, args.warmup, sync)
+    if args.pmc_child:   # the profiler has what it came for
+        return
     pct = lambda q: per_step[min(len(per_step) - 1, int(q * len(per_step)))]
-    events, ops.SPMM_EVENTS = ops.SPMM_EVENTS, None
     loss_val = float(loss)
 
     if world > 1:
@@ -244,50 +507,19 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt)
 
+    out = None
     if rank == 0:
-        # The roofline is quoted on the DENSE propagate (every entry of the adjacency slice gathered): kernels
-        # spmm_*_kernel<..., false>.  The sparse-operand launches of the byte-saving step (last forward layer at
-        # the batch rows, first backward layer over the non-zero gradient rows) gather a data-dependent subset and
-        # are reported beside it, not mixed in.
-        dense = [(s.elapsed_time(e), a) for s, e, kind, _, _, a in events if kind == "dense"]
-        sparse_ms = [s.elapsed_time(e) for s, e, kind, _, _, _ in events if kind == "sparse"]
-        # the last backward product carries the Adam update in its epilogue (+6 table streams): timed apart
-        fused_ms = [s.elapsed_time(e) for s, e, kind, _, _, _ in events if kind == "dense_adam"]
-        nnz_of = {}
-        for _, a in dense:
-            if id(a) not in nnz_of:  # entries of a row slice = rowptr[last] - rowptr[first]
-                nnz_of[id(a)] = int(a.rowptr[-1]) - int(a.rowptr[0])
-        spmm_ms = [ms for ms, _ in dense]
-        algo_total = sum(spmm_bytes(nnz_of[id(a)], a.n_rows, D) for _, a in dense)
-        avg_ms = sum(spmm_ms) / max(len(spmm_ms), 1)
-        algo = algo_total / max(len(dense), 1)
-        algo_gbs = algo_total / (sum(spmm_ms) * 1e-3) / 1e9 if spmm_ms else 0.0
-        compulsory = nnz * 8 + (n_rows + 1) * 4 + 2 * n_rows * D * 4  # every operand read once / written once
-        comp_gbs = compulsory / (avg_ms * 1e-3) / 1e9 if spmm_ms else 0.0
-        # L2-miss (fabric) bytes per dense launch from the rocprofv3 PMC passes of this same command
-        # (tools/prof_bench.sh -> profiles/traffic.json): NOT measured in this run — counters need the profiler —
-        # so the file carries the hash of the kernel sources it was taken on and is refused when they changed.
         traffic, traffic_src = None, None
-        tf = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tf) and default_workload and world == 1:
-            try:
-                tj = json.load(open(tf))
-                if tj.get("kernel_source_hash") == kernel_source_hash():
-                    traffic = tj.get("spmm_hbm_bytes_per_launch")
-                    traffic_src = (f"profiles/traffic.json <- {tj.get('source')}: offline rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
-                                   f"of this command on the kernels with source hash {tj.get('kernel_source_hash')} (matches this build); "
-                                   f"(2*FETCH_SIZE+WRITE_SIZE)*1024 per MI355X_MICROARCH.md; counts L2 misses incl. Infinity-Cache hits, "
-                                   f"i.e. an upper bound on HBM bytes")
-                else:
-                    traffic_src = "profiles/traffic.json is stale (kernel sources changed since it was collected): not used"
-            except Exception:
-                traffic = None
-        if traffic:
-            achieved = traffic / (avg_ms * 1e-3) / 1e9
-            basis = "measured L2-miss traffic (PMC) / HIP-event launch time"
-        else:  # no counter figure for this workload: the compulsory bytes are the only physically meaningful numerator
-            achieved = comp_gbs
-            basis = "compulsory bytes (every operand once) / HIP-event launch time; no PMC traffic figure for this workload"
+        if args.config in pmc:
+            traffic, _, traffic_src = pmc[args.config]
+            if traffic is None:
+                traffic_src = f"live PMC passes failed ({traffic_src})"
+        if traffic is None and world == 1:
+            off, off_src = offline_traffic(default_workload)
+            if off is not None:
+                traffic, traffic_src = off, off_src
+            elif off_src and not traffic_src:
+                traffic_src = off_src
         out = {
             "metric": "positive-edges/sec (train step)",
             "value": world * B * args.steps / elapsed,
@@ -308,32 +540,17 @@ def main():
                                     f"BPR + dense Adam; BASELINE.json configs[1]"),
                        "parallelism": "1 GPU" if world == 1 else f"user-sharded x{world}, items replicated, "
                                                                  f"{'RCCL' if backend == 'nccl' else backend} all-reduce of item rows per layer"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "basis": basis, "traffic_source": traffic_src,
-                         "kernel": "mi_spmm_csr_f32 dense launch (spmm_items_kernel + spmm_rows_kernel + spmm_fixup_kernel, SPARSE=false)",
-                         "avg_launch_ms": avg_ms,
-                         "compulsory": {"bytes_per_launch": compulsory, "GBps": comp_gbs, "frac_of_peak": comp_gbs / HBM_PEAK_GBS,
-                                        "note": "every operand read once, every output written once (SURVEY 8d lower bound)"},
-                         "algorithmic": {"bytes_per_launch": algo, "GBps": algo_gbs, "frac_of_peak": algo_gbs / HBM_PEAK_GBS,
-                                         "note": "SURVEY 8d byte model: one gathered row per entry, NO cache-reuse credit; "
-                                                 "a work rate, not a bound (exceeds the HBM peak when rows are served by L2)"},
-                         "launches_timed": len(spmm_ms),
-                         "dense_launches_per_step": len(dense) / args.steps,
-                         "sparse_launches_per_step": len(sparse_ms) / args.steps,
-                         "sparse_launch_avg_ms": (sum(sparse_ms) / len(sparse_ms)) if sparse_ms else None,
-                         "dense_launches_with_adam_epilogue_per_step": len(fused_ms) / args.steps,
-                         "dense_with_adam_epilogue_avg_ms": (sum(fused_ms) / len(fused_ms)) if fused_ms else None},
+            "roofline": roofline_block(events, nnz, n_rows, D, args.steps, traffic, traffic_src),
             "step_form": "plain" if args.plain_step else "sparse_batch",
             "node_order": "locality (items by popularity, users by coldest item)" if getattr(trainer, "order", None) is not None else "generator ids",
-            "loss": loss_val, "graph_gen_s": round(t_gen, 1), "backend": backend if world > 1 else None,
+            "loss": loss_val, "graph_gen_s": round(w["t_gen"], 1), "backend": backend if world > 1 else None,
         }
-    else:
-        out = None
 
     # ---- extra legs, N=1 only, after the timed region ------------------------------------------------
     if world == 1 and not args.plain_step and not args.no_plain_leg:
         # the straightforward step shape (full `final`, dense gradient buffer, separate Adam): same parameters to
-        # rounding (tests/test_gpu_lightgcn.py::test_sparse_batch_step_equals_plain_step), more bytes
+        # rounding (tests/test_gpu_lightgcn.py::test_sparse_batch_step_equals_plain_step), more bytes.  Quote the
+        # plain figure whenever the number is compared with a reference-shaped step.
         trainer.to_original_order()  # the second trainer relabels the table itself
         plain = LightGCNTrainer(model, adj, inter, lr=1e-3, Lambda=1e-6, batch_size=B, seed=11, sparse_batch=False)
         for _ in range(max(args.warmup, 1)):
@@ -344,14 +561,28 @@ def main():
             plain.step()
         t.cuda.synchronize()
         out["plain_step_ms"] = 1e3 * (time.perf_counter() - t1) / args.steps
+        out["plain_step_positive_edges_per_s"] = B * 1e3 / out["plain_step_ms"]
         plain.finish()
         del plain
-    if world == 1 and not args.no_map and not strong and not args.uniform:
-        held = S.heldout_edges(spec, ei, args.map_users).to(dev)
-        out["map_at_12"] = map_at_12(model, trainer, inter, held, args.map_steps)
+    if rank == 0 and want_cpu:
+        trainer.finish()
+        out["cpu_baseline"] = cpu_baseline(ei, U, I, K, B, w["table0"], steps=args.cpu_steps, warm=True,
+                                           faithful=not args.no_cpu_faithful and args.config == "c2")
+    if world == 1 and rank == 0:
+        # free the headline's state before the other configurations
+        del trainer, model, inter, adj, w, events
+        t.cuda.empty_cache()
+        if not args.no_map and not strong and not args.uniform:
+            out["map_at_12"] = map_leg(args, dev)
+            t.cuda.empty_cache()
+        if want_c4_leg:
+            c4_traffic, _, c4_src = pmc.get("c4", (None, None, "live PMC passes off (--no-pmc)"))
+            if c4_traffic is None:
+                c4_src = f"no live figure ({c4_src})"
+            out["c4_n1"] = c4_block(args, dev, c4_traffic, c4_src)
+        if args.config == "c2" and not args.no_ranker:
+            out["ranker_c3"] = ranker_block(args)
     if rank == 0:
-        if table0 is not None:
-            out["cpu_baseline"] = cpu_baseline(ei, U, I, args, B, table0)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

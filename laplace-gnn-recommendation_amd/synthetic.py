@@ -24,6 +24,11 @@ class SyntheticSpec:
     zipf_s: float = 1.05
     item_perm_seed: int = 12345  # shared by all shards of one graph: same popular items everywhere
     uniform: bool = False        # i.i.d. uniform endpoints (the locality-free control)
+    # Planted structure (round 3, for the MAP@12 leg): users and items belong to `communities` latent groups; a user
+    # draws an item from its own group's popularity with probability `community_mix`, from the global popularity
+    # otherwise.  0 = none: popularity is then all there is to learn, and no predictor can beat the popularity baseline.
+    communities: int = 0
+    community_mix: float = 0.8
 
 
 C1 = SyntheticSpec(943, 1682, 100_000, seed=0, deg_sigma=1.0, deg_min=20, deg_max=737, zipf_s=1.0)
@@ -50,6 +55,51 @@ def item_popularity(spec: SyntheticSpec) -> np.ndarray:
     return out
 
 
+def item_community(spec: SyntheticSpec) -> np.ndarray:
+    """Group of every item: popularity rank mod communities, so that every group has the same popularity profile."""
+    order = np.argsort(-item_popularity(spec), kind="stable")
+    out = np.empty(spec.num_items, dtype=np.int64)
+    out[order] = np.arange(spec.num_items) % max(spec.communities, 1)
+    return out
+
+
+def user_community(spec: SyntheticSpec) -> np.ndarray:
+    return np.random.default_rng(spec.seed + 31337).integers(0, max(spec.communities, 1), spec.num_users)
+
+
+class ItemSampler:
+    """Draws items for given users from the spec's law: the global popularity, or the planted mixture."""
+
+    def __init__(self, spec: SyntheticSpec):
+        self.spec = spec
+        p = item_popularity(spec)
+        self.cdf = np.cumsum(p)
+        self.cdf[-1] = 1.0
+        self.groups = None
+        if spec.communities > 1:
+            ic = item_community(spec)
+            self.uc = user_community(spec)
+            self.groups = []
+            for k in range(spec.communities):
+                ids = np.nonzero(ic == k)[0]
+                c = np.cumsum(p[ids])
+                c /= c[-1]
+                self.groups.append((ids, c))
+
+    def draw(self, users: np.ndarray, rng: np.random.Generator) -> np.ndarray:
+        I = self.spec.num_items
+        i = np.minimum(np.searchsorted(self.cdf, rng.random(users.size), side="right"), I - 1).astype(np.int64)
+        if self.groups is not None:
+            own = rng.random(users.size) < self.spec.community_mix
+            cu = self.uc[users]
+            r = rng.random(users.size)
+            for k, (ids, c) in enumerate(self.groups):
+                sel = np.nonzero(own & (cu == k))[0]
+                if sel.size:
+                    i[sel] = ids[np.minimum(np.searchsorted(c, r[sel], side="right"), ids.size - 1)]
+        return i
+
+
 def user_degrees(spec: SyntheticSpec, rng: np.random.Generator) -> np.ndarray:
     mean = spec.num_edges / spec.num_users
     mu = np.log(max(mean, 1.0)) - 0.5 * spec.deg_sigma ** 2
@@ -71,9 +121,7 @@ def generate(spec: SyntheticSpec) -> t.Tensor:
             keys = np.unique(np.concatenate([keys, rng.integers(0, U * I, size=int((E - keys.size) * 1.1) + 16)]))
         keys = keys[rng.permutation(keys.size)[:E]]
         return t.from_numpy(np.stack([keys // I, keys % I]))
-    p = item_popularity(spec)
-    cdf = np.cumsum(p)
-    cdf[-1] = 1.0
+    sampler = ItemSampler(spec)
     deg = user_degrees(spec, rng)
     keys = np.empty(0, dtype=np.int64)
     have = np.zeros(U, dtype=np.int64)
@@ -86,8 +134,7 @@ def generate(spec: SyntheticSpec) -> t.Tensor:
             extra = rng.integers(0, U, size=int((E - keys.size) * 1.2) + 16)
             n_draw = np.bincount(extra, minlength=U)
         u = np.repeat(np.arange(U, dtype=np.int64), n_draw)
-        i = np.searchsorted(cdf, rng.random(u.size), side="right").astype(np.int64)
-        np.minimum(i, I - 1, out=i)
+        i = sampler.draw(u, rng)
         keys = np.unique(np.concatenate([keys, u * I + i]))
         have = np.bincount(keys // I, minlength=U)
     while keys.size < E:  # dense small graphs: the Zipf head saturates; fill up with uniform pairs
@@ -148,8 +195,7 @@ def heldout_edges(spec: SyntheticSpec, ei: t.Tensor, n_eval: int, seed: int = 99
     among the user's edges in `ei`: the held-out positives a MAP@12 is scored on.  int64 [2, n], users ascending."""
     rng = np.random.default_rng(seed)
     U, I = spec.num_users, spec.num_items
-    cdf = np.cumsum(item_popularity(spec))
-    cdf[-1] = 1.0
+    sampler = ItemSampler(spec)   # the same law the graph was drawn from (planted structure included)
     keys = np.sort(ei[0].numpy() * I + ei[1].numpy())
     users = np.sort(rng.choice(U, size=min(n_eval, U), replace=False)).astype(np.int64)
     item = np.full(users.size, -1, dtype=np.int64)
@@ -157,7 +203,7 @@ def heldout_edges(spec: SyntheticSpec, ei: t.Tensor, n_eval: int, seed: int = 99
         todo = np.nonzero(item < 0)[0]
         if todo.size == 0:
             break
-        cand = np.minimum(np.searchsorted(cdf, rng.random(todo.size), side="right"), I - 1).astype(np.int64)
+        cand = sampler.draw(users[todo], rng)
         k = users[todo] * I + cand
         pos = np.minimum(np.searchsorted(keys, k), keys.size - 1)
         fresh = keys[pos] != k

@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--users", type=int, default=200_000)
     ap.add_argument("--items", type=int, default=50_000)
@@ -29,7 +29,25 @@ def main():
                     help="print ONE line in bench.py's schema (metric / value / roofline / cpu_baseline) for the overlapped training loop")
     ap.add_argument("--pipelined", action="store_true",
                     help="with --device-sampler: time the plain training loop (sampling of batch i+1 overlaps step i)")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
+
+
+def bench_line(users: int, items: int, edges: int, batch: int = 24, steps: int = 400, warmup: int = 50, hops: int = 2,
+               fanout: int = 64, cpu: bool = True) -> dict:
+    """The overlapped training loop in bench.py's schema, as a dict (bench.py's "ranker_c3" block)."""
+    args = parse_args(["--users", str(users), "--items", str(items), "--edges", str(edges), "--batch", str(batch), "--steps", str(steps),
+                       "--warmup", str(warmup), "--hops", str(hops), "--fanout", str(fanout), "--device-sampler", "--bench-line"]
+                      + (["--cpu"] if cpu else []))
+    return run(args)
+
+
+def main():
+    out = run(parse_args())
+    if out is not None:
+        print(json.dumps(out))
+
+
+def run(args):
     import torch as t
     from types import SimpleNamespace
     from laplace_amd import synthetic as S
@@ -137,8 +155,7 @@ def main():
                                    "sample": f"5 model-only training iterations of the torch-only twin (oracle/ranker_ref.py) on batches "
                                              f"sampled by the device sampler, {1e3 * cdt:.0f} ms/iteration; the reference's own sampler "
                                              f"(python sets / lists per user) is not in this figure"}
-        print(json.dumps(out))
-        return
+        return out
     if args.pipelined:
         assert args.device_sampler
         labels = []
@@ -153,11 +170,10 @@ def main():
         t.cuda.synchronize()
         dt = time.perf_counter() - t0
         pos = int(sum(int(l.sum()) for l in labels))
-        print(json.dumps({"workload": f"ranker training loop, sampling overlapped, H&M-shaped synthetic {args.users}x{args.items}, "
-                                      f"{args.edges} edges, batch {args.batch} users, {args.hops} hops, fan-out {args.fanout}",
-                          "steps": args.steps, "ms_per_iteration": 1e3 * dt / args.steps,
-                          "positive_edges_per_s": pos / dt, "loss": float(loss)}))
-        return
+        return {"workload": f"ranker training loop, sampling overlapped, H&M-shaped synthetic {args.users}x{args.items}, "
+                            f"{args.edges} edges, batch {args.batch} users, {args.hops} hops, fan-out {args.fanout}",
+                "steps": args.steps, "ms_per_iteration": 1e3 * dt / args.steps,
+                "positive_edges_per_s": pos / dt, "loss": float(loss)}
     t_sample = t_dev = 0.0
     pos_edges = n_nodes = n_edges = 0
     for i in range(args.warmup + args.steps):
@@ -206,7 +222,7 @@ def main():
             opt_r.step()
         out["cpu_ms_per_step_model_only"] = 1e3 * (time.perf_counter() - t0) / (len(batches) - 1)
         out["cpu_threads"] = t.get_num_threads()
-    print(json.dumps(out))
+    return out
 
 
 if __name__ == "__main__":
