@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MI_ABI_VERSION 8
+#define MI_ABI_VERSION 9
 
 #define MI_ERR_BAD_ARG      (-1)  /* null pointer, negative size, misaligned buffer   */
 #define MI_ERR_TOO_LARGE    (-2)  /* a size does not fit int32 indexing                */
@@ -403,6 +403,9 @@ typedef struct mi_gemm_problem {
 } mi_gemm_problem;
 size_t mi_gemm_group_workspace_bytes(const mi_gemm_problem* problems, int32_t n);
 int mi_gemm_group_f32(const mi_gemm_problem* problems, int32_t n, void* ws, size_t ws_bytes, mi_stream_t stream);
+/* 1 when mi_gemm_group_f32 would take every problem (float4-addressable operands), 0 when it would return
+ * MI_ERR_UNSUPPORTED; enqueues nothing. */
+int mi_gemm_group_supported(const mi_gemm_problem* problems, int32_t n);
 
 /* ------------------------------------------------------------------------------------
  * K10  batched exact top-K with per-user exclusion.
@@ -511,6 +514,86 @@ int mi_gather_cat_f32(int64_t n_edges, int64_t cu, int64_t ci, const int64_t* ro
 int64_t mi_gather_cat_bwd_max_edges(void);
 int mi_gather_cat_bwd_f32(int64_t n_edges, int64_t c, int64_t off, const int64_t* idx,
                           const float* dOut, int64_t ldo, float* dZ, int64_t ldz, mi_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * b9  native executor of ONE ranker training iteration (round 3).
+ * replaces: the loop body of training.py:19-34 (`zero_grad -> model(...) -> BCEWithLogitsLoss -> backward ->
+ *           optimizer.step`) for the model shape the reference builds by default (model/encoder_decoder.py:75-150,
+ *           run_pipeline.py:47-73): two node types (customer, article) with categorical features and frozen embedding
+ *           tables, the two relations customer -buys-> article and its reverse, L SAGEConv layers (add / mean) duplicated
+ *           per relation, per-type BatchNorm1d, an MLP decoder over cat(z_customer[row], z_article[col]), Adam.
+ * One call enqueues the whole iteration — the same mi_* launches, in the same order and with the same operands, as
+ * the package's FusedRankerStep issues one by one from Python — so the host cost is one FFI call instead of ~75 op
+ * calls.  Every buffer the iteration needs is carved from `ws` (mi_ranker_step_workspace_bytes); gradients are
+ * written to the caller's persistent gradient buffers and consumed by a multi-tensor Adam launch (skippable:
+ * data-parallel callers all-reduce the gradients first).  Feature dropout draws Philox4x32-10 masks keyed on
+ * (seed, step, site) and regenerates them in the backward.  Returns MI_ERR_UNSUPPORTED (nothing enqueued) for shapes
+ * outside the above; the caller then runs the op-by-op path.
+ * ---------------------------------------------------------------------------------- */
+#define MI_RANKER_MAX_LAYERS 4
+#define MI_RANKER_MAX_COLS 16
+#define MI_RANKER_MAX_PARAMS 48
+typedef struct mi_ranker_conv {        /* SAGEConv of one relation in one layer: out = lin_l(AGG x_src) + lin_r(x_dst) */
+    const float *w_l, *b_l, *w_r;      /* [c_out, c_src], [c_out] (nullable), [c_out, c_dst] */
+    float *gw_l, *gb_l, *gw_r;         /* gradients, same shapes (gb_l nullable with b_l) */
+    int32_t c_src, c_dst, c_out, reserved;
+} mi_ranker_conv;
+typedef struct mi_ranker_norm {        /* BatchNorm1d of one node type */
+    const float *gamma, *beta;         /* nullable (affine=False) */
+    float *running_mean, *running_var; /* nullable (track_running_stats=False) */
+    int64_t* num_batches_tracked;      /* nullable; incremented by one */
+    float *g_gamma, *g_beta;
+    float momentum, eps;
+} mi_ranker_norm;
+typedef struct mi_ranker_linear {
+    const float *w, *b;                /* [out, in], [out] (nullable) */
+    float *gw, *gb;
+    int32_t in, out;
+} mi_ranker_linear;
+typedef struct mi_ranker_param {       /* one tensor of the optimizer's parameter list */
+    float *p, *g, *m, *v;
+    int64_t n;
+} mi_ranker_param;
+typedef struct mi_ranker_model {
+    int32_t n_enc_layers, n_dec_layers;
+    int32_t aggr;                      /* 0 = add, 1 = mean */
+    int32_t batch_normalize;
+    float   p_dropout;                 /* feature dropout in front of every non-last encoder / decoder layer; 0 = none */
+    float   max_norm;                  /* of the embedding lookups (reference: 1) */
+    /* node type 0 = customer, 1 = article */
+    int32_t n_cols[2];
+    const float* tables[2][MI_RANKER_MAX_COLS];
+    int64_t table_rows[2][MI_RANKER_MAX_COLS];
+    int32_t dims[2][MI_RANKER_MAX_COLS];
+    /* conv[l][0]: customer -> article (destination: article); conv[l][1]: article -> customer */
+    mi_ranker_conv conv[MI_RANKER_MAX_LAYERS][2];
+    mi_ranker_norm norm[2];
+    mi_ranker_linear dec[MI_RANKER_MAX_LAYERS];
+    int32_t n_params, apply_adam;      /* apply_adam = 0: stop after the gradients */
+    mi_ranker_param params[MI_RANKER_MAX_PARAMS];
+    double lr, beta1, beta2, eps;
+    int64_t step;                      /* Adam step of THIS iteration, counts from 1 */
+    const float* ones4;                /* device float[n_ones, 4] of ones (bias gradients ride in the grouped dW launch) */
+    int64_t n_ones;
+} mi_ranker_model;
+typedef struct mi_ranker_batch {
+    int64_t n_nodes[2];                /* customers, articles of the batch */
+    const int64_t* x[2];               /* int64[n_nodes[t], n_cols[t]] categorical features */
+    /* the batch's `buys` edges as two sorted CSRs (what mi_sampler_emit_csr writes) */
+    const int32_t *by_customer_ptr, *by_customer_col;   /* rows = customers, columns = articles */
+    const int32_t *by_article_ptr, *by_article_col;     /* rows = articles, columns = customers */
+    int64_t nnz;
+    int64_t n_label;
+    const int64_t *label_row, *label_col;  /* customer / article index of every label edge */
+    const int64_t* label;                  /* int64[n_label] 0 / 1 (the sampler's edge_label), or null when ... */
+    uint64_t seed, step;                   /* dropout stream */
+    float* loss;                           /* device float[1] */
+    const float* label_f32;                /* ... the caller already holds the labels as float[n_label] */
+} mi_ranker_batch;
+int64_t mi_ranker_sizeof(int32_t which);  /* sizeof of: 0 model, 1 batch, 2 conv, 3 norm, 4 linear, 5 param (binding self-check) */
+size_t mi_ranker_step_workspace_bytes(const mi_ranker_model* model, const mi_ranker_batch* batch);
+int    mi_ranker_step_f32(const mi_ranker_model* model, const mi_ranker_batch* batch, void* ws, size_t ws_bytes,
+                          mi_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * N3  candidate matcher: items bought by users who share an item with the query user.

@@ -10,7 +10,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 # the package directory is never overwritten by an experiment.  It is still this library or nothing — no fallback.
 LIB_PATH = os.environ.get("LAPLACE_HIP_LIB") or os.path.join(PKG_DIR, "liblaplace_hip.so")
 
-MI_ABI_VERSION = 8
+MI_ABI_VERSION = 9
 MI_SPMM_GROUP = 32
 
 
@@ -69,6 +69,44 @@ class SamplerDesc(Structure):
                 ("cand_ptr", c_void_p), ("cand_idx", c_void_p)]
 
 
+MI_RANKER_MAX_LAYERS, MI_RANKER_MAX_COLS, MI_RANKER_MAX_PARAMS = 4, 16, 48
+
+
+class RankerConv(Structure):
+    _fields_ = [("w_l", c_void_p), ("b_l", c_void_p), ("w_r", c_void_p), ("gw_l", c_void_p), ("gb_l", c_void_p), ("gw_r", c_void_p),
+                ("c_src", c_int32), ("c_dst", c_int32), ("c_out", c_int32), ("reserved", c_int32)]
+
+
+class RankerNorm(Structure):
+    _fields_ = [("gamma", c_void_p), ("beta", c_void_p), ("running_mean", c_void_p), ("running_var", c_void_p),
+                ("num_batches_tracked", c_void_p), ("g_gamma", c_void_p), ("g_beta", c_void_p), ("momentum", c_float), ("eps", c_float)]
+
+
+class RankerLinear(Structure):
+    _fields_ = [("w", c_void_p), ("b", c_void_p), ("gw", c_void_p), ("gb", c_void_p), ("in_", c_int32), ("out", c_int32)]
+
+
+class RankerParam(Structure):
+    _fields_ = [("p", c_void_p), ("g", c_void_p), ("m", c_void_p), ("v", c_void_p), ("n", c_int64)]
+
+
+class RankerModel(Structure):
+    _fields_ = [("n_enc_layers", c_int32), ("n_dec_layers", c_int32), ("aggr", c_int32), ("batch_normalize", c_int32),
+                ("p_dropout", c_float), ("max_norm", c_float), ("n_cols", c_int32 * 2),
+                ("tables", (c_void_p * MI_RANKER_MAX_COLS) * 2), ("table_rows", (c_int64 * MI_RANKER_MAX_COLS) * 2),
+                ("dims", (c_int32 * MI_RANKER_MAX_COLS) * 2), ("conv", (RankerConv * 2) * MI_RANKER_MAX_LAYERS),
+                ("norm", RankerNorm * 2), ("dec", RankerLinear * MI_RANKER_MAX_LAYERS), ("n_params", c_int32), ("apply_adam", c_int32),
+                ("params", RankerParam * MI_RANKER_MAX_PARAMS), ("lr", c_double), ("beta1", c_double), ("beta2", c_double),
+                ("eps", c_double), ("step", c_int64), ("ones4", c_void_p), ("n_ones", c_int64)]
+
+
+class RankerBatch(Structure):
+    _fields_ = [("n_nodes", c_int64 * 2), ("x", c_void_p * 2), ("by_customer_ptr", c_void_p), ("by_customer_col", c_void_p),
+                ("by_article_ptr", c_void_p), ("by_article_col", c_void_p), ("nnz", c_int64), ("n_label", c_int64),
+                ("label_row", c_void_p), ("label_col", c_void_p), ("label", c_void_p), ("seed", c_uint64), ("step", c_uint64),
+                ("loss", c_void_p), ("label_f32", c_void_p)]
+
+
 P = c_void_p
 _PROTOTYPES = {
     # name: (restype, [argtypes])
@@ -120,6 +158,10 @@ _PROTOTYPES = {
     "mi_gather_cat_bwd_max_edges": (c_int64, []),
     "mi_gather_cat_bwd_f32": (c_int32, [c_int64, c_int64, c_int64, P, P, c_int64, P, c_int64, P]),
     "mi_match_common_items_i32": (c_int32, [c_int64, P, P, P, P, P, c_int32, P, P, P]),
+    "mi_gemm_group_supported": (c_int32, [P, c_int32]),
+    "mi_ranker_sizeof": (c_int64, [c_int32]),
+    "mi_ranker_step_workspace_bytes": (c_size_t, [POINTER(RankerModel), POINTER(RankerBatch)]),
+    "mi_ranker_step_f32": (c_int32, [POINTER(RankerModel), POINTER(RankerBatch), P, c_size_t, P]),
     "mi_match_same_location_i32": (c_int32, [c_int64, P, P, P, P, P, P, c_int32, P, P, P]),
     "mi_sampler_workspace_bytes": (c_size_t, [POINTER(SamplerDesc)]),
     "mi_sampler_count": (c_int32, [POINTER(SamplerDesc), P, c_uint64, c_uint64, P, c_size_t, POINTER(c_int64), P]),

@@ -509,6 +509,18 @@ extern "C" size_t mi_gemm_group_workspace_bytes(const mi_gemm_problem* probs, in
     return total;
 }
 
+extern "C" int mi_gemm_group_supported(const mi_gemm_problem* probs, int32_t n) {
+    if (n < 0 || (n > 0 && !probs)) return 0;
+    for (int i = 0; i < n; ++i) {
+        const mi_gemm_problem& d = probs[i];
+        if (d.m == 0 || d.n == 0) continue;
+        MiGemmGroupProblem g;
+        memset(&g, 0, sizeof(g));
+        if (!group_fill(d, g)) return 0;
+    }
+    return 1;
+}
+
 extern "C" int mi_gemm_group_f32(const mi_gemm_problem* probs, int32_t n, void* ws, size_t ws_bytes,
                                  mi_stream_t stream) {
     MI_CHECK_ARG(n >= 0 && (n == 0 || probs));

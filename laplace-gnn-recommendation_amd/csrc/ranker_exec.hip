@@ -1,0 +1,503 @@
+// b9: native executor of one ranker training iteration (include/laplace_hip.h, mi_ranker_step_f32).
+//
+// The reference's loop body (training.py:19-34) on the default model (model/encoder_decoder.py:75-150) is ~75 kernel
+// launches of 5-40 us each at the reference's batch size (24 users, ~3*10^4 nodes): issued op by op from Python the
+// iteration is bound by the host (0.87 ms of launches against 0.77 ms of kernels).  This file
+// issues the SAME launches — the same extern "C" entry points with the same operands, in the order
+// laplace_amd/ranker_step.py::FusedRankerStep issues them — from one C call.  What is new here is only glue:
+//   * the workspace layout (every activation, saved tensor and gradient temporary of the iteration),
+//   * Philox feature dropout (forward and, regenerated from the same counters, backward),
+//   * the per-relation aggregation weights (ones / 1 / in-degree) and the int64 -> f32 label cast in one launch,
+//   * a multi-tensor Adam over the optimizer's parameter list (mi_adam_update4: mi_adam_dense_f32's arithmetic).
+// The body runs three times over the same code: COUNT (workspace size), CHECK (every operand of every product is
+// validated against the kernels' requirements — nothing has been enqueued if it returns MI_ERR_UNSUPPORTED), LAUNCH.
+#include "common.hpp"
+#include <algorithm>
+
+extern "C" int mi_gemm_group_supported(const mi_gemm_problem* problems, int32_t n);
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kTypes = 2;  // 0 = customer, 1 = article
+
+// ---- small kernels ------------------------------------------------------------------------------------------------------
+
+// Aggregation weights of both relations and the label cast, one launch.
+//   v_art[p]  (by_article CSR, relation 0 forward):   mean ? 1 / deg(article row)          : 1
+//   v_cus[p]  (by_customer CSR, relation 1 forward):  mean ? 1 / deg(customer row)         : 1
+//   vt_cus[p] (by_customer CSR, relation 0 backward): mean ? 1 / deg(article = column)     : 1
+//   vt_art[p] (by_article CSR, relation 1 backward):  mean ? 1 / deg(customer = column)    : 1
+// (BipartiteGraph.weights of model/layers.py: scale_csr(by_dst, inv) and scale_csr(by_src, col_scale = inv).)
+__global__ __launch_bounds__(kBlock) void ranker_prep_kernel(int64_t nnz, int64_t n_c, int64_t n_a, int mean,
+                                                             const int32_t* __restrict__ cptr, const int32_t* __restrict__ ccol,
+                                                             const int32_t* __restrict__ aptr, const int32_t* __restrict__ acol,
+                                                             float* __restrict__ v_cus, float* __restrict__ vt_cus,
+                                                             float* __restrict__ v_art, float* __restrict__ vt_art,
+                                                             int64_t n_label, const int64_t* __restrict__ label,
+                                                             float* __restrict__ label_f) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (label && i < n_label) label_f[i] = (float)label[i];
+    if (!mean) {
+        if (i < nnz) v_cus[i] = vt_cus[i] = v_art[i] = vt_art[i] = 1.f;
+        return;
+    }
+    // one thread per ROW of each CSR writes that row's entries (rows are short: fan-out-capped subgraphs)
+    if (i < n_c) {
+        const int32_t b = cptr[i], e = cptr[i + 1];
+        const float inv = e > b ? 1.0f / (float)(e - b) : 0.f;
+        for (int32_t p = b; p < e; ++p) {
+            v_cus[p] = inv;
+            const int32_t a = ccol[p];
+            const int32_t da = aptr[a + 1] - aptr[a];
+            vt_cus[p] = da > 0 ? 1.0f / (float)da : 0.f;
+        }
+    }
+    if (i < n_a) {
+        const int32_t b = aptr[i], e = aptr[i + 1];
+        const float inv = e > b ? 1.0f / (float)(e - b) : 0.f;
+        for (int32_t p = b; p < e; ++p) {
+            v_art[p] = inv;
+            const int32_t c = acol[p];
+            const int32_t dc = cptr[c + 1] - cptr[c];
+            vt_art[p] = dc > 0 ? 1.0f / (float)dc : 0.f;
+        }
+    }
+}
+
+// y = x * keep / (1 - p), keep ~ Bernoulli(1 - p) from Philox4x32-10 keyed on (seed, step) with counter (element / 4, site):
+// four elements per draw, the same call on dY regenerates the mask in the backward.  In place allowed.
+__global__ __launch_bounds__(kBlock) void dropout_kernel(int64_t n4, const float4* __restrict__ x, float4* __restrict__ y,
+                                                         float p, float scale, uint32_t k0, uint32_t k1, uint32_t site,
+                                                         uint32_t step_lo) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n4) return;
+    const MiPhilox r = mi_philox4x32((uint32_t)i, (uint32_t)((uint64_t)i >> 32), site, step_lo, k0, k1);
+    const uint32_t thr = (uint32_t)fminf(4294967040.f, p * 4294967296.f);  // keep when the draw is >= p * 2^32
+    float4 v = x[i];
+    v.x = r.c[0] >= thr ? v.x * scale : 0.f;
+    v.y = r.c[1] >= thr ? v.y * scale : 0.f;
+    v.z = r.c[2] >= thr ? v.z * scale : 0.f;
+    v.w = r.c[3] >= thr ? v.w * scale : 0.f;
+    y[i] = v;
+}
+
+struct AdamTable {
+    mi_ranker_param p[MI_RANKER_MAX_PARAMS];
+    int32_t g_stride[MI_RANKER_MAX_PARAMS];   // 1, or 4: the gradient is column 0 of a [n, 4] product (bias rows)
+    float* g_dst[MI_RANKER_MAX_PARAMS];       // where a strided gradient is also written densely (the caller's .grad)
+    int32_t n;
+};
+
+// blockIdx.y = parameter tensor, blockIdx.x strides over its elements; also bumps the BatchNorm batch counters
+__global__ __launch_bounds__(kBlock) void adam_multi_kernel(AdamTable tb, MiAdamConsts c, int apply, int64_t* nbt0, int64_t* nbt1) {
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+        if (nbt0) *nbt0 += 1;
+        if (nbt1) *nbt1 += 1;
+    }
+    const mi_ranker_param q = tb.p[blockIdx.y];
+    const int gs = tb.g_stride[blockIdx.y];
+    float* gd = tb.g_dst[blockIdx.y];
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < q.n; i += (int64_t)gridDim.x * kBlock) {
+        const float g = q.g[i * gs];
+        if (gd) gd[i] = g;
+        if (!apply) continue;
+        float4 pp = make_float4(q.p[i], 0.f, 0.f, 0.f), mm = make_float4(q.m[i], 0.f, 0.f, 0.f), vv = make_float4(q.v[i], 1.f, 1.f, 1.f);
+        mi_adam_update4(pp, make_float4(g, 0.f, 0.f, 0.f), mm, vv, false, 0.f, c);
+        q.p[i] = pp.x;
+        q.m[i] = mm.x;
+        q.v[i] = vv.x;
+    }
+}
+
+// ---- the iteration --------------------------------------------------------------------------------------------------------
+
+enum Mode { COUNT = 0, CHECK = 1, LAUNCH = 2 };
+
+struct Exec {
+    const mi_ranker_model& M;
+    const mi_ranker_batch& B;
+    MiArena ar;
+    Mode mode;
+    hipStream_t s;
+    int rc = 0;
+    bool oom = false;
+
+    Exec(const mi_ranker_model& m, const mi_ranker_batch& b, void* ws, size_t cap, Mode md, hipStream_t st)
+        : M(m), B(b), ar(ws, cap), mode(md), s(st) {}
+
+    float* take(int64_t rows, int64_t cols) {
+        const size_t n = (size_t)std::max<int64_t>(rows, 1) * (size_t)std::max<int64_t>(cols, 1);
+        float* p = ar.take<float>(n);
+        if (!p) oom = true;
+        return p;
+    }
+    char* take_bytes(size_t n) {
+        char* p = ar.take<char>(std::max<size_t>(n, 1));
+        if (!p) oom = true;
+        return p;
+    }
+    bool go() const { return mode == LAUNCH && rc == 0 && !oom; }
+    void fail(int code) { if (rc == 0) rc = code; }
+    void ok(int code) { if (code != 0 && rc == 0) rc = code; }
+
+    // acc = A(csr, val) @ X  [+ in-place: S = addend + acc]; plan-less launches (per-batch subgraphs)
+    void spmm(int64_t n_rows, int64_t d, const int32_t* rowptr, const int32_t* col, const float* val, const float* X, float* Y,
+              const float* addend, float* S) {
+        if (mode == CHECK && (d % 4 != 0 || d > 512)) fail(MI_ERR_UNSUPPORTED);
+        if (!go()) return;
+        ok(mi_spmm_csr_ex_f32(n_rows, d, rowptr, col, val, X, d, Y, d, addend, d, S, d, 1.0f, nullptr, nullptr, nullptr, 0,
+                              (mi_stream_t)s));
+    }
+
+    // one grouped launch (<= 8 problems); problems without a mask fall back to mi_gemm_f32 one by one when an operand
+    // is not float4-addressable (the decoder's last layer: [n, 1] gradients), exactly as model/layers.py::_run_products
+    void products(mi_gemm_problem* pr, int n) {
+        const size_t wsb = mi_gemm_group_workspace_bytes(pr, n);
+        char* w = wsb ? take_bytes(wsb) : nullptr;
+        bool grouped = true;
+        if (mode != COUNT) grouped = mi_gemm_group_supported(pr, n) != 0;
+        size_t single_ws = 0;
+        if (mode == COUNT || !grouped) {
+            // COUNT cannot know (pointers are not final): reserve the per-product split-K scratch as well
+            for (int i = 0; i < n; ++i) single_ws = std::max(single_ws, mi_gemm_workspace_bytes(pr[i].m, pr[i].n, pr[i].k));
+        }
+        char* w1 = single_ws ? take_bytes(single_ws) : nullptr;
+        if (!grouped) {
+            for (int i = 0; i < n; ++i)
+                if (pr[i].a_mask || pr[i].k2 > 0) { fail(MI_ERR_UNSUPPORTED); return; }
+        }
+        if (!go()) return;
+        if (grouped) {
+            ok(mi_gemm_group_f32(pr, n, w, wsb, (mi_stream_t)s));
+            return;
+        }
+        for (int i = 0; i < n && rc == 0; ++i) {
+            const mi_gemm_problem& q = pr[i];
+            const size_t need = mi_gemm_workspace_bytes(q.m, q.n, q.k);
+            ok(mi_gemm_f32(q.trans_a, q.trans_b, q.m, q.n, q.k, q.A, q.lda, q.B, q.ldb, q.bias, q.C, q.ldc, q.accumulate, q.act,
+                           need ? w1 : nullptr, need, (mi_stream_t)s));
+        }
+    }
+
+    void dropout(const float* x, float* y, int64_t n, uint32_t site) {
+        if (mode == CHECK && n % 4 != 0) fail(MI_ERR_UNSUPPORTED);
+        if (!go() || n == 0) return;
+        const float p = M.p_dropout;
+        hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)mi_ceil_div(n / 4, kBlock)), dim3(kBlock), 0, s, n / 4,
+                           reinterpret_cast<const float4*>(x), reinterpret_cast<float4*>(y), p, 1.0f / (1.0f - p),
+                           (uint32_t)B.seed, (uint32_t)(B.seed >> 32), site, (uint32_t)B.step);
+        ok(mi_launch_status());
+    }
+
+    static mi_gemm_problem prob(int ta, int tb, int64_t m, int64_t n, int64_t k, const float* A, int64_t lda, const float* Bm,
+                                int64_t ldb, float* C, int64_t ldc, const float* mask = nullptr, const float* bias = nullptr,
+                                int act = 0) {
+        mi_gemm_problem q;
+        memset(&q, 0, sizeof(q));
+        q.trans_a = ta; q.trans_b = tb; q.m = m; q.n = n; q.k = k;
+        q.A = A; q.lda = lda; q.B = Bm; q.ldb = ldb; q.C = C; q.ldc = ldc;
+        q.a_mask = mask; q.bias = bias; q.act = act;
+        return q;
+    }
+
+    int run();
+};
+
+int Exec::run() {
+    const int L = M.n_enc_layers, LD = M.n_dec_layers;
+    const int64_t n[2] = {B.n_nodes[0], B.n_nodes[1]};
+    const int64_t nnz = B.nnz, nl = B.n_label;
+    const bool drop = M.p_dropout > 0.f;
+    // relation r: src / dst type, forward CSR (rows = dst), backward CSR (rows = src)
+    const int src_of[2] = {0, 1}, dst_of[2] = {1, 0};
+    const int32_t* fptr[2] = {B.by_article_ptr, B.by_customer_ptr};
+    const int32_t* fcol[2] = {B.by_article_col, B.by_customer_col};
+    const int32_t* bptr[2] = {B.by_customer_ptr, B.by_article_ptr};
+    const int32_t* bcol[2] = {B.by_customer_col, B.by_article_col};
+
+    if (mode == CHECK) {
+        if (L < 1 || L > MI_RANKER_MAX_LAYERS || LD < 1 || LD > MI_RANKER_MAX_LAYERS) return MI_ERR_UNSUPPORTED;
+        if (M.aggr != 0 && M.aggr != 1) return MI_ERR_UNSUPPORTED;
+        if (!(M.p_dropout >= 0.f && M.p_dropout < 1.f)) return MI_ERR_BAD_ARG;
+        if (nnz >= (1 << 20)) return MI_ERR_UNSUPPORTED;                       // the op-by-op path plans such adjacencies
+        if (nl > mi_gather_cat_bwd_max_edges()) return MI_ERR_UNSUPPORTED;
+        if (n[0] <= 0 || n[1] <= 0 || nl <= 0 || nnz < 0) return MI_ERR_UNSUPPORTED;
+        if (M.n_ones < std::max(std::max(n[0], n[1]), nl) || !M.ones4) return MI_ERR_BAD_ARG;
+        if (M.n_params < 0 || M.n_params > MI_RANKER_MAX_PARAMS) return MI_ERR_BAD_ARG;
+        for (int t = 0; t < kTypes; ++t)
+            if (M.n_cols[t] < 1 || M.n_cols[t] > MI_RANKER_MAX_COLS || !B.x[t]) return MI_ERR_UNSUPPORTED;
+        if (!B.by_customer_ptr || !B.by_article_ptr || !B.label_row || !B.label_col || (!B.label && !B.label_f32) || !B.loss) return MI_ERR_BAD_ARG;
+    }
+
+    // ---- embeddings (K7) ------------------------------------------------------------------------------------------
+    int64_t width[2] = {0, 0};
+    for (int t = 0; t < kTypes; ++t)
+        for (int c = 0; c < M.n_cols[t]; ++c) width[t] += M.dims[t][c];
+    float* x0[2];
+    for (int t = 0; t < kTypes; ++t) {
+        x0[t] = take(n[t], width[t]);
+        if (go())
+            ok(mi_embed_concat_f32(n[t], M.n_cols[t], B.x[t], M.tables[t], M.table_rows[t], M.dims[t], M.max_norm, x0[t], width[t],
+                                   (mi_stream_t)s));
+    }
+    // ---- aggregation weights + labels
+    float* v_cus = take(nnz, 1);
+    float* vt_cus = take(nnz, 1);
+    float* v_art = take(nnz, 1);
+    float* vt_art = take(nnz, 1);
+    float* label_f = take(nl, 1);
+    if (go()) {
+        const int64_t span = std::max(std::max(nnz, nl), std::max(n[0], n[1]));
+        hipLaunchKernelGGL(ranker_prep_kernel, dim3((unsigned)mi_ceil_div(span, kBlock)), dim3(kBlock), 0, s, nnz, n[0], n[1],
+                           M.aggr == 1 ? 1 : 0, B.by_customer_ptr, B.by_customer_col, B.by_article_ptr, B.by_article_col, v_cus,
+                           vt_cus, v_art, vt_art, nl, B.label_f32 ? nullptr : B.label, label_f);
+        ok(mi_launch_status());
+    }
+    const float* fval[2] = {v_art, v_cus};     // forward values of relation r (CSR by destination)
+    const float* bval[2] = {vt_cus, vt_art};   // backward values of relation r (CSR by source)
+
+    // ---- encoder forward ------------------------------------------------------------------------------------------
+    float* xin[MI_RANKER_MAX_LAYERS][2];   // layer input after dropout
+    float* agg[MI_RANKER_MAX_LAYERS][2];
+    float* out[MI_RANKER_MAX_LAYERS][2];   // by relation: out[l][r] has n[dst_of[r]] rows
+    int64_t cw[2] = {width[0], width[1]};  // current feature width per type
+    float* cur[2] = {x0[0], x0[1]};
+    for (int l = 0; l < L; ++l) {
+        const bool last = l == L - 1;
+        for (int t = 0; t < kTypes; ++t) {
+            xin[l][t] = cur[t];
+            if (!last && drop) {
+                xin[l][t] = take(n[t], cw[t]);
+                dropout(cur[t], xin[l][t], n[t] * cw[t], (uint32_t)(l * 2 + t));
+            }
+        }
+        mi_gemm_problem pr[2];
+        for (int r = 0; r < 2; ++r) {
+            const mi_ranker_conv& cv = M.conv[l][r];
+            const int st = src_of[r], dt = dst_of[r];
+            if (mode == CHECK && (cv.c_src != cw[st] || cv.c_dst != cw[dt] || !cv.w_l || !cv.w_r || !cv.gw_l || !cv.gw_r ||
+                                  (cv.b_l && !cv.gb_l) || cv.c_src % 4 || cv.c_dst % 4 || cv.c_out % 4))
+                return MI_ERR_UNSUPPORTED;
+            agg[l][r] = take(n[dt], cv.c_src);
+            out[l][r] = take(n[dt], cv.c_out);
+            spmm(n[dt], cv.c_src, fptr[r], fcol[r], fval[r], xin[l][st], agg[l][r], nullptr, nullptr);
+            pr[r] = prob(0, 1, n[dt], cv.c_out, cv.c_src, agg[l][r], cv.c_src, cv.w_l, cv.c_src, out[l][r], cv.c_out, nullptr,
+                         cv.b_l, last ? 0 : 1);
+            pr[r].k2 = cv.c_dst; pr[r].A2 = xin[l][dt]; pr[r].lda2 = cv.c_dst; pr[r].B2 = cv.w_r; pr[r].ldb2 = cv.c_dst;
+        }
+        products(pr, 2);
+        for (int r = 0; r < 2; ++r) {
+            cur[dst_of[r]] = out[l][r];
+            cw[dst_of[r]] = M.conv[l][r].c_out;
+        }
+    }
+    if (mode == CHECK && cw[0] != cw[1]) return MI_ERR_UNSUPPORTED;
+    const int64_t C = cw[0];
+    // ---- BatchNorm (K8) -------------------------------------------------------------------------------------------
+    float* z[2] = {cur[0], cur[1]};
+    float* zpre[2] = {cur[0], cur[1]};
+    float *bn_mean[2] = {nullptr, nullptr}, *bn_inv[2] = {nullptr, nullptr};
+    char* bn_ws = nullptr;
+    const size_t bn_ws_bytes = mi_batchnorm_workspace_bytes(C);
+    if (M.batch_normalize) {
+        bn_ws = take_bytes(bn_ws_bytes);
+        for (int t = 0; t < kTypes; ++t) {
+            const mi_ranker_norm& bn = M.norm[t];
+            if (mode == CHECK && ((bn.gamma && (!bn.beta || !bn.g_gamma || !bn.g_beta)) || C > 512)) return MI_ERR_UNSUPPORTED;
+            z[t] = take(n[t], C);
+            bn_mean[t] = take(C, 1);
+            bn_inv[t] = take(C, 1);
+            if (go())
+                ok(mi_batchnorm_fwd_f32(n[t], C, zpre[t], C, bn.gamma, bn.beta, bn.running_mean, bn.running_var, bn.momentum, bn.eps,
+                                        1, bn_mean[t], bn_inv[t], z[t], C, bn_ws, bn_ws_bytes, (mi_stream_t)s));
+        }
+    }
+    // ---- decoder forward (b7) -------------------------------------------------------------------------------------
+    float* h = take(nl, 2 * C);
+    if (go()) ok(mi_gather_cat_f32(nl, C, C, B.label_row, B.label_col, z[0], C, z[1], C, h, 2 * C, (mi_stream_t)s));
+    float* din[MI_RANKER_MAX_LAYERS];
+    float* dout[MI_RANKER_MAX_LAYERS];
+    int64_t hw = 2 * C;
+    for (int j = 0; j < LD; ++j) {
+        const mi_ranker_linear& ln = M.dec[j];
+        const bool last = j == LD - 1;
+        if (mode == CHECK && (ln.in != hw || !ln.w || !ln.gw || (ln.b && !ln.gb) || (last && ln.out != 1))) return MI_ERR_UNSUPPORTED;
+        din[j] = h;
+        if (!last && drop) {
+            din[j] = take(nl, hw);
+            dropout(h, din[j], nl * hw, (uint32_t)(64 + j));
+        }
+        dout[j] = take(nl, ln.out);
+        const size_t need = mi_gemm_workspace_bytes(nl, ln.out, hw);
+        char* w = need ? take_bytes(need) : nullptr;
+        if (go())
+            ok(mi_gemm_f32(0, 1, nl, ln.out, hw, din[j], hw, ln.w, hw, ln.b, dout[j], ln.out, 0, last ? 0 : 1, w, need, (mi_stream_t)s));
+        h = dout[j];
+        hw = ln.out;
+    }
+    // ---- loss (b9)
+    float* dlogits = take(nl, 1);
+    if (go()) ok(mi_bce_logits_f32(nl, h, B.label_f32 ? B.label_f32 : label_f, B.loss, dlogits, (mi_stream_t)s));
+
+    // ---- decoder backward -----------------------------------------------------------------------------------------
+    AdamTable tb;
+    memset(&tb, 0, sizeof(tb));
+    auto grad_src = [&](const float* param, const float* src, int stride, float* dense) {
+        // a bias gradient lives in column 0 of a [n, 4] product: the Adam launch reads it there and copies it out
+        for (int i = 0; i < M.n_params; ++i)
+            if (M.params[i].p == param) {
+                tb.p[i].g = const_cast<float*>(src);
+                tb.g_stride[i] = stride;
+                tb.g_dst[i] = dense;
+            }
+    };
+    float* dh = dlogits;
+    for (int j = LD - 1; j >= 0; --j) {
+        const mi_ranker_linear& ln = M.dec[j];
+        const bool last = j == LD - 1;
+        const float* mask = last ? nullptr : dout[j];
+        float* dx = take(nl, ln.in);
+        mi_gemm_problem pr[3];
+        int np = 0;
+        pr[np++] = prob(0, 0, nl, ln.in, ln.out, dh, ln.out, ln.w, ln.in, dx, ln.in, mask);
+        pr[np++] = prob(1, 0, ln.out, ln.in, nl, dh, ln.out, din[j], ln.in, ln.gw, ln.in, mask);
+        if (ln.b) {
+            float* db4 = take(ln.out, 4);
+            pr[np++] = prob(1, 0, ln.out, 4, nl, dh, ln.out, M.ones4, 4, db4, 4, mask);
+            grad_src(ln.b, db4, 4, ln.gb);
+        }
+        products(pr, np);
+        dh = dx;
+        if (!last && drop) dropout(dx, dx, nl * ln.in, (uint32_t)(64 + j));   // the forward's mask, regenerated
+    }
+    // ---- gather-cat backward
+    float* dz[2];
+    for (int t = 0; t < kTypes; ++t) {
+        dz[t] = take(n[t], C);
+        if (go()) {
+            ok((int)hipMemsetAsync(dz[t], 0, (size_t)n[t] * C * sizeof(float), s));
+            ok(mi_gather_cat_bwd_f32(nl, C, t == 0 ? 0 : C, t == 0 ? B.label_row : B.label_col, dh, 2 * C, dz[t], C, (mi_stream_t)s));
+        }
+    }
+    // ---- BatchNorm backward
+    if (M.batch_normalize) {
+        for (int t = 0; t < kTypes; ++t) {
+            const mi_ranker_norm& bn = M.norm[t];
+            float* dx = take(n[t], C);
+            if (go())
+                ok(mi_batchnorm_bwd_f32(n[t], C, zpre[t], C, dz[t], C, bn.gamma, bn_mean[t], bn_inv[t], dx, C, bn.gamma ? bn.g_gamma : nullptr,
+                                        bn.gamma ? bn.g_beta : nullptr, bn_ws, bn_ws_bytes, (mi_stream_t)s));
+            dz[t] = dx;
+        }
+    }
+    // ---- encoder backward -----------------------------------------------------------------------------------------
+    float* dxs[2] = {dz[0], dz[1]};
+    for (int l = L - 1; l >= 0; --l) {
+        const bool last = l == L - 1, need_x = l > 0;   // layer 0 reads frozen embeddings
+        const float* dy[2];
+        const float* mask[2];
+        for (int r = 0; r < 2; ++r) {
+            dy[r] = dxs[dst_of[r]];
+            mask[r] = last ? nullptr : out[l][r];
+        }
+        float* dxn[2] = {nullptr, nullptr};
+        if (need_x) {
+            mi_gemm_problem pr[4];
+            float* dagg[2];
+            int np = 0;
+            for (int r = 0; r < 2; ++r) {
+                const mi_ranker_conv& cv = M.conv[l][r];
+                const int dt = dst_of[r];
+                dagg[r] = take(n[dt], cv.c_src);
+                float* dxd = take(n[dt], cv.c_dst);
+                pr[np++] = prob(0, 0, n[dt], cv.c_src, cv.c_out, dy[r], cv.c_out, cv.w_l, cv.c_src, dagg[r], cv.c_src, mask[r]);
+                pr[np++] = prob(0, 0, n[dt], cv.c_dst, cv.c_out, dy[r], cv.c_out, cv.w_r, cv.c_dst, dxd, cv.c_dst, mask[r]);
+                dxn[dt] = dxd;
+            }
+            products(pr, np);
+            for (int r = 0; r < 2; ++r) {   // dX_src += A^T dAgg, in the epilogue
+                const mi_ranker_conv& cv = M.conv[l][r];
+                const int st = src_of[r];
+                spmm(n[st], cv.c_src, bptr[r], bcol[r], bval[r], dagg[r], nullptr, dxn[st], dxn[st]);
+            }
+        }
+        mi_gemm_problem pw[6];
+        int nw = 0;
+        for (int r = 0; r < 2; ++r) {
+            const mi_ranker_conv& cv = M.conv[l][r];
+            const int dt = dst_of[r];
+            pw[nw++] = prob(1, 0, cv.c_out, cv.c_src, n[dt], dy[r], cv.c_out, agg[l][r], cv.c_src, cv.gw_l, cv.c_src, mask[r]);
+            if (cv.b_l) {
+                float* db4 = take(cv.c_out, 4);
+                pw[nw++] = prob(1, 0, cv.c_out, 4, n[dt], dy[r], cv.c_out, M.ones4, 4, db4, 4, mask[r]);
+                grad_src(cv.b_l, db4, 4, cv.gb_l);
+            }
+            pw[nw++] = prob(1, 0, cv.c_out, cv.c_dst, n[dt], dy[r], cv.c_out, xin[l][dt], cv.c_dst, cv.gw_r, cv.c_dst, mask[r]);
+        }
+        products(pw, nw);
+        if (need_x) {
+            for (int t = 0; t < kTypes; ++t) {
+                dxs[t] = dxn[t];
+                // the mask this layer's forward drew for its input of type t (relation t is the one whose source is t)
+                if (!last && drop) dropout(dxn[t], dxn[t], n[t] * M.conv[l][t].c_src, (uint32_t)(l * 2 + t));
+            }
+        }
+    }
+    if (oom) return MI_ERR_WORKSPACE;
+    if (rc) return rc;
+    // ---- Adam over the parameter list (a9's arithmetic) + the BatchNorm batch counters ------------------------------------
+    if (mode != LAUNCH) return 0;
+    int64_t longest = 1;
+    for (int i = 0; i < M.n_params; ++i) {
+        const float* strided = tb.p[i].g;
+        tb.p[i] = M.params[i];
+        if (strided) tb.p[i].g = const_cast<float*>(strided); else tb.g_stride[i] = 1;
+        longest = std::max(longest, M.params[i].n);
+    }
+    tb.n = M.n_params;
+    int64_t* nbt0 = M.batch_normalize ? M.norm[0].num_batches_tracked : nullptr;
+    int64_t* nbt1 = M.batch_normalize ? M.norm[1].num_batches_tracked : nullptr;
+    if (M.n_params > 0 || nbt0 || nbt1) {
+        const MiAdamConsts c = mi_adam_consts(M.lr, M.beta1, M.beta2, M.eps, M.step > 0 ? M.step : 1);
+        const unsigned gx = (unsigned)std::min<int64_t>(mi_ceil_div(longest, kBlock), 64);
+        hipLaunchKernelGGL(adam_multi_kernel, dim3(gx, (unsigned)std::max(M.n_params, 1)), dim3(kBlock), 0, s, tb, c,
+                           (M.apply_adam && M.n_params > 0) ? 1 : 0, nbt0, nbt1);
+        ok(mi_launch_status());
+    }
+    return rc;
+}
+
+}  // namespace
+
+extern "C" int64_t mi_ranker_sizeof(int32_t which) {
+    switch (which) {
+        case 0: return (int64_t)sizeof(mi_ranker_model);
+        case 1: return (int64_t)sizeof(mi_ranker_batch);
+        case 2: return (int64_t)sizeof(mi_ranker_conv);
+        case 3: return (int64_t)sizeof(mi_ranker_norm);
+        case 4: return (int64_t)sizeof(mi_ranker_linear);
+        case 5: return (int64_t)sizeof(mi_ranker_param);
+        default: return -1;
+    }
+}
+
+extern "C" size_t mi_ranker_step_workspace_bytes(const mi_ranker_model* model, const mi_ranker_batch* batch) {
+    if (!model || !batch) return 0;
+    // counting pass over a fictitious base: only offsets matter
+    Exec e(*model, *batch, reinterpret_cast<void*>((uintptr_t)4096), (size_t)1 << 46, COUNT, nullptr);
+    e.run();
+    return e.ar.off + 4096;
+}
+
+extern "C" int mi_ranker_step_f32(const mi_ranker_model* model, const mi_ranker_batch* batch, void* ws, size_t ws_bytes,
+                                  mi_stream_t stream) {
+    MI_CHECK_ARG(model && batch && ws && mi_aligned16(ws));
+    {
+        Exec chk(*model, *batch, ws, ws_bytes, CHECK, (hipStream_t)stream);
+        const int rc = chk.run();
+        if (rc) return rc;
+    }
+    Exec run(*model, *batch, ws, ws_bytes, LAUNCH, (hipStream_t)stream);
+    return run.run();
+}

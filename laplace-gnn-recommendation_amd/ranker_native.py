@@ -1,0 +1,255 @@
+"""One ranker training iteration as ONE C call (include/laplace_hip.h: mi_ranker_step_f32, csrc/ranker_exec.hip).
+
+`ranker_step.FusedRankerStep` already runs the iteration of the reference's training.py:19-34 as straight-line code —
+but still as ~75 op calls from Python, and at the reference's batch size (24 users) each of them costs more on the host
+than its kernel does on the GPU.  `NativeRankerStep` hands the C executor a description of the model (parameter,
+gradient and Adam-state pointers, built once) and of the batch (feature tensors, the two sorted CSRs the device sampler
+emits, the label edges) and the executor enqueues the same launches in the same order itself, dropout (Philox) and the
+multi-tensor Adam update included: no at::native kernel is left in the loop.
+
+The model, its parameters / buffers / state_dict and the optimizer object stay torch's own: gradients land in
+`param.grad`, Adam's moments in `optimizer.state[p]["exp_avg" / "exp_avg_sq"]`, its step count in `state[p]["step"]`.
+Shapes the executor does not take (MI_ERR_UNSUPPORTED, nothing enqueued) fall to FusedRankerStep / autograd.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Dict, Optional
+
+import torch as t
+from torch import Tensor
+
+from . import _lib, ops
+from ._lib import RankerBatch, RankerModel
+from .model.encoder_decoder import Encoder_Decoder_Model, _key
+from .model.layers import Linear, SAGEConv, _ones4
+from .utils.constants import Constants
+
+
+class NativeRankerStep:
+    def __init__(self, model: Encoder_Decoder_Model, optimizer: t.optim.Optimizer, before_step=None, seed: Optional[int] = None):
+        """before_step: called once the gradients are in place and BEFORE the update (data-parallel callers all-reduce
+        there); the executor then stops after the gradients and `optimizer.step()` applies them."""
+        why = self.unsupported_reason(model, optimizer)
+        if why:
+            raise ValueError(f"NativeRankerStep: {why}")
+        self.model, self.optimizer, self.before_step = model, optimizer, before_step
+        self.seed = int(t.initial_seed() if seed is None else seed) & ((1 << 64) - 1)
+        self.iteration = 0
+        self._desc: Optional[RankerModel] = None
+        self._keep = []            # tensors the descriptor points into
+        self._ws: Optional[Tensor] = None
+        self._adam_step = 0
+        self.declined: Optional[str] = None
+
+    # ------------------------------------------------------------------------------------------
+    @staticmethod
+    def unsupported_reason(model, optimizer) -> Optional[str]:
+        if not isinstance(model, Encoder_Decoder_Model):
+            return "not an Encoder_Decoder_Model"
+        enc, dec = model.encoder, model.decoder
+        if not model.embedding:
+            return "dense (non-categorical) node features"
+        if enc.node_types != [Constants.node_user, Constants.node_item]:
+            return "node types other than [customer, article]"
+        if [tuple(e) for e in enc.edge_types] != [tuple(Constants.edge_key), tuple(Constants.rev_edge_key)]:
+            return "edge types other than buys / rev_buys"
+        if not (1 <= len(enc.layers) <= _lib.MI_RANKER_MAX_LAYERS and 1 <= len(dec.layers) <= _lib.MI_RANKER_MAX_LAYERS):
+            return "layer count"
+        aggrs = set()
+        for convs in enc.layers:
+            for conv in convs.values():
+                if not isinstance(conv, SAGEConv) or conv.normalize or not conv.root_weight or conv.lin_l.weight is None:
+                    return "a conv that is not a materialised SAGEConv with root weight"
+                aggrs.add("add" if conv.aggr in ("add", "sum") else conv.aggr)
+        if len(aggrs) != 1 or next(iter(aggrs)) not in ("add", "mean"):
+            return "aggregation other than add / mean"
+        if not all(isinstance(l, Linear) and l.weight is not None for l in dec.layers):
+            return "a decoder layer that is not a materialised Linear"
+        for bn in (model.encoder_layer_norm_customer, model.encoder_layer_norm_article):
+            if model.batch_normalize and (bn.momentum is None or (bn.weight is None) != (bn.bias is None)):
+                return "BatchNorm with cumulative momentum"
+        for tables in model.embedding_layers.values():
+            if len(tables) > _lib.MI_RANKER_MAX_COLS:
+                return "more categorical columns than the executor takes"
+        if type(optimizer) is not t.optim.Adam or len(optimizer.param_groups) != 1:
+            return "optimizer other than a single-group torch.optim.Adam"
+        g = optimizer.param_groups[0]
+        if g.get("amsgrad") or g.get("weight_decay", 0) or g.get("maximize") or g.get("capturable") or g.get("differentiable"):
+            return "Adam options (amsgrad / weight_decay / maximize / capturable)"
+        if isinstance(g["lr"], Tensor):
+            return "tensor learning rate"
+        if len(g["params"]) > _lib.MI_RANKER_MAX_PARAMS or any(p.dtype != t.float32 or not p.is_cuda for p in g["params"]):
+            return "parameter list"
+        return None
+
+    @classmethod
+    def supports(cls, model, optimizer) -> bool:
+        return cls.unsupported_reason(model, optimizer) is None
+
+    # ------------------------------------------------------------------------------------------
+    def _build(self) -> RankerModel:
+        model, opt = self.model, self.optimizer
+        enc, dec = model.encoder, model.decoder
+        d = RankerModel()
+        keep = self._keep = []
+
+        def grad_of(p: Tensor) -> int:
+            if p.grad is None or p.grad.shape != p.shape or not p.grad.is_contiguous():
+                p.grad = t.zeros_like(p)
+            keep.append(p.grad)
+            return p.grad.data_ptr()
+
+        d.n_enc_layers, d.n_dec_layers = len(enc.layers), len(dec.layers)
+        first = next(iter(enc.layers[0].values()))
+        d.aggr = 1 if first.aggr == "mean" else 0
+        d.batch_normalize = 1 if model.batch_normalize else 0
+        d.max_norm = 1.0
+        for ti, key in enumerate((Constants.node_user, Constants.node_item)):
+            tables = model.embedding_layers[key]
+            d.n_cols[ti] = len(tables)
+            for c, tb in enumerate(tables):
+                if not tb.is_contiguous():
+                    raise ValueError("embedding tables must be contiguous")
+                d.tables[ti][c] = tb.data_ptr()
+                d.table_rows[ti][c] = int(tb.shape[0])
+                d.dims[ti][c] = int(tb.shape[1])
+        for l, convs in enumerate(enc.layers):
+            for r, et in enumerate((Constants.edge_key, Constants.rev_edge_key)):
+                conv = convs[_key(tuple(et))]
+                cv = d.conv[l][r]
+                cv.w_l, cv.w_r = conv.lin_l.weight.data_ptr(), conv.lin_r.weight.data_ptr()
+                cv.gw_l, cv.gw_r = grad_of(conv.lin_l.weight), grad_of(conv.lin_r.weight)
+                if conv.lin_l.bias is not None:
+                    cv.b_l, cv.gb_l = conv.lin_l.bias.data_ptr(), grad_of(conv.lin_l.bias)
+                cv.c_out, cv.c_src = (int(x) for x in conv.lin_l.weight.shape)
+                cv.c_dst = int(conv.lin_r.weight.shape[1])
+        for ti, bn in enumerate((model.encoder_layer_norm_customer, model.encoder_layer_norm_article)):
+            nm = d.norm[ti]
+            if bn.weight is not None:
+                nm.gamma, nm.beta = bn.weight.data_ptr(), bn.bias.data_ptr()
+                nm.g_gamma, nm.g_beta = grad_of(bn.weight), grad_of(bn.bias)
+            if bn.track_running_stats:
+                nm.running_mean, nm.running_var = bn.running_mean.data_ptr(), bn.running_var.data_ptr()
+                nm.num_batches_tracked = bn.num_batches_tracked.data_ptr()
+            nm.momentum, nm.eps = float(bn.momentum if bn.momentum is not None else 0.1), float(bn.eps)
+        for j, layer in enumerate(dec.layers):
+            ln = d.dec[j]
+            ln.w, ln.gw = layer.weight.data_ptr(), grad_of(layer.weight)
+            if layer.bias is not None:
+                ln.b, ln.gb = layer.bias.data_ptr(), grad_of(layer.bias)
+            ln.out, ln.in_ = (int(x) for x in layer.weight.shape)
+        # the optimizer's parameter list with its state (created the way torch.optim.Adam creates it on its first step)
+        group = opt.param_groups[0]
+        d.n_params = len(group["params"])
+        for i, p in enumerate(group["params"]):
+            st = opt.state[p]
+            if len(st) == 0:
+                on_device = bool(group.get("fused") or group.get("capturable"))
+                st["step"] = t.zeros((), dtype=t.float32, device=p.device) if on_device else t.tensor(0.0, dtype=t.float32)
+                st["exp_avg"] = t.zeros_like(p, memory_format=t.preserve_format)
+                st["exp_avg_sq"] = t.zeros_like(p, memory_format=t.preserve_format)
+            q = d.params[i]
+            q.p, q.g, q.m, q.v, q.n = p.data_ptr(), grad_of(p), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel()
+        steps = [opt.state[p]["step"] for p in group["params"]]
+        self._adam_step = int(steps[0]) if steps else 0     # one read-back when the steps live on the device (fused=True)
+        return d
+
+    def _params_current(self, d: RankerModel) -> bool:
+        """The descriptor holds raw pointers: rebuilt when a parameter, gradient or state tensor was replaced."""
+        group = self.optimizer.param_groups[0]
+        if d.n_params != len(group["params"]):
+            return False
+        for i, p in enumerate(group["params"]):
+            st = self.optimizer.state.get(p)
+            if (p.grad is None or not st or d.params[i].p != p.data_ptr() or d.params[i].g != p.grad.data_ptr()
+                    or d.params[i].m != st["exp_avg"].data_ptr()):
+                return False
+        return True
+
+    # ------------------------------------------------------------------------------------------
+    def step(self, x_dict: Dict[str, Tensor], edge_index_dict: dict, edge_label_index: Tensor, labels: Tensor) -> Optional[Tensor]:
+        """One iteration; the loss as a 1-element device tensor, or None when the executor declines this batch (nothing
+        has been enqueued then; the caller runs FusedRankerStep / autograd)."""
+        model = self.model
+        self.declined = None       # why the last call returned None (diagnostics)
+        if not model.training:
+            self.declined = "model in eval mode"
+            return None
+        if model.batch_normalize and not (model.encoder_layer_norm_customer.training and model.encoder_layer_norm_article.training):
+            self.declined = "BatchNorm layers in eval mode"
+            return None
+        ei = None
+        for k, v in edge_index_dict.items():
+            if tuple(k) == tuple(Constants.edge_key):
+                ei = v
+        if ei is None or edge_label_index.dtype != t.int64:
+            self.declined = "no buys relation / label index not int64"
+            return None
+        if labels.dtype not in (t.int64, t.float32):
+            self.declined = "labels are neither int64 nor float32"
+            return None
+        xc, xa = x_dict[Constants.node_user], x_dict[Constants.node_item]
+        if xc.dtype != t.int64 or xa.dtype != t.int64:
+            self.declined = "features are not int64 categorical columns"
+            return None
+        n_c, n_a = int(xc.shape[0]), int(xa.shape[0])
+        pre = getattr(ei, "_sorted_csr", None)
+        if pre is not None and pre[0].n_rows == n_c and pre[1].n_rows == n_a:
+            by_c, by_a = pre
+        else:  # a batch from a host loader: the two sorts the device sampler would have done
+            src, dst = ei[0].contiguous(), ei[1].contiguous()
+            by_c = ops.coo_to_csr(src, dst, n_c, n_a, want_perm=False)
+            by_a = ops.coo_to_csr(dst, src, n_a, n_c, want_perm=False)
+        if self._desc is None or not self._params_current(self._desc):
+            self._desc = self._build()
+        d = self._desc
+        p = model.encoder.p_dropout_features
+        d.p_dropout = float(p) if p else 0.0
+        group = self.optimizer.param_groups[0]
+        d.lr, (d.beta1, d.beta2), d.eps = float(group["lr"]), (float(b) for b in group["betas"]), float(group["eps"])
+        d.apply_adam = 0 if self.before_step is not None else 1
+        steps = [self.optimizer.state[q]["step"] for q in group["params"]]
+        d.step = self._adam_step + 1
+        xc, xa = xc.contiguous(), xa.contiguous()
+        row, col = edge_label_index[0].contiguous(), edge_label_index[1].contiguous()
+        labels = labels.contiguous()
+        n_lab = int(labels.numel())
+        ones = _ones4(max(n_c, n_a, n_lab), xc.device)
+        d.ones4, d.n_ones = ones.data_ptr(), int(ones.shape[0])
+        b = RankerBatch()
+        b.n_nodes[0], b.n_nodes[1] = n_c, n_a
+        b.x[0], b.x[1] = xc.data_ptr(), xa.data_ptr()
+        b.by_customer_ptr, b.by_customer_col = by_c.rowptr.data_ptr(), (by_c.col.data_ptr() if by_c.nnz else by_c.rowptr.data_ptr())
+        b.by_article_ptr, b.by_article_col = by_a.rowptr.data_ptr(), (by_a.col.data_ptr() if by_a.nnz else by_a.rowptr.data_ptr())
+        b.nnz, b.n_label = by_c.nnz, n_lab
+        b.label_row, b.label_col = row.data_ptr(), col.data_ptr()
+        if labels.dtype == t.int64:     # the sampler's edge_label as it is: cast inside the executor
+            b.label = labels.data_ptr()
+        else:
+            b.label_f32 = labels.data_ptr()
+        b.seed, b.step = self.seed, self.iteration
+        loss = t.empty(1, dtype=t.float32, device=xc.device)
+        b.loss = loss.data_ptr()
+        L = _lib.lib()
+        need = int(L.mi_ranker_step_workspace_bytes(ctypes.byref(d), ctypes.byref(b)))
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = t.empty(int(need * 1.25) + (1 << 20), dtype=t.uint8, device=xc.device)
+        rc = L.mi_ranker_step_f32(ctypes.byref(d), ctypes.byref(b), self._ws.data_ptr(), self._ws.numel(), _lib.current_stream())
+        if rc == _lib.MI_ERR_UNSUPPORTED:
+            self.declined = "mi_ranker_step_f32: MI_ERR_UNSUPPORTED (shape outside the executor's)"
+            return None
+        _lib.check(rc, "mi_ranker_step_f32")
+        self.iteration += 1
+        if self.before_step is not None:       # gradients are in param.grad: exchange them, then torch's own update
+            self.before_step()
+            self.optimizer.step()
+            self._adam_step = int(steps[0]) if steps and not steps[0].is_cuda else self._adam_step + 1
+        else:
+            self._adam_step += 1
+            if steps and steps[0].is_cuda:      # fused=True keeps its step counts on the device: one foreach launch
+                t._foreach_add_(steps, 1)
+            else:
+                for s in steps:                 # the default Adam's host scalars
+                    s += 1
+        return loss

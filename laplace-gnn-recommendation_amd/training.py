@@ -5,9 +5,10 @@
     after every step (training.py:75), which here would also stall the sampler that prepares the next batch on a
     side stream (data/device_sampler.py);
   * the criterion object is built once per epoch, not once per batch;
-  * the iteration runs without the autograd engine where the model has the default shape (`ranker_step.py`: the
-    same launches, hand-derived backward, gradients handed to the caller's optimizer); otherwise backward runs in the
-    calling thread (the iteration is launch-bound: see model/layers.py).
+  * the iteration is ONE C call where the model has the reference's default shape (`ranker_native.py` ->
+    mi_ranker_step_f32: forward, backward, dropout and Adam enqueued by a native executor); otherwise it runs without
+    the autograd engine (`ranker_step.py`: the same launches, hand-derived backward, gradients handed to the caller's
+    optimizer), or, failing that, with backward in the calling thread (the iteration is launch-bound: model/layers.py).
 
 Objective and evaluation arithmetic are the reference's: BCE-with-logits (mean) on the label edges, Adam step per
 batch (training.py:19-34); recall / precision @ k of `infer`'s per-user candidate matrix (training.py:37-57).
@@ -54,13 +55,21 @@ def train_with_dataloader(model: Module, optimizer: Optimizer, data_loader: Iter
     meter = _EpochMeter()
     # the backward graph is a chain of small custom nodes: running it in the calling thread saves the hand-over to
     # autograd's device thread at every one of them (measured: 1.54 -> 1.35 ms per iteration, tools/prof_host_ranker.py)
+    from .ranker_native import NativeRankerStep
     from .ranker_step import FusedRankerStep
     fused = FusedRankerStep(model, optimizer) if (FusedRankerStep.supports(model) and model.training) else None
+    # the whole iteration as one C call where the model has the reference's default shape (ranker_native.py)
+    native = NativeRankerStep(model, optimizer) if (model.training and NativeRankerStep.supports(model, optimizer)) else None
     with t.autograd.set_multithreading_enabled(False):
         for batch in data_loader:
             batch = batch.to(device)
             value = None
-            if fused is not None:  # the same launches as forward + autograd, as straight-line code (ranker_step.py)
+            if native is not None:
+                labelled = batch[Constants.edge_key]   # labels as the sampler wrote them (int64): the executor casts
+                value = native.step(batch.x_dict, batch.edge_index_dict, labelled.edge_label_index, labelled.edge_label)
+                if value is None:
+                    native = None  # a batch / shape the executor declines: the op-by-op paths from here on
+            if value is None and fused is not None:  # the same launches as forward + autograd, as straight-line code (ranker_step.py)
                 value = fused.step(*select_properties(batch))
                 if value is None:
                     fused = None   # this model / metadata is not of the fused form: autograd from here on

@@ -47,6 +47,12 @@ def test_size_queries_run_without_gpu():
     info = _lib.SpmmPlanInfo()
     assert L.mi_spmm_plan_count(10, 10, None, None, 256, 0, None, 0, ctypes.byref(info), None) == -1  # MI_ERR_BAD_ARG
     assert ctypes.sizeof(_lib.SpmmPlanStruct) == 56 and ctypes.sizeof(_lib.SpmmPlanInfo) == 88
+    # the ranker executor's descriptors: the binding's layout is the library's
+    for which, cls in enumerate((_lib.RankerModel, _lib.RankerBatch, _lib.RankerConv, _lib.RankerNorm, _lib.RankerLinear,
+                                 _lib.RankerParam)):
+        assert ctypes.sizeof(cls) == L.mi_ranker_sizeof(which), cls.__name__
+    assert L.mi_ranker_sizeof(99) == -1
+    assert L.mi_ranker_step_f32(None, None, None, 0, None) == -1
 
 
 def test_ops_refuse_cpu_tensors():

@@ -394,3 +394,120 @@ def test_fused_ranker_step_equals_the_autograd_iteration(aggr, embedding):
     t.manual_seed(77)
     l2 = float(f2.step({k: v.clone() for k, v in x.items()}, ei, eli, y))
     assert np.isfinite(l1) and l1 == l2
+
+
+# ---- the iteration as ONE C call (mi_ranker_step_f32, ranker_native.NativeRankerStep) ------------------------------------------
+
+@pytest.mark.parametrize("aggr", ["add", "mean"])
+def test_native_ranker_step_equals_the_fused_step(aggr):
+    """The native executor issues FusedRankerStep's launches itself: same loss, same gradients (bit for bit: the same
+    kernels on the same operands), same BatchNorm statistics; its multi-tensor Adam gives torch.optim.Adam's update.
+    The executor keeps the optimizer's own state tensors up to date (exp_avg, exp_avg_sq, step)."""
+    from laplace_amd.ranker_native import NativeRankerStep
+    from laplace_amd.ranker_step import FusedRankerStep
+    from laplace_amd.utils.get_info import select_properties
+    import copy
+    model, loader, first = _hetero_setup(seed=3, aggr=aggr, embedding=True, p_drop=0.0)
+    twin = copy.deepcopy(model)
+    twin.embedding_layers = model.embedding_layers
+    opt_a = t.optim.Adam(model.parameters(), lr=0.01)
+    opt_b = t.optim.Adam(twin.parameters(), lr=0.01)
+    assert NativeRankerStep.unsupported_reason(model, opt_a) is None
+    native, fused = NativeRankerStep(model, opt_a), FusedRankerStep(twin, opt_b)
+    model.train(); twin.train()
+    for step, batch in enumerate(loader):
+        if step == 5:
+            break
+        x, ei, eli, y = select_properties(batch.to(DEV))
+        la = native.step({k: v.clone() for k, v in x.items()}, ei, eli, y)
+        lb = fused.step({k: v.clone() for k, v in x.items()}, ei, eli, y)
+        assert la is not None and lb is not None, native.declined
+        assert float(la) == float(lb), step
+        gb = dict(twin.named_parameters())
+        for n, p in model.named_parameters():
+            assert p.grad is not None and t.equal(p.grad, gb[n].grad), (step, n)
+        for bn in ("encoder_layer_norm_customer", "encoder_layer_norm_article"):
+            for k in ("running_mean", "running_var", "num_batches_tracked"):
+                assert t.equal(getattr(getattr(model, bn), k), getattr(getattr(twin, bn), k)), (step, bn, k)
+        for (n, p), q in zip(model.named_parameters(), twin.parameters()):
+            assert float((p - q).abs().max()) <= 2e-6, (step, n)           # Adam: same update to rounding
+            sa, sb = opt_a.state[p], opt_b.state[q]
+            assert float(sa["step"]) == float(sb["step"]) == step + 1
+            assert t.allclose(sa["exp_avg"], sb["exp_avg"], rtol=1e-5, atol=1e-9)
+            assert t.allclose(sa["exp_avg_sq"], sb["exp_avg_sq"], rtol=1e-5, atol=1e-12)
+        twin.load_state_dict(model.state_dict())   # cut the chain at rounding level, as the tests above do
+        for (p, q) in zip(model.parameters(), twin.parameters()):
+            for k in ("exp_avg", "exp_avg_sq"):
+                opt_b.state[q][k].copy_(opt_a.state[p][k])
+
+
+def test_native_ranker_step_with_the_device_sampler_and_training_loop():
+    """training.train_with_dataloader picks the native executor for the default model; batches come from the device
+    sampler with its emitted CSRs (no sort in the loop); the loss falls."""
+    from laplace_amd import synthetic as S
+    from laplace_amd.data.device_sampler import DeviceGraphSampler
+    from laplace_amd.model.encoder_decoder import Encoder_Decoder_Model
+    from laplace_amd.model.layers import get_SAGEConv_layers, get_linear_layers
+    from laplace_amd.ranker_native import NativeRankerStep
+    from laplace_amd.training import train_with_dataloader
+    from laplace_amd.utils.get_info import get_feature_info
+    spec = S.SyntheticSpec(3000, 500, 40_000, seed=4, deg_min=2, deg_max=200)
+    graph, users, articles = S.generate_hetero(spec, customer_cards=(300, 2, 84, 4, 5, 2), article_cards=(100, 132, 30, 50))
+    cfg = SimpleNamespace(k=12, num_neighbors=16, n_hop_neighbors=2, positive_edges_ratio=0.5, negative_edges_ratio=3.0, batch_size=24)
+    loader = DeviceGraphSampler(cfg, graph, users, articles, device=DEV, seed=0)
+    first = next(iter(loader))
+    t.manual_seed(0)
+    model = Encoder_Decoder_Model(get_SAGEConv_layers(2, 128, 64, "add"), get_linear_layers(2, 128, 128, 1), get_feature_info(graph),
+                                  first.metadata(), True, "sum", True, 0.0, 0.3).to(DEV)
+    model.initialize_encoder_input_size(first)
+    opt = t.optim.Adam(model.parameters(), lr=0.01)
+    assert NativeRankerStep.supports(model, opt)
+    model.train()
+    losses = train_with_dataloader(model, opt, loader, 0, DEV)
+    assert len(losses) >= 20 and all(np.isfinite(losses))
+    assert np.mean(losses[-5:]) < np.mean(losses[:5])
+    assert float(opt.state[next(model.parameters())]["step"]) == len(losses)   # every iteration went through an Adam update
+    assert int(model.encoder_layer_norm_customer.num_batches_tracked) == len(losses) + 0   # ... and through the BatchNorm
+
+
+def test_native_ranker_dropout_is_reproducible_and_its_backward_uses_the_forward_masks():
+    """Philox feature dropout inside the executor: (seed, iteration) fixes the masks — two runs give the same bits — and
+    the gradient it reports is the gradient of THAT masked network: central differences of the loss on a few weights,
+    with the learning rate at zero so that nothing moves."""
+    from laplace_amd.ranker_native import NativeRankerStep
+    from laplace_amd.utils.get_info import select_properties
+    model, loader, first = _hetero_setup(seed=6, aggr="add", embedding=True, p_drop=0.3)
+    opt = t.optim.Adam(model.parameters(), lr=0.0)
+    native = NativeRankerStep(model, opt, seed=1234)
+    model.train()
+    batch = next(iter(loader)).to(DEV)
+    x, ei, eli, y = select_properties(batch)
+
+    def loss_at(iteration):
+        native.iteration = iteration
+        return native.step({k: v.clone() for k, v in x.items()}, ei, eli, y)
+
+    l0 = float(loss_at(7))
+    g0 = {n: p.grad.clone() for n, p in model.named_parameters()}
+    assert float(loss_at(7)) == l0 and all(t.equal(p.grad, g0[n]) for n, p in model.named_parameters())
+    assert float(loss_at(8)) != l0                                     # another iteration draws other masks
+    # finite differences on the largest-gradient entries of three weight tensors
+    checked = 0
+    for name, p in model.named_parameters():
+        if not (name.endswith("lin_l.weight") or name.endswith("layers.0.weight")):
+            continue
+        g = g0[name]
+        idx = int(g.abs().argmax())
+        eps = 2e-2
+        with t.no_grad():
+            flat = p.view(-1)
+            orig = float(flat[idx])
+            flat[idx] = orig + eps
+            lp = float(loss_at(7))
+            flat[idx] = orig - eps
+            lm = float(loss_at(7))
+            flat[idx] = orig
+        fd = (lp - lm) / (2 * eps)
+        assert abs(fd - float(g.view(-1)[idx])) <= 0.15 * abs(float(g.view(-1)[idx])) + 2e-4, (name, fd, float(g.view(-1)[idx]))
+        checked += 1
+    assert checked >= 3

@@ -75,14 +75,25 @@ def run(args):
     model = Encoder_Decoder_Model(get_SAGEConv_layers(2, 128, 64, "add"), get_linear_layers(2, 128, 128, 1),
                                   get_feature_info(graph), first.metadata(), True, "sum", True, 0.2, 0.3).to(dev)
     model.initialize_encoder_input_size(first.to(dev))
-    opt = t.optim.Adam(model.parameters(), lr=0.01, fused=True)  # one multi-tensor launch, same update
+    native_ok = os.environ.get("LAPLACE_RANKER_NATIVE", "1") != "0" and os.environ.get("LAPLACE_RANKER_AUTOGRAD") != "1"
+    # the reference's optimizer (training.py / run_pipeline.py: Adam(lr=0.01)); the op-by-op paths use torch's fused form
+    opt = t.optim.Adam(model.parameters(), lr=0.01, fused=not native_ok)
     crit = t.nn.BCEWithLogitsLoss()
     model.train()
 
     from laplace_amd.ranker_step import FusedRankerStep
+    from laplace_amd.ranker_native import NativeRankerStep
     fused = None if os.environ.get("LAPLACE_RANKER_AUTOGRAD") == "1" else FusedRankerStep(model, opt)
+    native = NativeRankerStep(model, opt) if (native_ok and NativeRankerStep.supports(model, opt)) else None
+    path_used = {"native": 0, "fused": 0, "autograd": 0}
 
     def step(batch):  # = one iteration of training.train_with_dataloader
+        if native is not None:      # the whole iteration as one C call (mi_ranker_step_f32), as training.train_with_dataloader calls it
+            labelled = batch[("customer", "buys", "article")]
+            loss = native.step(batch.x_dict, batch.edge_index_dict, labelled.edge_label_index, labelled.edge_label)
+            if loss is not None:
+                path_used["native"] += 1
+                return loss
         x, ei, eli, y = select_properties(batch)
         if fused is not None:
             loss = fused.step(x, ei, eli, y)
@@ -132,10 +143,10 @@ def run(args):
                           "parallelism": "1 GPU"},
                "roofline": {"bound": "mfma", "achieved": achieved, "peak": 157.0, "unit": "TFLOP/s", "frac": achieved / 157.0,
                             "traffic": None, "flops_per_iteration": flops,
-                            "note": "a 24-user batch is ~3*10^4 nodes: the iteration is launch- and host-bound (~95 launches, "
-                                    "~1 ms), nowhere near the f32 MFMA roof; the figure is reported because the schema asks for one",
+                            "note": "a 24-user batch is ~3*10^4 nodes: ~75 launches of 5-40 us each, nowhere near the f32 MFMA roof "
+                                    "(the iteration is one C call: mi_ranker_step_f32); the figure is reported because the schema asks for one",
                             "avg_customers_articles_label_edges_per_batch": [n_c, n_a, n_lab]},
-               "loss": float(loss)}
+               "loss": float(loss), "iteration_path": dict(path_used)}
         if args.cpu:
             from oracle import ranker_ref as RR
             ref = RR.ref_from_product(model, first.x_dict)
