@@ -589,6 +589,10 @@ typedef struct mi_ranker_batch {
     uint64_t seed, step;                   /* dropout stream */
     float* loss;                           /* device float[1] */
     const float* label_f32;                /* ... the caller already holds the labels as float[n_label] */
+    /* optional second stream: pairs of independent small launches (customer / article twins) then run side by side.
+     * aux_stream: a hipStream_t; ev_fork / ev_join: two hipEvent_t (timing disabled) owned by the caller and used by no one
+     * else while the call is in flight.  All three null = everything on `stream`.  Results do not depend on it. */
+    void *aux_stream, *ev_fork, *ev_join;
 } mi_ranker_batch;
 int64_t mi_ranker_sizeof(int32_t which);  /* sizeof of: 0 model, 1 batch, 2 conv, 3 norm, 4 linear, 5 param (binding self-check) */
 size_t mi_ranker_step_workspace_bytes(const mi_ranker_model* model, const mi_ranker_batch* batch);

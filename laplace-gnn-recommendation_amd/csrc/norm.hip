@@ -65,6 +65,124 @@ __global__ __launch_bounds__(kBlock) void bn_partial_kernel(int64_t n, int c, co
     }
 }
 
+// The same partial sums with 16-byte loads (round 3): c a power of two between 4 and 256 and float4-addressable rows.
+// A row is covered by LPR = c / 4 lanes, so one wave-load fetches 64 / LPR rows (c = 64: four rows, 1 KiB) and a block
+// needs a quarter of the iterations of the one-row-per-wave walk above — at ~3*10^4 rows the walk is a chain of
+// dependent load latencies, not bandwidth (20 -> 7 us).  Per-lane sums over "its" rows in ascending order, then a fixed
+// xor tree over the wave's row groups, then the block's waves in order: deterministic, a different association from
+// the scalar walk (both within rounding of the exact double sum).
+template <bool BWD>
+__global__ __launch_bounds__(kBlock) void bn_partial4_kernel(int64_t n, int c, const float* __restrict__ X, int64_t ldx,
+                                                             const float* __restrict__ dY, int64_t ldy,
+                                                             const float* __restrict__ mean,
+                                                             const float* __restrict__ invstd,
+                                                             double* __restrict__ part /* [kBnParts, 2, c] */) {
+    __shared__ double red[kWaves][2][256];
+    const int lane = mi_lane(), wave = threadIdx.x / MI_WAVE, p = blockIdx.x;
+    const int lpr = c >> 2, rpw = MI_WAVE / lpr;
+    const int sub = lane / lpr, q = lane - sub * lpr;
+    double a[4] = {0.0, 0.0, 0.0, 0.0}, b[4] = {0.0, 0.0, 0.0, 0.0};
+    float4 mu = mi_f4_zero(), is = mi_f4_zero();
+    if (BWD) {
+        mu = *reinterpret_cast<const float4*>(mean + 4 * q);
+        is = *reinterpret_cast<const float4*>(invstd + 4 * q);
+    }
+    constexpr int U = 4;
+    const int64_t stride = (int64_t)kBnParts * kWaves * rpw;
+    for (int64_t r0 = ((int64_t)p * kWaves + wave) * rpw + sub; r0 < n; r0 += U * stride) {
+        float4 x[U], g[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t r = r0 + u * stride;
+            x[u] = r < n ? *reinterpret_cast<const float4*>(X + r * ldx + 4 * q) : mi_f4_zero();
+            g[u] = (BWD && r < n) ? *reinterpret_cast<const float4*>(dY + r * ldy + 4 * q) : mi_f4_zero();
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#define MI_BN_ACC(f, k)                                                                  \
+            if (BWD) { a[k] += (double)g[u].f; b[k] += (double)g[u].f * (double)((x[u].f - mu.f) * is.f); } \
+            else     { a[k] += (double)x[u].f; b[k] += (double)x[u].f * (double)x[u].f; }
+            MI_BN_ACC(x, 0) MI_BN_ACC(y, 1) MI_BN_ACC(z, 2) MI_BN_ACC(w, 3)
+#undef MI_BN_ACC
+        }
+    }
+    for (int m = MI_WAVE / 2; m >= lpr; m >>= 1) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            a[k] += __shfl_xor(a[k], m, MI_WAVE);
+            b[k] += __shfl_xor(b[k], m, MI_WAVE);
+        }
+    }
+    if (sub == 0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            red[wave][0][4 * q + k] = a[k];
+            red[wave][1][4 * q + k] = b[k];
+        }
+    }
+    __syncthreads();
+    for (int ch = threadIdx.x; ch < c; ch += kBlock) {
+        double sa = red[0][0][ch], sb = red[0][1][ch];
+#pragma unroll
+        for (int w = 1; w < kWaves; ++w) { sa += red[w][0][ch]; sb += red[w][1][ch]; }
+        part[((int64_t)p * 2 + 0) * c + ch] = sa;
+        part[((int64_t)p * 2 + 1) * c + ch] = sb;
+    }
+}
+
+// Sum of the kBnParts partials of every channel, by the whole block: G = kBlock / cp groups of cp threads (cp = c rounded
+// up to a power of two, <= 256) each add every G-th part, the groups are combined in order through LDS.  One thread per
+// channel walking all 128 parts alone was a 13 us chain at the top of BOTH apply kernels, whatever the batch size.
+__device__ __forceinline__ void bn_sum_parts(const double* __restrict__ part, int c, double (*tmp)[2][256], double* sa_out,
+                                             double* sb_out) {
+    int cp = 4;
+    while (cp < c) cp <<= 1;
+    if (cp > 256) {  // wide layers: one thread per channel (in chunks), parts in order
+        for (int ch = threadIdx.x; ch < c; ch += kBlock) {
+            double sa = 0.0, sb = 0.0;
+            for (int p = 0; p < kBnParts; ++p) {
+                sa += part[((int64_t)p * 2 + 0) * c + ch];
+                sb += part[((int64_t)p * 2 + 1) * c + ch];
+            }
+            sa_out[ch] = sa;
+            sb_out[ch] = sb;
+        }
+        __syncthreads();
+        return;
+    }
+    const int G = kBlock / cp, grp = threadIdx.x / cp, ch = threadIdx.x % cp;
+    double sa = 0.0, sb = 0.0;
+    if (ch < c) {
+        constexpr int UB = 8;  // loads in flight: the adds stay in part order
+        for (int p0 = grp; p0 < kBnParts; p0 += UB * G) {
+            double va[UB], vb[UB];
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                const int p = p0 + u * G;
+                va[u] = p < kBnParts ? part[((int64_t)p * 2 + 0) * c + ch] : 0.0;
+                vb[u] = p < kBnParts ? part[((int64_t)p * 2 + 1) * c + ch] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < UB; ++u) { sa += va[u]; sb += vb[u]; }
+        }
+    }
+    // tmp has room for 4 groups of 256 at cp = 64..256; smaller cp means more groups of fewer channels: same footprint
+    double* flat = &tmp[0][0][0];
+    flat[(grp * 2 + 0) * cp + ch] = sa;
+    flat[(grp * 2 + 1) * cp + ch] = sb;
+    __syncthreads();
+    if (threadIdx.x < c) {
+        double ta = 0.0, tb = 0.0;
+        for (int g = 0; g < G; ++g) {
+            ta += flat[(g * 2 + 0) * cp + threadIdx.x];
+            tb += flat[(g * 2 + 1) * cp + threadIdx.x];
+        }
+        sa_out[threadIdx.x] = ta;
+        sb_out[threadIdx.x] = tb;
+    }
+    __syncthreads();
+}
+
 // y = (x - mean) * invstd * gamma + beta.  TRAIN: mean / invstd come from the partial sums (re-reduced by every block
 // in part order); block 0 also stores them for the backward and updates the running statistics (momentum, unbiased
 // variance) exactly as torch.nn.BatchNorm1d does.  Eval: mean / var are the running statistics.
@@ -75,16 +193,15 @@ __global__ __launch_bounds__(kBlock) void bn_apply_kernel(int64_t n, int c, cons
                                                           float* __restrict__ run_mean, float* __restrict__ run_var,
                                                           float momentum, float eps, float* __restrict__ save_mean,
                                                           float* __restrict__ save_invstd, float* __restrict__ Y,
-                                                          int64_t ldy) {
+                                                          int64_t ldy, int vec4) {
     __shared__ float s_scale[kBnMaxC], s_shift[kBnMaxC];
+    __shared__ double s_tmp[kBlock / 64][2][256];
+    __shared__ double s_sa[kBnMaxC], s_sb[kBnMaxC];
+    if (TRAIN) bn_sum_parts(part, c, s_tmp, s_sa, s_sb);
     for (int ch = threadIdx.x; ch < c; ch += kBlock) {
         float mu, is;
         if (TRAIN) {
-            double sa = 0.0, sb = 0.0;
-            for (int p = 0; p < kBnParts; ++p) {
-                sa += part[((int64_t)p * 2 + 0) * c + ch];
-                sb += part[((int64_t)p * 2 + 1) * c + ch];
-            }
+            const double sa = s_sa[ch], sb = s_sb[ch];
             const double m = sa / (double)n;
             double var = sb / (double)n - m * m;  // biased; double sums: no cancellation at fp32 resolution
             if (var < 0.0) var = 0.0;
@@ -108,6 +225,22 @@ __global__ __launch_bounds__(kBlock) void bn_apply_kernel(int64_t n, int c, cons
         s_shift[ch] = b - mu * is * g;
     }
     __syncthreads();
+    if (vec4) {  // c, ldx, ldy multiples of 4 and 16-byte aligned bases (checked by the launcher): the same fma, four at a time
+        const int c4 = c >> 2;
+        const int64_t total4 = n * (int64_t)c4;
+        for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total4; i += (int64_t)gridDim.x * kBlock) {
+            const int64_t r = i / c4;
+            const int ch = (int)(i - r * c4) * 4;
+            const float4 x = *reinterpret_cast<const float4*>(X + r * ldx + ch);
+            float4 y;
+            y.x = fmaf(x.x, s_scale[ch], s_shift[ch]);
+            y.y = fmaf(x.y, s_scale[ch + 1], s_shift[ch + 1]);
+            y.z = fmaf(x.z, s_scale[ch + 2], s_shift[ch + 2]);
+            y.w = fmaf(x.w, s_scale[ch + 3], s_shift[ch + 3]);
+            *reinterpret_cast<float4*>(Y + r * ldy + ch) = y;
+        }
+        return;
+    }
     const int64_t total = n * (int64_t)c;
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
         const int64_t r = i / c;
@@ -124,14 +257,13 @@ __global__ __launch_bounds__(kBlock) void bn_bwd_apply_kernel(int64_t n, int c, 
                                                               const float* __restrict__ mean,
                                                               const float* __restrict__ invstd, float* __restrict__ dX,
                                                               int64_t lddx, float* __restrict__ dgamma,
-                                                              float* __restrict__ dbeta) {
+                                                              float* __restrict__ dbeta, int vec4) {
     __shared__ float s_a[kBnMaxC], s_b[kBnMaxC], s_mu[kBnMaxC], s_is[kBnMaxC], s_g[kBnMaxC];
+    __shared__ double s_tmp[kBlock / 64][2][256];
+    __shared__ double s_sa[kBnMaxC], s_sb[kBnMaxC];
+    bn_sum_parts(part, c, s_tmp, s_sa, s_sb);
     for (int ch = threadIdx.x; ch < c; ch += kBlock) {
-        double sa = 0.0, sb = 0.0;
-        for (int p = 0; p < kBnParts; ++p) {
-            sa += part[((int64_t)p * 2 + 0) * c + ch];
-            sb += part[((int64_t)p * 2 + 1) * c + ch];
-        }
+        const double sa = s_sa[ch], sb = s_sb[ch];
         if (blockIdx.x == 0) {
             if (dbeta) dbeta[ch] = (float)sa;
             if (dgamma) dgamma[ch] = (float)sb;
@@ -144,6 +276,22 @@ __global__ __launch_bounds__(kBlock) void bn_bwd_apply_kernel(int64_t n, int c, 
     }
     __syncthreads();
     if (!dX) return;
+    if (vec4) {
+        const int c4 = c >> 2;
+        const int64_t total4 = n * (int64_t)c4;
+        for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total4; i += (int64_t)gridDim.x * kBlock) {
+            const int64_t r = i / c4;
+            const int ch = (int)(i - r * c4) * 4;
+            const float4 x = *reinterpret_cast<const float4*>(X + r * ldx + ch);
+            const float4 g = *reinterpret_cast<const float4*>(dY + r * ldy + ch);
+            float4 o;
+#define MI_BN_DX(f, k) { const float xh = (x.f - s_mu[ch + k]) * s_is[ch + k]; o.f = s_g[ch + k] * (g.f - s_a[ch + k] - xh * s_b[ch + k]); }
+            MI_BN_DX(x, 0) MI_BN_DX(y, 1) MI_BN_DX(z, 2) MI_BN_DX(w, 3)
+#undef MI_BN_DX
+            *reinterpret_cast<float4*>(dX + r * lddx + ch) = o;
+        }
+        return;
+    }
     const int64_t total = n * (int64_t)c;
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
         const int64_t r = i / c;
@@ -173,6 +321,9 @@ __global__ __launch_bounds__(kBlock) void gather_cat_kernel(int64_t n_e, int cu,
 // in edge order — one writer per row, fixed order, no atomics, no sort.  The all-pairs scan costs n_e^2 / 64 compares
 // per wavefront: meant for the decoder's label edges (10^3..10^4 per batch); the host falls back to a sorted reduction
 // beyond kGatherBwdMaxEdges.  Rows no edge names stay zero (dZ is zero-filled by the caller).
+// (a user's ~45 label edges are consecutive, and only a few dozen wavefronts own a row on the customer side: the walk is a
+// chain of load latencies — 4 rows in flight: 27 us per launch at 24 users / batch, round 3)
+constexpr int kGcbRows = 16;
 __global__ __launch_bounds__(kBlock) void gather_cat_bwd_kernel(int64_t n_e, int c, int off, const int64_t* __restrict__ idx,
                                                                 const float* __restrict__ dOut, int64_t ldo,
                                                                 float* __restrict__ dZ, int64_t ldz) {
@@ -189,18 +340,18 @@ __global__ __launch_bounds__(kBlock) void gather_cat_bwd_kernel(int64_t n_e, int
         for (int64_t q0 = e + 1; q0 < n_e; q0 += MI_WAVE) {
             const int64_t q = q0 + lane;
             unsigned long long m = __ballot(q < n_e && idx[q] == v);
-            while (m) {  // matching edges of this chunk, ascending; four rows in flight, added in edge order
-                int l[4];
-                float x[4];
+            while (m) {  // matching edges of this chunk, ascending; kGcbRows rows in flight, added in edge order
+                int l[kGcbRows];
+                float x[kGcbRows];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < kGcbRows; ++u) {
                     l[u] = m ? __ffsll((long long)m) - 1 : -1;
                     if (m) m &= m - 1;
                 }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) x[u] = (l[u] >= 0 && k < c) ? dOut[(q0 + l[u]) * ldo + off + k] : 0.f;
+                for (int u = 0; u < kGcbRows; ++u) x[u] = (l[u] >= 0 && k < c) ? dOut[(q0 + l[u]) * ldo + off + k] : 0.f;
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
+                for (int u = 0; u < kGcbRows; ++u)
                     if (l[u] >= 0) acc += x[u];
             }
         }
@@ -231,6 +382,8 @@ __global__ __launch_bounds__(1024) void bce_logits_kernel(int64_t n, const float
 
 }  // namespace
 
+static inline bool bn_pow2_rows(int64_t c) { return c >= 4 && c <= 256 && (c & (c - 1)) == 0; }
+
 extern "C" {
 
 int mi_bce_logits_f32(int64_t n, const float* logits, const float* labels, float* loss, float* dlogits, mi_stream_t stream) {
@@ -251,18 +404,23 @@ int mi_batchnorm_fwd_f32(int64_t n, int64_t c, const float* X, int64_t ldx, cons
     MI_CHECK_ARG(X && Y && ldx >= c && ldy >= c);
     hipStream_t s = (hipStream_t)stream;
     const unsigned grid = (unsigned)std::min<int64_t>(1024, mi_ceil_div(n * c, kBlock * 4));
+    const int vec4 = (c % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && mi_aligned16(X) && mi_aligned16(Y)) ? 1 : 0;
     if (training) {
         MI_CHECK_ARG(save_mean && save_invstd && ws && ws_bytes >= mi_batchnorm_workspace_bytes(c));
         MI_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr));
         double* part = reinterpret_cast<double*>(ws);
-        hipLaunchKernelGGL(bn_partial_kernel<false>, dim3(kBnParts), dim3(kBlock), 0, s, n, (int)c, X, ldx, nullptr, 0,
-                           nullptr, nullptr, part);
+        if (bn_pow2_rows(c) && ldx % 4 == 0 && mi_aligned16(X))
+            hipLaunchKernelGGL(bn_partial4_kernel<false>, dim3(kBnParts), dim3(kBlock), 0, s, n, (int)c, X, ldx, nullptr, 0,
+                               nullptr, nullptr, part);
+        else
+            hipLaunchKernelGGL(bn_partial_kernel<false>, dim3(kBnParts), dim3(kBlock), 0, s, n, (int)c, X, ldx, nullptr, 0,
+                               nullptr, nullptr, part);
         hipLaunchKernelGGL(bn_apply_kernel<true>, dim3(grid ? grid : 1), dim3(kBlock), 0, s, n, (int)c, X, ldx, part, gamma,
-                           beta, running_mean, running_var, momentum, eps, save_mean, save_invstd, Y, ldy);
+                           beta, running_mean, running_var, momentum, eps, save_mean, save_invstd, Y, ldy, vec4);
     } else {
         MI_CHECK_ARG(running_mean && running_var);
         hipLaunchKernelGGL(bn_apply_kernel<false>, dim3(grid ? grid : 1), dim3(kBlock), 0, s, n, (int)c, X, ldx, nullptr,
-                           gamma, beta, running_mean, running_var, momentum, eps, nullptr, nullptr, Y, ldy);
+                           gamma, beta, running_mean, running_var, momentum, eps, nullptr, nullptr, Y, ldy, vec4);
     }
     return mi_launch_status();
 }
@@ -277,11 +435,18 @@ int mi_batchnorm_bwd_f32(int64_t n, int64_t c, const float* X, int64_t ldx, cons
     MI_CHECK_ARG(ws && ws_bytes >= mi_batchnorm_workspace_bytes(c));
     hipStream_t s = (hipStream_t)stream;
     double* part = reinterpret_cast<double*>(ws);
-    hipLaunchKernelGGL(bn_partial_kernel<true>, dim3(kBnParts), dim3(kBlock), 0, s, n, (int)c, X, ldx, dY, ldy, save_mean,
-                       save_invstd, part);
+    if (bn_pow2_rows(c) && ldx % 4 == 0 && ldy % 4 == 0 && mi_aligned16(X) && mi_aligned16(dY) && mi_aligned16(save_mean) &&
+        mi_aligned16(save_invstd))
+        hipLaunchKernelGGL(bn_partial4_kernel<true>, dim3(kBnParts), dim3(kBlock), 0, s, n, (int)c, X, ldx, dY, ldy, save_mean,
+                           save_invstd, part);
+    else
+        hipLaunchKernelGGL(bn_partial_kernel<true>, dim3(kBnParts), dim3(kBlock), 0, s, n, (int)c, X, ldx, dY, ldy, save_mean,
+                           save_invstd, part);
     const unsigned grid = dX ? (unsigned)std::min<int64_t>(1024, mi_ceil_div(n * c, kBlock * 4)) : 1u;
+    const int vec4 = (dX && c % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && lddx % 4 == 0 && mi_aligned16(X) && mi_aligned16(dY) &&
+                      mi_aligned16(dX)) ? 1 : 0;
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid ? grid : 1), dim3(kBlock), 0, s, n, (int)c, X, ldx, dY, ldy, part,
-                       gamma, save_mean, save_invstd, dX, lddx, dgamma, dbeta);
+                       gamma, save_mean, save_invstd, dX, lddx, dgamma, dbeta, vec4);
     return mi_launch_status();
 }
 

@@ -119,12 +119,31 @@ struct Exec {
     const mi_ranker_batch& B;
     MiArena ar;
     Mode mode;
-    hipStream_t s;
+    hipStream_t s;        // the caller's stream: everything that is on the critical path (the article side, every GEMM)
+    hipStream_t s2;       // batch->aux_stream or s: the small customer-side twins of a pair of independent launches
+    hipStream_t cur;      // where the helpers below enqueue
     int rc = 0;
     bool oom = false;
 
     Exec(const mi_ranker_model& m, const mi_ranker_batch& b, void* ws, size_t cap, Mode md, hipStream_t st)
-        : M(m), B(b), ar(ws, cap), mode(md), s(st) {}
+        : M(m), B(b), ar(ws, cap), mode(md), s(st), s2(st), cur(st) {
+        if (b.aux_stream && b.ev_fork && b.ev_join) s2 = (hipStream_t)b.aux_stream;
+    }
+    // Pairs of launches that do not depend on each other (customer / article twins: embeddings, dropout, the two
+    // relations' aggregations, the two BatchNorms, the two gather-cat backward sums) are small and latency-bound; with an
+    // auxiliary stream the customer twin runs beside the article twin.  fork(): aux waits for everything enqueued on s so
+    // far; join(): s waits for everything enqueued on aux.  Without an auxiliary stream both are no-ops.
+    void fork() {
+        if (s2 == s || !go()) return;
+        ok((int)hipEventRecord((hipEvent_t)B.ev_fork, s));
+        ok((int)hipStreamWaitEvent(s2, (hipEvent_t)B.ev_fork, 0));
+    }
+    void join() {
+        if (s2 == s || !go()) return;
+        ok((int)hipEventRecord((hipEvent_t)B.ev_join, s2));
+        ok((int)hipStreamWaitEvent(s, (hipEvent_t)B.ev_join, 0));
+    }
+    void on(int type) { cur = type == 0 ? s2 : s; }   // customer-side work to the auxiliary stream
 
     float* take(int64_t rows, int64_t cols) {
         const size_t n = (size_t)std::max<int64_t>(rows, 1) * (size_t)std::max<int64_t>(cols, 1);
@@ -147,7 +166,7 @@ struct Exec {
         if (mode == CHECK && (d % 4 != 0 || d > 512)) fail(MI_ERR_UNSUPPORTED);
         if (!go()) return;
         ok(mi_spmm_csr_ex_f32(n_rows, d, rowptr, col, val, X, d, Y, d, addend, d, S, d, 1.0f, nullptr, nullptr, nullptr, 0,
-                              (mi_stream_t)s));
+                              (mi_stream_t)cur));
     }
 
     // one grouped launch (<= 8 problems); problems without a mask fall back to mi_gemm_f32 one by one when an operand
@@ -184,7 +203,7 @@ struct Exec {
         if (mode == CHECK && n % 4 != 0) fail(MI_ERR_UNSUPPORTED);
         if (!go() || n == 0) return;
         const float p = M.p_dropout;
-        hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)mi_ceil_div(n / 4, kBlock)), dim3(kBlock), 0, s, n / 4,
+        hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)mi_ceil_div(n / 4, kBlock)), dim3(kBlock), 0, cur, n / 4,
                            reinterpret_cast<const float4*>(x), reinterpret_cast<float4*>(y), p, 1.0f / (1.0f - p),
                            (uint32_t)B.seed, (uint32_t)(B.seed >> 32), site, (uint32_t)B.step);
         ok(mi_launch_status());
@@ -235,12 +254,15 @@ int Exec::run() {
     for (int t = 0; t < kTypes; ++t)
         for (int c = 0; c < M.n_cols[t]; ++c) width[t] += M.dims[t][c];
     float* x0[2];
+    fork();
     for (int t = 0; t < kTypes; ++t) {
         x0[t] = take(n[t], width[t]);
+        on(t);
         if (go())
             ok(mi_embed_concat_f32(n[t], M.n_cols[t], B.x[t], M.tables[t], M.table_rows[t], M.dims[t], M.max_norm, x0[t], width[t],
-                                   (mi_stream_t)s));
+                                   (mi_stream_t)cur));
     }
+    on(1);
     // ---- aggregation weights + labels
     float* v_cus = take(nnz, 1);
     float* vt_cus = take(nnz, 1);
@@ -262,16 +284,22 @@ int Exec::run() {
     float* agg[MI_RANKER_MAX_LAYERS][2];
     float* out[MI_RANKER_MAX_LAYERS][2];   // by relation: out[l][r] has n[dst_of[r]] rows
     int64_t cw[2] = {width[0], width[1]};  // current feature width per type
-    float* cur[2] = {x0[0], x0[1]};
+    float* xcur[2] = {x0[0], x0[1]};
     for (int l = 0; l < L; ++l) {
         const bool last = l == L - 1;
+        // (layer 0: the auxiliary stream is still inside the fork opened for the embeddings; later layers open their own)
+        if (l > 0) fork();
         for (int t = 0; t < kTypes; ++t) {
-            xin[l][t] = cur[t];
+            xin[l][t] = xcur[t];
             if (!last && drop) {
                 xin[l][t] = take(n[t], cw[t]);
-                dropout(cur[t], xin[l][t], n[t] * cw[t], (uint32_t)(l * 2 + t));
+                on(t);
+                dropout(xcur[t], xin[l][t], n[t] * cw[t], (uint32_t)(l * 2 + t));
             }
         }
+        on(1);
+        join();    // each aggregation reads the OTHER type's input
+        fork();
         mi_gemm_problem pr[2];
         for (int r = 0; r < 2; ++r) {
             const mi_ranker_conv& cv = M.conv[l][r];
@@ -281,28 +309,33 @@ int Exec::run() {
                 return MI_ERR_UNSUPPORTED;
             agg[l][r] = take(n[dt], cv.c_src);
             out[l][r] = take(n[dt], cv.c_out);
+            on(dt);   // relation 1 (destination: customers) is the small one
             spmm(n[dt], cv.c_src, fptr[r], fcol[r], fval[r], xin[l][st], agg[l][r], nullptr, nullptr);
             pr[r] = prob(0, 1, n[dt], cv.c_out, cv.c_src, agg[l][r], cv.c_src, cv.w_l, cv.c_src, out[l][r], cv.c_out, nullptr,
                          cv.b_l, last ? 0 : 1);
             pr[r].k2 = cv.c_dst; pr[r].A2 = xin[l][dt]; pr[r].lda2 = cv.c_dst; pr[r].B2 = cv.w_r; pr[r].ldb2 = cv.c_dst;
         }
+        on(1);
+        join();
         products(pr, 2);
         for (int r = 0; r < 2; ++r) {
-            cur[dst_of[r]] = out[l][r];
+            xcur[dst_of[r]] = out[l][r];
             cw[dst_of[r]] = M.conv[l][r].c_out;
         }
     }
     if (mode == CHECK && cw[0] != cw[1]) return MI_ERR_UNSUPPORTED;
     const int64_t C = cw[0];
     // ---- BatchNorm (K8) -------------------------------------------------------------------------------------------
-    float* z[2] = {cur[0], cur[1]};
-    float* zpre[2] = {cur[0], cur[1]};
+    float* z[2] = {xcur[0], xcur[1]};
+    float* zpre[2] = {xcur[0], xcur[1]};
     float *bn_mean[2] = {nullptr, nullptr}, *bn_inv[2] = {nullptr, nullptr};
-    char* bn_ws = nullptr;
+    char* bn_ws[2] = {nullptr, nullptr};
     const size_t bn_ws_bytes = mi_batchnorm_workspace_bytes(C);
     if (M.batch_normalize) {
-        bn_ws = take_bytes(bn_ws_bytes);
+        fork();
         for (int t = 0; t < kTypes; ++t) {
+            bn_ws[t] = take_bytes(bn_ws_bytes);
+            on(t);
             const mi_ranker_norm& bn = M.norm[t];
             if (mode == CHECK && ((bn.gamma && (!bn.beta || !bn.g_gamma || !bn.g_beta)) || C > 512)) return MI_ERR_UNSUPPORTED;
             z[t] = take(n[t], C);
@@ -310,8 +343,10 @@ int Exec::run() {
             bn_inv[t] = take(C, 1);
             if (go())
                 ok(mi_batchnorm_fwd_f32(n[t], C, zpre[t], C, bn.gamma, bn.beta, bn.running_mean, bn.running_var, bn.momentum, bn.eps,
-                                        1, bn_mean[t], bn_inv[t], z[t], C, bn_ws, bn_ws_bytes, (mi_stream_t)s));
+                                        1, bn_mean[t], bn_inv[t], z[t], C, bn_ws[t], bn_ws_bytes, (mi_stream_t)cur));
         }
+        on(1);
+        join();
     }
     // ---- decoder forward (b7) -------------------------------------------------------------------------------------
     float* h = take(nl, 2 * C);
@@ -373,24 +408,30 @@ int Exec::run() {
     }
     // ---- gather-cat backward
     float* dz[2];
+    fork();
     for (int t = 0; t < kTypes; ++t) {
         dz[t] = take(n[t], C);
+        on(t);
         if (go()) {
-            ok((int)hipMemsetAsync(dz[t], 0, (size_t)n[t] * C * sizeof(float), s));
-            ok(mi_gather_cat_bwd_f32(nl, C, t == 0 ? 0 : C, t == 0 ? B.label_row : B.label_col, dh, 2 * C, dz[t], C, (mi_stream_t)s));
+            ok((int)hipMemsetAsync(dz[t], 0, (size_t)n[t] * C * sizeof(float), cur));
+            ok(mi_gather_cat_bwd_f32(nl, C, t == 0 ? 0 : C, t == 0 ? B.label_row : B.label_col, dh, 2 * C, dz[t], C, (mi_stream_t)cur));
         }
     }
+    on(1);
     // ---- BatchNorm backward
-    if (M.batch_normalize) {
+    if (M.batch_normalize) {   // still inside the fork: each type's chain is gather-cat backward -> BatchNorm backward
         for (int t = 0; t < kTypes; ++t) {
             const mi_ranker_norm& bn = M.norm[t];
             float* dx = take(n[t], C);
+            on(t);
             if (go())
                 ok(mi_batchnorm_bwd_f32(n[t], C, zpre[t], C, dz[t], C, bn.gamma, bn_mean[t], bn_inv[t], dx, C, bn.gamma ? bn.g_gamma : nullptr,
-                                        bn.gamma ? bn.g_beta : nullptr, bn_ws, bn_ws_bytes, (mi_stream_t)s));
+                                        bn.gamma ? bn.g_beta : nullptr, bn_ws[t], bn_ws_bytes, (mi_stream_t)cur));
             dz[t] = dx;
         }
+        on(1);
     }
+    join();
     // ---- encoder backward -----------------------------------------------------------------------------------------
     float* dxs[2] = {dz[0], dz[1]};
     for (int l = L - 1; l >= 0; --l) {
@@ -416,11 +457,14 @@ int Exec::run() {
                 dxn[dt] = dxd;
             }
             products(pr, np);
+            fork();
             for (int r = 0; r < 2; ++r) {   // dX_src += A^T dAgg, in the epilogue
                 const mi_ranker_conv& cv = M.conv[l][r];
                 const int st = src_of[r];
+                on(st);
                 spmm(n[st], cv.c_src, bptr[r], bcol[r], bval[r], dagg[r], nullptr, dxn[st], dxn[st]);
             }
+            on(1);
         }
         mi_gemm_problem pw[6];
         int nw = 0;
@@ -435,13 +479,16 @@ int Exec::run() {
             }
             pw[nw++] = prob(1, 0, cv.c_out, cv.c_dst, n[dt], dy[r], cv.c_out, xin[l][dt], cv.c_dst, cv.gw_r, cv.c_dst, mask[r]);
         }
-        products(pw, nw);
+        products(pw, nw);   // the weight gradients need nothing of the aggregations above: they run beside them
         if (need_x) {
             for (int t = 0; t < kTypes; ++t) {
                 dxs[t] = dxn[t];
+                on(t);
                 // the mask this layer's forward drew for its input of type t (relation t is the one whose source is t)
                 if (!last && drop) dropout(dxn[t], dxn[t], n[t] * M.conv[l][t].c_src, (uint32_t)(l * 2 + t));
             }
+            on(1);
+            join();
         }
     }
     if (oom) return MI_ERR_WORKSPACE;

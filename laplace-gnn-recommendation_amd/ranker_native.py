@@ -14,6 +14,7 @@ Shapes the executor does not take (MI_ERR_UNSUPPORTED, nothing enqueued) fall to
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Dict, Optional
 
 import torch as t
@@ -41,6 +42,19 @@ class NativeRankerStep:
         self._ws: Optional[Tensor] = None
         self._adam_step = 0
         self.declined: Optional[str] = None
+        # a second stream for the customer-side twins of independent launch pairs (mi_ranker_batch.aux_stream).  OFF by
+        # default: measured at the H&M shape, 24 users per batch (round 3): 0.775 ms per iteration with it against 0.750
+        # without — eight fork / join event pairs per iteration cost more than running 5-20 us kernels side by side returns.
+        # LAPLACE_RANKER_AUX=1 switches it on (results are identical either way: tests/test_gpu_ranker.py).
+        self._aux = None
+        if os.environ.get("LAPLACE_RANKER_AUX", "0") == "1":
+            dev = next(model.parameters()).device
+            with t.cuda.device(dev):
+                st = t.cuda.Stream(device=dev)
+                ev = (t.cuda.Event(enable_timing=False), t.cuda.Event(enable_timing=False))
+                for e in ev:
+                    e.record(st)        # events are created lazily: materialise the handles
+            self._aux = (st, ev[0], ev[1])
 
     # ------------------------------------------------------------------------------------------
     @staticmethod
@@ -231,6 +245,8 @@ class NativeRankerStep:
         b.seed, b.step = self.seed, self.iteration
         loss = t.empty(1, dtype=t.float32, device=xc.device)
         b.loss = loss.data_ptr()
+        if self._aux is not None:
+            b.aux_stream, b.ev_fork, b.ev_join = self._aux[0].cuda_stream, self._aux[1].cuda_event, self._aux[2].cuda_event
         L = _lib.lib()
         need = int(L.mi_ranker_step_workspace_bytes(ctypes.byref(d), ctypes.byref(b)))
         if self._ws is None or self._ws.numel() < need:
