@@ -714,6 +714,40 @@ int    mi_pinsage_neighbors(int64_t n_seeds, const int64_t* seeds,
                             int64_t* neighbors, int64_t* weights,
                             void* ws, size_t ws_bytes, mi_stream_t stream);
 
+/* N5, whole batch on the device (round 3): item pairs -> seeds -> per layer (neighbours -> block), six launches for the
+ * reference's two layers, no host read-back inside.  replaces: sample_from_item_pairs + sample_blocks at
+ * pinsage/sampler.py:73-106 (dgl.to_block numbering: destination nodes first, new sources ascending; frontier edges
+ * that repeat a label pair removed) AND the two sorts per block the model needed for its weighted-mean aggregation
+ * (pinsage/layers.py:150-160): every block comes with its CSR by destination and by source, values
+ * w / max(sum of the destination's w, 1).
+ * Buffers are sized for the upper bounds n_max(0) = 3 * batch, n_max(l + 1) = n_max(l) * (1 + num_neighbors); the actual
+ * counts land in counts: [0] surviving pairs, [1] seeds, [2 + 2l] nodes of block l, [3 + 2l] edges of block l (block 0 =
+ * the one built FIRST, around the seeds; the model consumes them in reverse).  MI_ERR_UNSUPPORTED when batch > 1024 or a
+ * layer's n_max * num_neighbors exceeds 16384 (the caller then builds the blocks with its own index ops). */
+#define MI_PINSAGE_MAX_LAYERS 4
+typedef struct mi_pinsage_batch_desc {
+    int64_t batch, n_items;
+    const int32_t *iu_ptr, *iu_idx, *ui_ptr, *ui_idx;
+    int32_t walk_length, num_walks, num_neighbors, num_layers;
+    double  restart_prob;
+    int32_t* pos_scratch;          /* device int32[n_items], all -1 on entry and on return */
+} mi_pinsage_batch_desc;
+typedef struct mi_pinsage_block_out {
+    int64_t *src_ids, *edge_src, *edge_dst;   /* [n_max*(1+T)], [n_max*T], [n_max*T] */
+    float*   weights;                          /* [n_max*T] visit counts */
+    int32_t *dst_rowptr, *dst_col; float* dst_val;   /* [n_max+1], [n_max*T], [n_max*T] */
+    int32_t *src_rowptr, *src_col; float* src_val;   /* [n_max*(1+T)+1], [n_max*T], [n_max*T] */
+} mi_pinsage_block_out;
+typedef struct mi_pinsage_batch_out {
+    int64_t *seeds, *pos_u, *pos_v, *neg_v;   /* [3*batch], [batch] x 3: positions of head / tail / negative in seeds */
+    int32_t* counts;                          /* [2 + 2*num_layers] */
+    mi_pinsage_block_out blocks[MI_PINSAGE_MAX_LAYERS];
+} mi_pinsage_batch_out;
+size_t mi_pinsage_batch_workspace_bytes(int64_t batch, int32_t walk_length, int32_t num_walks, int32_t num_neighbors,
+                                        int32_t num_layers);
+int    mi_pinsage_sample_batch(const mi_pinsage_batch_desc* desc, uint64_t seed, uint64_t step,
+                               const mi_pinsage_batch_out* out, void* ws, size_t ws_bytes, mi_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -107,6 +107,26 @@ class RankerBatch(Structure):
                 ("loss", c_void_p), ("label_f32", c_void_p), ("aux_stream", c_void_p), ("ev_fork", c_void_p), ("ev_join", c_void_p)]
 
 
+MI_PINSAGE_MAX_LAYERS = 4
+
+
+class PinsageBatchDesc(Structure):
+    _fields_ = [("batch", c_int64), ("n_items", c_int64), ("iu_ptr", c_void_p), ("iu_idx", c_void_p), ("ui_ptr", c_void_p),
+                ("ui_idx", c_void_p), ("walk_length", c_int32), ("num_walks", c_int32), ("num_neighbors", c_int32),
+                ("num_layers", c_int32), ("restart_prob", c_double), ("pos_scratch", c_void_p)]
+
+
+class PinsageBlockOut(Structure):
+    _fields_ = [("src_ids", c_void_p), ("edge_src", c_void_p), ("edge_dst", c_void_p), ("weights", c_void_p),
+                ("dst_rowptr", c_void_p), ("dst_col", c_void_p), ("dst_val", c_void_p),
+                ("src_rowptr", c_void_p), ("src_col", c_void_p), ("src_val", c_void_p)]
+
+
+class PinsageBatchOut(Structure):
+    _fields_ = [("seeds", c_void_p), ("pos_u", c_void_p), ("pos_v", c_void_p), ("neg_v", c_void_p), ("counts", c_void_p),
+                ("blocks", PinsageBlockOut * MI_PINSAGE_MAX_LAYERS)]
+
+
 P = c_void_p
 _PROTOTYPES = {
     # name: (restype, [argtypes])
@@ -172,6 +192,8 @@ _PROTOTYPES = {
     "mi_pinsage_neighbors_workspace_bytes": (c_size_t, [c_int64, c_int32, c_int32]),
     "mi_pinsage_neighbors": (c_int32, [c_int64, P, P, P, P, P, c_int32, c_double, c_int32, c_int32, c_int32,
                                        c_uint64, c_uint64, P, P, P, c_size_t, P]),
+    "mi_pinsage_batch_workspace_bytes": (c_size_t, [c_int64, c_int32, c_int32, c_int32, c_int32]),
+    "mi_pinsage_sample_batch": (c_int32, [POINTER(PinsageBatchDesc), c_uint64, c_uint64, POINTER(PinsageBatchOut), P, c_size_t, P]),
     "mi_adam_dense_f32": (c_int32, [c_int64, c_int64, P, c_int64, P, c_int64, P, P, P,
                                     c_double, c_double, c_double, c_double, c_int64, P]),
 }

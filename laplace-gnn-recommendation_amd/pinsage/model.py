@@ -56,7 +56,10 @@ class _WeightedSumFn(t.autograd.Function):
 
 
 def block_csr(block: dict) -> Tuple[ops.DeviceCSR, ops.DeviceCSR]:
-    """(CSR by destination, CSR by source) of a block with values w / clamp(sum_dst w, min=1)."""
+    """(CSR by destination, CSR by source) of a block with values w / clamp(sum_dst w, min=1).  A block built on the
+    device (PinSAGESampler._sample_batch_device) brings both with it."""
+    if "csr" in block:
+        return block["csr"]
     n_src, n_dst = block["src_ids"].numel(), block["n_dst"]
     es, ed, w = block["edge_src"].contiguous(), block["edge_dst"].contiguous(), block["weights"].contiguous()
     ws = t.zeros(n_dst, device=w.device).index_add_(0, ed, w).clamp(min=1)

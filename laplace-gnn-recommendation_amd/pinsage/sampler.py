@@ -32,7 +32,9 @@ class PinSAGESampler:
         self.batch_size, self.L, self.p = int(batch_size), int(random_walk_length), float(random_walk_restart_prob)
         self.W, self.T, self.n_layers, self.seed = int(num_random_walks), int(num_neighbors), int(num_layers), int(seed)
         self._pos = t.full((num_items,), -1, dtype=t.int64, device=self.device)  # scratch for relabelling
+        self._pos32 = t.full((num_items,), -1, dtype=t.int32, device=self.device)  # the device path's scratch (kept all -1)
         self.step = 0
+        self.device_batches = True   # whole-batch construction on the device (mi_pinsage_sample_batch) where it applies
 
     def _stream(self):
         return _lib.current_stream()
@@ -87,11 +89,59 @@ class PinSAGESampler:
             seeds = src_ids
         return blocks
 
+    def _sample_batch_device(self, step: int) -> Optional[dict]:
+        """The whole batch in one C call (six launches for two layers) and ONE host read-back (the counts); None when
+        the sizes are outside the single-workgroup kernels' (the caller then takes the index-op path)."""
+        from ..ops import DeviceCSR
+        L, dev = _lib.lib(), self.device
+        B, T, NL = self.batch_size, self.T, self.n_layers
+        if NL > _lib.MI_PINSAGE_MAX_LAYERS:
+            return None
+        desc = _lib.PinsageBatchDesc(B, self.num_items, self.iu_ptr.data_ptr(), self.iu_idx.data_ptr(), self.ui_ptr.data_ptr(),
+                                     self.ui_idx.data_ptr(), self.L, self.W, T, NL, self.p, self._pos32.data_ptr())
+        out = _lib.PinsageBatchOut()
+        i64 = lambda n: t.empty(n, dtype=t.int64, device=dev)
+        i32 = lambda n: t.empty(n, dtype=t.int32, device=dev)
+        f32 = lambda n: t.empty(n, dtype=t.float32, device=dev)
+        seeds, pos_u, pos_v, neg_v, counts = i64(3 * B), i64(B), i64(B), i64(B), i32(2 + 2 * NL)
+        out.seeds, out.pos_u, out.pos_v, out.neg_v, out.counts = (x.data_ptr() for x in (seeds, pos_u, pos_v, neg_v, counts))
+        bufs, n_max = [], 3 * B
+        for l in range(NL):
+            e_max, s_max = n_max * T, n_max * (1 + T)
+            b = dict(src_ids=i64(s_max), edge_src=i64(e_max), edge_dst=i64(e_max), weights=f32(e_max), dst_rowptr=i32(n_max + 1),
+                     dst_col=i32(e_max), dst_val=f32(e_max), src_rowptr=i32(s_max + 1), src_col=i32(e_max), src_val=f32(e_max))
+            for k, v in b.items():
+                setattr(out.blocks[l], k, v.data_ptr())
+            bufs.append(b)
+            n_max = s_max
+        ws = t.empty(int(L.mi_pinsage_batch_workspace_bytes(B, self.L, self.W, T, NL)), dtype=t.uint8, device=dev)
+        rc = L.mi_pinsage_sample_batch(ctypes.byref(desc), self.seed & (2**64 - 1), step, ctypes.byref(out), ws.data_ptr(),
+                                       ws.numel(), self._stream())
+        if rc == _lib.MI_ERR_UNSUPPORTED:
+            return None
+        check(rc, "mi_pinsage_sample_batch")
+        c = counts.cpu().tolist()          # the batch's one host read-back
+        n_pairs, n_seeds = c[0], c[1]
+        blocks, n_dst = [], n_seeds
+        for l, b in enumerate(bufs):
+            n_src, n_e = c[2 + 2 * l], c[3 + 2 * l]
+            by_dst = DeviceCSR(n_dst, n_src, b["dst_rowptr"][: n_dst + 1], b["dst_col"][:n_e], b["dst_val"][:n_e])
+            by_src = DeviceCSR(n_src, n_dst, b["src_rowptr"][: n_src + 1], b["src_col"][:n_e], b["src_val"][:n_e])
+            blocks.insert(0, {"src_ids": b["src_ids"][:n_src], "n_dst": n_dst, "edge_src": b["edge_src"][:n_e],
+                              "edge_dst": b["edge_dst"][:n_e], "weights": b["weights"][:n_e], "csr": (by_dst, by_src)})
+            n_dst = n_src
+        pu = pos_u[:n_pairs]
+        return {"seeds": seeds[:n_seeds], "pos": (pu, pos_v[:n_pairs]), "neg": (pu, neg_v[:n_pairs]), "blocks": blocks}
+
     def sample_batch(self, step: Optional[int] = None) -> dict:
         """One training batch: pair graphs compacted to `seeds`, blocks rooted at them (sampler.py:93-106)."""
         if step is None:
             step = self.step
             self.step += 1
+        if self.device_batches:
+            batch = self._sample_batch_device(step)
+            if batch is not None:
+                return batch
         heads, tails, negs = self.item_pairs(step)
         seeds = t.unique(t.cat([heads, tails, negs]))
         loc = lambda x: t.searchsorted(seeds, x)
