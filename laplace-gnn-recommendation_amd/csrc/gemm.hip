@@ -99,17 +99,23 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(MiGemmArgs g) {
 }
 
 // Fast path (operands 16-byte aligned, leading dimensions and K multiples of 4).  One global-load phase
-// stages a 64 x KC panel of each operand (KC = 128: every lane keeps 16 independent 16-byte loads in
-// flight), one barrier, then KC/2 MFMAs back to back per wavefront; the accumulator walks K in ascending
+// stages a 64 x KC panel of each operand (KC = 64: every lane keeps 8 independent 16-byte loads in
+// flight, four workgroups per CU), one barrier, then KC/2 MFMAs back to back per wavefront; the accumulator walks K in ascending
 // order exactly as in the generic kernel, so results are bitwise the same.  Either operand may be
 // K-contiguous (x @ W^T: nn.Linear forward, the top-K score block) or contiguous along its output
 // dimension (dX = dY @ W, dW = dY^T @ X): the float4 is loaded along whichever dimension is contiguous
-// and written to the same [row][k] LDS panel.  Rows are padded to 129 floats: conflict-free fragment
+// and written to the same [row][k] LDS panel.  Rows are padded to KC + 1 floats: conflict-free fragment
 // reads (bank = (row + k) mod 32).
 #ifndef MI_GEMM_MFMA_UNROLL
 #define MI_GEMM_MFMA_UNROLL 16  // 64: +1 % (tools/bench_gemm.py: 2 621 x 100 K x 128 53.0 -> 53.3, 4 096^3 72.4 -> 72.9 TF/s)
 #endif
-constexpr int KC = 128, KPAD = 129;
+#ifndef MI_GEMM_KC
+#define MI_GEMM_KC 64   // K per staged panel.  Round 3 A/B (tools/bench_gemm.py, tools/iter_timeline.py): 128 -> 64 halves the LDS per
+#endif                  // workgroup (66 -> 33 KB), so four workgroups share a CU instead of two and one's loads hide behind the
+#ifndef MI_GEMM_WGS     // others' MFMAs: 4096^3 72.8 -> 102.9 TF/s (0.65 of the f32 MFMA peak), 169 000 x 128 x 84 34.8 -> 50.7,
+#define MI_GEMM_WGS 4   // the top-K score block 53.3 -> 67.0; the ranker's forward / dX grouped launches 51 -> 38, 32 -> 28, 46 -> 33 us
+#endif                  // (same k-ascending chain per output element: results are bitwise what KC = 128 gave)
+constexpr int KC = MI_GEMM_KC, KPAD = KC + 1;
 
 // A 64 x KC panel of an operand whose element (row, k) sits at base[row * s_row + k * s_k]; rows >= n_rows
 // and k >= kw read as zero.  Split in two so that both operands' global loads are in flight before the
@@ -164,7 +170,7 @@ __device__ __forceinline__ void panel_commit(float (*panel)[KPAD], const float4 
 }
 
 template <bool A_KFAST, bool B_KFAST>
-__global__ __launch_bounds__(256, 2) void gemm_fast_kernel(MiGemmArgs g) {
+__global__ __launch_bounds__(256, MI_GEMM_WGS) void gemm_fast_kernel(MiGemmArgs g) {
     __shared__ float As[BM][KPAD];
     __shared__ float Bs[BN][KPAD];
     const int tid = threadIdx.x;
@@ -270,7 +276,7 @@ __device__ __forceinline__ void panel_mask(float4 (&v)[kN4], const float* __rest
     }
 }
 
-__global__ __launch_bounds__(256, 2) void gemm_group_kernel(MiGemmGroupArgs ga) {
+__global__ __launch_bounds__(256, MI_GEMM_WGS) void gemm_group_kernel(MiGemmGroupArgs ga) {
     __shared__ float As[BM][KPAD];
     __shared__ float Bs[BN][KPAD];
     int pi = 0;
@@ -418,7 +424,7 @@ int mi_gemm_splits(int64_t M, int64_t N, int64_t K) {
     const bool tiny = blocks <= 8;
     if (blocks >= 128 || K < (tiny ? 512 : 2048)) return 1;
     int64_t s = mi_ceil_div(512, blocks);
-    const int64_t max_s = K / (tiny ? KC : 256);  // at least one 128-wide panel (256 of K for wider outputs) per slice
+    const int64_t max_s = K / (tiny ? 128 : 256);  // at least 128 of K (256 for wider outputs) per slice, whatever the panel width
     if (s > max_s) s = max_s;
     return s < 2 ? 1 : (int)s;
 }

@@ -131,12 +131,16 @@ def train_epoch(model: PinSAGEModel, optimizer: t.optim.Optimizer, sampler, batc
     from ..dist_ranker import allreduce_gradients
     losses = []
     model.train()
-    for _ in range(batches):
-        b = sampler.sample_batch()
-        loss = model(b["seeds"], b["pos"], b["neg"], b["blocks"]).mean()
-        optimizer.zero_grad()
-        loss.backward()
-        allreduce_gradients(model.parameters(), group)
-        optimizer.step()
-        losses.append(float(loss.detach()))
-    return losses
+    # the backward graph is a chain of small nodes: running it in the calling thread saves the hand-over to autograd's
+    # device thread at every one of them (as training.train_with_dataloader does for the ranker); the losses are read
+    # back once per epoch, not once per step
+    with t.autograd.set_multithreading_enabled(False):
+        for _ in range(batches):
+            b = sampler.sample_batch()
+            loss = model(b["seeds"], b["pos"], b["neg"], b["blocks"]).mean()
+            optimizer.zero_grad()
+            loss.backward()
+            allreduce_gradients(model.parameters(), group)
+            optimizer.step()
+            losses.append(loss.detach())
+    return t.stack(losses).cpu().tolist() if losses else []

@@ -7,7 +7,7 @@ variant = sys.argv[1]
 band = int(sys.argv[2]) if len(sys.argv) > 2 else None
 pkg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'laplace-gnn-recommendation_amd')
 if variant != 'base':
-    shutil.copy(f'{pkg}/liblaplace_hip_{variant}.so', f'{pkg}/liblaplace_hip.so')
+    os.environ['LAPLACE_HIP_LIB'] = f'{pkg}/liblaplace_hip_{variant}.so'  # never overwrite the product library
 import torch as t
 from laplace_amd import ops, synthetic as S
 from laplace_amd.interactions import Interactions

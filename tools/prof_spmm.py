@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 if os.environ.get('AB_LIB'):
     import shutil
     _pkg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'laplace-gnn-recommendation_amd')
-    shutil.copy(f"{_pkg}/liblaplace_hip_{os.environ['AB_LIB']}.so", f'{_pkg}/liblaplace_hip.so')
+    os.environ['LAPLACE_HIP_LIB'] = f"{_pkg}/liblaplace_hip_{os.environ['AB_LIB']}.so"  # never overwrite the product library
 import torch as t
 from laplace_amd import ops, synthetic as S
 from laplace_amd.interactions import Interactions
