@@ -107,13 +107,17 @@ def main():
     ranker = Encoder_Decoder_Model(get_SAGEConv_layers(2, 128, 64, "add"), get_linear_layers(2, 128, 128, 1),
                                    get_feature_info(graph), first.metadata(), True, "sum", True, 0.0, 0.3).to(dev)
     ranker.initialize_encoder_input_size(first)
-    opt = t.optim.Adam(ranker.parameters(), lr=0.01, fused=True)
+    opt = t.optim.Adam(ranker.parameters(), lr=0.01)     # the reference's optimizer (run_pipeline.py)
     ranker.train()
+    from laplace_amd.ranker_native import NativeRankerStep
     from laplace_amd.ranker_step import FusedRankerStep
-    fused = FusedRankerStep(ranker, opt)   # what training.train_with_dataloader runs per batch
+    native = NativeRankerStep(ranker, opt)   # what training.train_with_dataloader runs per batch: one C call per iteration
+    fused = FusedRankerStep(ranker, opt)
 
     def step(batch):
-        return fused.step(*select_properties(batch))
+        lab = batch[Constants.edge_key]
+        loss = native.step(batch.x_dict, batch.edge_index_dict, lab.edge_label_index, lab.edge_label)
+        return loss if loss is not None else fused.step(*select_properties(batch))
 
     for _ in range(5):
         step(next(it))
