@@ -150,3 +150,50 @@ def test_bench_self_launch_parent_never_needs_a_gpu_and_reports_worker_failure()
     assert r.returncode != 0
     assert "needs a GPU" in r.stderr and "exited with code" in r.stderr
     assert r.stdout.strip() == ""
+
+
+def test_bench_classifies_the_dense_propagate_kernels_and_parses_pmc_passes(tmp_path, monkeypatch):
+    """bench.py's live-traffic figure: which kernels make up ONE dense propagate launch, and how the two rocprofv3 --pmc
+    passes are turned into bytes ((2*FETCH_SIZE + WRITE_SIZE)*1024 per dispatch, averaged per kernel, summed)."""
+    import subprocess
+    import bench
+    dense = ["void (anonymous namespace)::spmm_rows_kernel<32, 1, 8, 1, false, false>(long, int, int const*)",
+             "void (anonymous namespace)::spmm_sweep_kernel<32, 8, false>(mi_spmm_sweep, int)",
+             "void (anonymous namespace)::spmm_items_kernel<32, 1, 8, 1, false>(long, int)",
+             "void (anonymous namespace)::spmm_fixup_kernel<32, 1, false, false>(int, int)",
+             "void (anonymous namespace)::spmm_rows_hot_kernel<32, 8, false>(long, int)"]
+    other = ["void (anonymous namespace)::spmm_rows_kernel<32, 1, 8, 1, false, true>(long)",      # Adam epilogue
+             "void (anonymous namespace)::spmm_rows_kernel<32, 1, 8, 1, true, false>(long)",      # sparse operands
+             "void (anonymous namespace)::spmm_sweep_kernel<32, 8, true>(mi_spmm_sweep)",
+             "void (anonymous namespace)::spmm_fixup_kernel<32, 1, false, true>(int)",
+             "void (anonymous namespace)::adam_kernel(long)", "bpr_slot_kernel"]
+    for k in dense:
+        assert bench.is_dense_spmm_kernel(bench._short_kernel(k)), k
+    for k in other:
+        assert not bench.is_dense_spmm_kernel(bench._short_kernel(k)), k
+
+    def fake_run(cmd, **kw):   # stands in for rocprofv3: writes the counter file the real tool would
+        counter = cmd[cmd.index("--pmc") + 1]
+        out = cmd[cmd.index("-d") + 1]
+        assert "--kernel-trace" not in cmd and "--sys-trace" not in cmd          # counters only, as the pool requires
+        assert cmd[cmd.index("--") + 1].endswith("python") or "python" in cmd[cmd.index("--") + 1]
+        os.makedirs(os.path.join(out, "host"), exist_ok=True)
+        rows = {"FETCH_SIZE": {dense[0]: [1000.0, 3000.0], dense[1]: [500.0], other[0]: [9999.0]},
+                "WRITE_SIZE": {dense[0]: [100.0, 300.0], dense[3]: [50.0], other[0]: [7.0]}}[counter]
+        with open(os.path.join(out, "host", "1_counter_collection.csv"), "w") as fh:
+            fh.write("Kernel_Name,Counter_Name,Counter_Value\n")
+            for name, vals in rows.items():
+                for v in vals:
+                    fh.write(f'"{name}",{counter},{v}\n')
+        return subprocess.CompletedProcess(cmd, 0, b"", b"")
+
+    monkeypatch.setattr(bench.subprocess, "run", fake_run)
+    monkeypatch.setattr(bench.shutil, "which", lambda name: "/bin/true")
+    total, per_kernel, note = bench.pmc_traffic("c2", ["--dim", "128"])
+    want = (2 * 2000.0 + 200.0) * 1024 + (2 * 500.0) * 1024 + 50.0 * 1024     # rows (avg of two dispatches) + sweep + fix-up
+    assert total == want and "live" in note
+    assert per_kernel["spmm_rows_kernel<32, 1, 8, 1, false, true>"] == (2 * 9999.0 + 7.0) * 1024
+    # a failing pass is reported, not guessed around
+    monkeypatch.setattr(bench.subprocess, "run", lambda cmd, **kw: subprocess.CompletedProcess(cmd, 3, b"", b"boom"))
+    total, _, why = bench.pmc_traffic("c2", [])
+    assert total is None and "failed" in why
