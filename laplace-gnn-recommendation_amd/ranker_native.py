@@ -170,15 +170,24 @@ class NativeRankerStep:
         return d
 
     def _params_current(self, d: RankerModel) -> bool:
-        """The descriptor holds raw pointers: rebuilt when a parameter, gradient or state tensor was replaced."""
+        """The descriptor holds raw pointers: rebuilt when a parameter, gradient, optimizer-state, BatchNorm buffer or
+        embedding table was replaced (zero_grad(set_to_none=True), model.to(...), load of a new optimizer state, ...)."""
         group = self.optimizer.param_groups[0]
         if d.n_params != len(group["params"]):
             return False
         for i, p in enumerate(group["params"]):
             st = self.optimizer.state.get(p)
             if (p.grad is None or not st or d.params[i].p != p.data_ptr() or d.params[i].g != p.grad.data_ptr()
-                    or d.params[i].m != st["exp_avg"].data_ptr()):
+                    or d.params[i].m != st["exp_avg"].data_ptr() or d.params[i].v != st["exp_avg_sq"].data_ptr()):
                 return False
+        model = self.model
+        for ti, (key, bn) in enumerate(((Constants.node_user, model.encoder_layer_norm_customer),
+                                        (Constants.node_item, model.encoder_layer_norm_article))):
+            if bn.track_running_stats and d.norm[ti].running_mean != bn.running_mean.data_ptr():
+                return False
+            for c, tb in enumerate(model.embedding_layers[key]):
+                if d.tables[ti][c] != tb.data_ptr():
+                    return False
         return True
 
     # ------------------------------------------------------------------------------------------

@@ -419,6 +419,8 @@ def test_native_ranker_step_equals_the_fused_step(aggr):
         if step == 5:
             break
         x, ei, eli, y = select_properties(batch.to(DEV))
+        if step == 2:   # the caller drops the gradient tensors: the executor's descriptor (raw pointers) must notice
+            opt_a.zero_grad(set_to_none=True)
         la = native.step({k: v.clone() for k, v in x.items()}, ei, eli, y)
         lb = fused.step({k: v.clone() for k, v in x.items()}, ei, eli, y)
         assert la is not None and lb is not None, native.declined
