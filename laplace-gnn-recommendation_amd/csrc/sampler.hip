@@ -336,57 +336,68 @@ __global__ __launch_bounds__(kSelThreads) void smp_select_users_kernel(Smp p, in
         const int n_expl = sh_nexpl;
         const uint32_t c3 = (P_USER_REJ & 0xFFu) | ((uint32_t)(p.step & 0xFFFFFFu) << 8);
         const uint32_t k0 = (uint32_t)p.seed, k1 = (uint32_t)((p.seed >> 32) ^ (p.step >> 24));
-        while (true) {  // one round = kSelThreads draws evaluated in parallel, committed in counter order
+        // One round = R draws evaluated in parallel, committed in counter order.  Round 3: R follows the fan-out instead of
+        // being the block size — a pick is accepted with probability (distinct users) / (list entries), typically well over
+        // one half, so n = 64 picks need ~100 draws, and evaluating 1 024 per round meant every wavefront walked 64
+        // candidates' article lists where 8 do (280 -> ~60 us per launch at the H&M shape).  The draws themselves and the
+        // order they are committed in are unchanged: draw t is Philox(t), whatever the round it falls in.
+        __shared__ int32_t cand_m[kSelThreads];
+        int R = 2 * p.n;
+        R = (R + MI_WAVE - 1) / MI_WAVE * MI_WAVE;
+        R = max(2 * MI_WAVE, min(R, kSelThreads));
+        const int lane = tid & (MI_WAVE - 1), wv = tid / MI_WAVE;
+        while (true) {
             const int t0 = sh_t0;
             if (sh_np >= p.n || t0 >= kRejectCap) break;  // block-uniform (shared)
             MiPhilox w = mi_philox4x32((uint32_t)(t0 + tid), (uint32_t)hop, (uint32_t)u, c3, k0, k1);
-            const int64_t pos = (int64_t)((((uint64_t)w.c[0] << 32) | w.c[1]) % (uint64_t)L);
-            int lo = 0, hi = naq;  // last q with pre[q] <= pos
-            while (hi - lo > 1) {
-                const int mid = (lo + hi) >> 1;
-                if (pre[mid] <= pos) lo = mid; else hi = mid;
-            }
-            const int32_t v = p.aidx[p.aptr[aq[lo]] + (pos - pre[lo])];
-            // m = number of queued articles (duplicates counted) that v bought.  Positions are drawn in proportion to
-            // list length, so the 1 024 candidates of a round are the HEAVY users (10^3 articles): one thread walking
-            // its own candidate's list made the round as slow as the heaviest of them (round 1: 0.5-1.2 ms per launch).
-            // Each wavefront now walks the lists of its 64 candidates with all its lanes, one candidate after the other.
-            cand_v[tid] = v;
-            cand_b[tid] = p.uptr[v];
-            cand_e[tid] = p.uptr[v + 1];
-            uint32_t m = 0;
-            {
-                const int lane = tid & (MI_WAVE - 1), wbase = tid & ~(MI_WAVE - 1);
-                for (int ci = 0; ci < MI_WAVE; ++ci) {
-                    const int32_t xb = cand_b[wbase + ci], xe = cand_e[wbase + ci];  // written by this wavefront itself
-                    uint32_t cnt = 0;
-                    for (int32_t x = xb + lane; x < xe; x += MI_WAVE) {
-                        const int32_t a = p.uidx[x];
-                        int l2 = 0, h2 = naq;
-                        while (l2 < h2) {
-                            const int mid = (l2 + h2) >> 1;
-                            if (aq_sorted[mid] < a) l2 = mid + 1; else h2 = mid;
-                        }
-                        while (l2 < naq && aq_sorted[l2] == a) { ++cnt; ++l2; }
-                    }
-#pragma unroll
-                    for (int off = MI_WAVE / 2; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off, MI_WAVE);
-                    if (lane == ci) m = cnt;
+            int32_t v = -1;
+            if (tid < R) {
+                const int64_t pos = (int64_t)((((uint64_t)w.c[0] << 32) | w.c[1]) % (uint64_t)L);
+                int lo = 0, hi = naq;  // last q with pre[q] <= pos
+                while (hi - lo > 1) {
+                    const int mid = (lo + hi) >> 1;
+                    if (pre[mid] <= pos) lo = mid; else hi = mid;
                 }
+                v = p.aidx[p.aptr[aq[lo]] + (pos - pre[lo])];
+                cand_v[tid] = v;
+                cand_b[tid] = p.uptr[v];
+                cand_e[tid] = p.uptr[v + 1];
             }
-            bool ok = (m > 0) && (w.c[2] % m == 0);
-            if (n_expl >= 0) {
-                for (int q = 0; ok && q < n_expl; ++q) ok &= (expl[q] != v);
-            } else {
-                for (int h = 0; ok && h <= hop; ++h)
-                    for (int q = 0; q < uq_n[h]; ++q) ok &= (uq[h * p.n + q] != v);
+            __syncthreads();
+            // m(v) = number of queued articles (duplicates counted) that v bought: every wavefront walks the article lists of
+            // its share of the round's candidates (interleaved: wavefront wv takes wv, wv + 16, ...) with all its lanes
+            for (int ci = wv; ci < R; ci += kSelThreads / MI_WAVE) {
+                const int32_t xb = cand_b[ci], xe = cand_e[ci];
+                uint32_t cnt = 0;
+                for (int32_t x = xb + lane; x < xe; x += MI_WAVE) {
+                    const int32_t a = p.uidx[x];
+                    int l2 = 0, h2 = naq;
+                    while (l2 < h2) {
+                        const int mid = (l2 + h2) >> 1;
+                        if (aq_sorted[mid] < a) l2 = mid + 1; else h2 = mid;
+                    }
+                    while (l2 < naq && aq_sorted[l2] == a) { ++cnt; ++l2; }
+                }
+#pragma unroll
+                for (int off = MI_WAVE / 2; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off, MI_WAVE);
+                if (lane == 0) cand_m[ci] = (int32_t)cnt;
             }
-            cand_v[tid] = v;
-            cand_ok[tid] = ok ? 1 : 0;
+            __syncthreads();
+            if (tid < R) {
+                const uint32_t m = (uint32_t)cand_m[tid];
+                bool ok = (m > 0) && (w.c[2] % m == 0);
+                if (n_expl >= 0) {
+                    for (int q = 0; ok && q < n_expl; ++q) ok &= (expl[q] != v);
+                } else {
+                    for (int h = 0; ok && h <= hop; ++h)
+                        for (int q = 0; q < uq_n[h]; ++q) ok &= (uq[h * p.n + q] != v);
+                }
+                cand_ok[tid] = ok ? 1 : 0;
+            }
             __syncthreads();
             if (tid < MI_WAVE) {
                 int np = sh_np;
-                for (int c = 0; c < kSelThreads / MI_WAVE && np < p.n; ++c) {
+                for (int c = 0; c < R / MI_WAVE && np < p.n; ++c) {
                     const int32_t cv = cand_v[c * MI_WAVE + tid];
                     unsigned long long mask = __ballot(cand_ok[c * MI_WAVE + tid] != 0);
                     while (mask && np < p.n) {
@@ -403,7 +414,7 @@ __global__ __launch_bounds__(kSelThreads) void smp_select_users_kernel(Smp p, in
                 }
                 if (tid == 0) {
                     sh_np = np;
-                    sh_t0 = t0 + kSelThreads;
+                    sh_t0 = t0 + R;
                 }
             }
             __syncthreads();
