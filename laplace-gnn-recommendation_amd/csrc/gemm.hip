@@ -255,11 +255,27 @@ struct MiGemmGroupProblem {
     int splits; int64_t k_per_split; float* partial;  // split-K of pair 0 (single-pair problems only)
     int tiles_n, tiles_mn;                            // tile grid of this problem
 };
+// A SHARE SET: consecutive split problems that read the same A operand over the same K with the same slicing (the weight
+// gradients dW_l / db / dW_r of one relation: dY^T @ [agg | 1 | x_dst]).  Launched problem after problem, each K slice
+// of dY (and of its relu mask) is fetched once per output tile of every member — 310 MB of L2-miss traffic for the
+// 50 MB the ranker's layer-0 launch needs (PMC, round 3).  In a set the workgroups are ordered slice-major and a slice's
+// G = sum of the members' tiles workgroups are all placed on ONE XCD (workgroup w runs on XCD w mod 8: local index
+// w = ((z / 8) * G + g) * 8 + z mod 8), so they find the slice in that XCD's L2 after its first reader.
+struct MiGemmShareSet {
+    int first, count;        // members: problems first .. first + count - 1
+    int G, S;                // workgroups per slice, slices
+    int64_t start;           // first linear workgroup (a multiple of 8), set size = ceil(S / 8) * 8 * G
+    int tile_off[kMaxGroup + 1];  // member j's tiles are g in [tile_off[j], tile_off[j + 1])
+};
+constexpr int kMaxSets = 4;
 struct MiGemmGroupArgs {
     int n;
     int64_t block_start[kMaxGroup + 1];   // first linear workgroup of each problem
     int64_t out_start[kMaxGroup + 1];     // first linear output element of each split problem (reduce kernel)
     MiGemmGroupProblem p[kMaxGroup];
+    int n_sets;
+    int set_of[kMaxGroup];                // share set of each problem, -1 = none
+    MiGemmShareSet set[kMaxSets];
 };
 
 template <bool KFAST>
@@ -283,10 +299,27 @@ __global__ __launch_bounds__(256, MI_GEMM_WGS) void gemm_group_kernel(MiGemmGrou
 #pragma unroll
     for (int q = 1; q < kMaxGroup; ++q)
         if (q < ga.n && (int64_t)blockIdx.x >= ga.block_start[q]) pi = q;
+    int z, t2;
+    if (ga.set_of[pi] >= 0) {   // slice-major, one XCD per slice (see MiGemmShareSet); block-uniform
+        const MiGemmShareSet& st = ga.set[ga.set_of[pi]];
+        const int64_t w = (int64_t)blockIdx.x - st.start;
+        const int64_t q = w >> 3;
+        z = (int)(q / st.G) * 8 + (int)(w & 7);
+        if (z >= st.S) return;                        // padding of the last group of eight slices
+        const int gi = (int)(q % st.G);
+        int j = 0;
+#pragma unroll
+        for (int m = 1; m < kMaxGroup; ++m)
+            if (m < st.count && gi >= st.tile_off[m]) j = m;
+        pi = st.first + j;
+        t2 = gi - st.tile_off[j];
+    } else {
+        const int64_t local = (int64_t)blockIdx.x - ga.block_start[pi];
+        z = (int)(local / ga.p[pi].tiles_mn);
+        t2 = (int)(local % ga.p[pi].tiles_mn);
+        if (z >= ga.p[pi].splits) return;             // alignment padding in front of a share set
+    }
     const MiGemmGroupProblem& g = ga.p[pi];
-    const int64_t local = (int64_t)blockIdx.x - ga.block_start[pi];
-    const int z = (int)(local / g.tiles_mn);
-    const int t2 = (int)(local % g.tiles_mn);
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave & 1, wn = wave >> 1;
@@ -567,6 +600,62 @@ extern "C" int mi_gemm_group_f32(const mi_gemm_problem* probs, int32_t n, void* 
         ga.n = cnt;
         for (int i = cnt; i <= kMaxGroup; ++i) { ga.block_start[i] = blocks; ga.out_start[i] = outs; }
         if (blocks == 0) continue;
+        // share sets (MiGemmShareSet): runs of split problems over the same A / K get ONE slicing (the coarsest of the
+        // members': slabs were sized for at least as many slices) and the slice-major layout; the workgroup ranges are
+        // re-laid from the first problem on
+        auto same_a = [&](const MiGemmGroupProblem& x, const MiGemmGroupProblem& y) {
+            return x.M > 0 && y.M > 0 && x.splits > 1 && y.splits > 1 && x.n_pairs == 1 && y.n_pairs == 1 &&
+                   x.pair[0].A == y.pair[0].A && x.pair[0].K == y.pair[0].K && x.pair[0].sa_m == y.pair[0].sa_m &&
+                   x.pair[0].sa_k == y.pair[0].sa_k && x.a_mask == y.a_mask;
+        };
+        for (int i = 0; i < cnt;) {
+            int j = i + 1;
+            while (j < cnt && same_a(ga.p[i], ga.p[j])) ++j;
+            if (j - i >= 2) {
+                int64_t kps = 0;
+                for (int m = i; m < j; ++m) kps = std::max(kps, ga.p[m].k_per_split);
+                for (int m = i; m < j; ++m) {
+                    ga.p[m].k_per_split = kps;
+                    ga.p[m].splits = (int)mi_ceil_div(ga.p[m].pair[0].K, kps);
+                }
+            }
+            i = j;
+        }
+        for (int i = 0; i < kMaxGroup; ++i) ga.set_of[i] = -1;
+        ga.n_sets = 0;
+        {
+            int64_t run = 0;
+            int i = 0;
+            while (i < cnt) {
+                MiGemmGroupProblem& a0 = ga.p[i];
+                int j = i + 1;
+                if (a0.M > 0 && a0.splits > 1 && a0.n_pairs == 1) {
+                    while (j < cnt && ga.p[j].M > 0 && ga.p[j].splits == a0.splits && ga.p[j].k_per_split == a0.k_per_split &&
+                           ga.p[j].n_pairs == 1 && ga.p[j].pair[0].A == a0.pair[0].A && ga.p[j].pair[0].K == a0.pair[0].K &&
+                           ga.p[j].pair[0].sa_m == a0.pair[0].sa_m && ga.p[j].pair[0].sa_k == a0.pair[0].sa_k &&
+                           ga.p[j].a_mask == a0.a_mask)
+                        ++j;
+                }
+                if (j - i >= 2 && ga.n_sets < kMaxSets) {
+                    MiGemmShareSet& st = ga.set[ga.n_sets];
+                    st.first = i; st.count = j - i; st.S = a0.splits; st.G = 0;
+                    for (int m = i; m < j; ++m) { st.tile_off[m - i] = st.G; st.G += ga.p[m].tiles_mn; ga.set_of[m] = ga.n_sets; }
+                    for (int m = j - i; m <= kMaxGroup; ++m) st.tile_off[m] = st.G;
+                    run = (run + 7) / 8 * 8;
+                    st.start = run;
+                    for (int m = i; m < j; ++m) ga.block_start[m] = run;   // the whole set answers to one range
+                    run += (int64_t)((st.S + 7) / 8) * 8 * st.G;
+                    ++ga.n_sets;
+                    i = j;
+                } else {
+                    ga.block_start[i] = run;
+                    run += (int64_t)a0.tiles_mn * (a0.M > 0 ? a0.splits : 0);
+                    ++i;
+                }
+            }
+            blocks = run;
+            for (int m = cnt; m <= kMaxGroup; ++m) ga.block_start[m] = blocks;
+        }
         if (blocks >= INT32_MAX) return MI_ERR_TOO_LARGE;
         hipLaunchKernelGGL(gemm_group_kernel, dim3((unsigned)blocks), dim3(256), 0, s, ga);
         if (any_split)
