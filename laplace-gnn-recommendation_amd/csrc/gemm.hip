@@ -184,14 +184,28 @@ __global__ __launch_bounds__(256, MI_GEMM_WGS) void gemm_fast_kernel(MiGemmArgs 
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 
-    for (int64_t kc = k_lo; kc < k_hi; kc += KC) {
-        const int kw = (int)min((int64_t)KC, k_hi - kc);  // multiple of 4
-        float4 va[kN4], vb[kN4];
-        panel_issue<A_KFAST>(va, g.A, g.sa_m, g.sa_k, g.a_rows, m0, g.M, kc, kw, tid);
-        panel_issue<B_KFAST>(vb, g.B, g.sb_n, g.sb_k, nullptr, n0, g.N, kc, kw, tid);
+    // Software pipeline (round 3): the NEXT panel's global loads are issued before the MFMAs of the current one and land
+    // in registers while the matrix cores work; they are committed to LDS after the barrier that ends the current
+    // panel.  Before, a workgroup's loads and its MFMAs never overlapped (a phase of ~8 us held 0.85 us of MFMA).
+    // The accumulator still walks K in ascending order: results are bitwise the same.
+    float4 va[kN4], vb[kN4];
+    if (k_lo < k_hi) {
+        const int kw0 = (int)min((int64_t)KC, k_hi - k_lo);
+        panel_issue<A_KFAST>(va, g.A, g.sa_m, g.sa_k, g.a_rows, m0, g.M, k_lo, kw0, tid);
+        panel_issue<B_KFAST>(vb, g.B, g.sb_n, g.sb_k, nullptr, n0, g.N, k_lo, kw0, tid);
         panel_commit<A_KFAST>(As, va, tid);
         panel_commit<B_KFAST>(Bs, vb, tid);
-        __syncthreads();
+    }
+    __syncthreads();
+    for (int64_t kc = k_lo; kc < k_hi; kc += KC) {
+        const int kw = (int)min((int64_t)KC, k_hi - kc);  // multiple of 4
+        const int64_t kn = kc + KC;
+        const bool has_next = kn < k_hi;
+        const int kwn = has_next ? (int)min((int64_t)KC, k_hi - kn) : 0;
+        if (has_next) {
+            panel_issue<A_KFAST>(va, g.A, g.sa_m, g.sa_k, g.a_rows, m0, g.M, kn, kwn, tid);
+            panel_issue<B_KFAST>(vb, g.B, g.sb_n, g.sb_k, nullptr, n0, g.N, kn, kwn, tid);
+        }
         const float* ap = &As[wm * 32 + (lane & 31)][lane >> 5];
         const float* bp = &Bs[wn * 32 + (lane & 31)][lane >> 5];
         if (kw == KC) {
@@ -201,7 +215,12 @@ __global__ __launch_bounds__(256, MI_GEMM_WGS) void gemm_fast_kernel(MiGemmArgs 
             // the panel is zero beyond kw, so an odd tail pairs its last k with a zero
             for (int s = 0; s < (kw + 1) / 2; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * s], bp[2 * s], acc, 0, 0, 0);
         }
-        __syncthreads();
+        __syncthreads();                       // every wavefront is done with this panel's LDS image
+        if (has_next) {
+            panel_commit<A_KFAST>(As, va, tid);
+            panel_commit<B_KFAST>(Bs, vb, tid);
+            __syncthreads();
+        }
     }
 
     const int64_t gn = n0 + wn * 32 + (lane & 31);
@@ -329,6 +348,9 @@ __global__ __launch_bounds__(256, MI_GEMM_WGS) void gemm_group_kernel(MiGemmGrou
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 
+    // Not software-pipelined like gemm_fast_kernel: measured (tools/ab_gemm_pipe.sh, round 3) the ranker's grouped launches
+    // are short-K and bound by their operand traffic, four resident workgroups per CU already overlap one another's
+    // loads and MFMAs, and the prologue's extra barrier cost 3-9 us per launch (iteration 0.641 -> 0.672 ms).
     for (int pp = 0; pp < g.n_pairs; ++pp) {
         const MiGemmPairArgs& pr = g.pair[pp];
         const bool a_kfast = pr.sa_k == 1, b_kfast = pr.sb_k == 1;
