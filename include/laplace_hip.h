@@ -598,6 +598,11 @@ int64_t mi_ranker_sizeof(int32_t which);  /* sizeof of: 0 model, 1 batch, 2 conv
 size_t mi_ranker_step_workspace_bytes(const mi_ranker_model* model, const mi_ranker_batch* batch);
 int    mi_ranker_step_f32(const mi_ranker_model* model, const mi_ranker_batch* batch, void* ws, size_t ws_bytes,
                           mi_stream_t stream);
+/* The update alone, for data-parallel callers: run mi_ranker_step_f32 with apply_adam = 0, all-reduce(sum) the gradient
+ * buffers (params[i].g; the host side keeps them in ONE flat allocation so that is one collective), then this:
+ * Adam (a9's arithmetic, model->lr/beta/eps/step) over model->params with every gradient multiplied by grad_scale
+ * (1 / world size) first.  The gradient buffers are left as reduced (unscaled).  One launch. */
+int    mi_ranker_adam_f32(const mi_ranker_model* model, float grad_scale, mi_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * N3  candidate matcher: items bought by users who share an item with the query user.

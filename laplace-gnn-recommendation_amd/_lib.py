@@ -182,6 +182,7 @@ _PROTOTYPES = {
     "mi_ranker_sizeof": (c_int64, [c_int32]),
     "mi_ranker_step_workspace_bytes": (c_size_t, [POINTER(RankerModel), POINTER(RankerBatch)]),
     "mi_ranker_step_f32": (c_int32, [POINTER(RankerModel), POINTER(RankerBatch), P, c_size_t, P]),
+    "mi_ranker_adam_f32": (c_int32, [POINTER(RankerModel), ctypes.c_float, P]),
     "mi_match_same_location_i32": (c_int32, [c_int64, P, P, P, P, P, P, c_int32, P, P, P]),
     "mi_sampler_workspace_bytes": (c_size_t, [POINTER(SamplerDesc)]),
     "mi_sampler_count": (c_int32, [POINTER(SamplerDesc), P, c_uint64, c_uint64, P, c_size_t, POINTER(c_int64), P]),

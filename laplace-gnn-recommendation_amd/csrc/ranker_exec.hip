@@ -90,7 +90,8 @@ struct AdamTable {
 };
 
 // blockIdx.y = parameter tensor, blockIdx.x strides over its elements; also bumps the BatchNorm batch counters
-__global__ __launch_bounds__(kBlock) void adam_multi_kernel(AdamTable tb, MiAdamConsts c, int apply, int64_t* nbt0, int64_t* nbt1) {
+__global__ __launch_bounds__(kBlock) void adam_multi_kernel(AdamTable tb, MiAdamConsts c, int apply, int64_t* nbt0, int64_t* nbt1,
+                                                            float g_scale) {
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
         if (nbt0) *nbt0 += 1;
         if (nbt1) *nbt1 += 1;
@@ -99,9 +100,10 @@ __global__ __launch_bounds__(kBlock) void adam_multi_kernel(AdamTable tb, MiAdam
     const int gs = tb.g_stride[blockIdx.y];
     float* gd = tb.g_dst[blockIdx.y];
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < q.n; i += (int64_t)gridDim.x * kBlock) {
-        const float g = q.g[i * gs];
+        float g = q.g[i * gs];
         if (gd) gd[i] = g;
         if (!apply) continue;
+        if (g_scale != 1.f) g *= g_scale;   // data-parallel: the all-reduced SUM times 1 / world
         float4 pp = make_float4(q.p[i], 0.f, 0.f, 0.f), mm = make_float4(q.m[i], 0.f, 0.f, 0.f), vv = make_float4(q.v[i], 1.f, 1.f, 1.f);
         mi_adam_update4(pp, make_float4(g, 0.f, 0.f, 0.f), mm, vv, false, 0.f, c);
         q.p[i] = pp.x;
@@ -509,7 +511,7 @@ int Exec::run() {
         const MiAdamConsts c = mi_adam_consts(M.lr, M.beta1, M.beta2, M.eps, M.step > 0 ? M.step : 1);
         const unsigned gx = (unsigned)std::min<int64_t>(mi_ceil_div(longest, kBlock), 64);
         hipLaunchKernelGGL(adam_multi_kernel, dim3(gx, (unsigned)std::max(M.n_params, 1)), dim3(kBlock), 0, s, tb, c,
-                           (M.apply_adam && M.n_params > 0) ? 1 : 0, nbt0, nbt1);
+                           (M.apply_adam && M.n_params > 0) ? 1 : 0, nbt0, nbt1, 1.f);
         ok(mi_launch_status());
     }
     return rc;
@@ -547,4 +549,25 @@ extern "C" int mi_ranker_step_f32(const mi_ranker_model* model, const mi_ranker_
     }
     Exec run(*model, *batch, ws, ws_bytes, LAUNCH, (hipStream_t)stream);
     return run.run();
+}
+
+extern "C" int mi_ranker_adam_f32(const mi_ranker_model* model, float grad_scale, mi_stream_t stream) {
+    MI_CHECK_ARG(model && model->n_params >= 0 && model->n_params <= MI_RANKER_MAX_PARAMS && grad_scale > 0.f);
+    if (model->n_params == 0) return 0;
+    AdamTable tb;
+    int64_t longest = 1;
+    for (int i = 0; i < model->n_params; ++i) {
+        const mi_ranker_param& q = model->params[i];
+        MI_CHECK_ARG(q.p && q.g && q.m && q.v && q.n >= 0);
+        tb.p[i] = q;
+        tb.g_stride[i] = 1;
+        tb.g_dst[i] = nullptr;
+        longest = std::max(longest, q.n);
+    }
+    tb.n = model->n_params;
+    const MiAdamConsts c = mi_adam_consts(model->lr, model->beta1, model->beta2, model->eps, model->step > 0 ? model->step : 1);
+    const unsigned gx = (unsigned)std::min<int64_t>(mi_ceil_div(longest, kBlock), 64);
+    hipLaunchKernelGGL(adam_multi_kernel, dim3(gx, (unsigned)model->n_params), dim3(kBlock), 0, (hipStream_t)stream, tb, c, 1,
+                       (int64_t*)nullptr, (int64_t*)nullptr, grad_scale);
+    return mi_launch_status();
 }

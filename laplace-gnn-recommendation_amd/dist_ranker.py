@@ -51,6 +51,15 @@ def fused_step(model: nn.Module, optimizer: t.optim.Optimizer, group=None):
     return FusedRankerStep(model, optimizer, before_step=lambda: allreduce_gradients(model.parameters(), group))
 
 
+def native_step(model: nn.Module, optimizer: t.optim.Optimizer, group=None, seed=None):
+    """The data-parallel iteration on the native executor (ranker_native.NativeRankerStep, data_parallel=True): gradients in
+    one flat buffer, ONE all-reduce of it, mean + Adam in one launch.  Every rank must pass the same seed only if it wants
+    the same dropout masks; by default a rank's masks are keyed on its own torch seed.  Raises ValueError for a model /
+    optimizer the executor does not take (callers then use fused_step)."""
+    from .ranker_native import NativeRankerStep
+    return NativeRankerStep(model, optimizer, data_parallel=True, group=group, seed=seed)
+
+
 def train_step(model: nn.Module, optimizer: t.optim.Optimizer, batch, group=None) -> Tensor:
     """training.py:19-34 with the gradient all-reduce between backward and step."""
     from .utils.get_info import select_properties

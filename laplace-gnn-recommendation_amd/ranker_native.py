@@ -28,13 +28,22 @@ from .utils.constants import Constants
 
 
 class NativeRankerStep:
-    def __init__(self, model: Encoder_Decoder_Model, optimizer: t.optim.Optimizer, before_step=None, seed: Optional[int] = None):
-        """before_step: called once the gradients are in place and BEFORE the update (data-parallel callers all-reduce
-        there); the executor then stops after the gradients and `optimizer.step()` applies them."""
+    def __init__(self, model: Encoder_Decoder_Model, optimizer: t.optim.Optimizer, before_step=None, seed: Optional[int] = None,
+                 data_parallel: bool = False, group=None):
+        """before_step: called once the gradients are in place and BEFORE the update; the executor then stops after the
+        gradients and `optimizer.step()` applies them (the generic hook).
+        data_parallel: the native data-parallel iteration (ranker half) — the executor stops after the
+        gradients, which live in ONE flat buffer (`flat_grads`; every `param.grad` is a view into it), that buffer is
+        all-reduced (sum) over `group` in one collective, and mi_ranker_adam_f32 applies mean gradient + Adam in one
+        launch.  Three host calls per iteration instead of cat / all-reduce / split / foreach-Adam."""
         why = self.unsupported_reason(model, optimizer)
         if why:
             raise ValueError(f"NativeRankerStep: {why}")
+        if data_parallel and before_step is not None:
+            raise ValueError("NativeRankerStep: data_parallel and before_step are two ways of doing the same thing; pass one")
         self.model, self.optimizer, self.before_step = model, optimizer, before_step
+        self.data_parallel, self.group = bool(data_parallel), group
+        self.flat_grads: Optional[Tensor] = None
         self.seed = int(t.initial_seed() if seed is None else seed) & ((1 << 64) - 1)
         self.iteration = 0
         self._desc: Optional[RankerModel] = None
@@ -107,6 +116,26 @@ class NativeRankerStep:
         enc, dec = model.encoder, model.decoder
         d = RankerModel()
         keep = self._keep = []
+
+        # every gradient is a view into one flat buffer (16-byte aligned pieces): a data-parallel caller exchanges it in
+        # one collective; parameters that are not the optimizer's keep an allocation of their own
+        plist = opt.param_groups[0]["params"]
+        offs, total = {}, 0
+        for p in plist:
+            offs[id(p)] = total
+            total += (p.numel() + 3) // 4 * 4
+        flat = self.flat_grads
+        ok = flat is not None and flat.numel() == total and all(
+            p.grad is not None and p.grad.data_ptr() == flat.data_ptr() + 4 * offs[id(p)] for p in plist)
+        if not ok and plist:
+            flat = t.zeros(total, dtype=t.float32, device=plist[0].device)
+            for p in plist:
+                view = flat[offs[id(p)]: offs[id(p)] + p.numel()].view(p.shape)
+                if p.grad is not None and p.grad.shape == p.shape:
+                    view.copy_(p.grad)
+                p.grad = view
+            self.flat_grads = flat
+        keep.append(flat)
 
         def grad_of(p: Tensor) -> int:
             if p.grad is None or p.grad.shape != p.shape or not p.grad.is_contiguous():
@@ -231,7 +260,7 @@ class NativeRankerStep:
         d.p_dropout = float(p) if p else 0.0
         group = self.optimizer.param_groups[0]
         d.lr, (d.beta1, d.beta2), d.eps = float(group["lr"]), (float(b) for b in group["betas"]), float(group["eps"])
-        d.apply_adam = 0 if self.before_step is not None else 1
+        d.apply_adam = 0 if (self.before_step is not None or self.data_parallel) else 1
         steps = [self.optimizer.state[q]["step"] for q in group["params"]]
         d.step = self._adam_step + 1
         xc, xa = xc.contiguous(), xa.contiguous()
@@ -270,11 +299,17 @@ class NativeRankerStep:
             self.before_step()
             self.optimizer.step()
             self._adam_step = int(steps[0]) if steps and not steps[0].is_cuda else self._adam_step + 1
+            return loss
+        if self.data_parallel:
+            import torch.distributed as dist
+            world = dist.get_world_size(self.group) if dist.is_initialized() else 1
+            if world > 1:
+                dist.all_reduce(self.flat_grads, op=dist.ReduceOp.SUM, group=self.group)
+            _lib.check(L.mi_ranker_adam_f32(ctypes.byref(d), 1.0 / world, _lib.current_stream()), "mi_ranker_adam_f32")
+        self._adam_step += 1
+        if steps and steps[0].is_cuda:      # fused=True keeps its step counts on the device: one foreach launch
+            t._foreach_add_(steps, 1)
         else:
-            self._adam_step += 1
-            if steps and steps[0].is_cuda:      # fused=True keeps its step counts on the device: one foreach launch
-                t._foreach_add_(steps, 1)
-            else:
-                for s in steps:                 # the default Adam's host scalars
-                    s += 1
+            for s in steps:                 # the default Adam's host scalars
+                s += 1
         return loss

@@ -1,4 +1,5 @@
 """GPU parity of the ranker (SAGEConv encoder / MLP decoder) against the torch-only oracle twin."""
+import os
 from types import SimpleNamespace
 
 import numpy as np
@@ -513,3 +514,96 @@ def test_native_ranker_dropout_is_reproducible_and_its_backward_uses_the_forward
         assert abs(fd - float(g.view(-1)[idx])) <= 0.15 * abs(float(g.view(-1)[idx])) + 2e-4, (name, fd, float(g.view(-1)[idx]))
         checked += 1
     assert checked >= 3
+
+
+def test_native_data_parallel_step_world_one_is_the_native_step():
+    """data_parallel=True with one process: executor without its Adam + mi_ranker_adam_f32(scale 1) must give exactly the
+    single-launch iteration; every .grad is a view into the flat buffer the collective would exchange."""
+    from laplace_amd.ranker_native import NativeRankerStep
+    from laplace_amd.utils.get_info import select_properties
+    import copy
+    model, loader, first = _hetero_setup(seed=5, aggr="add", embedding=True, p_drop=0.2)
+    twin = copy.deepcopy(model)
+    twin.embedding_layers = model.embedding_layers
+    opt_a, opt_b = t.optim.Adam(model.parameters(), lr=0.01), t.optim.Adam(twin.parameters(), lr=0.01)
+    dp, plain = NativeRankerStep(model, opt_a, data_parallel=True, seed=11), NativeRankerStep(twin, opt_b, seed=11)
+    model.train(); twin.train()
+    for step, batch in enumerate(loader):
+        if step == 4:
+            break
+        x, ei, eli, y = select_properties(batch.to(DEV))
+        la = dp.step({k: v.clone() for k, v in x.items()}, ei, eli, y)
+        lb = plain.step({k: v.clone() for k, v in x.items()}, ei, eli, y)
+        assert la is not None and lb is not None, (dp.declined, plain.declined)
+        assert float(la) == float(lb)
+        flat = dp.flat_grads
+        lo, hi = flat.data_ptr(), flat.data_ptr() + 4 * flat.numel()
+        for (n, p), q in zip(model.named_parameters(), twin.parameters()):
+            assert lo <= p.grad.data_ptr() < hi, n
+            assert t.equal(p.grad, q.grad), (step, n)
+            assert t.equal(p, q), (step, n)
+            assert t.equal(opt_a.state[p]["exp_avg_sq"], opt_b.state[q]["exp_avg_sq"])
+            assert float(opt_a.state[p]["step"]) == step + 1
+    with pytest.raises(ValueError):
+        NativeRankerStep(model, opt_a, data_parallel=True, before_step=lambda: None)
+
+
+def _dp_worker(rank, world, port, ret):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)   # both ranks share the one card: gloo carries the exchange
+    try:
+        from laplace_amd.dist_ranker import broadcast_parameters, native_step
+        from laplace_amd.ranker_native import NativeRankerStep
+        from laplace_amd.utils.get_info import select_properties
+        import copy
+        t.manual_seed(50 + rank)                                   # different initial weights on purpose
+        model, loader, first = _hetero_setup(seed=3, aggr="add", embedding=True, p_drop=0.0)
+        broadcast_parameters(model)
+        for tabs in model.embedding_layers.values():               # the frozen tables are "identical by construction"
+            for tb in tabs:
+                dist.broadcast(tb.data, src=0)
+        local = copy.deepcopy(model)
+        local.embedding_layers = model.embedding_layers
+        opt, opt_l = t.optim.Adam(model.parameters(), lr=0.01), t.optim.Adam(local.parameters(), lr=0.01)
+        step = native_step(model, opt, seed=1)
+        probe = NativeRankerStep(local, opt_l, before_step=lambda: None, seed=1)   # this rank's own gradients
+        model.train(); local.train()
+        batches = [b for i, b in zip(range(2 * world), loader)]
+        x, ei, eli, y = select_properties(batches[rank].to(DEV))  # a different batch per rank
+        before = [p.detach().clone() for p in model.parameters()]
+        loss = step.step({k: v.clone() for k, v in x.items()}, ei, eli, y)
+        assert loss is not None, step.declined
+        probe.step({k: v.clone() for k, v in x.items()}, ei, eli, y)
+        t.cuda.synchronize()
+        ret[rank] = {"params": [p.detach().cpu() for p in model.parameters()], "before": [b.cpu() for b in before],
+                     "sum_grads": [p.grad.detach().cpu() for p in model.parameters()],
+                     "own_grads": [p.grad.detach().cpu() for p in local.parameters()],
+                     "m": [opt.state[p]["exp_avg"].cpu() for p in model.parameters()]}
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_native_data_parallel_step_two_ranks_one_collective():
+    """Two processes on the card, a different batch each: after the step the flat gradient buffer holds the SUM of the two
+    ranks' own gradients, both replicas hold the same parameters, and the update is Adam's on the MEAN gradient."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_dp_worker, args=(2, port, ret), nprocs=2, join=True)
+    a, b = ret[0], ret[1]
+    for i in range(len(a["params"])):
+        assert t.equal(a["before"][i], b["before"][i])
+        assert t.equal(a["sum_grads"][i], b["sum_grads"][i])
+        assert t.allclose(a["sum_grads"][i], a["own_grads"][i] + b["own_grads"][i], rtol=1e-6, atol=1e-7)
+        assert t.equal(a["params"][i], b["params"][i])
+        g = 0.5 * a["sum_grads"][i]
+        assert t.allclose(a["m"][i], 0.1 * g, rtol=1e-5, atol=1e-9)                     # exp_avg after step 1
+        want = a["before"][i] - 0.01 * g / (g.abs() + 1e-8)                              # Adam step 1: lr * g / (|g| + eps)
+        assert t.allclose(a["params"][i], want, rtol=1e-4, atol=1e-6)
+    assert not all(t.equal(x, y) for x, y in zip(a["own_grads"], b["own_grads"]))        # the batches did differ
