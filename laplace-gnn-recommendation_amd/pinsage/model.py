@@ -135,8 +135,9 @@ def train_epoch(model: PinSAGEModel, optimizer: t.optim.Optimizer, sampler, batc
     # device thread at every one of them (as training.train_with_dataloader does for the ranker); the losses are read
     # back once per epoch, not once per step
     with t.autograd.set_multithreading_enabled(False):
-        for _ in range(batches):
-            b = sampler.sample_batch()
+        # sampler.batches: batch i + 1 is drawn on a side stream while this loop trains on batch i
+        source = sampler.batches(batches) if hasattr(sampler, "batches") else (sampler.sample_batch() for _ in range(batches))
+        for b in source:
             loss = model(b["seeds"], b["pos"], b["neg"], b["blocks"]).mean()
             optimizer.zero_grad()
             loss.backward()

@@ -89,16 +89,10 @@ class PinSAGESampler:
             seeds = src_ids
         return blocks
 
-    def _sample_batch_device(self, step: int) -> Optional[dict]:
-        """The whole batch in one C call (six launches for two layers) and ONE host read-back (the counts); None when
-        the sizes are outside the single-workgroup kernels' (the caller then takes the index-op path)."""
-        from ..ops import DeviceCSR
-        L, dev = _lib.lib(), self.device
+    def _batch_buffers(self) -> dict:
+        """Output buffers of one device-built batch at their upper bounds + the descriptor structs that point into them."""
+        dev = self.device
         B, T, NL = self.batch_size, self.T, self.n_layers
-        if NL > _lib.MI_PINSAGE_MAX_LAYERS:
-            return None
-        desc = _lib.PinsageBatchDesc(B, self.num_items, self.iu_ptr.data_ptr(), self.iu_idx.data_ptr(), self.ui_ptr.data_ptr(),
-                                     self.ui_idx.data_ptr(), self.L, self.W, T, NL, self.p, self._pos32.data_ptr())
         out = _lib.PinsageBatchOut()
         i64 = lambda n: t.empty(n, dtype=t.int64, device=dev)
         i32 = lambda n: t.empty(n, dtype=t.int32, device=dev)
@@ -114,24 +108,94 @@ class PinSAGESampler:
                 setattr(out.blocks[l], k, v.data_ptr())
             bufs.append(b)
             n_max = s_max
-        ws = t.empty(int(L.mi_pinsage_batch_workspace_bytes(B, self.L, self.W, T, NL)), dtype=t.uint8, device=dev)
-        rc = L.mi_pinsage_sample_batch(ctypes.byref(desc), self.seed & (2**64 - 1), step, ctypes.byref(out), ws.data_ptr(),
-                                       ws.numel(), self._stream())
+        ws = t.empty(int(_lib.lib().mi_pinsage_batch_workspace_bytes(B, self.L, self.W, T, NL)), dtype=t.uint8, device=dev)
+        host = t.empty(2 + 2 * NL, dtype=t.int32).pin_memory() if dev.type == "cuda" else t.empty(2 + 2 * NL, dtype=t.int32)
+        return dict(out=out, seeds=seeds, pos_u=pos_u, pos_v=pos_v, neg_v=neg_v, counts=counts, bufs=bufs, ws=ws, host=host)
+
+    def _launch_batch(self, step: int, buf: Optional[dict] = None) -> Optional[dict]:
+        """Enqueue the whole batch (one C call, six launches for two layers) and the copy of its counts to pinned host
+        memory on the current stream; None when the sizes are outside the single-workgroup kernels'."""
+        if self.n_layers > _lib.MI_PINSAGE_MAX_LAYERS:
+            return None
+        buf = buf if buf is not None else self._batch_buffers()
+        desc = _lib.PinsageBatchDesc(self.batch_size, self.num_items, self.iu_ptr.data_ptr(), self.iu_idx.data_ptr(),
+                                     self.ui_ptr.data_ptr(), self.ui_idx.data_ptr(), self.L, self.W, self.T, self.n_layers, self.p,
+                                     self._pos32.data_ptr())
+        rc = _lib.lib().mi_pinsage_sample_batch(ctypes.byref(desc), self.seed & (2**64 - 1), step, ctypes.byref(buf["out"]),
+                                                buf["ws"].data_ptr(), buf["ws"].numel(), self._stream())
         if rc == _lib.MI_ERR_UNSUPPORTED:
             return None
         check(rc, "mi_pinsage_sample_batch")
-        c = counts.cpu().tolist()          # the batch's one host read-back
+        buf["host"].copy_(buf["counts"], non_blocking=True)
+        return buf
+
+    def _finish_batch(self, buf: dict) -> dict:
+        """Views of the batch at its actual sizes; the caller has made sure the count copy has landed."""
+        from ..ops import DeviceCSR
+        c = buf["host"].tolist()
         n_pairs, n_seeds = c[0], c[1]
         blocks, n_dst = [], n_seeds
-        for l, b in enumerate(bufs):
+        for l, b in enumerate(buf["bufs"]):
             n_src, n_e = c[2 + 2 * l], c[3 + 2 * l]
             by_dst = DeviceCSR(n_dst, n_src, b["dst_rowptr"][: n_dst + 1], b["dst_col"][:n_e], b["dst_val"][:n_e])
             by_src = DeviceCSR(n_src, n_dst, b["src_rowptr"][: n_src + 1], b["src_col"][:n_e], b["src_val"][:n_e])
             blocks.insert(0, {"src_ids": b["src_ids"][:n_src], "n_dst": n_dst, "edge_src": b["edge_src"][:n_e],
                               "edge_dst": b["edge_dst"][:n_e], "weights": b["weights"][:n_e], "csr": (by_dst, by_src)})
             n_dst = n_src
-        pu = pos_u[:n_pairs]
-        return {"seeds": seeds[:n_seeds], "pos": (pu, pos_v[:n_pairs]), "neg": (pu, neg_v[:n_pairs]), "blocks": blocks}
+        pu = buf["pos_u"][:n_pairs]
+        return {"seeds": buf["seeds"][:n_seeds], "pos": (pu, buf["pos_v"][:n_pairs]), "neg": (pu, buf["neg_v"][:n_pairs]),
+                "blocks": blocks}
+
+    def _sample_batch_device(self, step: int) -> Optional[dict]:
+        """The whole batch in one C call and ONE host read-back (the counts); None when the sizes are outside the
+        single-workgroup kernels' (the caller then takes the index-op path)."""
+        buf = self._launch_batch(step)
+        if buf is None:
+            return None
+        if self.device.type == "cuda":
+            t.cuda.current_stream(self.device).synchronize()
+        return self._finish_batch(buf)
+
+    def batches(self, n: int):
+        """n training batches (steps self.step ...), batch i + 1 sampled on a side stream while the caller trains on batch
+        i: the walks, the block construction and the read-back of the counts leave the critical path (round 3: the
+        reference-default iteration 1.9 -> see profiles/r03_pinsage_n1.json).  Same batches as n calls of sample_batch().
+        Three rotating buffer sets: a batch's tensors stay valid until the caller has asked for the batch after the next."""
+        if not (self.device_batches and self.device.type == "cuda") or n <= 0:
+            for _ in range(max(n, 0)):
+                yield self.sample_batch()
+            return
+        main = t.cuda.current_stream(self.device)
+        if getattr(self, "_side", None) is None:
+            self._side = t.cuda.Stream(device=self.device)
+            self._sets = [None, None, None]
+        side = self._side
+        first = self.step
+
+        def launch(i: int):
+            k = i % 3
+            side.wait_stream(main)       # the set's previous batch (three back) has been consumed by then
+            with t.cuda.stream(side):
+                if self._sets[k] is None:
+                    self._sets[k] = self._batch_buffers()
+                buf = self._launch_batch(first + i, self._sets[k])
+                ev = t.cuda.Event()
+                ev.record(side)
+            return buf, ev
+
+        pending = launch(0)
+        for i in range(n):
+            buf, ev = pending
+            if buf is None:              # sizes outside the device path: everything through sample_batch
+                self.step = first + i
+                for _ in range(n - i):
+                    yield self.sample_batch()
+                return
+            pending = launch(i + 1) if i + 1 < n else None
+            ev.synchronize()             # host: the counts are in pinned memory
+            main.wait_event(ev)          # device: the batch's tensors are complete
+            self.step = first + i + 1
+            yield self._finish_batch(buf)
 
     def sample_batch(self, step: Optional[int] = None) -> dict:
         """One training batch: pair graphs compacted to `seeds`, blocks rooted at them (sampler.py:93-106)."""

@@ -69,3 +69,37 @@ def test_training_on_device_built_batches():
     for _ in range(3):
         last = train_epoch(model, opt, smp, 40)
     assert np.isfinite(last).all() and np.mean(last) < np.mean(first)
+
+
+def test_overlapped_batches_are_the_serial_batches():
+    """PinSAGESampler.batches(n): batch i + 1 drawn on a side stream under the training of batch i, rotating buffer sets;
+    the batches are exactly those of n sample_batch() calls, a batch stays intact while the next one is in the caller's
+    hands, and the step counter ends where the serial calls leave it.  Kernels are enqueued on the training stream between
+    the batches so that the side stream really runs beside something."""
+    from laplace_amd.pinsage.sampler import PinSAGESampler
+    U, I = 3000, 900
+    users, items = _graph(9, U, I, 50000)
+    mk = lambda: PinSAGESampler(users, items, U, I, batch_size=48, seed=21)
+    a, b = mk(), mk()
+    serial = [a.sample_batch() for _ in range(7)]
+    busy = t.randn(2048, 2048, device="cuda")
+    flat = lambda batch: [batch["seeds"], *batch["pos"], *batch["neg"]] + [x for blk in batch["blocks"] for x in (
+        blk["src_ids"], blk["edge_src"], blk["edge_dst"], blk["weights"], blk["csr"][0].rowptr, blk["csr"][0].col, blk["csr"][0].val,
+        blk["csr"][1].rowptr, blk["csr"][1].col, blk["csr"][1].val)]
+    prev = None
+    for i, batch in enumerate(b.batches(7)):
+        if prev is not None:      # the previous batch was not touched by the sampling of this one or of the one in flight
+            for x, y in zip(flat(prev), flat(serial[i - 1])):
+                assert t.equal(x, y), i
+        for _ in range(3):
+            busy = busy @ busy * 1e-3
+        for x, y in zip(flat(batch), flat(serial[i])):
+            assert x.shape == y.shape and t.equal(x, y), i
+        prev = batch
+    assert b.step == a.step == 7
+    assert bool((b._pos32 == -1).all())
+    again = [x for x in b.batches(2)]                                  # a second call continues the sequence
+    want = [a.sample_batch() for _ in range(2)]
+    for g, w in zip(again, want):
+        for x, y in zip(flat(g), flat(w)):
+            assert t.equal(x, y)

@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--hidden", type=int, default=64)
     ap.add_argument("--iters", type=int, default=200)
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--serial", action="store_true", help="sample each batch on the training stream (no overlap)")
     args = ap.parse_args()
     from laplace_amd import launch
     if args.gpus > 1 and not launch.launched():
@@ -55,8 +56,8 @@ def main():
     model.train()
     t.autograd.set_multithreading_enabled(False)                  # as pinsage.model.train_epoch does
 
-    def one():
-        b = smp.sample_batch()
+    def one(b=None):
+        b = smp.sample_batch() if b is None else b
         loss = model(b["seeds"], b["pos"], b["neg"], b["blocks"]).mean()
         opt.zero_grad()
         loss.backward()
@@ -69,8 +70,9 @@ def main():
     t.cuda.synchronize()
     t0 = time.perf_counter()
     pairs = 0
-    for _ in range(args.iters):
-        loss, b = one()
+    serial = "--serial" in sys.argv   # sample_batch() per iteration instead of the overlapped iterator
+    for b in ((None for _ in range(args.iters)) if serial else smp.batches(args.iters)):
+        loss, b = one(b)
         pairs += int(b["pos"][0].numel())
     t.cuda.synchronize()
     if world > 1:
@@ -95,6 +97,7 @@ def main():
                       "workload": f"PinSAGE item-item training, H&M-shaped synthetic {args.users}x{args.items}, {args.edges} edges; "
                                   f"batch {args.batch} pairs, walks {args.walks} x length {args.walk_length}, restart {args.restart}, "
                                   f"T={args.neighbors}, {args.layers} layers, hidden {args.hidden}",
+                      "sampling": "serial" if serial else "overlapped (side stream, one batch ahead)",
                       "ms_per_iteration": round(1e3 * dt / args.iters, 3), "positive_pairs_per_s": round(pairs / dt),
                       "sampler_ms_per_batch": round(1e3 * ds, 3), "loss": round(float(loss.detach()), 4)}))
     if world > 1:
