@@ -95,7 +95,7 @@ __device__ __forceinline__ void bitonic_desc(unsigned long long* cand, int p2) {
 struct SelectShared {
     int hist[256];
     int scan_sh[kBlock / 64 + 1];
-    unsigned long long cand[kCand];
+    alignas(16) unsigned long long cand[kCand];
     uint32_t prefix;
     int need, count, eq_total;
 };
@@ -168,6 +168,93 @@ __device__ __forceinline__ uint32_t sample_threshold(const uint32_t* skey, int m
         __syncthreads();
         radix_pick_bin(sh, prefix, shift);
     }
+    return sh.prefix;
+}
+
+// The same value without the radix passes when m <= kBlock (it always is for the ranks sample_rank() returns on the fused
+// path's sizes).  The first radix pass put nearly all 4 096 keys — scores of one row share sign and exponent — into two or
+// three LDS counters: ~4 000 serialised atomics.  Instead: every thread keeps the maximum of its 16 keys; t1 = the m-th
+// largest of a set of those maxima is <= the answer, because m distinct keys are >= t1; the keys >= t1 are few (a small
+// multiple of m) and are ranked against each other: the m-th largest VALUE among them is the m-th largest of the whole
+// sample.  `scratch`: kSample words of LDS that do not alias skey.  More than kFastList keys >= t1 (massive ties): the
+// radix select.  (Round 3, per 2 684-row chunk: 42 us -> see profiles/r03_topk.md.)
+constexpr int kFastList = 1024;
+__device__ __forceinline__ uint32_t sample_threshold_small(const uint32_t* skey, int m, SelectShared& sh, uint32_t* scratch) {
+    const int tid = threadIdx.x;
+    m = min(m, kSample);
+    if (m > kBlock) return sample_threshold(skey, m, sh);   // block-uniform
+    uint32_t mine[kSample / kBlock];
+    uint32_t mx = 0u;
+#pragma unroll
+    for (int j = 0; j < kSample / kBlock; ++j) {
+        mine[j] = skey[tid + kBlock * j];
+        mx = max(mx, mine[j]);
+    }
+    uint32_t* tmax = reinterpret_cast<uint32_t*>(sh.hist);   // 256 words
+    tmax[tid] = mx;
+    if (tid == 0) sh.count = 0;
+    __syncthreads();
+    // v is the m-th largest VALUE of a set iff #{> v} <= m - 1 < #{>= v} (equal values all qualify and write the same
+    // word).  The loads do not depend on the counts: unrolled, the loops run at LDS issue rate.  Ranking the 256 maxima
+    // against each other is 65 K compares per row and VALU-bound (19 us of the kernel); for m <= 64 every wavefront ranks
+    // its own 64 maxima instead (4 x 4 K compares): each wavefront's m-th largest is a valid lower bound, the largest of
+    // the four is used.
+    uint32_t t1;
+    if (m <= 64) {
+        const int wave = tid >> 6;
+        int gt = 0, ge = 0;
+        const uint4* t4 = reinterpret_cast<const uint4*>(tmax + 64 * wave);
+#pragma unroll 8
+        for (int j = 0; j < 16; ++j) {
+            const uint4 o = t4[j];
+            gt += (o.x > mx) + (o.y > mx) + (o.z > mx) + (o.w > mx);
+            ge += (o.x >= mx) + (o.y >= mx) + (o.z >= mx) + (o.w >= mx);
+        }
+        uint32_t* twave = reinterpret_cast<uint32_t*>(sh.scan_sh);
+        if (gt <= m - 1 && m - 1 < ge) twave[wave] = mx;
+        __syncthreads();
+        t1 = max(max(twave[0], twave[1]), max(twave[2], twave[3]));
+    } else {
+        int gt = 0, ge = 0;
+        const uint4* t4 = reinterpret_cast<const uint4*>(tmax);
+#pragma unroll 8
+        for (int j = 0; j < kBlock / 4; ++j) {
+            const uint4 o = t4[j];
+            gt += (o.x > mx) + (o.y > mx) + (o.z > mx) + (o.w > mx);
+            ge += (o.x >= mx) + (o.y >= mx) + (o.z >= mx) + (o.w >= mx);
+        }
+        if (gt <= m - 1 && m - 1 < ge) sh.prefix = mx;
+        __syncthreads();
+        t1 = sh.prefix;
+    }
+#pragma unroll
+    for (int j = 0; j < kSample / kBlock; ++j) {
+        if (mine[j] >= t1) {
+            const int slot = atomicAdd(&sh.count, 1);
+            scratch[slot] = mine[j];            // slot < kSample always
+        }
+    }
+    __syncthreads();
+    const int c = sh.count;                     // >= m
+    if (c > kFastList) {
+        __syncthreads();
+        return sample_threshold(skey, m, sh);
+    }
+    for (int i = c + tid; i < ((c + 3) & ~3); i += kBlock) scratch[i] = 0u;   // pad to whole uint4 (0 < every live key)
+    __syncthreads();
+    for (int i = tid; i < c; i += kBlock) {
+        const uint32_t x = scratch[i];
+        int gt = 0, ge = 0;
+        const uint4* s4 = reinterpret_cast<const uint4*>(scratch);
+#pragma unroll 4
+        for (int j = 0; j < (c + 3) / 4; ++j) {
+            const uint4 o = s4[j];
+            gt += (o.x > x) + (o.y > x) + (o.z > x) + (o.w > x);
+            ge += (o.x >= x) + (o.y >= x) + (o.z >= x) + (o.w >= x);
+        }
+        if (gt <= m - 1 && m - 1 < ge) sh.prefix = x;
+    }
+    __syncthreads();
     return sh.prefix;
 }
 
@@ -252,9 +339,77 @@ __device__ void select_row_exact(const float* __restrict__ row, int64_t n_items,
 }
 
 // Sort cnt candidates (cnt >= kk) already in sh.cand and write the row.
+#ifndef MI_TOPK_RANK_FINISH
+#define MI_TOPK_RANK_FINISH 1   // 0: always the bitonic sort (A/B)
+#endif
+constexpr int kRankFinish = MI_TOPK_RANK_FINISH;
 __device__ __forceinline__ void finish_candidates(int cnt, int k, int kk, int kpow2, int64_t q,
                                                   int64_t* __restrict__ out_idx, float* __restrict__ out_score,
                                                   SelectShared& sh) {
+    if (kRankFinish && kk <= 64 && cnt <= kCand / 2) {
+        // Small k (evaluation's k = 12 with ~270 candidates): no sort.  (1) S of the candidates' keys (S = 64 / 128 / 256 >=
+        // 4 kk, or all of them) are ranked against each other — the kk-th largest of a subset is a lower bound of the
+        // kk-th largest of all; (2) the candidates that reach it (about kk * cnt / S) are compacted; (3) each of those
+        // counts the ones that beat it — composites are unique, the item id is part of them — and the ones of rank < kk
+        // write themselves to their place.  Work ~S^2 + n2^2 compares instead of the 45-55 barrier stages of the padded
+        // bitonic sort (or cnt^2 for ranking everything: VALU-bound at ~25 us per chunk).
+        const int tid = threadIdx.x;
+        const int S = min(cnt, kk <= 16 ? 64 : (kk <= 32 ? 128 : 256));
+        uint32_t* keys = reinterpret_cast<uint32_t*>(sh.hist);           // 256 words
+        unsigned long long* list2 = sh.cand + kCand / 2;
+        const uint32_t x = tid < S ? (uint32_t)(sh.cand[tid] >> 32) : 0u;
+        keys[tid] = x;                                                    // zero beyond S: pads of the uint4 reads
+        if (tid == 0) sh.count = 0;
+        __syncthreads();
+        if (tid < S) {
+            int gt = 0, ge = 0;
+            const uint4* k4 = reinterpret_cast<const uint4*>(keys);
+#pragma unroll 8
+            for (int j = 0; j < (S + 3) / 4; ++j) {
+                const uint4 o = k4[j];
+                gt += (o.x > x) + (o.y > x) + (o.z > x) + (o.w > x);
+                ge += (o.x >= x) + (o.y >= x) + (o.z >= x) + (o.w >= x);
+            }
+            if (gt <= kk - 1 && kk - 1 < ge) sh.prefix = x;               // the kk-th largest value of the subset
+        }
+        __syncthreads();
+        const uint32_t t2 = sh.prefix;
+        for (int i = tid; i < cnt; i += kBlock) {
+            const unsigned long long c = sh.cand[i];
+            if ((uint32_t)(c >> 32) >= t2) {
+                const int slot = atomicAdd(&sh.count, 1);
+                if (slot < kBlock) list2[slot] = c;
+            }
+        }
+        __syncthreads();
+        const int n2 = sh.count;                                          // >= kk
+        if (n2 <= kBlock) {                                               // block-uniform
+            if (tid == 0 && (n2 & 1)) list2[n2] = 0ull;                   // the pair reads see a pad that beats nobody
+            __syncthreads();
+            if (tid < n2) {
+                const unsigned long long me = list2[tid];
+                int rank = 0;
+                const ulonglong2* c2 = reinterpret_cast<const ulonglong2*>(list2);
+#pragma unroll 8
+                for (int j = 0; j < (n2 + 1) / 2; ++j) {
+                    const ulonglong2 o = c2[j];
+                    rank += (o.x > me ? 1 : 0) + (o.y > me ? 1 : 0);
+                }
+                if (rank < kk) {
+                    const float sc = key_score((uint32_t)(me >> 32));
+                    const bool live = sc != -INFINITY;
+                    out_idx[q * k + rank] = live ? (int64_t)(0xFFFFFFFFu - (uint32_t)me) : -1;
+                    if (out_score) out_score[q * k + rank] = live ? sc : -INFINITY;
+                }
+            }
+            for (int j = kk + tid; j < k; j += kBlock) {                  // k > n_items: the tail of the row
+                out_idx[q * k + j] = -1;
+                if (out_score) out_score[q * k + j] = -INFINITY;
+            }
+            return;
+        }
+        __syncthreads();   // massive ties at the bound: the sort below
+    }
     int p2 = kpow2;
     while (p2 < cnt) p2 <<= 1;
     for (int i = cnt + threadIdx.x; i < p2; i += kBlock) sh.cand[i] = 0ull;
@@ -357,31 +512,43 @@ __global__ void gather_sample_rows_kernel(int64_t n_items, int d, const float* _
     for (int c = threadIdx.x; c < d; c += blockDim.x) Is[(int64_t)p * d + c] = I[item * ldi + c];
 }
 
-__global__ void exclude_bitmap_kernel(int64_t n_q, int64_t n_items, const int32_t* __restrict__ excl_ptr,
-                                      const int32_t* __restrict__ excl_idx, uint32_t* __restrict__ bitmap, int64_t words,
-                                      float* __restrict__ sample_scores) {
-    const int64_t q = blockIdx.x;
-    if (q >= n_q) return;
-    const int64_t gap = n_items / (kSample / kSampleRun);
-    for (int32_t p = excl_ptr[q] + threadIdx.x; p < excl_ptr[q + 1]; p += blockDim.x) {
-        const int32_t i = excl_idx[p];
-        if (i < 0 || i >= n_items) continue;
-        atomicOr(&bitmap[q * words + (i >> 5)], 1u << (i & 31));
-        const int64_t run = i / gap, off = i - run * gap;
-        if (run < kSample / kSampleRun && off < kSampleRun) sample_scores[q * kSample + run * kSampleRun + off] = -INFINITY;
-    }
-}
-
+// One block per query: the row's exclusion list -> bits of its bitmap row and -inf over the sampled scores it covers (in
+// LDS: the global sample block is read once and never patched), the sampled threshold, and the row's candidate counter
+// reset.  (Round 3: was exclude_bitmap_kernel + threshold_kernel + a memset of the counters.)
 __global__ __launch_bounds__(kBlock) void threshold_kernel(int64_t n_q, int64_t n_items, int k,
                                                            const float* __restrict__ sample_scores,
-                                                           uint32_t* __restrict__ thr) {
+                                                           const int32_t* __restrict__ excl_ptr,
+                                                           const int32_t* __restrict__ excl_idx,
+                                                           uint32_t* __restrict__ bitmap, int64_t words,
+                                                           uint32_t* __restrict__ thr, int* __restrict__ cnt) {
     __shared__ SelectShared sh;
     const int64_t q = blockIdx.x;
     if (q >= n_q) return;
     uint32_t* skey = reinterpret_cast<uint32_t*>(sh.cand);
-    for (int i = threadIdx.x; i < kSample; i += kBlock) skey[i] = score_key(sample_scores[q * kSample + i]);
+    const float4* src = reinterpret_cast<const float4*>(sample_scores + q * kSample);
+    for (int i = threadIdx.x; i < kSample / 4; i += kBlock) {
+        const float4 v = src[i];
+        skey[4 * i] = score_key(v.x); skey[4 * i + 1] = score_key(v.y); skey[4 * i + 2] = score_key(v.z); skey[4 * i + 3] = score_key(v.w);
+    }
+    if (threadIdx.x == 0) cnt[q] = 0;
     __syncthreads();
-    const uint32_t t_lo = sample_threshold(skey, sample_rank((int)min((int64_t)k, n_items), n_items), sh);
+    if (excl_ptr) {
+        const int64_t gap = n_items / (kSample / kSampleRun);
+        const uint32_t gone = score_key(-INFINITY);
+        for (int32_t p = excl_ptr[q] + threadIdx.x; p < excl_ptr[q + 1]; p += kBlock) {
+            const int32_t i = excl_idx[p];
+            if (i < 0 || i >= n_items) continue;
+            atomicOr(&bitmap[q * words + (i >> 5)], 1u << (i & 31));
+            const int64_t run = i / gap, off = i - run * gap;
+            if (run < kSample / kSampleRun && off < kSampleRun) skey[run * kSampleRun + off] = gone;
+        }
+        __syncthreads();
+    }
+#if defined(MI_TOPK_PROBE) && MI_TOPK_PROBE == 1   // timing probe only: loads + exclusions, no selection
+    const uint32_t t_lo = skey[17] | 0xFF000000u;
+#else
+    const uint32_t t_lo = sample_threshold_small(skey, sample_rank((int)min((int64_t)k, n_items), n_items), sh, skey + kSample);
+#endif
     if (threadIdx.x == 0) thr[q] = t_lo;
 }
 
@@ -948,6 +1115,10 @@ __global__ __launch_bounds__(kBlock) void topk_finalize_kernel(FusedArgs a, int 
     if (cnt >= kk && cnt <= kCap) {  // every winner is in the list
         for (int i = tid; i < cnt; i += kBlock) sh.cand[i] = a.cand[q * kCap + i];
         __syncthreads();
+#if defined(MI_TOPK_PROBE) && MI_TOPK_PROBE == 2   // timing probe only: the loads, no selection
+        if (tid < k) out_idx[q * k + tid] = (int64_t)sh.cand[tid];
+        return;
+#endif
         finish_candidates(cnt, k, kk, kpow2, q, out_idx, out_score, sh);
         return;
     }
@@ -1050,12 +1221,8 @@ int mi_topk_excl_f32(int64_t n_q, int64_t n_items, int64_t d, int64_t k, const i
             if (rc) return rc;
         }
         MI_HIP(hipMemsetAsync(bitmap, 0, (size_t)n_q * words * sizeof(uint32_t), s));
-        MI_HIP(hipMemsetAsync(cnt, 0, (size_t)n_q * sizeof(int), s));
-        if (excl_ptr)
-            hipLaunchKernelGGL(exclude_bitmap_kernel, dim3((unsigned)n_q), dim3(kBlock), 0, s, n_q, n_items, excl_ptr,
-                               excl_idx, bitmap, words, sample_scores);
         hipLaunchKernelGGL(threshold_kernel, dim3((unsigned)n_q), dim3(kBlock), 0, s, n_q, n_items, (int)k, sample_scores,
-                           thr);
+                           excl_ptr, excl_idx, bitmap, words, thr, cnt);
         a.thr = thr; a.bitmap = bitmap; a.words = words; a.cand = cand; a.cnt = cnt;
         const int64_t n_tiles = mi_ceil_div(n_items, FN);
         // Every workgroup does the same work and two fit on a CU, so the launch runs in ceil(grid / (2 * CUs)) rounds of
