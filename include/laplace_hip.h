@@ -210,7 +210,7 @@ typedef struct mi_spmm_sweep {
     int32_t        n_streams;   /* sub-groups per XCD: a multiple of 32, at most 32 * 32                                */
     int32_t        n_slots;
     int32_t*       progress;    /* reserved (null)                                                                          */
-    int32_t        epoch;       /* reserved (0)                                                                             */
+    int32_t        epoch;       /* bands per XCD of the plan (read by the MI_SWEEP_WG_SYNC experiment build only; else ignored)      */
     int32_t        slack;       /* pacing: ticks of the 100 MHz device clock per band; wavefronts do not start band t before
                                    t * slack ticks after their start (a late wavefront never waits).  0 = no pacing.  For the
                                    L2 hit rate only: results do not depend on it                                          */

@@ -652,6 +652,16 @@ __global__ __launch_bounds__(1024) void spmm_sweep_kernel(mi_spmm_sweep sw, int 
             my_c = sw.col[beg + base + li];
             my_v = sw.val[beg + base + li];
         }
+#ifdef MI_SWEEP_WG_SYNC
+        // EXPERIMENT (profiles/r03_sweep.md): the 16 wavefronts of a workgroup advance band by band
+        // in lockstep — a wavefront whose first stream enters band t first passes barriers up to t; every wavefront
+        // executes exactly sw.epoch (= bands per XCD) barriers in all.  Band = 2 048 columns, XCD-interleaved.
+        {
+            const int first_c = __builtin_amdgcn_readfirstlane(my_c);
+            const int tb0 = first_c >= 0 ? (((first_c & kColMask) >> 11) >> 3) : sw.epoch;
+            while (my_band < tb0 && my_band < sw.epoch) { __syncthreads(); ++my_band; }
+        }
+#endif
         unsigned long long band_starts = 0ull;  // bit j: entry j of this batch opens a band (first sub-group's stream)
         if (pace) {
             const unsigned long long fl = __ballot(my_c >= 0 && (my_c & 0x08000000));
@@ -697,6 +707,9 @@ __global__ __launch_bounds__(1024) void spmm_sweep_kernel(mi_spmm_sweep sw, int 
             }
         }
     }
+#ifdef MI_SWEEP_WG_SYNC
+    while (my_band < sw.epoch) { __syncthreads(); ++my_band; }
+#endif
     if (cur >= 0) mine[cur * LPR + li] = mi_f4_add(mine[cur * LPR + li], run);
 #pragma unroll
     for (int q = 0; q < 8; ++q) {

@@ -345,8 +345,9 @@ def build_sweep_plan(a: DeviceCSR, chunk: int = DEFAULT_CHUNK, band: int = SWEEP
     st.long_rows, st.item_ptr, st.items = long_rows32.data_ptr(), item_ptr.data_ptr(), None
     st.long_index = long_index.data_ptr()
     st.band, st.n_bands = band, n_b
+    # `epoch` carries the bands per XCD: read only by the MI_SWEEP_WG_SYNC experiment build of the kernel (profiles/r03_sweep.md)
     sw = SpmmSweepStruct(col_s.data_ptr(), val_s.data_ptr(), stream_ptr.data_ptr(), slot_of_t.data_ptr(), n_streams, n_slots,
-                         None, 0, max(SWEEP_PACE, 0))
+                         None, int(n_t), max(SWEEP_PACE, 0))
     return SpmmPlan(st, long_rows32, item_ptr, None, long_index, sweep=sw, sweep_t=(col_s, val_s, stream_ptr, slot_of_t))
 
 

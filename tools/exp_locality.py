@@ -18,7 +18,9 @@ ap.add_argument('--reorder', default='none')
 ap.add_argument('--slices', type=int, default=1)
 ap.add_argument('--n', type=int, default=10)
 ap.add_argument('--band', type=int, default=-1)
+ap.add_argument('--pace', type=int, default=0, help='sweep time table: ticks (10 ns) per band')
 args = ap.parse_args()
+ops.SWEEP_PACE = args.pace
 
 spec = S.C2
 ei = S.generate(spec).numpy()
