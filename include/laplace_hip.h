@@ -753,6 +753,60 @@ size_t mi_pinsage_batch_workspace_bytes(int64_t batch, int32_t walk_length, int3
 int    mi_pinsage_sample_batch(const mi_pinsage_batch_desc* desc, uint64_t seed, uint64_t step,
                                const mi_pinsage_batch_out* out, void* ws, size_t ws_bytes, mi_stream_t stream);
 
+/* ------------------------------------------------------------------------------------
+ * N5  one PinSAGE training iteration as ONE call (round 3).
+ * replaces: the loop body of pinsage/model.py:118-131 (train) on PinSAGEModel (pinsage/model.py:16-34): LinearProjector
+ *           over the item-id feature (an embedding row per node), SAGENet of WeightedSAGEConv layers
+ *           (pinsage/layers.py:121-156: n = relu(Q dropout(h_src)), weighted mean over the sampled neighbours,
+ *           z = relu(W dropout([agg, h_dst])), row L2-normalisation), h_dst + SAGENet output, ItemToItemScorer
+ *           (pinsage/layers.py:181-203: dot + both endpoints' bias), hinge (neg - pos + 1).clamp(min = 0).mean(),
+ *           backward, torch.optim.Adam step.  Issued op by op through autograd the iteration is ~200 launches of a few
+ *           microseconds (1.8 ms at the reference's 32 pairs per batch); here ~40.
+ * The batch is one built by mi_pinsage_sample_batch (blocks in MODEL order: input layer first; destination nodes are the
+ * first rows of every block's src_ids, so the seeds are the first n_seeds rows of block 0's).  Dropout: Philox4x32-10
+ * masks keyed on (seed, step, site), regenerated in the backward.  Gradients: the embedding table's and the scorer
+ * bias's gradient buffers are DENSE and must be all zero on entry; the rows of this batch are written, Adam runs over
+ * the whole tables (torch.optim.Adam's dense semantics: every moment decays every step) and the rows are zeroed again
+ * — unless apply_adam = 0, which stops after the gradients and leaves them in place (the caller zeroes them).
+ * hidden % 4 == 0, hidden <= 128.  Everything is deterministic (no float atomics).
+ * ---------------------------------------------------------------------------------- */
+#define MI_PINSAGE_MAX_PARAMS 24
+typedef struct mi_pinsage_conv {
+    const float *q_w, *q_b, *w_w, *w_b;        /* Q [hidden, hidden] + [hidden]; W [hidden, 2 hidden] + [hidden] */
+    float *g_q_w, *g_q_b, *g_w_w, *g_w_b;      /* gradients, same shapes */
+} mi_pinsage_conv;
+typedef struct mi_pinsage_model {
+    int32_t n_layers, hidden;
+    int64_t n_items;
+    float *proj, *g_proj, *m_proj, *v_proj;    /* [n_items + 1, hidden]: table, dense gradient (zero on entry), Adam moments */
+    const float* bias; float* g_bias;          /* [n_items] scorer bias and its dense gradient (zero on entry) */
+    mi_pinsage_conv conv[MI_PINSAGE_MAX_LAYERS];
+    mi_ranker_param params[MI_PINSAGE_MAX_PARAMS];   /* every parameter EXCEPT proj (the scorer bias included): multi-tensor Adam */
+    int32_t n_params, apply_adam;
+    float   p_dropout; int32_t reserved;
+    double  lr, beta1, beta2, eps;
+    int64_t step;                               /* Adam step of THIS iteration, counts from 1 */
+    const float* ones4; int64_t n_ones;         /* [n_ones, 4] ones, n_ones >= the largest block's n_src */
+} mi_pinsage_model;
+typedef struct mi_pinsage_step_block {
+    int64_t n_src, n_dst, nnz;
+    const int64_t* src_ids;                                      /* [n_src] global item ids, destination nodes first */
+    const int32_t *dst_rowptr, *dst_col; const float* dst_val;   /* CSR by destination [n_dst x n_src], w / max(sum w, 1) */
+    const int32_t *src_rowptr, *src_col; const float* src_val;   /* the same entries by source [n_src x n_dst] */
+} mi_pinsage_step_block;
+typedef struct mi_pinsage_step_batch {
+    int32_t n_blocks, reserved;
+    mi_pinsage_step_block blocks[MI_PINSAGE_MAX_LAYERS];         /* model order */
+    int64_t n_seeds, n_pairs;
+    const int64_t *seeds, *pos_u, *pos_v, *neg_v;                /* [n_seeds] ids; [n_pairs] positions in seeds */
+    uint64_t seed, step;                                         /* dropout stream */
+    float*   loss;                                               /* device float[1] */
+} mi_pinsage_step_batch;
+int64_t mi_pinsage_step_sizeof(int32_t which);  /* sizeof of: 0 model, 1 batch, 2 conv, 3 block (binding self-check) */
+size_t mi_pinsage_step_workspace_bytes(const mi_pinsage_model* model, const mi_pinsage_step_batch* batch);
+int    mi_pinsage_step_f32(const mi_pinsage_model* model, const mi_pinsage_step_batch* batch, void* ws, size_t ws_bytes,
+                           mi_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -127,6 +127,35 @@ class PinsageBatchOut(Structure):
                 ("blocks", PinsageBlockOut * MI_PINSAGE_MAX_LAYERS)]
 
 
+MI_PINSAGE_MAX_PARAMS = 24
+
+
+class PinsageConv(Structure):
+    _fields_ = [("q_w", c_void_p), ("q_b", c_void_p), ("w_w", c_void_p), ("w_b", c_void_p),
+                ("g_q_w", c_void_p), ("g_q_b", c_void_p), ("g_w_w", c_void_p), ("g_w_b", c_void_p)]
+
+
+class PinsageModel(Structure):
+    _fields_ = [("n_layers", c_int32), ("hidden", c_int32), ("n_items", c_int64),
+                ("proj", c_void_p), ("g_proj", c_void_p), ("m_proj", c_void_p), ("v_proj", c_void_p),
+                ("bias", c_void_p), ("g_bias", c_void_p), ("conv", PinsageConv * MI_PINSAGE_MAX_LAYERS),
+                ("params", RankerParam * MI_PINSAGE_MAX_PARAMS), ("n_params", c_int32), ("apply_adam", c_int32),
+                ("p_dropout", c_float), ("reserved", c_int32), ("lr", c_double), ("beta1", c_double), ("beta2", c_double),
+                ("eps", c_double), ("step", c_int64), ("ones4", c_void_p), ("n_ones", c_int64)]
+
+
+class PinsageStepBlock(Structure):
+    _fields_ = [("n_src", c_int64), ("n_dst", c_int64), ("nnz", c_int64), ("src_ids", c_void_p),
+                ("dst_rowptr", c_void_p), ("dst_col", c_void_p), ("dst_val", c_void_p),
+                ("src_rowptr", c_void_p), ("src_col", c_void_p), ("src_val", c_void_p)]
+
+
+class PinsageStepBatch(Structure):
+    _fields_ = [("n_blocks", c_int32), ("reserved", c_int32), ("blocks", PinsageStepBlock * MI_PINSAGE_MAX_LAYERS),
+                ("n_seeds", c_int64), ("n_pairs", c_int64), ("seeds", c_void_p), ("pos_u", c_void_p), ("pos_v", c_void_p),
+                ("neg_v", c_void_p), ("seed", c_uint64), ("step", c_uint64), ("loss", c_void_p)]
+
+
 P = c_void_p
 _PROTOTYPES = {
     # name: (restype, [argtypes])
@@ -195,6 +224,9 @@ _PROTOTYPES = {
                                        c_uint64, c_uint64, P, P, P, c_size_t, P]),
     "mi_pinsage_batch_workspace_bytes": (c_size_t, [c_int64, c_int32, c_int32, c_int32, c_int32]),
     "mi_pinsage_sample_batch": (c_int32, [POINTER(PinsageBatchDesc), c_uint64, c_uint64, POINTER(PinsageBatchOut), P, c_size_t, P]),
+    "mi_pinsage_step_sizeof": (c_int64, [c_int32]),
+    "mi_pinsage_step_workspace_bytes": (c_size_t, [POINTER(PinsageModel), POINTER(PinsageStepBatch)]),
+    "mi_pinsage_step_f32": (c_int32, [POINTER(PinsageModel), POINTER(PinsageStepBatch), P, c_size_t, P]),
     "mi_adam_dense_f32": (c_int32, [c_int64, c_int64, P, c_int64, P, c_int64, P, P, P,
                                     c_double, c_double, c_double, c_double, c_int64, P]),
 }

@@ -128,9 +128,15 @@ def train_epoch(model: PinSAGEModel, optimizer: t.optim.Optimizer, sampler, batc
     sampler with its own seed (the item-item walks need the whole graph, 0.4 GB of int32 CSR, so it is replicated),
     and the gradients — dense layers plus the id-embedding table — are averaged with one flat all-reduce per
     step (dist_ranker.allreduce_gradients; a no-op when not initialised)."""
+    import torch.distributed as dist
     from ..dist_ranker import allreduce_gradients
+    from .native import NativePinSAGEStep
     losses = []
     model.train()
+    # one C call per iteration where the model / optimizer are the executor's (single process; the data-parallel run keeps
+    # the autograd path: its dense embedding gradient is what the all-reduce exchanges)
+    single = not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1)
+    native = NativePinSAGEStep(model, optimizer) if (single and NativePinSAGEStep.supports(model, optimizer)) else None
     # the backward graph is a chain of small nodes: running it in the calling thread saves the hand-over to autograd's
     # device thread at every one of them (as training.train_with_dataloader does for the ranker); the losses are read
     # back once per epoch, not once per step
@@ -138,6 +144,10 @@ def train_epoch(model: PinSAGEModel, optimizer: t.optim.Optimizer, sampler, batc
         # sampler.batches: batch i + 1 is drawn on a side stream while this loop trains on batch i
         source = sampler.batches(batches) if hasattr(sampler, "batches") else (sampler.sample_batch() for _ in range(batches))
         for b in source:
+            loss = native.step(b) if native is not None else None
+            if loss is not None:
+                losses.append(loss[0])
+                continue
             loss = model(b["seeds"], b["pos"], b["neg"], b["blocks"]).mean()
             optimizer.zero_grad()
             loss.backward()

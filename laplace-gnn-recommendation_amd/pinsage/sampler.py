@@ -210,4 +210,5 @@ class PinSAGESampler:
         seeds = t.unique(t.cat([heads, tails, negs]))
         loc = lambda x: t.searchsorted(seeds, x)
         blocks = self.sample_blocks(seeds, step, heads, tails, negs)
-        return {"seeds": seeds, "pos": (loc(heads), loc(tails)), "neg": (loc(heads), loc(negs)), "blocks": blocks}
+        pu = loc(heads)
+        return {"seeds": seeds, "pos": (pu, loc(tails)), "neg": (pu, loc(negs)), "blocks": blocks}

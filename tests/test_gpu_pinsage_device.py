@@ -103,3 +103,147 @@ def test_overlapped_batches_are_the_serial_batches():
     for g, w in zip(again, want):
         for x, y in zip(flat(g), flat(w)):
             assert t.equal(x, y)
+
+
+def _pin_setup(seed=0, p_drop=0.0, hidden=32, layers=2, B=48):
+    from laplace_amd.pinsage.model import PinSAGEModel
+    from laplace_amd.pinsage.sampler import PinSAGESampler
+    U, I = 2500, 800
+    users, items = _graph(seed + 3, U, I, 40000)
+    smp = PinSAGESampler(users, items, U, I, batch_size=B, num_layers=layers, seed=seed + 1)
+    t.manual_seed(seed)
+    model = PinSAGEModel(I, hidden, layers).to("cuda")
+    with t.no_grad():
+        model.bias.normal_(0, 0.1)          # the scorer bias starts at zero: give its gradient path something to show
+    for cv in model.convs:
+        cv.dropout.p = p_drop
+    return model, smp
+
+
+@pytest.mark.parametrize("hidden,layers", [(32, 2), (64, 2), (16, 3), (128, 1)])
+def test_native_pinsage_step_gradients_equal_autograd(hidden, layers):
+    """mi_pinsage_step_f32 (dropout off) against the op-by-op autograd iteration on the same batches: loss, every gradient
+    (the dense projector / bias gradients included) to float rounding; then the update against torch.optim.Adam."""
+    import copy
+    from laplace_amd.pinsage.native import NativePinSAGEStep
+    model, smp = _pin_setup(seed=2, hidden=hidden, layers=layers)
+    twin = copy.deepcopy(model)
+    opt_a, opt_b = t.optim.Adam(model.parameters(), lr=3e-3), t.optim.Adam(twin.parameters(), lr=3e-3)
+    assert NativePinSAGEStep.unsupported_reason(model, opt_a) is None
+    probe = NativePinSAGEStep(model, opt_a, keep_grads=True)
+    model.train(); twin.train()
+    for i in range(3):
+        b = smp.sample_batch()
+        la = probe.step(b)
+        assert la is not None, probe.declined
+        lb = twin(b["seeds"], b["pos"], b["neg"], b["blocks"]).mean()
+        opt_b.zero_grad()
+        lb.backward()
+        assert abs(float(la) - float(lb)) <= 1e-6 * max(1.0, abs(float(lb))), i
+        for (n, p), q in zip(model.named_parameters(), twin.parameters()):
+            scale = float(q.grad.abs().max()) + 1e-12
+            assert float((p.grad - q.grad).abs().max()) <= 2e-5 * scale + 1e-9, (i, n)
+        assert float(model.proj.weight.grad.abs().sum()) > 0 and float(model.bias.grad.abs().sum()) > 0
+    # the full step: Adam over every tensor, dense tables included; the two dense gradient buffers end all-zero.  Adam turns
+    # a gradient element of 1e-9 against 0 into a different step, so torch.optim.Adam is fed the executor's own gradients
+    # (the iteration is deterministic: the full step below computes exactly those again)
+    full = NativePinSAGEStep(model, opt_a)
+    for i in range(3):
+        b = smp.sample_batch()
+        twin.load_state_dict(model.state_dict())
+        for p, q in zip(model.parameters(), twin.parameters()):
+            if opt_a.state[p]:
+                if not opt_b.state[q]:
+                    opt_b.state[q] = {"step": t.tensor(0.0), "exp_avg": t.zeros_like(q), "exp_avg_sq": t.zeros_like(q)}
+                for k in ("exp_avg", "exp_avg_sq"):
+                    opt_b.state[q][k].copy_(opt_a.state[p][k])
+                opt_b.state[q]["step"].fill_(float(opt_a.state[p]["step"]))
+        assert probe.step(b) is not None
+        for p, q in zip(model.parameters(), twin.parameters()):
+            q.grad = p.grad.detach().clone()
+        opt_b.step()
+        model.proj.weight.grad.zero_(); model.bias.grad.zero_()      # what the probe left behind
+        la = full.step(b)
+        assert la is not None, full.declined
+        for (n, p), q in zip(model.named_parameters(), twin.parameters()):
+            assert float((p - q).abs().max()) <= 2e-6, (i, n)
+            assert float(opt_a.state[p]["step"]) == float(opt_b.state[q]["step"]) == i + 1
+            for k in ("exp_avg", "exp_avg_sq"):      # fused-multiply-add against two roundings: 1e-6 of the tensor's scale
+                ma, mb = opt_a.state[p][k], opt_b.state[q][k]
+                assert float((ma - mb).abs().max()) <= 1e-6 * float(mb.abs().max()) + 1e-20, (i, n, k)
+        assert float(model.proj.weight.grad.abs().max()) == 0.0 and float(model.bias.grad.abs().max()) == 0.0
+
+
+def test_native_pinsage_dropout_is_reproducible_and_training_learns():
+    """Philox dropout keyed on (seed, iteration): two executors with the same seed give the same loss and gradients on the
+    same batch, a different seed does not; train_epoch picks the native step by itself and the loss falls."""
+    import copy
+    from laplace_amd.pinsage.model import train_epoch
+    from laplace_amd.pinsage.native import NativePinSAGEStep
+    model, smp = _pin_setup(seed=4, p_drop=0.5, hidden=32, layers=2)
+    b = smp.sample_batch()
+    outs = []
+    for sd in (7, 7, 8):
+        m = copy.deepcopy(model)
+        o = t.optim.Adam(m.parameters(), lr=3e-3)
+        st = NativePinSAGEStep(m, o, seed=sd, keep_grads=True)
+        m.train()
+        loss = st.step(b)
+        assert loss is not None, st.declined
+        outs.append((float(loss), [p.grad.clone() for p in m.parameters()]))
+    assert outs[0][0] == outs[1][0] and all(t.equal(x, y) for x, y in zip(outs[0][1], outs[1][1]))
+    assert outs[0][0] != outs[2][0]
+    # dropout's backward uses the forward's masks: a finite difference of the loss along a random direction of Q_0 (same
+    # seed and iteration => same masks) agrees with the gradient
+    m = copy.deepcopy(model)
+    w = m.convs[0].Q.weight
+    g0 = outs[0][1][[id(p) for p in model.parameters()].index(id(model.convs[0].Q.weight))]
+    direction = t.randn_like(w)
+    direction /= direction.norm()
+    eps = 1e-2
+    vals = []
+    for sgn in (+1, -1):
+        mm = copy.deepcopy(model)
+        with t.no_grad():
+            mm.convs[0].Q.weight.add_(sgn * eps * direction)
+        st = NativePinSAGEStep(mm, t.optim.Adam(mm.parameters(), lr=3e-3), seed=7, keep_grads=True)
+        mm.train()
+        vals.append(float(st.step(b)))
+    fd = (vals[0] - vals[1]) / (2 * eps)
+    an = float((g0 * direction).sum())
+    assert abs(fd - an) <= 0.1 * max(abs(an), 1e-3) + 2e-3, (fd, an)
+    opt = t.optim.Adam(model.parameters(), lr=3e-3)
+    first = train_epoch(model, opt, smp, 40)
+    for _ in range(3):
+        last = train_epoch(model, opt, smp, 40)
+    assert np.isfinite(last).all() and np.mean(last) < np.mean(first)
+    assert float(opt.state[model.proj.weight]["step"]) == 160      # every iteration went through the executor's Adam
+
+
+def test_native_pinsage_step_declines_what_it_does_not_take():
+    from laplace_amd.pinsage.native import NativePinSAGEStep
+    model, smp = _pin_setup(seed=6)
+    assert NativePinSAGEStep.unsupported_reason(model, t.optim.SGD(model.parameters(), lr=0.1)) is not None
+    assert NativePinSAGEStep.unsupported_reason(model, t.optim.Adam(model.parameters(), lr=0.1, weight_decay=0.1)) is not None
+    opt = t.optim.Adam(model.parameters(), lr=3e-3)
+    st = NativePinSAGEStep(model, opt)
+    model.train()
+    smp.device_batches = False
+    b = smp.sample_batch()                                   # index-op batch: no CSRs with the blocks
+    before = [p.detach().clone() for p in model.parameters()]
+    st.build_csrs = False
+    assert st.step(b) is None and "CSR" in st.declined
+    assert all(t.equal(x, p) for x, p in zip(before, model.parameters()))
+    st.build_csrs = True                                     # the default: the executor builds them (two sorts per block)
+    smp.device_batches = True
+    same = smp.sample_batch(smp.step - 1)                    # the same batch, device-built
+    import copy
+    twin = copy.deepcopy(model)
+    st2 = NativePinSAGEStep(twin, t.optim.Adam(twin.parameters(), lr=3e-3), seed=st.seed)
+    twin.train()
+    la, lb = st.step(b), st2.step(same)
+    assert la is not None and lb is not None and float(la) == float(lb)
+    assert all(t.equal(p, q) for p, q in zip(model.parameters(), twin.parameters()))
+    model.eval()
+    smp.device_batches = True
+    assert st.step(smp.sample_batch()) is None and "eval" in st.declined

@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--iters", type=int, default=200)
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--serial", action="store_true", help="sample each batch on the training stream (no overlap)")
+    ap.add_argument("--autograd", action="store_true", help="the op-by-op autograd iteration instead of the native executor")
     args = ap.parse_args()
     from laplace_amd import launch
     if args.gpus > 1 and not launch.launched():
@@ -56,8 +57,17 @@ def main():
     model.train()
     t.autograd.set_multithreading_enabled(False)                  # as pinsage.model.train_epoch does
 
+    from laplace_amd.pinsage.native import NativePinSAGEStep
+    native = None
+    if world == 1 and not args.autograd and NativePinSAGEStep.supports(model, opt):
+        native = NativePinSAGEStep(model, opt)       # one C call per iteration (mi_pinsage_step_f32)
+
     def one(b=None):
         b = smp.sample_batch() if b is None else b
+        if native is not None:
+            loss = native.step(b)
+            if loss is not None:
+                return loss, b
         loss = model(b["seeds"], b["pos"], b["neg"], b["blocks"]).mean()
         opt.zero_grad()
         loss.backward()
@@ -97,6 +107,7 @@ def main():
                       "workload": f"PinSAGE item-item training, H&M-shaped synthetic {args.users}x{args.items}, {args.edges} edges; "
                                   f"batch {args.batch} pairs, walks {args.walks} x length {args.walk_length}, restart {args.restart}, "
                                   f"T={args.neighbors}, {args.layers} layers, hidden {args.hidden}",
+                      "iteration": "native executor (mi_pinsage_step_f32)" if native is not None else "autograd, op by op",
                       "sampling": "serial" if serial else "overlapped (side stream, one batch ahead)",
                       "ms_per_iteration": round(1e3 * dt / args.iters, 3), "positive_pairs_per_s": round(pairs / dt),
                       "sampler_ms_per_batch": round(1e3 * ds, 3), "loss": round(float(loss.detach()), 4)}))
