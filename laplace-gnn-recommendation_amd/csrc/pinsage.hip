@@ -45,26 +45,52 @@ __global__ void item_pairs_kernel(int64_t batch, int64_t n_items, Bip g, uint64_
     negs[b] = pw(P_NEG, (uint32_t)b, 0, 0, seed, step).c[0] % (uint32_t)n_items;
 }
 
+constexpr int kNbThreads = 256;
+// w_pad lanes per seed (a power of two >= num_walks), seeds per block, dynamic LDS; false when the walks of one seed do not
+// fit a block / the LDS budget (callers report MI_ERR_UNSUPPORTED: hundreds of walks per seed are not a PinSAGE setting)
+static bool neighbors_launch_shape(int num_walks, int walk_length, int* w_pad, int* spb, size_t* lds) {
+    int w = 1;
+    while (w < num_walks) w <<= 1;
+    if (w > kNbThreads) return false;
+    *w_pad = w;
+    *spb = kNbThreads / w;
+    *lds = (size_t)(*spb) * (size_t)num_walks * (size_t)walk_length * sizeof(int32_t);
+    return *lds <= 64 * 1024;
+}
+
+// One lane per (seed, walk): the walks of a seed are independent chains of dependent global loads (item -> user -> item per
+// traversal), so they run side by side — one thread per seed walked them one after another: ~120 dependent loads, 98 us
+// per launch at the reference's batch (round 3: two thirds of a training iteration's sampling).  A block serves
+// blockDim / w_pad seeds (w_pad = num_walks rounded up to a power of two); visits go to the seed's slots in LDS (-1 = the
+// walk ended before that traversal), then the seed's first lane sorts them and picks the T most visited.  Same Philox
+// counters as before: the result is bit for bit the serial kernel's (and the mirror's, tests/test_pinsage.py).
 __global__ void neighbors_kernel(int64_t n_seeds, const int32_t* __restrict__ n_seeds_dev, const int64_t* __restrict__ seeds,
                                  Bip g, int walk_length, uint32_t restart_thr, int num_walks, int T, int layer, uint64_t seed,
-                                 uint64_t step, int32_t* __restrict__ visit_ws, int64_t* __restrict__ nb,
-                                 int64_t* __restrict__ wt) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+                                 uint64_t step, int w_pad, int64_t* __restrict__ nb, int64_t* __restrict__ wt) {
+    extern __shared__ int32_t nvis[];   // [seeds per block][num_walks * walk_length]
+    const int spb = blockDim.x / w_pad;
+    const int ls = threadIdx.x / w_pad, wk = threadIdx.x % w_pad;
+    const int64_t i = (int64_t)blockIdx.x * spb + ls;
     if (n_seeds_dev) n_seeds = min(n_seeds, (int64_t)*n_seeds_dev);  // launched over an upper bound, the count is on the device
-    if (i >= n_seeds) return;
-    const int32_t s = (int32_t)seeds[i];
-    int32_t* vis = visit_ws + i * (int64_t)(num_walks * walk_length);
-    int m = 0;
-    for (int wk = 0; wk < num_walks; ++wk) {
+    const bool live = ls < spb && i < n_seeds;
+    const int slots = num_walks * walk_length;
+    int32_t* vis = nvis + (ls < spb ? ls : 0) * slots;
+    const int32_t s = live ? (int32_t)seeds[i] : 0;
+    if (live && wk < num_walks) {
         int32_t cur = s;
-        for (int tr = 0; tr < walk_length; ++tr) {
+        int tr = 0;
+        for (; tr < walk_length; ++tr) {
             MiPhilox w = pw(P_WALK, (uint32_t)(wk * walk_length + tr), (uint32_t)layer, (uint32_t)s, seed, step);
             if (tr > 0 && w.c[2] < restart_thr) break;
             cur = hop(g, cur, w.c[0], w.c[1]);
             if (cur == -1) break;
-            vis[m++] = cur;
+            vis[wk * walk_length + tr] = cur;
         }
+        for (; tr < walk_length; ++tr) vis[wk * walk_length + tr] = -1;
     }
+    __syncthreads();
+    if (!live || wk != 0) return;
+    int m = slots;   // the -1 slots sort first and are never picked
     // sort visited ids ascending, then take the T best runs by (count desc, id asc)
     for (int a = 1; a < m; ++a) {
         int32_t v = vis[a];
@@ -393,9 +419,12 @@ int mi_pinsage_neighbors(int64_t n_seeds, const int64_t* seeds, const int32_t* i
     if (ws_bytes < mi_pinsage_neighbors_workspace_bytes(n_seeds, walk_length, num_walks)) return MI_ERR_WORKSPACE;
     Bip g = {iu_ptr, iu_idx, ui_ptr, ui_idx};
     const uint32_t thr = (uint32_t)(restart_prob * 4294967296.0);
-    hipLaunchKernelGGL(neighbors_kernel, dim3((unsigned)mi_ceil_div(n_seeds, 64)), dim3(64), 0, (hipStream_t)stream, n_seeds,
-                       (const int32_t*)nullptr, seeds, g, walk_length, thr, num_walks, num_neighbors, layer, seed, step,
-                       static_cast<int32_t*>(ws), neighbors, weights);
+    int w_pad, spb;
+    size_t lds;
+    if (!neighbors_launch_shape(num_walks, walk_length, &w_pad, &spb, &lds)) return MI_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(neighbors_kernel, dim3((unsigned)mi_ceil_div(n_seeds, spb)), dim3(kNbThreads), lds, (hipStream_t)stream,
+                       n_seeds, (const int32_t*)nullptr, seeds, g, walk_length, thr, num_walks, num_neighbors, layer, seed, step,
+                       w_pad, neighbors, weights);
     return mi_launch_status();
 }
 
@@ -434,6 +463,9 @@ int mi_pinsage_sample_batch(const mi_pinsage_batch_desc* d, uint64_t seed, uint6
         }
     }
     if (ws_bytes < mi_pinsage_batch_workspace_bytes(B, d->walk_length, d->num_walks, T, NL)) return MI_ERR_WORKSPACE;
+    int nb_w_pad, nb_spb;
+    size_t nb_lds;
+    if (!neighbors_launch_shape(d->num_walks, d->walk_length, &nb_w_pad, &nb_spb, &nb_lds)) return MI_ERR_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
     MiArena ar(ws, ws_bytes);
     int64_t* heads = ar.take<int64_t>((size_t)B);
@@ -466,8 +498,9 @@ int mi_pinsage_sample_batch(const mi_pinsage_batch_desc* d, uint64_t seed, uint6
         int64_t* wt = ar.take<int64_t>((size_t)n_max * T);
         float* val_tmp = ar.take<float>((size_t)n_max * T);
         if (!vis || !nb || !wt || !val_tmp) return MI_ERR_WORKSPACE;
-        hipLaunchKernelGGL(neighbors_kernel, dim3((unsigned)mi_ceil_div(n_max, 64)), dim3(64), 0, s, n_max, n_dev, seeds, g,
-                           d->walk_length, thr, d->num_walks, T, l, seed, step, vis, nb, wt);
+        (void)vis;
+        hipLaunchKernelGGL(neighbors_kernel, dim3((unsigned)mi_ceil_div(n_max, nb_spb)), dim3(kNbThreads), nb_lds, s, n_max, n_dev,
+                           seeds, g, d->walk_length, thr, d->num_walks, T, l, seed, step, nb_w_pad, nb, wt);
         PinBlockOut o = {bo.src_ids, bo.edge_src, bo.edge_dst, bo.weights, bo.dst_rowptr, bo.dst_col, bo.dst_val,
                          bo.src_rowptr, bo.src_col, bo.src_val, val_tmp, out->counts + 2 + 2 * l};
         hipLaunchKernelGGL(pinsage_block_kernel, dim3(1), dim3(kBT), lds, s, (int)n_max, n_dev, T, d->n_items, seeds, nb, wt, banned,
