@@ -500,6 +500,16 @@ int mi_bce_logits_f32(int64_t n, const float* logits, const float* labels, float
                       mi_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
+ * b7  backward of a Linear layer with ONE output feature — the last decoder layer (model/encoder_decoder.py:66-72,
+ * Linear(128, 1)): dx[r, :] = dy[r] * w (nullable), gw = sum_r dy[r] x[r, :], gb = sum_r dy[r] (nullable).
+ * replaces: the three [n, 1]-shaped products autograd derives for that layer (torch.nn.Linear backward).
+ * Deterministic (bands of 64 rows reduced in band order).  ws: mi_linear1_bwd_workspace_bytes(n, in).
+ * ---------------------------------------------------------------------------------- */
+size_t mi_linear1_bwd_workspace_bytes(int64_t n, int64_t in);
+int    mi_linear1_bwd_f32(int64_t n, int64_t in, const float* dy, const float* w, const float* x, int64_t ldx,
+                          float* dx, int64_t lddx, float* gw, float* gb, void* ws, size_t ws_bytes, mi_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
  * b7  decoder input: z = cat(z_user[row], z_item[col], dim=-1) over the label edges.
  * replaces: EdgeDecoder.forward's two index_selects + cat at model/encoder_decoder.py:57-63
  *           and their backward (index_add into the two node tables).

@@ -208,6 +208,8 @@ _PROTOTYPES = {
     "mi_gather_cat_bwd_f32": (c_int32, [c_int64, c_int64, c_int64, P, P, c_int64, P, c_int64, P]),
     "mi_match_common_items_i32": (c_int32, [c_int64, P, P, P, P, P, c_int32, P, P, P]),
     "mi_gemm_group_supported": (c_int32, [P, c_int32]),
+    "mi_linear1_bwd_workspace_bytes": (c_size_t, [c_int64, c_int64]),
+    "mi_linear1_bwd_f32": (c_int32, [c_int64, c_int64, P, P, P, c_int64, P, c_int64, P, P, P, c_size_t, P]),
     "mi_ranker_sizeof": (c_int64, [c_int32]),
     "mi_ranker_step_workspace_bytes": (c_size_t, [POINTER(RankerModel), POINTER(RankerBatch)]),
     "mi_ranker_step_f32": (c_int32, [POINTER(RankerModel), POINTER(RankerBatch), P, c_size_t, P]),

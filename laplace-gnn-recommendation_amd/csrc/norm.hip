@@ -384,7 +384,66 @@ __global__ __launch_bounds__(1024) void bce_logits_kernel(int64_t n, const float
 
 static inline bool bn_pow2_rows(int64_t c) { return c >= 4 && c <= 256 && (c & (c - 1)) == 0; }
 
+// Backward of a Linear layer with ONE output (the decoder's last layer, model/layers.py + model/encoder_decoder.py:66-72):
+//   dx[r, c] = dy[r] w[c];  gw[c] = sum_r dy[r] x[r, c];  gb = sum_r dy[r].
+// As three [n, 1]-shaped products these were three launches of the scalar GEMM fallback plus two split-K reduces (48 us of
+// the ranker iteration); here a partial pass over 64-row bands (a thread per column) and a reduce over the bands in band
+// order — no atomics, the sums do not depend on scheduling.
+constexpr int kL1Rows = 64;
+__global__ __launch_bounds__(kBlock) void linear1_bwd_partial_kernel(int64_t n, int in, const float* __restrict__ dy,
+                                                                     const float* __restrict__ w, const float* __restrict__ x,
+                                                                     int64_t ldx, float* __restrict__ dx, int64_t lddx,
+                                                                     float* __restrict__ part /*[bands, in + 1]*/) {
+    __shared__ float sdy[kL1Rows];
+    const int64_t r0 = (int64_t)blockIdx.x * kL1Rows;
+    const int rows = (int)min((int64_t)kL1Rows, n - r0);
+    if (threadIdx.x < kL1Rows) sdy[threadIdx.x] = (int)threadIdx.x < rows ? dy[r0 + threadIdx.x] : 0.f;
+    __syncthreads();
+    for (int c = threadIdx.x; c < in; c += kBlock) {
+        const float wc = w[c];
+        float acc = 0.f;
+#pragma unroll 8
+        for (int r = 0; r < rows; ++r) {
+            const float g = sdy[r];
+            acc = fmaf(g, x[(r0 + r) * ldx + c], acc);
+            if (dx) dx[(r0 + r) * lddx + c] = g * wc;
+        }
+        part[(int64_t)blockIdx.x * (in + 1) + c] = acc;
+    }
+    if (threadIdx.x == 0) {
+        float sb = 0.f;
+        for (int r = 0; r < rows; ++r) sb += sdy[r];
+        part[(int64_t)blockIdx.x * (in + 1) + in] = sb;
+    }
+}
+__global__ __launch_bounds__(kBlock) void linear1_bwd_reduce_kernel(int64_t bands, int in, const float* __restrict__ part,
+                                                                    float* __restrict__ gw, float* __restrict__ gb) {
+    const int c = blockIdx.x * kBlock + threadIdx.x;
+    if (c > in) return;
+    float acc = 0.f;
+    for (int64_t b = 0; b < bands; ++b) acc += part[b * (in + 1) + c];
+    if (c < in) gw[c] = acc;
+    else if (gb) gb[0] = acc;
+}
+
 extern "C" {
+
+size_t mi_linear1_bwd_workspace_bytes(int64_t n, int64_t in) {
+    return (size_t)std::max<int64_t>(mi_ceil_div(n, kL1Rows), 1) * (size_t)(in + 1) * sizeof(float);
+}
+
+int mi_linear1_bwd_f32(int64_t n, int64_t in, const float* dy, const float* w, const float* x, int64_t ldx, float* dx,
+                       int64_t lddx, float* gw, float* gb, void* ws, size_t ws_bytes, mi_stream_t stream) {
+    MI_CHECK_ARG(n > 0 && in > 0 && dy && w && x && gw && ldx >= in && (!dx || lddx >= in));
+    MI_CHECK_ARG(ws && ws_bytes >= mi_linear1_bwd_workspace_bytes(n, in));
+    const int64_t bands = mi_ceil_div(n, kL1Rows);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(linear1_bwd_partial_kernel, dim3((unsigned)bands), dim3(kBlock), 0, s, n, (int)in, dy, w, x, ldx, dx, lddx,
+                       static_cast<float*>(ws));
+    hipLaunchKernelGGL(linear1_bwd_reduce_kernel, dim3((unsigned)mi_ceil_div(in + 1, kBlock)), dim3(kBlock), 0, s, bands, (int)in,
+                       static_cast<const float*>(ws), gw, gb);
+    return mi_launch_status();
+}
 
 int mi_bce_logits_f32(int64_t n, const float* logits, const float* labels, float* loss, float* dlogits, mi_stream_t stream) {
     MI_CHECK_ARG(n > 0 && logits && labels && loss);

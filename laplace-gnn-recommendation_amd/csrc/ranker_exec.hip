@@ -350,6 +350,15 @@ int Exec::run() {
         const bool last = j == LD - 1;
         const float* mask = last ? nullptr : dout[j];
         float* dx = take(nl, ln.in);
+        if (last && ln.out == 1) {   // Linear(in, 1): mi_linear1_bwd_f32 (as FusedRankerStep does)
+            const size_t need = mi_linear1_bwd_workspace_bytes(nl, ln.in);
+            char* w = take_bytes(need);
+            if (go())
+                ok(mi_linear1_bwd_f32(nl, ln.in, dh, ln.w, din[j], ln.in, dx, ln.in, ln.gw, ln.b ? ln.gb : nullptr, w, need,
+                                      (mi_stream_t)s));
+            dh = dx;
+            continue;   // the last layer has no dropout in front of its output and no relu behind it
+        }
         mi_gemm_problem pr[3];
         int np = 0;
         pr[np++] = prob(0, 0, nl, ln.in, ln.out, dh, ln.out, ln.w, ln.in, dx, ln.in, mask);

@@ -5,6 +5,7 @@
 //   K7        mi_embed_concat_f32 — Encoder_Decoder_Model.__embedding (model/encoder_decoder.py:116-125):
 //             per integer column an Embedding(max_norm=1) lookup, concatenated along dim 1.
 #include "common.hpp"
+#include <algorithm>
 
 namespace {
 
@@ -70,28 +71,53 @@ struct EmbedCols {
     int64_t rows[16];
 };
 
-// One wavefront per (node, column): lanes cover the column's embedding width; the row's L2 norm is
-// reduced across the wave and the max_norm scale applied on the fly.
+// One SG-lane sub-group per (node, column): lanes cover the column's embedding width; the row's L2 norm is reduced across
+// the sub-group and the max_norm scale applied on the fly.  SG = 16 when no column is wider than 64 floats (the H&M
+// tables: 4 (node, column) pairs per wavefront instead of one — the article side of a ranker batch went 35.6 -> see
+// profiles/r03_ranker_native.md), else a whole wavefront.
+template <int SG>
 __global__ __launch_bounds__(kBlock) void embed_concat_kernel(int64_t n, int n_cols,
                                                               const int64_t* __restrict__ x, EmbedCols ec,
                                                               float max_norm, float* __restrict__ out,
                                                               int64_t ldo) {
-    const int64_t w = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / MI_WAVE;
-    if (w >= n * n_cols) return;
-    const int64_t node = w / n_cols;
-    const int c = (int)(w - node * n_cols);
-    const int lane = mi_lane();
+    const int64_t w = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / SG;
+    const bool live = w < n * n_cols;          // no early return: the shuffles below want every lane of the wavefront
+    const int64_t node = live ? w / n_cols : 0;
+    const int c = live ? (int)(w - node * n_cols) : 0;
+    const int lane = (int)(threadIdx.x % SG);
     int64_t id = x[node * n_cols + c];
     if (id < 0) id = 0;
     if (id >= ec.rows[c]) id = ec.rows[c] - 1;
-    const float* src = ec.table[c] + id * ec.dim[c];
+    const int dim = ec.dim[c];
+    const float* src = ec.table[c] + id * dim;
+    float v[4];   // SG = 16: dim <= 64 -> at most four elements per lane, kept for the write
     float ss = 0.f;
-    for (int k = lane; k < ec.dim[c]; k += MI_WAVE) ss = fmaf(src[k], src[k], ss);
-    ss = mi_wave_sum(ss);
+    if (SG == 16) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = lane + 16 * j;
+            v[j] = k < dim ? src[k] : 0.f;
+            ss = fmaf(v[j], v[j], ss);
+        }
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) ss += __shfl_xor(ss, off, 16);
+    } else {
+        for (int k = lane; k < dim; k += MI_WAVE) ss = fmaf(src[k], src[k], ss);
+        ss = mi_wave_sum(ss);
+    }
+    if (!live) return;
     const float norm = sqrtf(ss);
     const float scale = (max_norm > 0.f && norm > max_norm) ? max_norm / (norm + 1e-7f) : 1.0f;
     float* dst = out + node * ldo + ec.off[c];
-    for (int k = lane; k < ec.dim[c]; k += MI_WAVE) dst[k] = src[k] * scale;
+    if (SG == 16) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = lane + 16 * j;
+            if (k < dim) dst[k] = v[j] * scale;
+        }
+    } else {
+        for (int k = lane; k < dim; k += MI_WAVE) dst[k] = src[k] * scale;
+    }
 }
 
 }  // namespace
@@ -140,9 +166,16 @@ int mi_embed_concat_f32(int64_t n, int32_t n_cols, const int64_t* x, const float
         off += dims[c];
     }
     MI_CHECK_ARG(ldo >= off);
-    dim3 g((unsigned)mi_ceil_div(n * n_cols * MI_WAVE, kBlock));
-    hipLaunchKernelGGL(embed_concat_kernel, g, dim3(kBlock), 0, (hipStream_t)stream, n, (int)n_cols, x, ec, max_norm,
-                       out, ldo);
+    int widest = 0;
+    for (int c = 0; c < n_cols; ++c) widest = std::max(widest, (int)dims[c]);
+    if (widest <= 64) {
+        dim3 g((unsigned)mi_ceil_div(n * n_cols * 16, kBlock));
+        hipLaunchKernelGGL(embed_concat_kernel<16>, g, dim3(kBlock), 0, (hipStream_t)stream, n, (int)n_cols, x, ec, max_norm, out, ldo);
+    } else {
+        dim3 g((unsigned)mi_ceil_div(n * n_cols * MI_WAVE, kBlock));
+        hipLaunchKernelGGL(embed_concat_kernel<MI_WAVE>, g, dim3(kBlock), 0, (hipStream_t)stream, n, (int)n_cols, x, ec, max_norm, out,
+                           ldo);
+    }
     return mi_launch_status();
 }
 

@@ -863,6 +863,25 @@ def gather_cat_bwd(d_out: Tensor, idx: Tensor, n_rows: int, c: int, off: int) ->
     return dz
 
 
+def linear1_bwd(dy: Tensor, weight: Tensor, x: Tensor, need_dx: bool = True):
+    """Backward of a Linear layer with one output feature (weight [1, in]): (dx [n, in] or None, dW [1, in], db [1]).
+    mi_linear1_bwd_f32: deterministic band sums instead of three [n, 1]-shaped products."""
+    _need(dy, t.float32, "dy"); _need(weight, t.float32, "weight")
+    ldx = _rows_ok(x, "x")
+    n, k = int(x.shape[0]), int(x.shape[1])
+    if dy.numel() != n or weight.numel() != k or not dy.is_contiguous() or not weight.is_contiguous():
+        raise ValueError("linear1_bwd: dy [n] / [n, 1], weight [1, in], x [n, in] expected")
+    dev = x.device
+    dx = t.empty(n, k, dtype=t.float32, device=dev) if need_dx else None
+    gw = t.empty(1, k, dtype=t.float32, device=dev)
+    gb = t.empty(1, dtype=t.float32, device=dev)
+    L = _lib.lib()
+    ws = t.empty(int(L.mi_linear1_bwd_workspace_bytes(n, k)), dtype=t.uint8, device=dev)
+    check(L.mi_linear1_bwd_f32(n, k, _ptr(dy), _ptr(weight), _ptr(x), ldx, _ptr(dx) if need_dx else None, k, _ptr(gw), _ptr(gb),
+                               _ptr(ws), ws.numel(), _stream()), "mi_linear1_bwd_f32")
+    return dx, gw, gb
+
+
 def batch_nodes(users: Tensor, pos: Tensor, neg: Tensor, n_users: int, n_nodes: int, *, gmap: Optional[Tensor] = None,
                 nodes: Optional[Tensor] = None, count: Optional[Tensor] = None, ws: Optional[Tensor] = None):
     """Unique node set of a BPR batch: (gmap int32[n_nodes], nodes int32[3B], count int32[2] on device:

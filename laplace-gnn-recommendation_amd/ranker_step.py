@@ -143,6 +143,14 @@ class FusedRankerStep:
         dev = logits.device
         dh = dlogits.view(h.shape)
         for layer, x_in, mask, out in reversed(dec_saved):
+            if layer.out_features == 1 and out is None and x_in.shape[0] > 0:
+                # the last layer, Linear(128, 1): one band-sum kernel pair instead of three [n, 1]-shaped products
+                dx, dw, db = ops.linear1_bwd(dh.reshape(-1), layer.weight, x_in)
+                layer.weight.grad = dw
+                if layer.bias is not None:
+                    layer.bias.grad = db
+                dh = _dropout_bwd(dx, mask, pd)
+                continue
             dw = t.empty_like(layer.weight)
             dx = t.empty(x_in.shape, device=dev)
             specs = [dict(A=dh, B=layer.weight, out=dx, trans_b=False, mask=out),

@@ -607,3 +607,25 @@ def test_native_data_parallel_step_two_ranks_one_collective():
         want = a["before"][i] - 0.01 * g / (g.abs() + 1e-8)                              # Adam step 1: lr * g / (|g| + eps)
         assert t.allclose(a["params"][i], want, rtol=1e-4, atol=1e-6)
     assert not all(t.equal(x, y) for x, y in zip(a["own_grads"], b["own_grads"]))        # the batches did differ
+
+
+@pytest.mark.parametrize("n,k", [(1, 128), (63, 128), (64, 8), (1100, 128), (5000, 300)])
+def test_linear1_bwd_matches_torch_linear_backward(n, k):
+    """mi_linear1_bwd_f32 against autograd of torch.nn.functional.linear with one output feature; deterministic."""
+    from laplace_amd import ops
+    g = t.Generator(device=DEV).manual_seed(n + k)
+    x = t.randn(n, k, device=DEV, generator=g)
+    w = t.randn(1, k, device=DEV, generator=g).requires_grad_()
+    b = t.zeros(1, device=DEV, requires_grad=True)
+    xr = x.clone().requires_grad_()
+    dy = t.randn(n, 1, device=DEV, generator=g)
+    t.nn.functional.linear(xr, w, b).backward(dy)
+    dx, gw, gb = ops.linear1_bwd(dy.reshape(-1), w.detach(), x)
+    assert t.equal(dx, xr.grad)                                    # one multiply per element: exact
+    scale = float(w.grad.abs().max()) + 1e-12
+    assert float((gw - w.grad).abs().max()) <= 1e-5 * scale
+    assert abs(float(gb) - float(b.grad)) <= 1e-5 * (float(dy.abs().sum()) + 1e-12)
+    dx2, gw2, gb2 = ops.linear1_bwd(dy.reshape(-1), w.detach(), x)
+    assert t.equal(gw, gw2) and t.equal(gb, gb2)
+    _, gw3, _ = ops.linear1_bwd(dy.reshape(-1), w.detach(), x, need_dx=False)
+    assert t.equal(gw, gw3)
