@@ -17,6 +17,8 @@ The default N=1 run carries, after the timed region, the metric's other configur
                from ONE CPU step)                                                            [--no-c4 to skip]
   "ranker_c3"  BASELINE configs[2]: the encoder-decoder ranker's training loop at the full H&M shape, 24 users per
                batch, on-device 2-hop sampling (tools/bench_ranker.py's bench line)          [--no-ranker to skip]
+  pinsage_c5   BASELINE configs[4] at N = 1: PinSAGE item-item training at the H&M shape, the reference's batch of 32
+               pairs (tools/bench_pinsage.py)                                               [--no-pinsage to skip]
   "map_at_12"  ranking quality on a PLANTED-structure graph (synthetic.SyntheticSpec.communities), layer-0 predictor vs
                propagated embeddings vs popularity                                           [--no-map to skip]
 
@@ -76,6 +78,8 @@ def parse_args():
     ap.add_argument("--no-c4", action="store_true", help="skip the c4_n1 block (BASELINE configs[3] on one GPU)")
     ap.add_argument("--c4-steps", type=int, default=10)
     ap.add_argument("--no-ranker", action="store_true", help="skip the ranker_c3 block (BASELINE configs[2])")
+    ap.add_argument("--no-pinsage", action="store_true", help="skip the pinsage_c5 block (BASELINE configs[4] at N = 1)")
+    ap.add_argument("--pinsage-iters", type=int, default=300)
     ap.add_argument("--ranker-steps", type=int, default=400)
     ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 --pmc passes (roofline.traffic falls back to profiles/traffic.json)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)  # the short run the PMC passes profile
@@ -440,6 +444,17 @@ def ranker_block(args) -> dict:
                           hops=2, fanout=64, cpu=not args.no_cpu_baseline)
 
 
+def pinsage_block(args) -> dict:
+    """BASELINE configs[4] at N = 1: PinSAGE item-item training at the H&M shape, the reference's defaults (32 pairs per batch,
+    10 walks of length 2, T = 3, 2 layers) — tools/bench_pinsage.py; the iteration is one C call (mi_pinsage_step_f32) with the
+    next batch sampled on a side stream."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_pinsage", os.path.join(ROOT, "tools", "bench_pinsage.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.bench_line(iters=args.pinsage_iters)
+
+
 def main():
     args = parse_args()
     from laplace_amd import launch
@@ -481,7 +496,7 @@ def main():
     from laplace_amd.trainer import LightGCNTrainer
 
     if os.environ.get("LAPLACE_SPMM_TWO_STREAMS") is not None:  # A/B switch
-        ops.SPMM_TWO_STREAMS = os.environ["LAPLACE_SPMM_TWO_STREAMS"] == "1"
+        ops.SPMM_TWO_STREAMS = int(os.environ["LAPLACE_SPMM_TWO_STREAMS"] or 0)   # 1: short rows enqueued first, 2: split rows first
     want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline and not args.pmc_child and (args.config == "c2" or args.cpu_baseline)
     w = build_workload(args.config, args, world, rank, dev, plain=args.plain_step, want_table0=want_cpu)
     spec, ei, U, I, D, K, B = w["spec"], w["ei"], w["U"], w["I"], w["D"], w["K"], w["B"]
@@ -582,6 +597,9 @@ def main():
             out["c4_n1"] = c4_block(args, dev, c4_traffic, c4_src)
         if args.config == "c2" and not args.no_ranker:
             out["ranker_c3"] = ranker_block(args)
+            t.cuda.empty_cache()
+        if args.config == "c2" and not args.no_pinsage:
+            out["pinsage_c5"] = pinsage_block(args)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -6,6 +6,7 @@ function requires GPU tensors and raises otherwise — there is no CPU path in t
 from __future__ import annotations
 
 import ctypes
+import os
 from os import environ as _os_environ
 from dataclasses import dataclass, field
 from typing import Optional, Tuple
@@ -24,11 +25,14 @@ MIN_BANDS = 16       # narrower adjacencies keep the row-major plan (nothing to 
 # recorded on the stream the kernels are launched on.  None = no timing overhead.
 SPMM_EVENTS = None
 
-# True: the short-row kernel of a planned product runs on a side stream beside the split-row kernels (mi_spmm_ex.parts).
-# Measured on C2 (bench.py, LAPLACE_SPMM_TWO_STREAMS=1): step 5.855 -> 5.782 ms — dense launch 1.023 -> 0.995, sparse
-# 0.605 -> 0.586, the Adam-epilogue launch 1.39 -> 1.44.  Off by default: 1 % does not pay for a second stream
-# beside RCCL's in the sharded step.
-SPMM_TWO_STREAMS = False
+# The short-row kernel of a planned product runs on a side stream beside the split-row kernels (mi_spmm_ex.parts): disjoint
+# output rows, the same kernels, bitwise the single-stream result (tests/test_gpu_lightgcn.py).  Round 1, against the
+# work-item form of the split rows: 1 % (step 5.855 -> 5.782 ms), left off.  Round 3, against the SWEEP form — one 1 024-thread
+# workgroup per CU that is bound by its L2 -> CU gathers (profiles/r03_sweep.md) and leaves half of every CU's wavefront
+# slots and the fabric to the short rows: dense launch 0.961 -> 0.902 ms, step 5.52 -> 5.34 ms on C2 (same box, bench.py
+# LAPLACE_SPMM_TWO_STREAMS=0 / 1; the enqueue order of the two halves does not matter).  On by default;
+# LAPLACE_SPMM_TWO_STREAMS=0 switches it off.  (2 = split rows enqueued first: an A/B setting.)
+SPMM_TWO_STREAMS = int(os.environ.get("LAPLACE_SPMM_TWO_STREAMS", "1") or 0)
 _SIDE = {}
 
 
@@ -492,8 +496,12 @@ def spmm(a: DeviceCSR, X: Tensor, *, Y: Optional[Tensor] = None, addend: Optiona
         cur = t.cuda.current_stream()
         side = _side_stream(a.device)
         side.wait_stream(cur)
-        launch(_lib.MI_SPMM_SHORT_ROWS, side.cuda_stream)
-        launch(_lib.MI_SPMM_SPLIT_ROWS, cur.cuda_stream)
+        if SPMM_TWO_STREAMS == 2:    # the split rows' one-workgroup-per-CU sweep takes its half of every CU first
+            launch(_lib.MI_SPMM_SPLIT_ROWS, cur.cuda_stream)
+            launch(_lib.MI_SPMM_SHORT_ROWS, side.cuda_stream)
+        else:
+            launch(_lib.MI_SPMM_SHORT_ROWS, side.cuda_stream)
+            launch(_lib.MI_SPMM_SPLIT_ROWS, cur.cuda_stream)
         cur.wait_stream(side)
     else:
         launch(0, _stream())

@@ -441,15 +441,18 @@ def test_spmm_halves_on_two_streams_equal_the_whole_product():
     g = t.Generator().manual_seed(5)
     X, A = t.randn(n, d, generator=g).to(DEV), t.randn(n, d, generator=g).to(DEV)
     Y0, S0 = t.empty(n, d, device=DEV), t.empty(n, d, device=DEV)
-    ops.spmm(a, X, Y=Y0, addend=A, S=S0, scale=0.5)
-    Y1, S1 = t.full((n, d), float("nan"), device=DEV), t.full((n, d), float("nan"), device=DEV)
-    ops.SPMM_TWO_STREAMS = True
+    was = ops.SPMM_TWO_STREAMS
     try:
-        ops.spmm(a, X, Y=Y1, addend=A, S=S1, scale=0.5)
+        ops.SPMM_TWO_STREAMS = 0
+        ops.spmm(a, X, Y=Y0, addend=A, S=S0, scale=0.5)
+        for mode in (1, 2):                                 # the default, and the other enqueue order
+            Y1, S1 = t.full((n, d), float("nan"), device=DEV), t.full((n, d), float("nan"), device=DEV)
+            ops.SPMM_TWO_STREAMS = mode
+            ops.spmm(a, X, Y=Y1, addend=A, S=S1, scale=0.5)
+            t.cuda.synchronize()
+            assert t.equal(Y0, Y1) and t.equal(S0, S1), mode
     finally:
-        ops.SPMM_TWO_STREAMS = False
-    t.cuda.synchronize()
-    assert t.equal(Y0, Y1) and t.equal(S0, S1)
+        ops.SPMM_TWO_STREAMS = was
 
 
 @pytest.mark.parametrize("band", [0, 16])

@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--users", type=int, default=1_371_980)
     ap.add_argument("--items", type=int, default=105_542)
@@ -30,7 +30,25 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--serial", action="store_true", help="sample each batch on the training stream (no overlap)")
     ap.add_argument("--autograd", action="store_true", help="the op-by-op autograd iteration instead of the native executor")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
+
+
+def bench_line(**kw) -> dict:
+    """The single-GPU measurement as a dict (bench.py's pinsage_c5 block): bench_line(iters=300)."""
+    args = parse_args([])
+    for k, v in kw.items():
+        setattr(args, k, v)
+    return run(args)
+
+
+def main():
+    args = parse_args()
+    out = run(args)
+    if out is not None:
+        print(json.dumps(out))
+
+
+def run(args):
     from laplace_amd import launch
     if args.gpus > 1 and not launch.launched():
         sys.exit(launch.self_launch(__file__, sys.argv[1:], args.gpus, result_marker='"workload"'))
@@ -80,7 +98,7 @@ def main():
     t.cuda.synchronize()
     t0 = time.perf_counter()
     pairs = 0
-    serial = "--serial" in sys.argv   # sample_batch() per iteration instead of the overlapped iterator
+    serial = bool(args.serial)        # sample_batch() per iteration instead of the overlapped iterator
     for b in ((None for _ in range(args.iters)) if serial else smp.batches(args.iters)):
         loss, b = one(b)
         pairs += int(b["pos"][0].numel())
@@ -102,17 +120,18 @@ def main():
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
-        return
-    print(json.dumps({"n_gpus": world, "backend": os.environ.get("LAPLACE_BENCH_BACKEND", "nccl") if world > 1 else None,
+        return None
+    out = ({"n_gpus": world, "backend": os.environ.get("LAPLACE_BENCH_BACKEND", "nccl") if world > 1 else None,
                       "workload": f"PinSAGE item-item training, H&M-shaped synthetic {args.users}x{args.items}, {args.edges} edges; "
                                   f"batch {args.batch} pairs, walks {args.walks} x length {args.walk_length}, restart {args.restart}, "
                                   f"T={args.neighbors}, {args.layers} layers, hidden {args.hidden}",
                       "iteration": "native executor (mi_pinsage_step_f32)" if native is not None else "autograd, op by op",
                       "sampling": "serial" if serial else "overlapped (side stream, one batch ahead)",
                       "ms_per_iteration": round(1e3 * dt / args.iters, 3), "positive_pairs_per_s": round(pairs / dt),
-                      "sampler_ms_per_batch": round(1e3 * ds, 3), "loss": round(float(loss.detach()), 4)}))
+                      "sampler_ms_per_batch": round(1e3 * ds, 3), "loss": round(float(loss.detach()), 4)})
     if world > 1:
         dist.destroy_process_group()
+    return out
 
 
 if __name__ == "__main__":

@@ -170,7 +170,13 @@ def run(args):
     if args.pipelined:
         assert args.device_sampler
         labels = []
+        prof = None
+        if os.environ.get("LAPLACE_HOST_PROFILE") == "1":   # where the HOST spends the iteration (cProfile, stderr)
+            import cProfile
+            prof = cProfile.Profile()
         for i in range(args.warmup + args.steps):
+            if prof is not None and i == args.warmup:
+                prof.enable()
             if i == args.warmup:
                 t.cuda.synchronize()
                 t0 = time.perf_counter()
@@ -178,6 +184,10 @@ def run(args):
             loss = step(batch)
             if i >= args.warmup:
                 labels.append(batch[("customer", "buys", "article")].edge_label)
+        if prof is not None:
+            prof.disable()
+            import pstats
+            pstats.Stats(prof, stream=sys.stderr).sort_stats("tottime").print_stats(28)
         t.cuda.synchronize()
         dt = time.perf_counter() - t0
         pos = int(sum(int(l.sum()) for l in labels))
