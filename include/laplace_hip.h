@@ -324,14 +324,15 @@ int mi_sample_bpr_batch(int64_t batch, int64_t nnz,
  * loss_out: device float[1], written (fixed-order reduction).
  * When g_final is non-null (dense [n, d], ALL ZERO on entry) the rows the batch touches are written with
  *   g_final[row,:] = g_scale * dL/dfinal[row,:]          (untouched rows stay zero)
- * and reg_w (float[n], zeroed by the caller; nullable) receives, per occurrence of a
- * node in the batch, reg_w[row] += 2*lambda*reg_scale, so that the L2 term's gradient is
- * reg_w[row] * e0[row,:] (applied by mi_adam_dense_f32 or by the caller).
+ * and reg_w (float[n], zeroed by the caller; nullable) receives reg_w[row] = (occurrences of the
+ * node in the batch) * 2*lambda*reg_scale, so that the L2 term's gradient is
+ * reg_w[row] * e0[row,:] (applied by mi_adam_dense_f32 or by the caller).  The count is the length
+ * of the node's run in the sorted reference list: one writer per entry, no atomics.
  * node_map (nullable, from mi_batch_nodes_i32): final_emb and g_final are then COMPACT
  * [count, d] tables addressed by node_map[node]; e0 and reg_w stay addressed by node id.
  * No float atomics on the gradient: the 3*batch row references are radix-sorted by row, summed in
  * 64-reference chunks in reference order and combined in chunk order, one writer per row — the
- * result is bitwise reproducible (reg_w adds equal constants, whose order cannot matter).  d <= 512.
+ * result is bitwise reproducible.  d <= 512.
  * ---------------------------------------------------------------------------------- */
 size_t mi_bpr_workspace_bytes(int64_t batch);
 int    mi_bpr_fwd_bwd_f32(int64_t batch, int64_t d, int64_t n_users,

@@ -75,7 +75,7 @@ __global__ __launch_bounds__(kBlock) void bpr_slot_kernel(
     const float* __restrict__ fin, int64_t ldf, const float* __restrict__ e0, int64_t lde,
     float inv_batch, float g_scale, float reg_coef /* = lambda*reg_scale */,
     float* __restrict__ softplus_out, float* __restrict__ reg_out,
-    float* __restrict__ coef_out, float* __restrict__ reg_w,
+    float* __restrict__ coef_out, float* __restrict__ reg_w /* only when no gradient pass follows */,
     const int32_t* __restrict__ node_map) {
     const int64_t b = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / MI_WAVE;
     if (b >= batch) return;
@@ -111,6 +111,8 @@ __global__ __launch_bounds__(kBlock) void bpr_slot_kernel(
         // loss = -mean softplus(x)  =>  dL/dx = -sigmoid'(x)/B; consumed by the segmented gradient kernels below
         coef_out[b] = -softplus_grad_ref(x) * inv_batch * g_scale;
     }
+    // (with a gradient pass the weights come from the sorted references instead, bpr_chunk_kernel: the atomics of the few
+    // hundred samples that share the most popular item serialised on one address — 49 of this kernel's 65 us at B = 16 384)
     if (reg_w && lane == 0) {
         const float w = 2.0f * reg_coef;
         atomicAdd(reg_w + u, w);
@@ -149,7 +151,8 @@ __global__ __launch_bounds__(kBlock) void bpr_chunk_kernel(
     int64_t batch, int d, int64_t n_users, const int64_t* __restrict__ users, const int64_t* __restrict__ pos,
     const int64_t* __restrict__ neg, const float* __restrict__ fin, int64_t ldf, const float* __restrict__ coef,
     const uint32_t* __restrict__ keys, const uint32_t* __restrict__ refs, const int32_t* __restrict__ node_map,
-    float* __restrict__ g_final, int64_t ldg, float* __restrict__ part_head, float* __restrict__ part_tail) {
+    float* __restrict__ g_final, int64_t ldg, float* __restrict__ part_head, float* __restrict__ part_tail,
+    float* __restrict__ reg_w, float reg_unit /* 2 * lambda * reg_scale: one reference's share */) {
     const int64_t n_ref = 3 * batch;
     const int64_t chunk = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / MI_WAVE;
     const int64_t j0 = chunk * kRefChunk;
@@ -171,6 +174,20 @@ __global__ __launch_bounds__(kBlock) void bpr_chunk_kernel(
         if (role == 0) { srcA = fp; wA = c; srcB = fn; wB = -c; }   // d x / d u = p - n
         else if (role == 1) { srcA = fu; wA = c; }
         else { srcA = fu; wA = -c; }
+        // L2 weight of the node: (its references in the batch) x reg_unit.  The reference that opens the node's run in the
+        // sorted list finds the run's end by bisection and is the entry's only writer (reg_w is zero on entry).
+        if (reg_w) {
+            const int64_t j = j0 + lane;
+            if (j == 0 || keys[j - 1] != my_key) {
+                int64_t lo = j + 1, hi = n_ref;        // first position in (j, n_ref] whose key differs
+                while (lo < hi) {
+                    const int64_t mid = (lo + hi) >> 1;
+                    if (keys[mid] == my_key) lo = mid + 1; else hi = mid;
+                }
+                const int64_t node = role == 0 ? u : (role == 1 ? p : n);
+                reg_w[node] = (float)(lo - j) * reg_unit;
+            }
+        }
     }
     const bool head_open = j0 > 0 && keys[j0 - 1] == __shfl(my_key, 0, MI_WAVE);
     const bool next_same = (j0 + n_here < n_ref) && keys[j0 + n_here] == __shfl(my_key, n_here - 1, MI_WAVE);
@@ -272,10 +289,10 @@ __global__ __launch_bounds__(1024) void bpr_finish_kernel(int64_t batch,
     __shared__ float sh_a[1024];
     __shared__ float sh_b[1024];
     const int t = threadIdx.x;
-    const int64_t per = (batch + 1023) / 1024;
     float a = 0.f, r = 0.f;
-    for (int64_t i = t * per; i < min(batch, (t + 1) * per); ++i) {
-        a += softplus_v[i];
+#pragma unroll 4
+    for (int64_t i = t; i < batch; i += 1024) {   // coalesced, independent loads (a contiguous slice per thread was a chain
+        a += softplus_v[i];                        // of 16 strided loads: 17 us at B = 16 384); fixed order all the same
         r += reg_v[i];
     }
     sh_a[t] = a;
@@ -498,7 +515,7 @@ int mi_bpr_fwd_bwd_f32(int64_t batch, int64_t d, int64_t n_users, const int64_t*
     dim3 g((unsigned)mi_ceil_div(batch * MI_WAVE, kBlock));
     hipLaunchKernelGGL(bpr_slot_kernel, g, dim3(kBlock), 0, s, batch, (int)d, n_users, users, pos, neg,
                        final_emb, ldf, e0, lde, inv_b, g_scale, reg_scale * lambda, spv, rgv,
-                       g_final ? coef : nullptr, reg_w, node_map);
+                       g_final ? coef : nullptr, g_final ? nullptr : reg_w, node_map);
     if (g_final) {
         hipLaunchKernelGGL(bpr_refs_kernel, dim3((unsigned)mi_ceil_div(n_ref, 256)), dim3(256), 0, s, batch, n_users, users,
                            pos, neg, node_map, k0, r0);
@@ -517,7 +534,8 @@ int mi_bpr_fwd_bwd_f32(int64_t batch, int64_t d, int64_t n_users, const int64_t*
 #define MI_BPR_GO(V)                                                                                                       \
     do {                                                                                                                    \
         hipLaunchKernelGGL(bpr_chunk_kernel<V>, gc, dim3(kBlock), 0, s, batch, (int)d, n_users, users, pos, neg, final_emb, \
-                           ldf, coef, keys.current(), refs.current(), node_map, g_final, ldg, part_head, part_tail);       \
+                           ldf, coef, keys.current(), refs.current(), node_map, g_final, ldg, part_head, part_tail,        \
+                           reg_w, 2.0f * (reg_scale * lambda));                                                             \
         hipLaunchKernelGGL(bpr_combine_kernel<V>, gc, dim3(kBlock), 0, s, batch, (int)d, keys.current(), part_head,         \
                            part_tail, g_final, ldg);                                                                        \
     } while (0)
