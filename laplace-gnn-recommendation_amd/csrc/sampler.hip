@@ -83,30 +83,102 @@ __device__ int floyd_subset(int64_t L, int n, uint32_t purpose, uint32_t seed_us
 
 __device__ __forceinline__ int s_of(const Smp& p, const int32_t* aq_n_ptr) { return (int)(aq_n_ptr - p.aq_n); }
 
-// positions (ascending) of the concatenated article lists of `users[0..nu)` -> article ids
-__device__ void cut_articles(const Smp& p, const int32_t* users, int nu, uint32_t seed_user, int hop, int32_t* sel,
-                             int32_t* aq_out, int32_t* aq_n_out) {
-    int64_t L = 0;
-    for (int t = 0; t < nu; ++t) L += p.uptr[users[t] + 1] - p.uptr[users[t]];
-    const int c = floyd_subset(L, p.n, P_ART_CUT, seed_user, (uint32_t)hop, p.seed, p.step, sel);
-    int t = 0;
-    int64_t base = 0;
-    for (int q = 0; q < c; ++q) {
-        while (t < nu && sel[q] >= base + (p.uptr[users[t] + 1] - p.uptr[users[t]])) {
-            base += p.uptr[users[t] + 1] - p.uptr[users[t]];
-            ++t;
-        }
-        aq_out[q] = p.uidx[p.uptr[users[t]] + (sel[q] - base)];
+// Ascending in-place sort of n DISTINCT values in LDS by rank (every thread places the values it owns): no serial
+// insertion sort.  tmp: LDS scratch of n entries.  Whole block; ends with a barrier.
+__device__ __forceinline__ void block_rank_sort_distinct(int32_t* a, int n, int32_t* tmp) {
+    for (int q = threadIdx.x; q < n; q += blockDim.x) tmp[q] = a[q];
+    __syncthreads();
+    for (int q = threadIdx.x; q < n; q += blockDim.x) {
+        const int32_t v = tmp[q];
+        int r = 0;
+        for (int x = 0; x < n; ++x) r += tmp[x] < v ? 1 : 0;
+        a[r] = v;
     }
-    *aq_n_out = c;
-    int64_t tot = 0;
-    for (int q = 0; q < c; ++q) tot += p.aptr[aq_out[q] + 1] - p.aptr[aq_out[q]];
-    p.aq_L[s_of(p, aq_n_out)] = tot;
+    __syncthreads();
+}
+
+// Floyd's subset by the whole block: the same draws and the same result as floyd_subset (draw j is Philox(j) and the
+// commit order is j ascending), but the n Philox draws are made in parallel, the "already drawn?" test of draw j is a
+// parallel compare over the j earlier picks, and the sort is by rank.  out / tmp: LDS, n entries each.  Returns the count
+// to every thread; ends with a barrier.
+__device__ int floyd_subset_block(int64_t L, int n, uint32_t purpose, uint32_t seed_user, uint32_t i, uint64_t seed,
+                                  uint64_t step, int32_t* out, int32_t* tmp) {
+    const int tid = threadIdx.x;
+    if (L <= n) {
+        for (int t = tid; t < (int)L; t += blockDim.x) out[t] = t;
+        __syncthreads();
+        return (int)L;
+    }
+    for (int c = tid; c < n; c += blockDim.x) {
+        const int64_t j = L - n + c;
+        tmp[c] = (int32_t)rand_below((uint64_t)(j + 1), purpose, seed_user, i, (uint32_t)j, seed, step);
+    }
+    __syncthreads();
+    // commit in order, by wavefront 0 alone (no barriers inside the loop: LDS operations of one wavefront execute in program
+    // order): pick c is tmp[c] unless one of the picks 0..c-1 already is that value — then it is j itself, which no earlier
+    // pick can be (earlier draws are <= their own j < this j)
+    if (tid < MI_WAVE) {
+        volatile int32_t* vo = out;
+        for (int c = 0; c < n; ++c) {
+            const int32_t t = tmp[c];
+            bool seen = false;
+            for (int q = tid; q < c; q += MI_WAVE) seen |= (vo[q] == t);
+            const bool any = __ballot(seen) != 0ull;
+            if (tid == 0) vo[c] = any ? (int32_t)(L - n + c) : t;
+        }
+    }
+    __syncthreads();
+    block_rank_sort_distinct(out, n, tmp);
+    return n;
+}
+
+// positions (ascending) of the concatenated article lists of `users[0..nu)` -> article ids.  Whole block (round 3: one
+// thread did all of it — n Philox draws, an O(n^2) membership test, an insertion sort and 3 n dependent global loads:
+// 108 us of smp_seed_kernel at fan-out 64).  sel / tmp: LDS int32[kMaxFan]; pre: LDS int64[kMaxFan + 1].
+__device__ void cut_articles_block(const Smp& p, const int32_t* users, int nu, uint32_t seed_user, int hop, int32_t* sel,
+                                   int32_t* tmp, int64_t* pre, int32_t* aq_out, int32_t* aq_n_out) {
+    const int tid = threadIdx.x;
+    for (int t = tid; t < nu; t += blockDim.x) tmp[t] = p.uptr[users[t] + 1] - p.uptr[users[t]];
+    __syncthreads();
+    if (tid == 0) {
+        int64_t run = 0;
+        for (int t = 0; t < nu; ++t) { pre[t] = run; run += tmp[t]; }
+        pre[nu] = run;
+    }
+    __syncthreads();
+    const int64_t L = pre[nu];
+    const int c = floyd_subset_block(L, p.n, P_ART_CUT, seed_user, (uint32_t)hop, p.seed, p.step, sel, tmp);
+    int64_t mine = 0;
+    for (int q = tid; q < c; q += blockDim.x) {
+        const int64_t pos = sel[q];
+        int lo = 0, hi = nu;   // last t with pre[t] <= pos
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (pre[mid] <= pos) lo = mid; else hi = mid;
+        }
+        const int32_t a = p.uidx[p.uptr[users[lo]] + (pos - pre[lo])];
+        aq_out[q] = a;
+        mine += p.aptr[a + 1] - p.aptr[a];
+    }
+    // total length of the queued articles' user lists: integer sum, any order
+    __syncthreads();
+    int64_t* acc = pre;   // pre is dead (every thread is past its binary searches)
+    if (tid == 0) acc[0] = 0;
+    __syncthreads();
+    if (mine) atomicAdd(reinterpret_cast<unsigned long long*>(acc), (unsigned long long)mine);
+    __syncthreads();
+    if (tid == 0) {
+        *aq_n_out = c;
+        p.aq_L[s_of(p, aq_n_out)] = acc[0];
+    }
+    __syncthreads();
 }
 
 // ---- phase 1: label edges + hop-0 article cut -------------------------------------------------
 __global__ __launch_bounds__(256) void smp_seed_kernel(Smp p) {
     __shared__ int32_t sel[kMaxFan];
+    __shared__ int32_t cut_tmp[kMaxFan];
+    __shared__ int64_t cut_pre[kMaxFan + 1];
     __shared__ int32_t sh_npos, sh_nneg, sh_fast;
     const int s = blockIdx.x, tid = threadIdx.x;
     const int32_t u = (int32_t)p.seeds[s];
@@ -197,10 +269,9 @@ __global__ __launch_bounds__(256) void smp_seed_kernel(Smp p) {
             base += wscan[blockDim.x];
             __syncthreads();
         }
-        if (tid == 0) {
-            p.n_neg[s] = deg > 0 ? (base < p.max_neg ? base : p.max_neg) : 0;
-            if (p.H >= 2 && deg > 0) cut_articles(p, &u, 1, (uint32_t)u, 0, sel, p.aq + (int64_t)s * p.n, p.aq_n + s);
-        }
+        if (tid == 0) p.n_neg[s] = deg > 0 ? (base < p.max_neg ? base : p.max_neg) : 0;
+        if (p.H >= 2 && deg > 0)   // block-uniform
+            cut_articles_block(p, &u, 1, (uint32_t)u, 0, sel, cut_tmp, cut_pre, p.aq + (int64_t)s * p.n, p.aq_n + s);
         return;
     }
     if (tid == 0) {
@@ -264,8 +335,10 @@ __global__ __launch_bounds__(256) void smp_seed_kernel(Smp p) {
             }
         }
         p.n_neg[s] = nn;
-        if (p.H >= 2 && deg > 0) cut_articles(p, &u, 1, (uint32_t)u, 0, sel, p.aq + (int64_t)s * p.n, p.aq_n + s);
     }
+    __syncthreads();   // thread 0 used sel[] in the exact negative path
+    if (p.H >= 2 && deg > 0)   // block-uniform
+        cut_articles_block(p, &u, 1, (uint32_t)u, 0, sel, cut_tmp, cut_pre, p.aq + (int64_t)s * p.n, p.aq_n + s);
 }
 
 // ---- phase 2 (per hop): mark the users of the queued articles -------------------------------------
@@ -286,7 +359,8 @@ __global__ __launch_bounds__(256) void smp_mark_users_kernel(Smp p) {
 __global__ __launch_bounds__(kSelThreads) void smp_select_users_kernel(Smp p, int hop) {
     __shared__ int32_t scan[kSelThreads + 1];
     __shared__ int32_t sel[kMaxFan];
-    __shared__ int32_t sh_nsel;
+    __shared__ int64_t pre[kMaxFan + 1];
+    __shared__ int32_t cand_v[kSelThreads];
     const int s = blockIdx.x, tid = threadIdx.x;
     uint32_t* bm = p.bm_users + (int64_t)s * p.WU;
     const int32_t u = (int32_t)p.seeds[s];
@@ -296,40 +370,46 @@ __global__ __launch_bounds__(kSelThreads) void smp_select_users_kernel(Smp p, in
         // Rejection pick (oracle/sampler_ref.py:reject_pick_users): position of the concatenated user lists ->
         // user v with probability ~ m(v); accept with probability 1/m(v); skip explored / picked; draws are
         // evaluated 64 at a time by wavefront 0 and committed in counter order.
-        __shared__ int64_t pre[kMaxFan + 1];
         __shared__ int32_t aq[kMaxFan];      // queue order: positions of the concatenated lists refer to it
         __shared__ int32_t aq_sorted[kMaxFan];  // ascending: multiplicity lookups by binary search
-        __shared__ int32_t cand_v[kSelThreads];
         __shared__ int32_t cand_ok[kSelThreads];
         __shared__ int32_t cand_b[kSelThreads], cand_e[kSelThreads];
         __shared__ int32_t expl[4 * kMaxFan];  // users explored so far (hops 0..hop), staged once
         __shared__ int sh_np, sh_t0, sh_nexpl;
         volatile int32_t* picked = sel;
         const int naq = p.aq_n[s];
-        for (int q = tid; q < naq; q += blockDim.x) aq[q] = p.aq[(int64_t)s * p.n + q];
-        if (tid == 0) {
-            int ne = 0;
-            for (int h = 0; h <= hop && ne >= 0; ++h)
-                for (int q = 0; q < uq_n[h]; ++q) {
-                    if (ne == 4 * kMaxFan) { ne = -1; break; }  // does not fit: read the lists from memory below
-                    expl[ne++] = uq[h * p.n + q];
+        // set-up by the whole block (round 3; one thread used to walk the explored users, the queued articles' list lengths
+        // — two dependent global loads each — and an insertion sort: about half of this kernel's 214 us at fan-out 64)
+        for (int q = tid; q < naq; q += blockDim.x) {
+            const int32_t a = p.aq[(int64_t)s * p.n + q];
+            aq[q] = a;
+            cand_e[q] = p.aptr[a + 1] - p.aptr[a];   // list length, staged for the prefix below (cand_e is free until the rounds)
+        }
+        {
+            int ne = 0;   // every thread: the explored users' offsets per hop (a handful of hops)
+            for (int h = 0; h <= hop; ++h) {
+                const int cnt = uq_n[h];
+                if (ne >= 0 && ne + cnt > 4 * kMaxFan) ne = -1;   // does not fit: read the lists from memory below
+                if (ne >= 0) {
+                    for (int q = tid; q < cnt; q += blockDim.x) expl[ne + q] = uq[h * p.n + q];
+                    ne += cnt;
                 }
-            sh_nexpl = ne;
+            }
+            if (tid == 0) sh_nexpl = ne;
         }
         __syncthreads();
         if (tid == 0) {
             int64_t run = 0;
-            for (int q = 0; q < naq; ++q) {
-                pre[q] = run;
-                run += p.aptr[aq[q] + 1] - p.aptr[aq[q]];
-                int32_t v = aq[q];  // insertion into aq_sorted
-                int b2 = q - 1;
-                while (b2 >= 0 && aq_sorted[b2] > v) { aq_sorted[b2 + 1] = aq_sorted[b2]; --b2; }
-                aq_sorted[b2 + 1] = v;
-            }
+            for (int q = 0; q < naq; ++q) { pre[q] = run; run += cand_e[q]; }
             pre[naq] = run;
             sh_np = 0;
             sh_t0 = 0;
+        }
+        for (int q = tid; q < naq; q += blockDim.x) {   // aq_sorted by rank (duplicates keep their queue order)
+            const int32_t v = aq[q];
+            int r = 0;
+            for (int x = 0; x < naq; ++x) r += (aq[x] < v || (aq[x] == v && x < q)) ? 1 : 0;
+            aq_sorted[r] = v;
         }
         __syncthreads();
         const int64_t L = pre[naq];
@@ -419,20 +499,18 @@ __global__ __launch_bounds__(kSelThreads) void smp_select_users_kernel(Smp p, in
             }
             __syncthreads();
         }
-        if (tid == 0) {
+        {
             const int np = sh_np;
-            for (int a = 1; a < np; ++a) {  // ascending
-                int32_t v = sel[a];
-                int b = a - 1;
-                while (b >= 0 && sel[b] > v) { sel[b + 1] = sel[b]; --b; }
-                sel[b + 1] = v;
+            block_rank_sort_distinct(sel, np, scan);   // ascending; the picks are distinct
+            for (int q = tid; q < np; q += blockDim.x) uq[(hop + 1) * p.n + q] = sel[q];
+            if (tid == 0) {
+                uq_n[hop + 1] = np;
+                p.aq_n[s] = 0;
+                p.aq_L[s] = 0;
             }
-            for (int q = 0; q < np; ++q) uq[(hop + 1) * p.n + q] = sel[q];
-            uq_n[hop + 1] = np;
-            p.aq_n[s] = 0;
-            p.aq_L[s] = 0;
-            if (hop + 1 <= p.H - 2 && np > 0)
-                cut_articles(p, uq + (hop + 1) * p.n, np, (uint32_t)u, hop + 1, sel, p.aq + (int64_t)s * p.n, p.aq_n + s);
+            __syncthreads();   // uq's new row is read back by the cut below
+            if (hop + 1 <= p.H - 2 && np > 0)   // block-uniform
+                cut_articles_block(p, uq + (hop + 1) * p.n, np, (uint32_t)u, hop + 1, sel, scan, pre, p.aq + (int64_t)s * p.n, p.aq_n + s);
         }
         return;
     }
@@ -456,9 +534,7 @@ __global__ __launch_bounds__(kSelThreads) void smp_select_users_kernel(Smp p, in
         scan[tid + 1] += (tid + 1 > off) ? v : 0;
         __syncthreads();
     }
-    if (tid == 0) sh_nsel = floyd_subset(scan[kSelThreads], p.n, P_USER_CUT, (uint32_t)u, (uint32_t)hop, p.seed, p.step, sel);
-    __syncthreads();
-    const int nsel = sh_nsel;
+    const int nsel = floyd_subset_block(scan[kSelThreads], p.n, P_USER_CUT, (uint32_t)u, (uint32_t)hop, p.seed, p.step, sel, cand_v);
     for (int q = tid; q < nsel; q += blockDim.x) {  // rank -> id
         const int32_t r = sel[q];
         int lo = 0, hi = kSelThreads;  // last t with scan[t] <= r
@@ -486,9 +562,10 @@ __global__ __launch_bounds__(kSelThreads) void smp_select_users_kernel(Smp p, in
         uq_n[hop + 1] = nsel;
         p.aq_n[s] = 0;
         p.aq_L[s] = 0;
-        if (hop + 1 <= p.H - 2 && nsel > 0)  // these users will be expanded too: cut their article lists
-            cut_articles(p, uq + (hop + 1) * p.n, nsel, (uint32_t)u, hop + 1, sel, p.aq + (int64_t)s * p.n, p.aq_n + s);
     }
+    __syncthreads();   // uq's new row (written above by the whole block) is read back by the cut
+    if (hop + 1 <= p.H - 2 && nsel > 0)  // block-uniform: these users will be expanded too: cut their article lists
+        cut_articles_block(p, uq + (hop + 1) * p.n, nsel, (uint32_t)u, hop + 1, sel, cand_v, pre, p.aq + (int64_t)s * p.n, p.aq_n + s);
 }
 
 // ---- phase 4: touched articles -> bitmap ---------------------------------------------------------
