@@ -812,11 +812,31 @@ typedef struct mi_pinsage_step_batch {
     const int64_t *seeds, *pos_u, *pos_v, *neg_v;                /* [n_seeds] ids; [n_pairs] positions in seeds */
     uint64_t seed, step;                                         /* dropout stream */
     float*   loss;                                               /* device float[1] */
+    /* data-parallel callers (both or neither; requires model->apply_adam = 0): the projector / bias gradients of THIS batch
+     * are written compactly — rows_out [blocks[0].n_src, hidden] (row r belongs to item blocks[0].src_ids[r]), bias_out
+     * [n_seeds] (entry s belongs to item seeds[s]) — instead of into the dense buffers, which are not touched. */
+    float*   rows_out;
+    float*   bias_out;
 } mi_pinsage_step_batch;
-int64_t mi_pinsage_step_sizeof(int32_t which);  /* sizeof of: 0 model, 1 batch, 2 conv, 3 block (binding self-check) */
+/* One list of compact gradient rows (a rank's contribution), as written by mi_pinsage_step_f32 through rows_out / bias_out. */
+typedef struct mi_pinsage_grad_list {
+    int64_t n_rows, n_seeds;
+    const int64_t* ids;        /* [n_rows] distinct item ids; the first n_seeds are the seeds */
+    const float*   rows;       /* [n_rows, hidden] */
+    const float*   bias;       /* [n_seeds] */
+} mi_pinsage_grad_list;
+int64_t mi_pinsage_step_sizeof(int32_t which);  /* sizeof of: 0 model, 1 batch, 2 conv, 3 block, 4 grad list (binding self-check) */
 size_t mi_pinsage_step_workspace_bytes(const mi_pinsage_model* model, const mi_pinsage_step_batch* batch);
 int    mi_pinsage_step_f32(const mi_pinsage_model* model, const mi_pinsage_step_batch* batch, void* ws, size_t ws_bytes,
                            mi_stream_t stream);
+/* The update of a data-parallel iteration: the lists of every rank (exchanged by the caller: an all-gather of a few hundred
+ * KB instead of an all-reduce of the dense 27 MB table gradient), in rank order, are added into the zero-kept dense
+ * buffers — projector rows times grad_scale (1 / world), bias entries as they are; lists are applied one after the other,
+ * ids within a list are distinct: one writer per entry at any time, the sum does not depend on scheduling — then Adam over
+ * model->params with every gradient times grad_scale (the caller has all-reduced(sum) those dense gradients), the dense
+ * Adam over the projector table, and the touched rows / entries are cleared again.  n_lists <= 64. */
+int    mi_pinsage_apply_f32(const mi_pinsage_model* model, const mi_pinsage_grad_list* lists, int32_t n_lists, float grad_scale,
+                            mi_stream_t stream);
 
 #ifdef __cplusplus
 }

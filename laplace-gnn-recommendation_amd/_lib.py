@@ -153,7 +153,12 @@ class PinsageStepBlock(Structure):
 class PinsageStepBatch(Structure):
     _fields_ = [("n_blocks", c_int32), ("reserved", c_int32), ("blocks", PinsageStepBlock * MI_PINSAGE_MAX_LAYERS),
                 ("n_seeds", c_int64), ("n_pairs", c_int64), ("seeds", c_void_p), ("pos_u", c_void_p), ("pos_v", c_void_p),
-                ("neg_v", c_void_p), ("seed", c_uint64), ("step", c_uint64), ("loss", c_void_p)]
+                ("neg_v", c_void_p), ("seed", c_uint64), ("step", c_uint64), ("loss", c_void_p),
+                ("rows_out", c_void_p), ("bias_out", c_void_p)]
+
+
+class PinsageGradList(Structure):
+    _fields_ = [("n_rows", c_int64), ("n_seeds", c_int64), ("ids", c_void_p), ("rows", c_void_p), ("bias", c_void_p)]
 
 
 P = c_void_p
@@ -229,6 +234,7 @@ _PROTOTYPES = {
     "mi_pinsage_step_sizeof": (c_int64, [c_int32]),
     "mi_pinsage_step_workspace_bytes": (c_size_t, [POINTER(PinsageModel), POINTER(PinsageStepBatch)]),
     "mi_pinsage_step_f32": (c_int32, [POINTER(PinsageModel), POINTER(PinsageStepBatch), P, c_size_t, P]),
+    "mi_pinsage_apply_f32": (c_int32, [POINTER(PinsageModel), POINTER(PinsageGradList), c_int32, ctypes.c_float, P]),
     "mi_adam_dense_f32": (c_int32, [c_int64, c_int64, P, c_int64, P, c_int64, P, P, P,
                                     c_double, c_double, c_double, c_double, c_int64, P]),
 }

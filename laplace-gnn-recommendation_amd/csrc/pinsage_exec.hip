@@ -127,6 +127,7 @@ __global__ __launch_bounds__(128) void pin_score_grad_kernel(int64_t n_seeds, in
                                                              const int64_t* __restrict__ pu, const int64_t* __restrict__ pv,
                                                              const int64_t* __restrict__ nv, const float* __restrict__ margin,
                                                              float* __restrict__ dhf, float* __restrict__ g_bias,
+                                                             float* __restrict__ bias_out /* compact, or null */,
                                                              float* __restrict__ loss) {
     __shared__ float red[128];
     __shared__ int match[1024];    // pairs that touch this seed, in pair order (n_pairs <= 1024: the sampler's batch limit)
@@ -165,7 +166,9 @@ __global__ __launch_bounds__(128) void pin_score_grad_kernel(int64_t n_seeds, in
         if (v == s) gb -= g;
     }
     if (c < h) dhf[s * h + c] = acc;
-    if (c == 0) g_bias[seeds[s]] = gb;
+    if (c == 0) {
+        if (bias_out) bias_out[s] = gb; else g_bias[seeds[s]] = gb;
+    }
     if (s == 0) {   // the loss: fixed-order tree over the pairs
         float part = 0.f;
         for (int64_t p = c; p < n_pairs; p += 128) part += fmaxf(margin[p], 0.f);
@@ -205,16 +208,17 @@ __global__ __launch_bounds__(kBlock) void pin_dh_merge_kernel(int64_t n_src, int
 }
 
 // Dense gradient of the projector table: row ids[r] <- dh0[r] (+ dhd[r] for the seeds, the first n_seeds rows); ids are
-// distinct.  zero = 1: the rows (and the seeds' bias entries) are cleared instead — after the update.
+// distinct.  mode 1: the rows (and the seeds' bias entries) are cleared instead — after the update.  mode 2: the rows go to
+// the compact buffer `g_table` [n, h] in list order (data-parallel callers exchange them).
 __global__ __launch_bounds__(kBlock) void pin_embed_grad_kernel(int64_t n, int64_t n_seeds, int h4, const int64_t* __restrict__ ids,
                                                                 const float4* __restrict__ dh0, const float4* __restrict__ dhd,
-                                                                float4* __restrict__ g_table, float* __restrict__ g_bias, int zero) {
+                                                                float4* __restrict__ g_table, float* __restrict__ g_bias, int mode) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n * h4) return;
     const int64_t r = i / h4;
     const int c = (int)(i % h4);
     const int64_t id = ids[r];
-    if (zero) {
+    if (mode == 1) {
         g_table[id * h4 + c] = mi_f4_zero();
         if (c == 0 && r < n_seeds) g_bias[id] = 0.f;
         return;
@@ -224,7 +228,24 @@ __global__ __launch_bounds__(kBlock) void pin_embed_grad_kernel(int64_t n, int64
         const float4 o = dhd[i];
         v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
     }
-    g_table[id * h4 + c] = v;
+    g_table[(mode == 2 ? r : id) * h4 + c] = v;
+}
+
+// One rank's list into the dense buffers: g_table[ids[r], :] += scale * rows[r, :], g_bias[ids[s]] += bias[s] (s < n_seeds).
+// ids distinct within the list, lists applied by consecutive launches: never two writers of an entry.
+__global__ __launch_bounds__(kBlock) void pin_apply_list_kernel(int64_t n, int64_t n_seeds, int h4, const int64_t* __restrict__ ids,
+                                                                const float4* __restrict__ rows, const float* __restrict__ bias,
+                                                                float scale, float4* __restrict__ g_table, float* __restrict__ g_bias) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n * h4) return;
+    const int64_t r = i / h4;
+    const int c = (int)(i % h4);
+    const int64_t id = ids[r];
+    const float4 x = rows[i];
+    float4 g = g_table[id * h4 + c];
+    g.x = fmaf(scale, x.x, g.x); g.y = fmaf(scale, x.y, g.y); g.z = fmaf(scale, x.z, g.z); g.w = fmaf(scale, x.w, g.w);
+    g_table[id * h4 + c] = g;
+    if (c == 0 && r < n_seeds) g_bias[id] += bias[r];
 }
 
 // ---- the iteration --------------------------------------------------------------------------------------------------------
@@ -300,6 +321,7 @@ int PinExec::run() {
         if (!M.proj || !M.g_proj || !M.m_proj || !M.v_proj || !M.bias || !M.g_bias || !M.ones4) return MI_ERR_BAD_ARG;
         if (M.n_params < 0 || M.n_params > MI_PINSAGE_MAX_PARAMS) return MI_ERR_BAD_ARG;
         if (B.n_pairs > 1024) return MI_ERR_UNSUPPORTED;   // pin_score_grad_kernel's LDS list (and the sampler's own batch limit)
+        if ((B.rows_out == nullptr) != (B.bias_out == nullptr) || (B.rows_out && M.apply_adam)) return MI_ERR_BAD_ARG;
         if (B.n_seeds <= 0 || B.n_pairs <= 0 || !B.seeds || !B.pos_u || !B.pos_v || !B.neg_v || !B.loss) return MI_ERR_UNSUPPORTED;
         int64_t want_dst = -1;
         for (int l = 0; l < NL; ++l) {
@@ -377,7 +399,7 @@ int PinExec::run() {
                            B.n_pairs, H, hd, hN, B.seeds, B.pos_u, B.pos_v, B.neg_v, M.bias, margin);
         ok(mi_launch_status());
         hipLaunchKernelGGL(pin_score_grad_kernel, dim3((unsigned)ns), dim3(128), 0, s, ns, B.n_pairs, H, hd, hN, B.seeds, B.pos_u,
-                           B.pos_v, B.neg_v, margin, dhf, M.g_bias, B.loss);
+                           B.pos_v, B.neg_v, margin, dhf, M.g_bias, B.bias_out, B.loss);
         ok(mi_launch_status());
     }
 
@@ -444,7 +466,7 @@ int PinExec::run() {
     // ---- projector gradient, Adam, and the dense gradient buffers back to zero ------------------------------------------------------
     hipLaunchKernelGGL(pin_embed_grad_kernel, dim3(grid(n0 * h4)), dim3(kBlock), 0, s, n0, ns, h4, B.blocks[0].src_ids,
                        reinterpret_cast<const float4*>(dh), reinterpret_cast<const float4*>(dhf),
-                       reinterpret_cast<float4*>(M.g_proj), M.g_bias, 0);
+                       reinterpret_cast<float4*>(B.rows_out ? B.rows_out : M.g_proj), M.g_bias, B.rows_out ? 2 : 0);
     ok(mi_launch_status());
     int64_t longest = 1;
     for (int i = 0; i < M.n_params; ++i) {
@@ -480,6 +502,7 @@ extern "C" int64_t mi_pinsage_step_sizeof(int32_t which) {
         case 1: return (int64_t)sizeof(mi_pinsage_step_batch);
         case 2: return (int64_t)sizeof(mi_pinsage_conv);
         case 3: return (int64_t)sizeof(mi_pinsage_step_block);
+        case 4: return (int64_t)sizeof(mi_pinsage_grad_list);
         default: return -1;
     }
 }
@@ -501,4 +524,54 @@ extern "C" int mi_pinsage_step_f32(const mi_pinsage_model* model, const mi_pinsa
     }
     PinExec run(*model, *batch, ws, ws_bytes, LAUNCH, (hipStream_t)stream);
     return run.run();
+}
+
+extern "C" int mi_pinsage_apply_f32(const mi_pinsage_model* model, const mi_pinsage_grad_list* lists, int32_t n_lists,
+                                    float grad_scale, mi_stream_t stream) {
+    MI_CHECK_ARG(model && lists && n_lists > 0 && n_lists <= 64 && grad_scale > 0.f);
+    const mi_pinsage_model& M = *model;
+    const int H = M.hidden, h4 = H / 4;
+    MI_CHECK_ARG(H >= 4 && H % 4 == 0 && M.proj && M.g_proj && M.m_proj && M.v_proj && M.g_bias);
+    MI_CHECK_ARG(M.n_params >= 0 && M.n_params <= MI_PINSAGE_MAX_PARAMS);
+    for (int l = 0; l < n_lists; ++l)
+        MI_CHECK_ARG(lists[l].n_rows >= 0 && lists[l].n_seeds >= 0 && lists[l].n_seeds <= lists[l].n_rows &&
+                     (lists[l].n_rows == 0 || (lists[l].ids && lists[l].rows && (lists[l].n_seeds == 0 || lists[l].bias))));
+    for (int i = 0; i < M.n_params; ++i) MI_CHECK_ARG(M.params[i].p && M.params[i].g && M.params[i].m && M.params[i].v);
+    // nothing has been enqueued up to here
+    hipStream_t s = (hipStream_t)stream;
+    auto grid = [](int64_t n) { return (unsigned)std::max<int64_t>(mi_ceil_div(n, kBlock), 1); };
+    for (int l = 0; l < n_lists; ++l) {
+        const mi_pinsage_grad_list& g = lists[l];
+        if (g.n_rows == 0) continue;
+        hipLaunchKernelGGL(pin_apply_list_kernel, dim3(grid(g.n_rows * h4)), dim3(kBlock), 0, s, g.n_rows, g.n_seeds, h4, g.ids,
+                           reinterpret_cast<const float4*>(g.rows), g.bias, grad_scale, reinterpret_cast<float4*>(M.g_proj), M.g_bias);
+    }
+    const int64_t step = M.step > 0 ? M.step : 1;
+    if (M.n_params > 0) {
+        AdamTable tb;
+        memset(&tb, 0, sizeof(tb));
+        int64_t longest = 1;
+        for (int i = 0; i < M.n_params; ++i) {
+            tb.p[i] = M.params[i];
+            tb.g_stride[i] = 1;
+            longest = std::max(longest, M.params[i].n);
+        }
+        tb.n = M.n_params;
+        const MiAdamConsts c = mi_adam_consts(M.lr, M.beta1, M.beta2, M.eps, step);
+        const unsigned gx = (unsigned)std::min<int64_t>(mi_ceil_div(longest, kBlock), 64);
+        hipLaunchKernelGGL(adam_multi_kernel, dim3(gx, (unsigned)M.n_params), dim3(kBlock), 0, s, tb, c, 1, (int64_t*)nullptr,
+                           (int64_t*)nullptr, grad_scale);
+    }
+    int rc = mi_launch_status();
+    if (rc) return rc;
+    rc = mi_adam_dense_f32(M.n_items + 1, H, M.proj, H, M.g_proj, H, M.m_proj, M.v_proj, nullptr, M.lr, M.beta1, M.beta2, M.eps, step,
+                           stream);
+    if (rc) return rc;
+    for (int l = 0; l < n_lists; ++l) {
+        const mi_pinsage_grad_list& g = lists[l];
+        if (g.n_rows == 0) continue;
+        hipLaunchKernelGGL(pin_embed_grad_kernel, dim3(grid(g.n_rows * h4)), dim3(kBlock), 0, s, g.n_rows, g.n_seeds, h4, g.ids,
+                           (const float4*)nullptr, (const float4*)nullptr, reinterpret_cast<float4*>(M.g_proj), M.g_bias, 1);
+    }
+    return mi_launch_status();
 }

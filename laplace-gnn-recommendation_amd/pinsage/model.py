@@ -133,10 +133,19 @@ def train_epoch(model: PinSAGEModel, optimizer: t.optim.Optimizer, sampler, batc
     from .native import NativePinSAGEStep
     losses = []
     model.train()
-    # one C call per iteration where the model / optimizer are the executor's (single process; the data-parallel run keeps
-    # the autograd path: its dense embedding gradient is what the all-reduce exchanges)
-    single = not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1)
-    native = NativePinSAGEStep(model, optimizer) if (single and NativePinSAGEStep.supports(model, optimizer)) else None
+    # one C call per iteration where the model / optimizer are the executor's.  Data-parallel: the executor's compact-row mode
+    # (the ranks exchange the batch's gradient rows, not the dense 27 MB table gradient) when the sampler's bounds are known;
+    # every rank must take the same path, which it does: the choice depends on the model, the optimizer and the sampler's
+    # configuration only.
+    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    native = None
+    if NativePinSAGEStep.supports(model, optimizer):
+        if not multi:
+            native = NativePinSAGEStep(model, optimizer)
+        elif all(hasattr(sampler, a) for a in ("batch_size", "T", "n_layers")):
+            native = NativePinSAGEStep(model, optimizer, data_parallel=True, group=group,
+                                       seed=(t.initial_seed() + dist.get_rank(group)) & ((1 << 63) - 1))
+            native.exchange_capacity = (3 * sampler.batch_size * (1 + sampler.T) ** sampler.n_layers, 3 * sampler.batch_size)
     # the backward graph is a chain of small nodes: running it in the calling thread saves the hand-over to autograd's
     # device thread at every one of them (as training.train_with_dataloader does for the ranker); the losses are read
     # back once per epoch, not once per step
@@ -148,6 +157,9 @@ def train_epoch(model: PinSAGEModel, optimizer: t.optim.Optimizer, sampler, batc
             if loss is not None:
                 losses.append(loss[0])
                 continue
+            if native is not None and multi:
+                # a declined batch in a data-parallel run would leave the ranks on different collective sequences
+                raise RuntimeError(f"NativePinSAGEStep declined a batch in a data-parallel run: {native.declined}")
             loss = model(b["seeds"], b["pos"], b["neg"], b["blocks"]).mean()
             optimizer.zero_grad()
             loss.backward()

@@ -24,11 +24,22 @@ from .model import PinSAGEModel
 
 
 class NativePinSAGEStep:
-    def __init__(self, model: PinSAGEModel, optimizer: t.optim.Optimizer, seed: Optional[int] = None, keep_grads: bool = False):
+    def __init__(self, model: PinSAGEModel, optimizer: t.optim.Optimizer, seed: Optional[int] = None, keep_grads: bool = False,
+                 data_parallel: bool = False, group=None):
+        """data_parallel (BASELINE configs[4]: 4 GPUs): every rank runs the executor on its own batch with the projector / bias
+        gradients written COMPACTLY (the rows of the batch), the ranks all-gather those lists (a few hundred KB instead of an
+        all-reduce of the dense 27 MB table gradient), all-reduce the dense layers' gradients (one flat buffer), and
+        mi_pinsage_apply_f32 adds every rank's rows in rank order, applies Adam on the mean gradient and clears the rows:
+        replicas stay bitwise identical.  Batches must keep the sampler's size bounds (they size the exchange buffer)."""
         why = self.unsupported_reason(model, optimizer)
         if why:
             raise ValueError(f"NativePinSAGEStep: {why}")
+        if data_parallel and keep_grads:
+            raise ValueError("NativePinSAGEStep: keep_grads is a single-process probe")
         self.model, self.optimizer, self.keep_grads = model, optimizer, bool(keep_grads)
+        self.data_parallel, self.group = bool(data_parallel), group
+        self._flat_small: Optional[Tensor] = None     # data-parallel: the dense layers' gradients, one allocation
+        self._xbuf = None                              # data-parallel: (send int32 buffer, gathered buffer, capacity in rows)
         self.build_csrs = True     # blocks that come without their CSRs (the sampler's index-op path) get them here
         self.seed = int(t.initial_seed() if seed is None else seed) & ((1 << 64) - 1)
         self.iteration = 0
@@ -77,6 +88,20 @@ class NativePinSAGEStep:
         d = PinsageModel()
         keep = self._keep = []
         group = opt.param_groups[0]
+        if self.data_parallel:   # every gradient except the two dense tables': views of one flat buffer (one all-reduce)
+            small = [p for p in group["params"] if p is not model.proj.weight and p is not model.bias]
+            offs, total = [], 0
+            for p in small:
+                offs.append(total)
+                total += (p.numel() + 3) // 4 * 4
+            flat = self._flat_small
+            if flat is None or flat.numel() != total or any(
+                    p.grad is None or p.grad.data_ptr() != flat.data_ptr() + 4 * o for p, o in zip(small, offs)):
+                flat = t.zeros(total, dtype=t.float32, device=model.proj.weight.device)
+                for p, o in zip(small, offs):
+                    p.grad = flat[o: o + p.numel()].view(p.shape)
+                self._flat_small = flat
+            keep.append(flat)
         for p in group["params"]:
             if p.grad is None or p.grad.shape != p.shape or not p.grad.is_contiguous():
                 p.grad = t.zeros_like(p)
@@ -167,7 +192,7 @@ class NativePinSAGEStep:
         group = self.optimizer.param_groups[0]
         d.p_dropout = float(model.convs[0].dropout.p)
         d.lr, (d.beta1, d.beta2), d.eps = float(group["lr"]), (float(b) for b in group["betas"]), float(group["eps"])
-        d.apply_adam = 0 if self.keep_grads else 1
+        d.apply_adam = 0 if (self.keep_grads or self.data_parallel) else 1
         d.step = self._adam_step + 1
         b = PinsageStepBatch()
         b.n_blocks = len(blocks)
@@ -189,6 +214,10 @@ class NativePinSAGEStep:
         b.loss = loss.data_ptr()
         ones = _ones4(max(int(blk["src_ids"].numel()) for blk in blocks), seeds.device)
         d.ones4, d.n_ones = ones.data_ptr(), int(ones.shape[0])
+        if self.data_parallel:
+            send = self._exchange_buffer(b, blocks[0]["src_ids"], seeds)
+            if send is None:
+                return None
         L = _lib.lib()
         need = int(L.mi_pinsage_step_workspace_bytes(ctypes.byref(d), ctypes.byref(b)))
         if self._ws is None or self._ws.numel() < need:
@@ -200,6 +229,8 @@ class NativePinSAGEStep:
             return None
         _lib.check(rc, "mi_pinsage_step_f32")
         self.iteration += 1
+        if self.data_parallel:
+            self._exchange_and_apply(d)
         if not self.keep_grads:
             self._adam_step += 1
             steps = [self.optimizer.state[q]["step"] for q in group["params"]]
@@ -209,3 +240,67 @@ class NativePinSAGEStep:
                 for s in steps:
                     s += 1
         return loss
+
+    # ------------------------------------------------------------------------------------------
+    # data-parallel exchange.  One int32 buffer per rank: [n_rows, n_seeds, 0, 0 | ids as int64 (2 words each, cap entries) |
+    # rows as float32 (cap * hidden) | bias as float32 (cap_seeds)]; the executor writes rows / bias straight into it.
+    def _layout(self, hidden: int):
+        cap, cap_s = self._xbuf[2], self._xbuf[3]
+        o_ids = 4
+        o_rows = o_ids + 2 * cap
+        o_bias = o_rows + cap * hidden
+        return cap, cap_s, o_ids, o_rows, o_bias, o_bias + cap_s
+
+    def _exchange_buffer(self, b: PinsageStepBatch, ids0: Tensor, seeds: Tensor):
+        import torch.distributed as dist
+        hidden = int(self.model.proj.weight.shape[1])
+        n0, ns = int(ids0.numel()), int(seeds.numel())
+        if self._xbuf is None:
+            # capacity from the sampler's bounds: 3 B seeds, (1 + T) growth per layer — the same on every rank.  Callers with
+            # other batch sources set .exchange_capacity = (rows, seeds) before the first step.
+            cap = getattr(self, "exchange_capacity", None)
+            if cap is None:
+                self.declined = "data_parallel needs .exchange_capacity = (max rows of block 0, max seeds), equal on every rank"
+                return None
+            world = dist.get_world_size(self.group) if dist.is_initialized() else 1
+            rows_cap, seeds_cap = (int(cap[0]) + 3) // 4 * 4, (int(cap[1]) + 3) // 4 * 4   # keeps every section 16-byte aligned
+            words = 4 + 2 * rows_cap + rows_cap * hidden + seeds_cap
+            dev = seeds.device
+            self._xbuf = (t.zeros(words, dtype=t.int32, device=dev), t.zeros(world, words, dtype=t.int32, device=dev), rows_cap,
+                          seeds_cap, world)
+        cap, cap_s, o_ids, o_rows, o_bias, _ = self._layout(hidden)
+        if n0 > cap or ns > cap_s:
+            self.declined = f"batch larger than the exchange capacity ({n0} rows / {ns} seeds vs {cap} / {cap_s})"
+            return None
+        send = self._xbuf[0]
+        send[0:2] = t.tensor([n0, ns], dtype=t.int32, device=send.device)
+        send[o_ids: o_ids + 2 * n0].view(t.int64).copy_(ids0)
+        b.rows_out = send.data_ptr() + 4 * o_rows
+        b.bias_out = send.data_ptr() + 4 * o_bias
+        return send
+
+    def _exchange_and_apply(self, d: PinsageModel) -> None:
+        import torch.distributed as dist
+        send, gathered, cap, cap_s, world = self._xbuf
+        hidden = int(self.model.proj.weight.shape[1])
+        _, _, o_ids, o_rows, o_bias, _ = self._layout(hidden)
+        if world > 1:
+            # the all-gather as an all-reduce(sum) of a [world, words] int32 buffer that is zero outside the rank's own
+            # slot (bit patterns + 0 = bit patterns): the payload is tiny (world x 0.4 MB), and gloo's all_gather takes
+            # 225 ms for it on this image (tools/probes/gloo_ops.py) where its all_reduce takes 0.3 ms
+            gathered.zero_()
+            gathered[dist.get_rank(self.group)].copy_(send)
+            dist.all_reduce(gathered, op=dist.ReduceOp.SUM, group=self.group)
+            dist.all_reduce(self._flat_small, op=dist.ReduceOp.SUM, group=self.group)
+        else:
+            gathered[0].copy_(send)
+        counts = gathered[:, 0:2].cpu().tolist()     # the one read-back of the exchange (2 ints per rank)
+        lists = (_lib.PinsageGradList * world)()
+        base, stride = gathered.data_ptr(), 4 * gathered.shape[1]
+        for r in range(world):
+            lists[r].n_rows, lists[r].n_seeds = int(counts[r][0]), int(counts[r][1])
+            lists[r].ids = base + r * stride + 4 * o_ids
+            lists[r].rows = base + r * stride + 4 * o_rows
+            lists[r].bias = base + r * stride + 4 * o_bias
+        _lib.check(_lib.lib().mi_pinsage_apply_f32(ctypes.byref(d), lists, world, 1.0 / world, _lib.current_stream()),
+                   "mi_pinsage_apply_f32")

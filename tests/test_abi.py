@@ -53,7 +53,8 @@ def test_size_queries_run_without_gpu():
         assert ctypes.sizeof(cls) == L.mi_ranker_sizeof(which), cls.__name__
     assert L.mi_ranker_sizeof(99) == -1
     assert L.mi_ranker_step_f32(None, None, None, 0, None) == -1
-    for which, cls in enumerate((_lib.PinsageModel, _lib.PinsageStepBatch, _lib.PinsageConv, _lib.PinsageStepBlock)):
+    for which, cls in enumerate((_lib.PinsageModel, _lib.PinsageStepBatch, _lib.PinsageConv, _lib.PinsageStepBlock,
+                                 _lib.PinsageGradList)):
         assert ctypes.sizeof(cls) == L.mi_pinsage_step_sizeof(which), cls.__name__
     assert L.mi_pinsage_step_f32(None, None, None, 0, None) == -1
 

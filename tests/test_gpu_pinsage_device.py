@@ -247,3 +247,91 @@ def test_native_pinsage_step_declines_what_it_does_not_take():
     model.eval()
     smp.device_batches = True
     assert st.step(smp.sample_batch()) is None and "eval" in st.declined
+
+
+def test_native_pinsage_data_parallel_world_one_is_the_plain_step():
+    """data_parallel=True with one process: compact gradient rows -> the exchange buffer -> mi_pinsage_apply_f32 with scale 1
+    must give exactly the single-call iteration (0 + x = x): parameters, moments, zero-kept buffers."""
+    import copy
+    from laplace_amd.pinsage.native import NativePinSAGEStep
+    model, smp = _pin_setup(seed=8, p_drop=0.5, hidden=32, layers=2)
+    twin = copy.deepcopy(model)
+    oa, ob = t.optim.Adam(model.parameters(), lr=3e-3), t.optim.Adam(twin.parameters(), lr=3e-3)
+    dp, plain = NativePinSAGEStep(model, oa, data_parallel=True, seed=5), NativePinSAGEStep(twin, ob, seed=5)
+    dp.exchange_capacity = (3 * smp.batch_size * (1 + smp.T) ** smp.n_layers, 3 * smp.batch_size)
+    model.train(); twin.train()
+    for i in range(4):
+        b = smp.sample_batch()
+        la, lb = dp.step(b), plain.step(b)
+        assert la is not None and lb is not None, (dp.declined, plain.declined)
+        assert float(la) == float(lb)
+        for (n, p), q in zip(model.named_parameters(), twin.parameters()):
+            assert t.equal(p, q), (i, n)
+            assert t.equal(oa.state[p]["exp_avg_sq"], ob.state[q]["exp_avg_sq"]), (i, n)
+        assert float(model.proj.weight.grad.abs().max()) == 0.0 and float(model.bias.grad.abs().max()) == 0.0
+
+
+def _pin_dp_worker(rank, world, port, ret):
+    import os
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)     # both ranks on the one card; gloo carries the exchange
+    try:
+        import copy
+        from laplace_amd.dist_ranker import broadcast_parameters
+        from laplace_amd.pinsage.model import train_epoch
+        from laplace_amd.pinsage.native import NativePinSAGEStep
+        from laplace_amd.pinsage.sampler import PinSAGESampler
+        U, I = 2500, 800
+        users, items = _graph(11, U, I, 40000)
+        smp = PinSAGESampler(users, items, U, I, batch_size=32, seed=100 + rank)      # a rank's own batches
+        t.manual_seed(50 + rank)
+        from laplace_amd.pinsage.model import PinSAGEModel
+        model = PinSAGEModel(I, 32, 2).to("cuda")
+        for cv in model.convs:
+            cv.dropout.p = 0.0
+        broadcast_parameters(model)
+        probe_model = copy.deepcopy(model)
+        opt = t.optim.Adam(model.parameters(), lr=3e-3)
+        before = [p.detach().clone() for p in model.parameters()]
+        # this rank's own gradients of its first batch (single-process probe on a copy)
+        probe = NativePinSAGEStep(probe_model, t.optim.Adam(probe_model.parameters(), lr=3e-3), keep_grads=True)
+        probe_model.train()
+        first = smp.sample_batch(0)
+        assert probe.step(first) is not None
+        losses = train_epoch(model, opt, smp, 1)                                       # picks the data-parallel executor
+        after1 = [p.detach().cpu().clone() for p in model.parameters()]
+        losses += train_epoch(model, opt, smp, 5)
+        t.cuda.synchronize()
+        ret[rank] = {"own": [p.grad.detach().cpu().clone() for p in probe_model.parameters()], "after1": after1,
+                     "before": [x.cpu() for x in before], "after": [p.detach().cpu() for p in model.parameters()],
+                     "losses": losses, "step": float(opt.state[model.proj.weight]["step"]),
+                     "dense_zero": float(model.proj.weight.grad.abs().max()) == 0.0}
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_native_pinsage_data_parallel_two_ranks():
+    """Two processes on the card, their own batches: replicas stay bitwise identical over 6 iterations, the dense gradient
+    buffers end zero, and the FIRST update is Adam's first step on the mean of the two ranks' own gradients."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ret = mp.Manager().dict()
+    mp.spawn(_pin_dp_worker, args=(2, port, ret), nprocs=2, join=True)
+    a, b = ret[0], ret[1]
+    assert a["step"] == b["step"] == 6 and a["dense_zero"] and b["dense_zero"]
+    assert all(np.isfinite(a["losses"])) and len(a["losses"]) == 6
+    for x, y in zip(a["after"], b["after"]):
+        assert t.equal(x, y)
+    assert not all(t.equal(x, y) for x, y in zip(a["own"], b["own"]))                 # the batches did differ
+    for i in range(len(a["own"])):
+        g = 0.5 * (a["own"][i] + b["own"][i])                                          # the mean gradient of iteration 1
+        want = a["before"][i] - 3e-3 * g / (g.abs() + 1e-8)                            # Adam, step 1
+        big = g.abs() > 1e-6                                                           # (a 1e-9 gradient is all rounding)
+        assert big.any()
+        assert t.allclose(a["after1"][i][big], want[big], rtol=1e-4, atol=2e-6), i
+        assert t.equal(a["after1"][i][g == 0], a["before"][i][g == 0])                 # untouched rows do not move

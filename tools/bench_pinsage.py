@@ -77,8 +77,12 @@ def run(args):
 
     from laplace_amd.pinsage.native import NativePinSAGEStep
     native = None
-    if world == 1 and not args.autograd and NativePinSAGEStep.supports(model, opt):
-        native = NativePinSAGEStep(model, opt)       # one C call per iteration (mi_pinsage_step_f32)
+    if not args.autograd and NativePinSAGEStep.supports(model, opt):
+        if world == 1:
+            native = NativePinSAGEStep(model, opt)       # one C call per iteration (mi_pinsage_step_f32)
+        else:   # data-parallel: compact gradient rows all-gathered, dense layers all-reduced, mi_pinsage_apply_f32
+            native = NativePinSAGEStep(model, opt, data_parallel=True, seed=1234 + rank)
+            native.exchange_capacity = (3 * args.batch * (1 + args.neighbors) ** args.layers, 3 * args.batch)
 
     def one(b=None):
         b = smp.sample_batch() if b is None else b
@@ -86,6 +90,8 @@ def run(args):
             loss = native.step(b)
             if loss is not None:
                 return loss, b
+            if world > 1:
+                raise RuntimeError(f"data-parallel native step declined a batch: {native.declined}")
         loss = model(b["seeds"], b["pos"], b["neg"], b["blocks"]).mean()
         opt.zero_grad()
         loss.backward()
@@ -125,7 +131,8 @@ def run(args):
                       "workload": f"PinSAGE item-item training, H&M-shaped synthetic {args.users}x{args.items}, {args.edges} edges; "
                                   f"batch {args.batch} pairs, walks {args.walks} x length {args.walk_length}, restart {args.restart}, "
                                   f"T={args.neighbors}, {args.layers} layers, hidden {args.hidden}",
-                      "iteration": "native executor (mi_pinsage_step_f32)" if native is not None else "autograd, op by op",
+                      "iteration": ("native executor (mi_pinsage_step_f32)" + (" + compact-row exchange (mi_pinsage_apply_f32)" if world > 1 else ""))
+                      if native is not None else "autograd, op by op",
                       "sampling": "serial" if serial else "overlapped (side stream, one batch ahead)",
                       "ms_per_iteration": round(1e3 * dt / args.iters, 3), "positive_pairs_per_s": round(pairs / dt),
                       "sampler_ms_per_batch": round(1e3 * ds, 3), "loss": round(float(loss.detach()), 4)})
