@@ -455,6 +455,16 @@ def pinsage_block(args) -> dict:
     return mod.bench_line(iters=args.pinsage_iters)
 
 
+_T0 = time.perf_counter()
+_LEGS = {}   # wall seconds of each leg of this invocation (reported as "wall_s": where a default run's minutes go)
+
+
+def _leg(name: str, since: float) -> float:
+    now = time.perf_counter()
+    _LEGS[name] = round(_LEGS.get(name, 0.0) + now - since, 1)
+    return now
+
+
 def main():
     args = parse_args()
     from laplace_amd import launch
@@ -476,9 +486,12 @@ def main():
             passthrough.append("--no-reorder")
         if args.uniform:
             passthrough.append("--uniform")
+        tl = time.perf_counter()
         pmc[args.config] = pmc_traffic(args.config, passthrough)
+        tl = _leg("pmc_children_" + args.config, tl)
         if want_c4_leg:
             pmc["c4"] = pmc_traffic("c4", ["--dim", str(args.dim), "--layers", str(args.layers)] + (["--no-reorder"] if args.no_reorder else []))
+            _leg("pmc_children_c4", tl)
 
     import torch as t
     import torch.distributed as dist
@@ -498,7 +511,9 @@ def main():
     if os.environ.get("LAPLACE_SPMM_TWO_STREAMS") is not None:  # A/B switch
         ops.SPMM_TWO_STREAMS = int(os.environ["LAPLACE_SPMM_TWO_STREAMS"] or 0)   # 1: short rows enqueued first, 2: split rows first
     want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline and not args.pmc_child and (args.config == "c2" or args.cpu_baseline)
+    tl = time.perf_counter()
     w = build_workload(args.config, args, world, rank, dev, plain=args.plain_step, want_table0=want_cpu)
+    tl = _leg("import_and_graph_setup", tl)
     spec, ei, U, I, D, K, B = w["spec"], w["ei"], w["U"], w["I"], w["D"], w["K"], w["B"]
     model, inter, adj, trainer, strong = w["model"], w["inter"], w["adj"], w["trainer"], w["strong"]
     default_workload = (args.config == "c2" and (spec.num_users, I, spec.num_edges, D, K) == (1_000_000, 100_000, 10_000_000, 128, 3)
@@ -514,6 +529,7 @@ def main():
     elapsed, per_step, events, loss = timed_steps(trainer, args.steps, args.warmup, sync)
     if args.pmc_child:   # the profiler has what it came for
         return
+    tl = _leg("trainer_setup_and_timed_region", tl)
     pct = lambda q: per_step[min(len(per_step) - 1, int(q * len(per_step)))]
     loss_val = float(loss)
 
@@ -562,6 +578,7 @@ def main():
         }
 
     # ---- extra legs, N=1 only, after the timed region ------------------------------------------------
+    tl = time.perf_counter()
     if world == 1 and not args.plain_step and not args.no_plain_leg:
         # the straightforward step shape (full `final`, dense gradient buffer, separate Adam): same parameters to
         # rounding (tests/test_gpu_lightgcn.py::test_sparse_batch_step_equals_plain_step), more bytes.  Quote the
@@ -579,10 +596,12 @@ def main():
         out["plain_step_positive_edges_per_s"] = B * 1e3 / out["plain_step_ms"]
         plain.finish()
         del plain
+        tl = _leg("plain_step_leg", tl)
     if rank == 0 and want_cpu:
         trainer.finish()
         out["cpu_baseline"] = cpu_baseline(ei, U, I, K, B, w["table0"], steps=args.cpu_steps, warm=True,
                                            faithful=not args.no_cpu_faithful and args.config == "c2")
+        tl = _leg("cpu_baseline", tl)
     if world == 1 and rank == 0:
         # free the headline's state before the other configurations
         del trainer, model, inter, adj, w, events
@@ -590,17 +609,23 @@ def main():
         if not args.no_map and not strong and not args.uniform:
             out["map_at_12"] = map_leg(args, dev)
             t.cuda.empty_cache()
+            tl = _leg("map_at_12", tl)
         if want_c4_leg:
             c4_traffic, _, c4_src = pmc.get("c4", (None, None, "live PMC passes off (--no-pmc)"))
             if c4_traffic is None:
                 c4_src = f"no live figure ({c4_src})"
             out["c4_n1"] = c4_block(args, dev, c4_traffic, c4_src)
+            tl = _leg("c4_n1 (incl. its one-step CPU baseline)", tl)
         if args.config == "c2" and not args.no_ranker:
             out["ranker_c3"] = ranker_block(args)
             t.cuda.empty_cache()
+            tl = _leg("ranker_c3 (incl. graph generation and the CPU twin)", tl)
         if args.config == "c2" and not args.no_pinsage:
             out["pinsage_c5"] = pinsage_block(args)
+            tl = _leg("pinsage_c5 (incl. graph generation)", tl)
     if rank == 0:
+        _LEGS["total"] = round(time.perf_counter() - _T0, 1)
+        out["wall_s"] = dict(_LEGS)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
