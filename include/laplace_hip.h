@@ -501,6 +501,27 @@ int mi_bce_logits_f32(int64_t n, const float* logits, const float* labels, float
                       mi_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
+ * b1  weight gradients of SAGEConv relations (model/layers.py:11-24: out = lin_l(AGG x_src) + lin_r(x_dst)):
+ *   gw1 [m, n1] = (dy * relu')^T b1,   gb [m] = (dy * relu')^T 1 (nullable),   gw2 [m, n2] = (dy * relu')^T b2 (n2 = 0: none)
+ * with dy [k, m] the gradient at the layer's output (k = destination nodes), mask [k, m] nullable (dy is read as 0 where
+ * mask <= 0: the relu behind the layer), b1 = the aggregated source features [k, n1], b2 = the destination features [k, n2].
+ * replaces: what autograd derives for the two Linear layers of torch_geometric.nn.SAGEConv (three transposed products).
+ * All matrices dense row-major (leading dimension = width).  m a multiple of 32, <= 128; n1, n2 <= 512; up to 4 problems
+ * per call (the two relations of a layer).  No LDS staging: rows of dy / b1 / b2 go straight into the operand registers
+ * of the f32 32x32x2 MFMA; K is cut into slices whose partial outputs are summed in slice order (deterministic).
+ * MI_ERR_UNSUPPORTED (nothing enqueued) for other shapes: callers use the grouped GEMM.
+ * ---------------------------------------------------------------------------------- */
+typedef struct mi_wgrad_problem {
+    int64_t k;
+    int32_t m, n1, n2, reserved;
+    const float *dy, *mask, *b1, *b2;
+    float *gw1, *gb, *gw2;
+} mi_wgrad_problem;
+int    mi_sage_wgrad_supported(const mi_wgrad_problem* problems, int32_t n);
+size_t mi_sage_wgrad_workspace_bytes(const mi_wgrad_problem* problems, int32_t n);
+int    mi_sage_wgrad_f32(const mi_wgrad_problem* problems, int32_t n, void* ws, size_t ws_bytes, mi_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
  * b7  backward of a Linear layer with ONE output feature — the last decoder layer (model/encoder_decoder.py:66-72,
  * Linear(128, 1)): dx[r, :] = dy[r] * w (nullable), gw = sum_r dy[r] x[r, :], gb = sum_r dy[r] (nullable).
  * replaces: the three [n, 1]-shaped products autograd derives for that layer (torch.nn.Linear backward).

@@ -127,6 +127,12 @@ class PinsageBatchOut(Structure):
                 ("blocks", PinsageBlockOut * MI_PINSAGE_MAX_LAYERS)]
 
 
+class WgradProblem(Structure):
+    _fields_ = [("k", c_int64), ("m", c_int32), ("n1", c_int32), ("n2", c_int32), ("reserved", c_int32),
+                ("dy", c_void_p), ("mask", c_void_p), ("b1", c_void_p), ("b2", c_void_p),
+                ("gw1", c_void_p), ("gb", c_void_p), ("gw2", c_void_p)]
+
+
 MI_PINSAGE_MAX_PARAMS = 24
 
 
@@ -213,6 +219,9 @@ _PROTOTYPES = {
     "mi_gather_cat_bwd_f32": (c_int32, [c_int64, c_int64, c_int64, P, P, c_int64, P, c_int64, P]),
     "mi_match_common_items_i32": (c_int32, [c_int64, P, P, P, P, P, c_int32, P, P, P]),
     "mi_gemm_group_supported": (c_int32, [P, c_int32]),
+    "mi_sage_wgrad_supported": (c_int32, [POINTER(WgradProblem), c_int32]),
+    "mi_sage_wgrad_workspace_bytes": (c_size_t, [POINTER(WgradProblem), c_int32]),
+    "mi_sage_wgrad_f32": (c_int32, [POINTER(WgradProblem), c_int32, P, c_size_t, P]),
     "mi_linear1_bwd_workspace_bytes": (c_size_t, [c_int64, c_int64]),
     "mi_linear1_bwd_f32": (c_int32, [c_int64, c_int64, P, P, P, c_int64, P, c_int64, P, P, P, c_size_t, P]),
     "mi_ranker_sizeof": (c_int64, [c_int32]),

@@ -432,6 +432,34 @@ int Exec::run() {
             }
             on(1);
         }
+        // the weight gradients need nothing of the aggregations above: they run beside them.  Round 3: both relations'
+        // three products each as ONE launch of the LDS-free transposed-product kernel (csrc/wgrad.hip) where its shapes
+        // allow (c_out a multiple of 32, <= 128); else the grouped GEMM as before.  FusedRankerStep makes the same choice
+        // (model/layers.py::hetero_layer_backward), so the two paths stay bitwise equal.
+        mi_wgrad_problem wq[2];
+        for (int r = 0; r < 2; ++r) {
+            const mi_ranker_conv& cv = M.conv[l][r];
+            const int dt = dst_of[r];
+            memset(&wq[r], 0, sizeof(wq[r]));
+            wq[r].k = n[dt]; wq[r].m = (int32_t)cv.c_out; wq[r].n1 = (int32_t)cv.c_src; wq[r].n2 = (int32_t)cv.c_dst;
+            wq[r].dy = dy[r]; wq[r].mask = mask[r]; wq[r].b1 = agg[l][r]; wq[r].b2 = xin[l][dt];
+            wq[r].gw1 = cv.gw_l; wq[r].gb = cv.b_l ? cv.gb_l : nullptr; wq[r].gw2 = cv.gw_r;
+        }
+        if (mi_sage_wgrad_supported(wq, 2)) {   // depends on the dimensions and on pointers being non-null only: same answer in every pass
+            const size_t need = mi_sage_wgrad_workspace_bytes(wq, 2);
+            char* w = take_bytes(need);
+            if (go()) ok(mi_sage_wgrad_f32(wq, 2, w, need, (mi_stream_t)s));
+            if (need_x) {
+                for (int t = 0; t < kTypes; ++t) {
+                    dxs[t] = dxn[t];
+                    on(t);
+                    if (!last && drop) dropout(dxn[t], dxn[t], n[t] * M.conv[l][t].c_src, (uint32_t)(l * 2 + t));
+                }
+                on(1);
+                join();
+            }
+            continue;
+        }
         mi_gemm_problem pw[6];
         int nw = 0;
         for (int r = 0; r < 2; ++r) {
@@ -445,7 +473,7 @@ int Exec::run() {
             }
             pw[nw++] = prob(1, 0, cv.c_out, cv.c_dst, n[dt], dy[r], cv.c_out, xin[l][dt], cv.c_dst, cv.gw_r, cv.c_dst, mask[r]);
         }
-        products(pw, nw);   // the weight gradients need nothing of the aggregations above: they run beside them
+        products(pw, nw);
         if (need_x) {
             for (int t = 0; t < kTypes; ++t) {
                 dxs[t] = dxn[t];

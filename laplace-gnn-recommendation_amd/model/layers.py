@@ -398,6 +398,23 @@ def hetero_layer_backward(rels, xs, wts, aggs, args, outs, dys, need):
             graph.by_src.plan = a.plan
     # ---- dW half: dW_l = dY^T agg, dW_r = dY^T x_dst, db = dY^T 1 for every relation in one split-K launch
     grads_w = [None] * (3 * n_rel)
+    # (round 3) every relation's three transposed products as one launch of the LDS-free kernel (csrc/wgrad.hip) when all
+    # of them are wanted and the shapes are the kernel's; the native executor makes the same choice, so the two stay bitwise equal
+    wq = []
+    for i, (si, di, graph, aggr) in enumerate(rels):
+        dy = dys[i]
+        w_l, b_l, w_r = wts[3 * i: 3 * i + 3]
+        if (dy is None or w_r is None or not need[n_x + 3 * i] or not need[n_x + 3 * i + 2]
+                or (b_l is not None and not need[n_x + 3 * i + 1])):
+            wq = None
+            break
+        wq.append(dict(dy=dy, mask=outs[i], b1=aggs[i], b2=xs[di], gw1=t.empty_like(w_l),
+                       gb=t.empty(w_l.shape[0], device=dev) if b_l is not None else None, gw2=t.empty_like(w_r)))
+    if wq and len(wq) <= 4 and all(q["b1"].is_contiguous() and q["b2"].is_contiguous() and (q["mask"] is None or q["mask"].is_contiguous())
+                                   for q in wq) and ops.sage_wgrad(wq):
+        for i, q in enumerate(wq):
+            grads_w[3 * i], grads_w[3 * i + 1], grads_w[3 * i + 2] = q["gw1"], q["gb"], q["gw2"]
+        return [dx[j] if need[j] else None for j in range(n_x)], grads_w
     specs, db4 = [], {}
     for i, (si, di, graph, aggr) in enumerate(rels):
         dy = dys[i]

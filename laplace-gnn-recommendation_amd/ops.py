@@ -871,6 +871,35 @@ def gather_cat_bwd(d_out: Tensor, idx: Tensor, n_rows: int, c: int, off: int) ->
     return dz
 
 
+def sage_wgrad(problems) -> bool:
+    """Weight gradients of up to four SAGEConv relations in one launch pair (mi_sage_wgrad_f32).  problems: dicts(dy [k, m],
+    mask [k, m] or None, b1 [k, n1], b2 [k, n2] or None, gw1 [m, n1], gb [m] or None, gw2 [m, n2] or None), all contiguous
+    float32.  False (nothing enqueued) when the shapes are outside the kernel's: the caller uses the grouped GEMM."""
+    n = len(problems)
+    if n == 0 or n > 4:
+        return False
+    arr = (_lib.WgradProblem * n)()
+    for q, s in zip(arr, problems):
+        dy, b1, b2 = s["dy"], s["b1"], s.get("b2")
+        tensors = [dy, b1, s["gw1"]] + [x for x in (s.get("mask"), b2, s.get("gb"), s.get("gw2")) if x is not None]
+        if any(x.dtype != t.float32 or not x.is_contiguous() for x in tensors) or (b2 is None) != (s.get("gw2") is None):
+            return False
+        if dy.dim() != 2 or b1.dim() != 2 or b1.shape[0] != dy.shape[0] or (b2 is not None and b2.shape[0] != dy.shape[0]):
+            return False
+        q.k, q.m, q.n1, q.n2 = int(dy.shape[0]), int(dy.shape[1]), int(b1.shape[1]), int(b2.shape[1]) if b2 is not None else 0
+        q.dy, q.mask, q.b1, q.b2 = _ptr(dy), _ptr(s.get("mask")), _ptr(b1), _ptr(b2)
+        q.gw1, q.gb, q.gw2 = _ptr(s["gw1"]), _ptr(s.get("gb")), _ptr(s.get("gw2"))
+    L = _lib.lib()
+    if not L.mi_sage_wgrad_supported(arr, n):
+        return False
+    ws = t.empty(max(int(L.mi_sage_wgrad_workspace_bytes(arr, n)), 256), dtype=t.uint8, device=problems[0]["dy"].device)
+    rc = L.mi_sage_wgrad_f32(arr, n, _ptr(ws), ws.numel(), _stream())
+    if rc == _lib.MI_ERR_UNSUPPORTED:
+        return False
+    check(rc, "mi_sage_wgrad_f32")
+    return True
+
+
 def linear1_bwd(dy: Tensor, weight: Tensor, x: Tensor, need_dx: bool = True):
     """Backward of a Linear layer with one output feature (weight [1, in]): (dx [n, in] or None, dW [1, in], db [1]).
     mi_linear1_bwd_f32: deterministic band sums instead of three [n, 1]-shaped products."""

@@ -304,3 +304,40 @@ def test_gemm_group_pairs_mask_split_and_layouts():
     # unaligned operands are refused as a whole (the caller falls back to gemm())
     odd = t.randn(50, 7, device=DEV)
     assert not ops.gemm_group([ops.gemm_problem(odd, t.randn(9, 7, device=DEV), t.empty(50, 9, device=DEV))])
+
+
+@pytest.mark.parametrize("k,m,n1,n2,bias,mask", [(1, 32, 4, 4, True, False), (127, 64, 84, 76, True, True), (128, 128, 128, 128, True, True),
+                                                  (129, 128, 84, 0, False, True), (30011, 128, 84, 84, True, True),
+                                                  (2049, 64, 128, 128, True, False), (5000, 96, 37, 200, True, True)])
+def test_sage_wgrad_matches_the_three_products(k, m, n1, n2, bias, mask):
+    """mi_sage_wgrad_f32: gw1 = (dy * relu')^T b1, gb = (dy * relu')^T 1, gw2 = (dy * relu')^T b2 against float64 products;
+    deterministic; several problems per call."""
+    import torch as t
+    from laplace_amd import ops
+    g = t.Generator(device="cuda").manual_seed(k + m)
+    dy = t.randn(k, m, device="cuda", generator=g)
+    mk = t.randn(k, m, device="cuda", generator=g) if mask else None
+    b1 = t.randn(k, n1, device="cuda", generator=g)
+    b2 = t.randn(k, n2, device="cuda", generator=g) if n2 else None
+    def problem():
+        return dict(dy=dy, mask=mk, b1=b1, b2=b2, gw1=t.full((m, n1), float("nan"), device="cuda"),
+                    gb=t.full((m,), float("nan"), device="cuda") if bias else None,
+                    gw2=t.full((m, n2), float("nan"), device="cuda") if n2 else None)
+    p, p2 = problem(), problem()
+    small = dict(dy=dy[:7].contiguous(), mask=None, b1=b1[:7].contiguous(), b2=None, gw1=t.empty(m, n1, device="cuda"), gb=None, gw2=None)
+    assert ops.sage_wgrad([p, small])
+    assert ops.sage_wgrad([p2])
+    a = (dy * (mk > 0) if mask else dy).double()
+    for got, want in ((p["gw1"], a.t() @ b1.double()), (p["gb"], a.sum(0) if bias else None), (p["gw2"], a.t() @ b2.double() if n2 else None)):
+        if want is None:
+            continue
+        scale = float(want.abs().max()) + 1e-12
+        assert float((got.double() - want).abs().max()) <= 2e-6 * scale * max(1.0, (k / 1000) ** 0.5), (got.shape,)
+    for key in ("gw1", "gb", "gw2"):
+        if p[key] is not None:
+            assert t.equal(p[key], p2[key])
+    assert float((small["gw1"].double() - dy[:7].double().t() @ b1[:7].double()).abs().max()) <= 1e-5
+    # shapes outside the kernel's: declined, nothing written
+    bad = dict(dy=t.randn(10, 48, device="cuda"), mask=None, b1=t.randn(10, 8, device="cuda"), b2=None,
+               gw1=t.zeros(48, 8, device="cuda"), gb=None, gw2=None)
+    assert not ops.sage_wgrad([bad]) and float(bad["gw1"].abs().sum()) == 0.0
