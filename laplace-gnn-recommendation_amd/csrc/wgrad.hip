@@ -66,8 +66,11 @@ __device__ __forceinline__ void wg_run(const WgProb& q, int slice, int ct, int l
         const int col = (ct - q.nt1 - q.has_bias) * 32 + i;
         b_ok = col < q.n2; bld = q.n2; bp = q.b2 + (b_ok ? col : 0);
     }
-    const float* ap = q.dy + i;
-    const float* mp = HAS_MASK ? q.mask + i : nullptr;
+    // Row tile mt of this wavefront holds the output rows m = MT * r + mt (r = the MFMA's row index 0..31), not the rows
+    // 32 mt + r: lane i then needs dy[k][MT i .. MT i + MT - 1] — ONE 16-byte load for four row tiles (a dy row is read by
+    // its 32 lanes as one contiguous 512-byte run) instead of four 4-byte loads 128 bytes apart; the mask likewise.
+    const float* ap = q.dy + MT * i;
+    const float* mp = HAS_MASK ? q.mask + MT * i : nullptr;
     // Software pipeline: the operands of the NEXT U k-pairs are loaded while the MFMAs of the current U run.  The loads are
     // branch-free (rows beyond the slice are clamped and multiplied away): a version with a branch per element compiled to
     // ~6 branches and 2 waits per MFMA and took 106 us for the first layer's two relations.
@@ -83,10 +86,32 @@ __device__ __forceinline__ void wg_run(const WgProb& q, int slice, int ct, int l
             float bv = b_ones ? 1.f : bp[kc * bld];
             b[u] = (live && b_ok) ? bv : 0.f;
             const int ro = kc * q.m;
+            float va[MT], vm[MT];
+            if constexpr (MT == 4) {
+                const float4 x = *reinterpret_cast<const float4*>(ap + ro);
+                va[0] = x.x; va[1] = x.y; va[2] = x.z; va[3] = x.w;
+                if (HAS_MASK) {
+                    const float4 y = *reinterpret_cast<const float4*>(mp + ro);
+                    vm[0] = y.x; vm[1] = y.y; vm[2] = y.z; vm[3] = y.w;
+                }
+            } else if constexpr (MT == 2) {
+                const float2 x = *reinterpret_cast<const float2*>(ap + ro);
+                va[0] = x.x; va[1] = x.y;
+                if (HAS_MASK) {
+                    const float2 y = *reinterpret_cast<const float2*>(mp + ro);
+                    vm[0] = y.x; vm[1] = y.y;
+                }
+            } else {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    va[mt] = ap[ro + mt];
+                    if (HAS_MASK) vm[mt] = mp[ro + mt];
+                }
+            }
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
-                float v = ap[ro + mt * 32];
-                if (HAS_MASK) v = mp[ro + mt * 32] > 0.f ? v : 0.f;
+                float v = va[mt];
+                if (HAS_MASK) v = vm[mt] > 0.f ? v : 0.f;
                 a[u][mt] = live ? v : 0.f;
             }
         }
@@ -111,7 +136,7 @@ __device__ __forceinline__ void wg_run(const WgProb& q, int slice, int ct, int l
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int row = mt * 32 + 4 * kk + (r & 3) + 8 * (r >> 2);
+            const int row = MT * (4 * kk + (r & 3) + 8 * (r >> 2)) + mt;   // the interleaved row tiles (see the loads)
             base[(int64_t)row * ld] = acc[mt][r];
         }
 }
@@ -145,53 +170,62 @@ __global__ __launch_bounds__(256) void sage_wgrad_kernel(WgArgs a) {
     }
 }
 
-// out element (row, col of the concatenated output) = sum over slices, ascending
+// out element (row, col of the concatenated output) = sum over the slices in a fixed order.  64 elements per workgroup, four
+// threads per element (thread g takes the slices s with s mod 4 == g, eight independent loads per step), combined through
+// LDS as (g0 + g1) + (g2 + g3): one thread per element walking all ~235 slices left the chip at ~120 workgroups and
+// 14.6 us for 27 MB of partials.
 __global__ __launch_bounds__(256) void sage_wgrad_reduce_kernel(WgArgs a, int64_t total) {
-    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (e >= total) return;
-    int64_t rest = e;
-    int pi = 0;
-    for (; pi < a.n; ++pi) {
-        const int64_t cnt = (int64_t)a.p[pi].m * a.p[pi].nt * 32;
-        if (rest < cnt) break;
-        rest -= cnt;
-    }
-    const WgProb& q = a.p[pi];
-    const int ld = q.nt * 32;
-    const int row = (int)(rest / ld), c = (int)(rest % ld);
-    const int ct = c >> 5, j = c & 31;
+    __shared__ float part[4][64];
+    const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int64_t e = (int64_t)blockIdx.x * 64 + lane;
+    float sum = 0.f;
     float* dst = nullptr;
-    if (ct < q.nt1) {
-        if (ct * 32 + j < q.n1) dst = q.gw1 + (int64_t)row * q.n1 + ct * 32 + j;
-    } else if (q.has_bias && ct == q.nt1) {
-        if (j == 0) dst = q.gb + row;
-    } else {
-        const int col = (ct - q.nt1 - q.has_bias) * 32 + j;
-        if (col < q.n2) dst = q.gw2 + (int64_t)row * q.n2 + col;
-    }
-    if (!dst) return;
-    // eight interleaved running sums (slice s goes to sum s mod 8), combined in a fixed order: the loads of a step are
-    // independent, so the walk over the slices is not a chain of load latencies (a plain loop was most of a first version's
-    // 160 us); the order of additions is fixed all the same
-    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    const float* src = q.partial + (int64_t)row * ld + c;
-    const int64_t stride = (int64_t)q.m * ld;
-    int s = 0;
-    for (; s + 8 <= q.slices; s += 8) {
-        float v[8];
+    if (e < total) {
+        int64_t rest = e;
+        int pi = 0;
+        for (; pi < a.n; ++pi) {
+            const int64_t cnt = (int64_t)a.p[pi].m * a.p[pi].nt * 32;
+            if (rest < cnt) break;
+            rest -= cnt;
+        }
+        const WgProb& q = a.p[pi];
+        const int ld = q.nt * 32;
+        const int row = (int)(rest / ld), c = (int)(rest % ld);
+        const int ct = c >> 5, j = c & 31;
+        if (ct < q.nt1) {
+            if (ct * 32 + j < q.n1) dst = q.gw1 + (int64_t)row * q.n1 + ct * 32 + j;
+        } else if (q.has_bias && ct == q.nt1) {
+            if (j == 0) dst = q.gb + row;
+        } else {
+            const int col = (ct - q.nt1 - q.has_bias) * 32 + j;
+            if (col < q.n2) dst = q.gw2 + (int64_t)row * q.n2 + col;
+        }
+        if (dst) {
+            float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            const float* src = q.partial + (int64_t)row * ld + c;
+            const int64_t stride = (int64_t)q.m * ld;
+            int s = g;
+            for (; s + 28 < q.slices; s += 32) {   // slices g, g + 4, ..., g + 28
+                float v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = src[(int64_t)(s + u) * stride];
+                for (int u = 0; u < 8; ++u) v[u] = src[(int64_t)(s + 4 * u) * stride];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) acc[u] += v[u];
+                for (int u = 0; u < 8; ++u) acc[u] += v[u];
+            }
+            for (int u = 0; s < q.slices; s += 4, ++u) acc[u] += src[(int64_t)s * stride];
+            sum = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+        }
     }
-    for (int u = 0; s < q.slices; ++s, ++u) acc[u] += src[(int64_t)s * stride];
-    *dst = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+    part[g][lane] = sum;
+    __syncthreads();
+    if (g == 0 && dst) *dst = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
 }
 
 bool wg_fill(const mi_wgrad_problem& d, WgProb& q) {
     if (d.k <= 0 || d.m <= 0 || d.m > 32 * kMaxMT || d.m % 32 != 0) return false;
     if (d.n1 <= 0 || d.n1 > 512 || d.n2 < 0 || d.n2 > 512) return false;
     if (d.k * (int64_t)std::max(d.m, std::max(d.n1, d.n2)) >= INT32_MAX) return false;   // the kernel's 32-bit row offsets
+    if (!mi_aligned16(d.dy) || (d.mask && !mi_aligned16(d.mask))) return false;           // 16-byte row loads
     if (!d.dy || !d.b1 || !d.gw1 || (d.n2 > 0 && (!d.b2 || !d.gw2))) return false;
     q.k = d.k; q.m = d.m; q.n1 = d.n1; q.n2 = d.n2; q.has_bias = d.gb ? 1 : 0;
     q.dy = d.dy; q.mask = d.mask; q.b1 = d.b1; q.b2 = d.b2; q.gw1 = d.gw1; q.gb = d.gb; q.gw2 = d.gw2;
@@ -246,7 +280,7 @@ int mi_sage_wgrad_f32(const mi_wgrad_problem* probs, int32_t n, void* ws, size_t
     if (wgs >= INT32_MAX) return MI_ERR_TOO_LARGE;
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(sage_wgrad_kernel, dim3((unsigned)wgs), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(sage_wgrad_reduce_kernel, dim3((unsigned)mi_ceil_div(outs, 256)), dim3(256), 0, s, a, outs);
+    hipLaunchKernelGGL(sage_wgrad_reduce_kernel, dim3((unsigned)mi_ceil_div(outs, 64)), dim3(256), 0, s, a, outs);
     return mi_launch_status();
 }
 
