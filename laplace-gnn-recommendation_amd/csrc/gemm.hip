@@ -348,6 +348,12 @@ __global__ __launch_bounds__(256, MI_GEMM_WGS) void gemm_group_kernel(MiGemmGrou
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 
+    // (Also measured and not kept, round 3: an LDS-free "row-stream" form of these launches — a wavefront owns 32 rows and all
+    // <= 4 column tiles, lane (i, kk) reads eight consecutive k of its row as two 16-byte loads, weights from L1 / L2, next
+    // group of eight loaded under the current MFMAs; bitwise the tile kernel's results.  The ranker's forward / dX launches
+    // went 34 / 25 / 33 us -> 38 / 42 / 34 us: every load instruction touches 32 cache lines, and with two wavefronts per SIMD
+    // a one-stage prefetch leaves ~0.8 us of latency per eight k exposed.  The same idea DOES pay for the transposed weight-
+    // gradient products, whose operand rows are contiguous per k: csrc/wgrad.hip.)
     // Not software-pipelined like gemm_fast_kernel: measured (tools/ab_gemm_pipe.sh, round 3) the ranker's grouped launches
     // are short-K and bound by their operand traffic, four resident workgroups per CU already overlap one another's
     // loads and MFMAs, and the prologue's extra barrier cost 3-9 us per launch (iteration 0.641 -> 0.672 ms).
