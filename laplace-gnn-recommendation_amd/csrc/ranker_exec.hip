@@ -211,6 +211,9 @@ int Exec::run() {
     for (int t = 0; t < kTypes; ++t)
         for (int c = 0; c < M.n_cols[t]; ++c) width[t] += M.dims[t][c];
     float* x0[2];
+    // (Measured and not kept, round 3: drawing the first layer's feature dropout inside the lookup, and the decoder's inside
+    // gather_cat — three launches fewer, ~15 us — made the producers compute a Philox block per ELEMENT instead of one per
+    // four: embed_concat 5.7 + 11 -> 19 + 33 us, gather_cat 4.8 -> 16 us, iteration 0.545 -> 0.62 ms.)
     fork();
     for (int t = 0; t < kTypes; ++t) {
         x0[t] = take(n[t], width[t]);
