@@ -410,6 +410,50 @@ __device__ __forceinline__ void finish_candidates(int cnt, int k, int kk, int kp
         }
         __syncthreads();   // massive ties at the bound: the sort below
     }
+    if (kRankFinish && kk > 64 && cnt > kpow2 && cnt <= kCand / 2) {
+        // Large k (the matcher dump's k = 256 with ~750 candidates): instead of sorting the list padded to 1 024 (55 barrier
+        // stages over 512 pairs), find the kk-th largest score key by a 4-pass radix select over the candidates in LDS, keep
+        // the candidates that reach it — exactly kk unless scores tie at the bound — and sort those (kpow2 entries: 36 stages
+        // over 128 pairs at k = 256).  Ties at the bound that do not fit: the full sort below, as before.
+        const int tid = threadIdx.x;
+        if (tid == 0) { sh.prefix = 0u; sh.need = kk; }
+        __syncthreads();
+        for (int pass = 0; pass < 4; ++pass) {
+            const int shift = 24 - 8 * pass;
+            const uint32_t hi_mask = pass == 0 ? 0u : (0xFFFFFFFFu << (shift + 8));
+            sh.hist[tid] = 0;
+            __syncthreads();
+            const uint32_t prefix = sh.prefix;
+            for (int i = tid; i < cnt; i += kBlock) {
+                const uint32_t key = (uint32_t)(sh.cand[i] >> 32);
+                if ((key & hi_mask) == prefix) atomicAdd(&sh.hist[(key >> shift) & 255u], 1);
+            }
+            __syncthreads();
+            radix_pick_bin(sh, prefix, shift);
+        }
+        const uint32_t thr = sh.prefix;          // the kk-th largest key
+        if (tid == 0) { sh.count = 0; sh.eq_total = 0; }
+        __syncthreads();
+        unsigned long long* list2 = sh.cand + kCand / 2;
+        for (int i = tid; i < cnt; i += kBlock) {
+            const unsigned long long c = sh.cand[i];
+            const uint32_t key = (uint32_t)(c >> 32);
+            if (key >= thr) {
+                const int slot = atomicAdd(&sh.count, 1);
+                if (slot < kpow2) list2[slot] = c;
+            }
+        }
+        __syncthreads();
+        const int n2 = sh.count;                  // >= kk; == kk unless several candidates carry the bound's score
+        if (n2 <= kpow2) {                        // block-uniform
+            for (int i = n2 + tid; i < kpow2; i += kBlock) list2[i] = 0ull;   // pads sort last
+            __syncthreads();
+            bitonic_desc(list2, kpow2);
+            write_row(list2, kk, k, q, out_idx, out_score);
+            return;
+        }
+        __syncthreads();
+    }
     int p2 = kpow2;
     while (p2 < cnt) p2 <<= 1;
     for (int i = cnt + threadIdx.x; i < p2; i += kBlock) sh.cand[i] = 0ull;
