@@ -1180,6 +1180,8 @@ __global__ __launch_bounds__(kBlock) void topk_finalize_kernel(FusedArgs a, int 
     select_row_exact(row, a.n_items, k, kk, kpow2, q, out_idx, out_score, sh);
 }
 
+#include "topk_prefilter.hpp"
+
 }  // namespace
 
 static int mi_cu_count() {
@@ -1192,6 +1194,66 @@ static int mi_cu_count() {
     return n_cu;
 }
 
+// bf16x3 prefilter (topk_prefilter.hpp): split tables, thresholds, slice-partitioned lists and their counters
+static size_t topk_prefilter_bytes(int64_t n_q, int64_t n_items) {
+    const size_t q_pad = (size_t)mi_ceil_div(n_q, 256) * 256, i_pad = (size_t)mi_ceil_div(n_items, 64) * 64;
+    return mi_align_up(i_pad * 128 * sizeof(float), 256) + mi_align_up(q_pad * 128 * sizeof(float), 256) +
+           2 * mi_align_up(q_pad * sizeof(float), 256) + 256 +
+           mi_align_up(q_pad * kPreCap * sizeof(unsigned long long), 256) + mi_align_up(q_pad * 256 * sizeof(int), 256);
+}
+
+static bool topk_prefilter_on() {
+    const char* e = getenv("LAPLACE_TOPK_PREFILTER");   // "0": the f32 fused path (A/B, tests of both); read per call
+    return !(e && e[0] == '0');
+}
+
+template <int D>
+static int topk_prefilter_launch(const FusedArgs& a, MiArena& ar, int k, int kpow2, float* scores, int64_t* out_idx,
+                                 float* out_score, int n_cu, hipStream_t s) {
+    const int64_t strips = mi_ceil_div(a.n_q, 256), q_pad = strips * 256;
+    const int64_t panels = mi_ceil_div(a.n_items, 64), i_pad = panels * 64;
+    uint2* Ib = reinterpret_cast<uint2*>(ar.take<float>((size_t)i_pad * 128));
+    uint2* Ub = reinterpret_cast<uint2*>(ar.take<float>((size_t)q_pad * 128));
+    float* thrf = ar.take<float>((size_t)q_pad);
+    float* epsv = ar.take<float>((size_t)q_pad);
+    uint32_t* n2max = ar.take<uint32_t>(64);
+    unsigned long long* pre = ar.take<unsigned long long>((size_t)q_pad * kPreCap);
+    int* pre_cnt = ar.take<int>((size_t)q_pad * 256);
+    if (!Ib || !Ub || !thrf || !epsv || !n2max || !pre || !pre_cnt) return MI_ERR_WORKSPACE;
+    // One workgroup per CU (its LDS ring), 8 XCDs: the workgroups of an XCD run ceil(strips * sl / per_xcd) rounds of
+    // panels / (8 sl) panels each (+ the prologue, ~2 panels' worth)
+    const int64_t per_xcd = std::max(1, n_cu / 8);
+    int64_t sl = 1, best = INT64_MAX;
+    for (int64_t l = 1; l <= 32; ++l) {
+        const int64_t cost = mi_ceil_div(strips * l, per_xcd) * (mi_ceil_div(panels, 8 * l) + 2);
+        if (cost < best) { best = cost; sl = l; }
+    }
+    PreArgs pa;
+    pa.n_q = a.n_q; pa.n_items = a.n_items; pa.panels = panels;
+    pa.Ub = reinterpret_cast<const uint4*>(Ub); pa.Ib = reinterpret_cast<const uint4*>(Ib);
+    pa.thrf = thrf; pa.pre = pre; pa.pre_cnt = pre_cnt;
+    pa.strips = (int)strips; pa.n_slices = (int)(8 * sl); pa.cap_s = kPreCap / pa.n_slices;
+    pa.panels_per_slice = mi_ceil_div(panels, pa.n_slices);
+    MI_HIP(hipMemsetAsync(n2max, 0, sizeof(uint32_t), s));
+    constexpr int RPB = 256 / (D / 4);
+    hipLaunchKernelGGL(topk_split_rows_kernel<D>, dim3((unsigned)mi_ceil_div(i_pad, RPB)), dim3(256), 0, s, a.n_items, i_pad,
+                       a.I, a.ldi, (const int64_t*)nullptr, Ib, n2max, (const uint32_t*)nullptr, (float*)nullptr, (float*)nullptr);
+    hipLaunchKernelGGL(topk_split_rows_kernel<D>, dim3((unsigned)mi_ceil_div(q_pad, RPB)), dim3(256), 0, s, a.n_q, q_pad,
+                       a.U, a.ldu, a.uid, Ub, n2max, a.thr, thrf, epsv);
+    auto kern = topk_prefilter_bf16_kernel<D>;
+    constexpr int lds = 3 * 64 * (D / 4) * 16;
+    static bool attr_set = false;  // per instantiation; idempotent
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+            return MI_ERR_UNSUPPORTED;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)(8 * sl * strips)), dim3(256), lds, s, pa);
+    hipLaunchKernelGGL(topk_refine_finalize_kernel, dim3((unsigned)a.n_q), dim3(kBlock), 0, s, a, pa, epsv, k, kpow2, scores,
+                       out_idx, out_score);
+    return mi_launch_status();
+}
+
 extern "C" {
 
 static size_t topk_fused_extra_bytes(int64_t n_q, int64_t n_items) {
@@ -1200,7 +1262,8 @@ static size_t topk_fused_extra_bytes(int64_t n_q, int64_t n_items) {
            mi_align_up((size_t)n_q * kSample * sizeof(float), 256) +             // sample scores
            mi_align_up((size_t)n_q * words * sizeof(uint32_t), 256) +            // exclusion bitmap
            2 * mi_align_up((size_t)n_q * sizeof(uint32_t), 256) +                // thresholds, counters
-           mi_align_up((size_t)n_q * kCap * sizeof(unsigned long long), 256);    // candidate lists
+           mi_align_up((size_t)n_q * kCap * sizeof(unsigned long long), 256) +   // candidate lists
+           topk_prefilter_bytes(n_q, n_items);
 }
 
 size_t mi_topk_workspace_bytes(int64_t n_q, int64_t n_items, int64_t k) {
@@ -1268,6 +1331,10 @@ int mi_topk_excl_f32(int64_t n_q, int64_t n_items, int64_t d, int64_t k, const i
         hipLaunchKernelGGL(threshold_kernel, dim3((unsigned)n_q), dim3(kBlock), 0, s, n_q, n_items, (int)k, sample_scores,
                            excl_ptr, excl_idx, bitmap, words, thr, cnt);
         a.thr = thr; a.bitmap = bitmap; a.words = words; a.cand = cand; a.cnt = cnt;
+        if (topk_prefilter_on() && (d == 128 || d == 64) && k <= kPreMaxK) {
+            if (d == 128) return topk_prefilter_launch<128>(a, ar, (int)k, kpow2, scores, out_idx, out_score, mi_cu_count(), s);
+            return topk_prefilter_launch<64>(a, ar, (int)k, kpow2, scores, out_idx, out_score, mi_cu_count(), s);
+        }
         const int64_t n_tiles = mi_ceil_div(n_items, FN);
         // Every workgroup does the same work and two fit on a CU, so the launch runs in ceil(grid / (2 * CUs)) rounds of
         // tiles_per_slice panels each: a grid one workgroup over a multiple of the chip's capacity (the old rule,

@@ -1,0 +1,405 @@
+// K10, bf16x3 PREFILTER of the fused top-K (included by topk.hip inside its anonymous namespace).
+//
+// The f32 MFMA chain of topk_scores_filter_dma_kernel is 0.71 of the f32 matrix peak and cannot go faster; the bf16
+// matrix rate is 16x the f32 one.  So the scores that decide WHO IS A CANDIDATE are computed in bf16 with a proven error
+// bound, and only the few candidates that can still reach the answer are scored again with the exact k-ordered f32 fma
+// chain (the oracle's bits, utils/metrics_lightgcn.py:137 restated in oracle/).  The ids and scores returned are the
+// same as on the f32 path, by construction:
+//
+//   x = hi + lo + r, hi = bf16(x), lo = bf16(x - hi):  |r| <= 2^-16 |x|.   s~ = sum_d uh*ih + ul*ih + uh*il  (bf16
+//   products are exact in f32; the MFMA accumulates in f32).  |s~ - s_chain| <= eps(u) for every item, with
+//     eps(u) = kPreC * |u|_2 * max_i |i|_2,   kPreC = 2^-12
+//   (dropped terms ul*il, uh*ir, ur*i: <= 3.02 * 2^-16; f32 accumulation of 3*D products, D <= 128: <= 4.9e-5; the
+//   exact chain's own rounding: <= D * 2^-24; Cauchy-Schwarz on sum |u_d||i_d|; total 1.05e-4 — kPreC is 2.3x that).
+//
+//   1. P = { i : s~_i >= thr - 3 eps }  (thr = the sampled f32 threshold of threshold_kernel).  Complete: nothing
+//      outside P has s~ >= thr - 3 eps.
+//   2. t2 <= the kk-th largest s~ in P.  kk items have s >= t2 - eps, so the exact kk-th largest score S_k >= t2 - eps,
+//      and every item with s >= S_k has s~ >= t2 - 2 eps.  If t2 - 2 eps >= thr - 3 eps they are all in P: the SURVIVORS
+//      { i in P : s~_i >= t2 - 2 eps } hold every winner (and every tie at the bound).  Otherwise the row takes the exact
+//      path, like a row whose list came out short on the f32 path.
+//   3. The survivors (about kk * |P| / 64 for kk <= 64, about kk above) are scored exactly and finish_candidates() picks
+//      the answer from them.
+//
+// Layout.  Both tables are split once per call into rows [hi(0..D) | lo(0..D)] of bf16 (the f32 row's size).  The
+// QUERIES are the MFMA's B operand and live in registers for the whole launch (a wavefront owns 64 of them: 128 VGPRs),
+// the ITEMS are the A operand and stream through a ring of three 64-item panels in LDS (16-byte chunks XOR-swizzled by
+// the row: conflict-free ds_read_b128).  ih is read once for two of the three products.  A lane holds ONE query per
+// 32x32 block (C layout: column = lane & 31), so its threshold is one register and its list position a register
+// counter: a query's candidates go straight to the (query, item-slice) region of the list that only this wavefront
+// writes — no staging, no atomics, no flush.  The votes on panel t-1 are issued between the MFMAs of panel t.
+// Workgroups that share an item slice are dealt to the same XCD, so that the slice is fetched into one L2.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr float kPreC = 2.44140625e-4f;   // 2^-12, see above
+constexpr int kPreCap = 8192;             // list slots per query in global memory, divided among the item slices
+constexpr int kPreMaxK = 256;             // beyond: the f32 path (the survivors of a row must fit the finish step)
+constexpr int kPreSurv = 2048;            // survivors per row the refine step takes
+
+struct PreArgs {
+    int64_t n_q, n_items;
+    int64_t panels;             // 64-item panels of the padded item table
+    const uint4* Ub;            // [strips * 256][D / 4]: 16-byte chunks, hi half then lo half
+    const uint4* Ib;            // [panels * 64][D / 4]
+    const float* thrf;          // [strips * 256]: thr - 3 eps; +inf for padding queries
+    unsigned long long* pre;    // [strips * 256][kPreCap]: (item << 32) | bits(s~)
+    int* pre_cnt;               // [strips * 256][n_slices]
+    int strips, n_slices, cap_s;
+    int64_t panels_per_slice;
+};
+
+__device__ __forceinline__ uint32_t bf16_rn_bits(float x) {
+    const uint32_t u = __float_as_uint(x);
+    if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (u >> 16) | 0x40u;  // NaN stays NaN
+    return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+
+// Rows of T (through row_map when given) -> [hi | lo] bf16 rows; rows in [n_rows, n_pad) are zero.  |row|^2 goes to
+// n2_max (items: the largest) or, with thr given (queries), into thrf / epsv.
+template <int D>
+__global__ __launch_bounds__(256) void topk_split_rows_kernel(int64_t n_rows, int64_t n_pad, const float* __restrict__ T,
+                                                              int64_t ld, const int64_t* __restrict__ row_map,
+                                                              uint2* __restrict__ out, uint32_t* __restrict__ n2_max,
+                                                              const uint32_t* __restrict__ thr, float* __restrict__ thrf,
+                                                              float* __restrict__ epsv) {
+    constexpr int LPR = D / 4, RPB = 256 / LPR;
+    const int li = threadIdx.x % LPR;
+    const int64_t r = (int64_t)blockIdx.x * RPB + threadIdx.x / LPR;
+    if (r >= n_pad) return;  // whole sub-groups leave together
+    float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r < n_rows) {
+        const int64_t row = row_map ? row_map[r] : r;
+        x = *reinterpret_cast<const float4*>(T + row * ld + 4 * li);
+    }
+    const float xs[4] = {x.x, x.y, x.z, x.w};
+    uint32_t hb[4], lb[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        hb[c] = bf16_rn_bits(xs[c]);
+        lb[c] = bf16_rn_bits(xs[c] - __uint_as_float(hb[c] << 16));   // exact difference
+    }
+    out[r * (D / 2) + li] = make_uint2(hb[0] | (hb[1] << 16), hb[2] | (hb[3] << 16));
+    out[r * (D / 2) + D / 4 + li] = make_uint2(lb[0] | (lb[1] << 16), lb[2] | (lb[3] << 16));
+    float n2 = x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w;
+#pragma unroll
+    for (int m = LPR / 2; m > 0; m >>= 1) n2 += __shfl_xor(n2, m, LPR);
+    if (li != 0) return;
+    if (thr) {  // queries
+        if (r < n_rows) {
+            const float eps = kPreC * 1.01f * sqrtf(n2) * sqrtf(__uint_as_float(*n2_max));
+            epsv[r] = eps;
+            thrf[r] = key_score(thr[r]) - 3.f * eps;   // NaN / -inf: everything passes, the row overflows -> exact path
+        } else {
+            thrf[r] = INFINITY;
+        }
+    } else if (r < n_rows) {
+        atomicMax(n2_max, __float_as_uint(n2));        // n2 >= 0: the bit patterns order like the values; NaN wins
+    }
+}
+
+// One vote of the previous panel: accumulator register e of `prev` against its query's threshold; the lanes that pass
+// write (item, s~) to their query's slice region.  cnt[ub] is the lane's copy of its query's fill (lanes r and r + 32
+// hold the same query and count each other's hits).
+// The count runs on past cap_s: that is how the refine step sees an overflow.
+__device__ __forceinline__ void pre_hit(unsigned long long hm, float v, uint32_t item, int lane, int& cnt, int cap_s,
+                                        unsigned long long* __restrict__ region) {
+    const int r = lane & 31;
+    const int lo_hit = (int)((hm >> r) & 1ull), hi_hit = (int)((hm >> (r + 32)) & 1ull);
+    if ((hm >> lane) & 1ull) {
+        const int slot = cnt + ((lane >> 5) & lo_hit);
+        if (slot < cap_s) region[slot] = ((unsigned long long)item << 32) | (unsigned long long)__float_as_uint(v);
+    }
+    cnt += lo_hit + hi_hit;
+}
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+template <int PIECES>
+__device__ __forceinline__ void pre_issue(u32x4 (&g)[PIECES], const uint4* __restrict__ src) {
+#pragma unroll
+    for (int j = 0; j < PIECES; ++j) g[j] = *reinterpret_cast<const u32x4*>(src + 256 * j);
+}
+template <int PIECES>
+__device__ __forceinline__ void pre_commit(const u32x4 (&g)[PIECES], unsigned char* buf, const uint32_t (&woff)[PIECES]) {
+#pragma unroll
+    for (int j = 0; j < PIECES; ++j) *reinterpret_cast<u32x4*>(buf + woff[j]) = g[j];
+}
+
+template <int D>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void topk_prefilter_bf16_kernel(PreArgs a) {
+    constexpr int S = D / 16;                  // k-steps per part
+    constexpr int CH = D / 4;                  // 16-byte chunks per row
+    constexpr int ROWB = CH * 16;
+    constexpr int PANELB = 64 * ROWB;
+    constexpr int PIECES = PANELB / 16 / 256;  // chunks a thread moves per panel
+    constexpr int NS = 12 * S;                 // MFMAs per panel and wavefront
+    extern __shared__ __align__(16) unsigned char pre_ring[];   // 3 panels
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int bx = blockIdx.x & 7, bj = blockIdx.x >> 3;
+    const int strip = bj % a.strips;
+    const int64_t slice = (int64_t)(bj / a.strips) * 8 + bx;
+    const int64_t p0 = slice * a.panels_per_slice;
+    const int64_t p1 = min(a.panels, p0 + a.panels_per_slice);
+    const int64_t u0 = (int64_t)strip * 256 + wave * 64;   // this wavefront's 64 queries
+    int* my_cnt_out = a.pre_cnt + (u0 + r) * a.n_slices + slice;
+    if (p0 >= p1) {  // block-uniform: an empty slice still owns its counters
+        if (h == 0) { my_cnt_out[0] = 0; my_cnt_out[32 * (int64_t)a.n_slices] = 0; }
+        return;
+    }
+    // queries: fragments of the B operand, lane (r, h) holds k = 8 h .. 8 h + 7 of k-step s for query 32 ub + r
+    bf16x8 uh[2][S], ul[2][S];
+#pragma unroll
+    for (int ub = 0; ub < 2; ++ub) {
+        const uint4* up = a.Ub + (u0 + 32 * ub + r) * CH + h;
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            uh[ub][s] = __builtin_bit_cast(bf16x8, up[2 * s]);
+            ul[ub][s] = __builtin_bit_cast(bf16x8, up[CH / 2 + 2 * s]);
+        }
+    }
+    const float tq[2] = {a.thrf[u0 + r], a.thrf[u0 + 32 + r]};
+    unsigned long long* region[2];
+#pragma unroll
+    for (int ub = 0; ub < 2; ++ub) {
+        const int64_t q = u0 + 32 * ub + r;   // (padding queries have rows of their own: they pass only on NaN scores)
+        region[ub] = a.pre + q * kPreCap + slice * a.cap_s;
+    }
+    int cnt[2] = {0, 0};
+    // item panels: a panel is one contiguous block of the split table; chunk (row, c) lives at row * ROWB + ((c ^ (row & 15)) << 4)
+    u32x4 g[PIECES];
+    uint32_t woff[PIECES];
+#pragma unroll
+    for (int j = 0; j < PIECES; ++j) {
+        const int idx = tid + 256 * j, row = idx / CH, c = idx % CH;
+        woff[j] = (uint32_t)(row * ROWB + ((c ^ (row & 15)) << 4));
+    }
+    pre_issue<PIECES>(g, a.Ib + p0 * (64 * CH) + tid);
+    pre_commit<PIECES>(g, pre_ring, woff);
+    if (p0 + 1 < p1) pre_issue<PIECES>(g, a.Ib + (p0 + 1) * (64 * CH) + tid);
+    // read offsets: item block ib, row 32 ib + r, chunk (part * CH / 2 + 2 s + h) ^ (r & 15) — one xor with a constant per read
+    const uint32_t rx[2] = {(uint32_t)(r * ROWB) ^ (uint32_t)((h ^ (r & 15)) << 4),
+                            (uint32_t)((32 + r) * ROWB) ^ (uint32_t)((h ^ (r & 15)) << 4)};
+    f32x16 acc0[4], acc1[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { acc0[i][e] = 0.f; acc1[i][e] = 0.f; }
+    unsigned long long prev_ok = 0ull;   // no previous panel yet
+    uint32_t item_prev = 0;
+    const uint32_t row4 = 4u * (uint32_t)h;
+    uint32_t cur = 0, nxt = PANELB;
+    __syncthreads();
+
+    // fragments of the A operand: [buffer][2 ib + part], read one k-step ahead of their MFMAs
+    bf16x8 fr[2][4];
+#define MI_PRE_READ(dst, buf, s)                                                                                        \
+    {                                                                                                                   \
+        _Pragma("unroll") for (int ib_ = 0; ib_ < 2; ++ib_) {                                                           \
+            dst[2 * ib_] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(pre_ring + (buf) + (rx[ib_] ^ (uint32_t)((2 * (s)) << 4)))); \
+            dst[2 * ib_ + 1] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(pre_ring + (buf) + (rx[ib_] ^ (uint32_t)((CH / 2 + 2 * (s)) << 4)))); \
+        }                                                                                                               \
+    }
+    MI_PRE_READ(fr[0], 0u, 0)
+#define MI_PRE_VOTE(prev, e)                                                                                            \
+    {                                                                                                                   \
+        const int ai_ = (e) >> 4, reg_ = (e) & 15;                                                                      \
+        const float v_ = prev[ai_][reg_];                                                                               \
+        const unsigned long long hm_ = __ballot(!(v_ < tq[ai_ & 1])) & prev_ok;                                         \
+        if (hm_)                                                                                                        \
+            pre_hit(hm_, v_, item_prev + (uint32_t)((ai_ >> 1) * 32 + (reg_ & 3) + 8 * (reg_ >> 2)) + row4, lane,      \
+                    cnt[ai_ & 1], a.cap_s, region[ai_ & 1]);                                                      \
+    }
+#define MI_PRE_PANEL(acc, prev, p)                                                                                      \
+    {                                                                                                                   \
+        if ((p) + 1 < p1) pre_commit<PIECES>(g, pre_ring + nxt, woff);   /* panel p + 1: loaded one panel ago */        \
+        if ((p) + 2 < p1) pre_issue<PIECES>(g, a.Ib + ((p) + 2) * (64 * CH) + tid);                                     \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                   \
+            _Pragma("unroll") for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;                                             \
+        _Pragma("unroll") for (int s = 0; s < S; ++s) {                                                                 \
+            if (s + 1 < S) MI_PRE_READ(fr[(s + 1) & 1], cur, s + 1)   /* a k-step ahead: the votes' branches pin it here */ \
+            _Pragma("unroll") for (int term = 0; term < 3; ++term)                                                      \
+                _Pragma("unroll") for (int ai = 0; ai < 4; ++ai) {                                                      \
+                    const int ib = ai >> 1, ub = ai & 1;                                                                \
+                    acc[ai] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[s & 1][2 * ib + (term == 2 ? 1 : 0)],         \
+                                                                      term == 1 ? ul[ub][s] : uh[ub][s], acc[ai], 0, 0, 0); \
+                    const int m = s * 12 + term * 4 + ai;                                                               \
+                    _Pragma("unroll") for (int e = m * 64 / NS; e < (m + 1) * 64 / NS; ++e) MI_PRE_VOTE(prev, e)        \
+                }                                                                                                       \
+        }                                                                                                               \
+        item_prev = (uint32_t)((p) * 64);                                                                               \
+        prev_ok = ~0ull;                                                                                                \
+        cur = nxt;                                                                                                      \
+        nxt = nxt + PANELB == 3 * PANELB ? 0u : nxt + PANELB;                                                           \
+        __syncthreads();  /* panel p + 1 is in LDS and everybody is done with panel p */                                \
+        if ((p) + 1 < p1) MI_PRE_READ(fr[0], cur, 0)                                                                    \
+    }
+
+    int64_t p = p0;
+    for (; p + 1 < p1; p += 2) {
+        MI_PRE_PANEL(acc0, acc1, p)
+        MI_PRE_PANEL(acc1, acc0, p + 1)
+    }
+    bool last_in_acc0 = false;
+    if (p < p1) {
+        MI_PRE_PANEL(acc0, acc1, p)
+        last_in_acc0 = true;
+    }
+    // the last panel's votes
+    if (last_in_acc0) {
+#pragma unroll
+        for (int e = 0; e < 64; ++e) MI_PRE_VOTE(acc0, e)
+    } else {
+#pragma unroll
+        for (int e = 0; e < 64; ++e) MI_PRE_VOTE(acc1, e)
+    }
+#undef MI_PRE_PANEL
+#undef MI_PRE_READ
+#undef MI_PRE_VOTE
+    if (h == 0) {
+#pragma unroll
+        for (int ub = 0; ub < 2; ++ub)
+            my_cnt_out[32 * ub * (int64_t)a.n_slices] = cnt[ub];
+    }
+}
+
+// The kk-th largest score key among the n composites in sh.cand (n >= kk): 4-pass radix select in LDS.
+__device__ __forceinline__ uint32_t kth_key_of_cands(SelectShared& sh, int n, int kk) {
+    const int tid = threadIdx.x;
+    if (tid == 0) { sh.prefix = 0u; sh.need = kk; }
+    __syncthreads();
+    for (int pass = 0; pass < 4; ++pass) {
+        const int shift = 24 - 8 * pass;
+        const uint32_t hi_mask = pass == 0 ? 0u : (0xFFFFFFFFu << (shift + 8));
+        sh.hist[tid] = 0;
+        __syncthreads();
+        const uint32_t prefix = sh.prefix;
+        for (int i = tid; i < n; i += kBlock) {
+            const uint32_t key = (uint32_t)(sh.cand[i] >> 32);
+            if ((key & hi_mask) == prefix) atomicAdd(&sh.hist[(key >> shift) & 255u], 1);
+        }
+        __syncthreads();
+        radix_pick_bin(sh, prefix, shift);
+    }
+    return sh.prefix;
+}
+
+// One block per query: the slice regions of its list -> LDS (exclusions and table padding dropped here), the survivor
+// bound of step 2, exact scores of the survivors, finish_candidates().  Rows that cannot be decided this way (a region
+// or the list overflowed, fewer than kk candidates, the bound dips below the list's own) are recomputed exactly, as on
+// the f32 path.
+__global__ __launch_bounds__(kBlock) void topk_refine_finalize_kernel(FusedArgs a, PreArgs pa, const float* __restrict__ epsv,
+                                                                      int k, int kpow2, float* __restrict__ scores,
+                                                                      int64_t* __restrict__ out_idx,
+                                                                      float* __restrict__ out_score) {
+    __shared__ SelectShared sh;
+    __shared__ uint32_t surv[kPreSurv];
+    __shared__ __align__(16) float urow[FKC];
+    __shared__ int bad;
+    const int64_t q = blockIdx.x;
+    if (q >= a.n_q) return;
+    const int tid = threadIdx.x;
+    const int kk = (int)min((int64_t)k, a.n_items);
+    const float* u = a.U + a.uid[q] * a.ldu;
+    if (tid == 0) { sh.count = 0; bad = 0; }
+    for (int c = tid; c < a.d; c += kBlock) urow[c] = u[c];
+    __syncthreads();
+    {   // gather: tps threads per slice region
+        const int n_sl = pa.n_slices;               // <= 256
+        const int tps = max(1, kBlock / n_sl);
+        const int* cq = pa.pre_cnt + q * n_sl;
+        const unsigned long long* pq = pa.pre + q * kPreCap;
+        for (int sl = tid / tps; sl < n_sl; sl += kBlock / tps) {
+            const int n = cq[sl];
+            if (n > pa.cap_s) bad = 1;               // benign race: every writer stores 1
+            const unsigned long long* reg = pq + (int64_t)sl * pa.cap_s;
+            for (int i = tid % tps; i < min(n, pa.cap_s); i += tps) {
+                const unsigned long long e = reg[i];
+                const uint32_t item = (uint32_t)(e >> 32);
+                if (item >= (uint32_t)a.n_items) continue;                                          // table padding
+                if ((a.bitmap[q * a.words + (item >> 5)] >> (item & 31)) & 1u) continue;         // excluded
+                const int slot = atomicAdd(&sh.count, 1);
+                if (slot < kCand) sh.cand[slot] = composite(score_key(__uint_as_float((uint32_t)e)), item);
+            }
+        }
+    }
+    __syncthreads();
+    const int cnt = sh.count;
+    bool ok = !bad && cnt >= kk && cnt <= kCand;   // block-uniform
+    if (ok) {
+        // t2: a lower bound of the kk-th largest approximate key
+        uint32_t t2;
+        if (kk <= 64) {   // the kk-th largest of the first S entries (cf. finish_candidates)
+            const int S = min(cnt, kk <= 16 ? 64 : (kk <= 32 ? 128 : 256));
+            uint32_t* keys = reinterpret_cast<uint32_t*>(sh.hist);
+            const uint32_t x = tid < S ? (uint32_t)(sh.cand[tid] >> 32) : 0u;
+            keys[tid] = x;
+            __syncthreads();
+            if (tid < S) {
+                int gt = 0, ge = 0;
+                const uint4* k4 = reinterpret_cast<const uint4*>(keys);
+#pragma unroll 8
+                for (int j = 0; j < (S + 3) / 4; ++j) {
+                    const uint4 o = k4[j];
+                    gt += (o.x > x) + (o.y > x) + (o.z > x) + (o.w > x);
+                    ge += (o.x >= x) + (o.y >= x) + (o.z >= x) + (o.w >= x);
+                }
+                if (gt <= kk - 1 && kk - 1 < ge) sh.prefix = x;
+            }
+            __syncthreads();
+            t2 = sh.prefix;
+        } else {
+            t2 = kth_key_of_cands(sh, cnt, kk);
+        }
+        const float eps = epsv[q];
+        const float t_l = key_score(t2) - 2.f * eps;
+        ok = t_l >= pa.thrf[q];                      // false on NaN as well
+        if (ok) {
+            if (tid == 0) sh.need = 0;
+            __syncthreads();
+            for (int i = tid; i < cnt; i += kBlock) {
+                const unsigned long long c = sh.cand[i];
+                if (!(key_score((uint32_t)(c >> 32)) < t_l)) {
+                    const int slot = atomicAdd(&sh.need, 1);
+                    if (slot < kPreSurv) surv[slot] = 0xFFFFFFFFu - (uint32_t)c;
+                }
+            }
+            __syncthreads();
+            const int n2 = sh.need;                  // >= kk
+            ok = n2 <= kPreSurv;
+            if (ok) {
+                // exact scores: the k-ordered fma chain, bit for bit the f32 MFMA's and the oracle's
+                for (int i = tid; i < n2; i += kBlock) {
+                    const uint32_t item = surv[i];
+                    const float4* it = reinterpret_cast<const float4*>(a.I + (int64_t)item * a.ldi);
+                    float acc = 0.f;
+                    for (int c4 = 0; c4 < a.d / 4; ++c4) {
+                        const float4 w = it[c4];
+                        const float4 uu = *reinterpret_cast<const float4*>(urow + 4 * c4);
+                        acc = fmaf(uu.x, w.x, acc);
+                        acc = fmaf(uu.y, w.y, acc);
+                        acc = fmaf(uu.z, w.z, acc);
+                        acc = fmaf(uu.w, w.w, acc);
+                    }
+                    sh.cand[i] = composite(score_key(acc), item);
+                }
+                __syncthreads();
+                finish_candidates(n2, k, kk, kpow2, q, out_idx, out_score, sh);
+                return;
+            }
+        }
+    }
+    __syncthreads();
+    // rare: materialise this row's scores and select exactly (as topk_finalize_kernel)
+    float* row = scores + q * a.n_items;
+    for (int64_t i = tid; i < a.n_items; i += kBlock) {
+        const float* it = a.I + i * a.ldi;
+        float acc = 0.f;
+        for (int c = 0; c < a.d; ++c) acc = fmaf(urow[c], it[c], acc);
+        if ((a.bitmap[q * a.words + (i >> 5)] >> (i & 31)) & 1u) acc = -INFINITY;
+        row[i] = acc;
+    }
+    __syncthreads();
+    select_row_exact(row, a.n_items, k, kk, kpow2, q, out_idx, out_score, sh);
+}

@@ -652,7 +652,10 @@ def gemm_group(problems) -> bool:
     return True
 
 
-TOPK_WS_BYTES = 1 << 30  # score block per launch; queries are processed in chunks of this size
+TOPK_WS_BYTES = 2 << 30  # score block per launch; queries are processed in chunks of this size
+TOPK_CHUNK_QUANTUM = 2048  # chunks are multiples of this when they can be: the bf16 prefilter kernel (csrc/topk_prefilter.hpp)
+                           # keeps 256 queries per workgroup and deals the workgroups of an item slice to one XCD's 32 CUs —
+                           # 2 048 / 4 096 queries fill the chip in one round (100 K items: 4 096 per chunk)
 # (Round 3, measured and not kept: alternating the chunks of one call over two streams, each with its own workspace, so that
 # one chunk's side kernels — sample scores, bitmap, threshold, finalize, ~18 % of its time — run under the other's fused
 # score + filter kernel: 3.50-3.55 M -> 2.95-3.02 M users/s at k = 12, unchanged at k = 256.  The fused kernel's grid is
@@ -676,6 +679,8 @@ def topk_excl(uid: Tensor, user_emb: Tensor, item_emb: Tensor, k: int, excl: Opt
     out_sc = t.empty(n_q, k, dtype=t.float32, device=dev) if want_scores else None
     L = _lib.lib()
     chunk = max(1, min(n_q, TOPK_WS_BYTES // max(4 * n_items, 1)))
+    if n_q > chunk >= TOPK_CHUNK_QUANTUM:
+        chunk -= chunk % TOPK_CHUNK_QUANTUM
     ws = _ws(L.mi_topk_workspace_bytes(chunk, n_items, k), dev)
     for q0 in range(0, n_q, chunk):
         q1 = min(n_q, q0 + chunk)

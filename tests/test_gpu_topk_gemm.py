@@ -142,6 +142,49 @@ def test_topk_large_rows_with_massive_ties_and_exclusions_fall_back_exactly(D):
     assert t.equal(got, want) and int((got[0] >= 0).sum()) == 60
 
 
+@pytest.mark.parametrize("D", [64, 128])
+@pytest.mark.parametrize("n_q,k", [(1, 1), (70, 12), (300, 100), (2100, 12), (515, 256)])
+def test_topk_bf16_prefilter_equals_the_f32_path(D, n_q, k, monkeypatch):
+    """The bf16x3 prefilter (csrc/topk_prefilter.hpp) only decides who is a candidate; the answer comes from the exact
+    fma chain.  Every item here has ~20 near copies whose scores differ by a few ulps — far inside the prefilter's error
+    bound, so approximate scores cannot rank them — plus exact duplicates (ties resolved by id) and exclusions of the
+    best items: ids and bitwise scores must equal the f32 fused kernel's and the oracle's."""
+    from laplace_amd import ops
+    g = t.Generator().manual_seed(100 * D + n_q + k)
+    groups, copies = 2000, 20
+    n_items = groups * copies
+    base = t.randn(groups, D, generator=g) * 0.1
+    ie = base.repeat(copies, 1)                                   # item i is a copy of base row i % groups
+    wiggle = t.randint(-3, 4, (n_items, D), generator=g).float() * 2.0 ** -23
+    wiggle[: 2 * groups] = 0.0                                    # the first two copies stay exact duplicates
+    ie = ie * (1.0 + wiggle)
+    U = max(n_q, 8)
+    ue = t.randn(U, D, generator=g) * 0.1
+    uid = t.randperm(U, generator=g)[:n_q]
+    exact = R.scores_fma(ue[uid[:40]], ie)
+    excl = []
+    for q in range(n_q):   # exclude some of the best items of the first rows, random ones elsewhere
+        if q < 40:
+            top = exact[q].topk(30).indices
+            excl.append(top[t.randperm(30, generator=g)[:11]])
+        else:
+            excl.append(t.randperm(n_items, generator=g)[: int(t.randint(0, 50, (1,), generator=g))])
+    rows = t.cat([t.full((len(e),), i) for i, e in enumerate(excl)]).long()
+    ex = ops.coo_to_csr(rows.to(DEV), t.cat(excl).to(DEV), n_q, n_items, want_perm=False)
+    args = (uid.to(DEV), ue.to(DEV), ie.to(DEV), k, ex)
+    monkeypatch.setenv("LAPLACE_TOPK_PREFILTER", "1")
+    ids_b, sc_b = ops.topk_excl(*args, want_scores=True)
+    monkeypatch.setenv("LAPLACE_TOPK_PREFILTER", "0")
+    ids_f, sc_f = ops.topk_excl(*args, want_scores=True)
+    assert t.equal(ids_b, ids_f)
+    assert t.equal(sc_b, sc_f)
+    m = min(n_q, 40)
+    want = R.topk_excl_exact(exact, excl[:m], k)
+    assert t.equal(ids_b[:m].cpu(), want)
+    valid = want >= 0
+    assert t.equal(sc_b[:m].cpu()[valid], exact.gather(1, want.clamp(min=0))[valid])
+
+
 def test_pipeline_end_to_end_small():
     from laplace_amd import synthetic as S
     from laplace_amd.config import LightGCNConfig
