@@ -1199,7 +1199,7 @@ static size_t topk_prefilter_bytes(int64_t n_q, int64_t n_items) {
     const size_t q_pad = (size_t)mi_ceil_div(n_q, 256) * 256, i_pad = (size_t)mi_ceil_div(n_items, 64) * 64;
     return mi_align_up(i_pad * 128 * sizeof(float), 256) + mi_align_up(q_pad * 128 * sizeof(float), 256) +
            2 * mi_align_up(q_pad * sizeof(float), 256) + 256 +
-           mi_align_up(q_pad * kPreCap * sizeof(unsigned long long), 256) + mi_align_up(q_pad * 256 * sizeof(int), 256);
+           mi_align_up(q_pad * kPreCap * sizeof(unsigned long long), 256) + mi_align_up(q_pad * 512 * sizeof(int), 256);
 }
 
 static bool topk_prefilter_on() {
@@ -1218,7 +1218,7 @@ static int topk_prefilter_launch(const FusedArgs& a, MiArena& ar, int k, int kpo
     float* epsv = ar.take<float>((size_t)q_pad);
     uint32_t* n2max = ar.take<uint32_t>(64);
     unsigned long long* pre = ar.take<unsigned long long>((size_t)q_pad * kPreCap);
-    int* pre_cnt = ar.take<int>((size_t)q_pad * 256);
+    int* pre_cnt = ar.take<int>((size_t)q_pad * 512);
     if (!Ib || !Ub || !thrf || !epsv || !n2max || !pre || !pre_cnt) return MI_ERR_WORKSPACE;
     // One workgroup per CU (its LDS ring), 8 XCDs: the workgroups of an XCD run ceil(strips * sl / per_xcd) rounds of
     // panels / (8 sl) panels each (+ the prologue, ~2 panels' worth)
@@ -1232,11 +1232,12 @@ static int topk_prefilter_launch(const FusedArgs& a, MiArena& ar, int k, int kpo
     pa.n_q = a.n_q; pa.n_items = a.n_items; pa.panels = panels;
     pa.Ub = reinterpret_cast<const uint4*>(Ub); pa.Ib = reinterpret_cast<const uint4*>(Ib);
     pa.thrf = thrf; pa.pre = pre; pa.pre_cnt = pre_cnt;
-    pa.strips = (int)strips; pa.n_slices = (int)(8 * sl); pa.cap_s = kPreCap / pa.n_slices;
+    pa.strips = (int)strips; pa.n_slices = (int)(8 * sl); pa.cap_s = 2;
+    while (pa.cap_s * 2 * pa.n_slices <= kPreCap) pa.cap_s *= 2;
     pa.panels_per_slice = mi_ceil_div(panels, pa.n_slices);
     MI_HIP(hipMemsetAsync(n2max, 0, sizeof(uint32_t), s));
     constexpr int RPB = 256 / (D / 4);
-    hipLaunchKernelGGL(topk_split_rows_kernel<D>, dim3((unsigned)mi_ceil_div(i_pad, RPB)), dim3(256), 0, s, a.n_items, i_pad,
+    hipLaunchKernelGGL(topk_split_rows_kernel<D>, dim3((unsigned)std::min<int64_t>(mi_ceil_div(i_pad, RPB), 4 * n_cu)), dim3(256), 0, s, a.n_items, i_pad,
                        a.I, a.ldi, (const int64_t*)nullptr, Ib, n2max, (const uint32_t*)nullptr, (float*)nullptr, (float*)nullptr);
     hipLaunchKernelGGL(topk_split_rows_kernel<D>, dim3((unsigned)mi_ceil_div(q_pad, RPB)), dim3(256), 0, s, a.n_q, q_pad,
                        a.U, a.ldu, a.uid, Ub, n2max, a.thr, thrf, epsv);

@@ -31,10 +31,14 @@
 // Workgroups that share an item slice are dealt to the same XCD, so that the slice is fetched into one L2.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
+#ifndef MI_PRE_PROBE
+#define MI_PRE_PROBE 0   // timing probes (wrong results): 1 = vote branches with empty hit bodies, 2 = compares only (no branch)
+#endif
 constexpr float kPreC = 2.44140625e-4f;   // 2^-12, see above
 constexpr int kPreCap = 8192;             // list slots per query in global memory, divided among the item slices
 constexpr int kPreMaxK = 256;             // beyond: the f32 path (the survivors of a row must fit the finish step)
 constexpr int kPreSurv = 2048;            // survivors per row the refine step takes
+constexpr int kPreList = kCand - kPreSurv / 2;   // list entries per row the refine step takes (the rest of sh.cand holds the survivors' ids)
 
 struct PreArgs {
     int64_t n_q, n_items;
@@ -43,8 +47,8 @@ struct PreArgs {
     const uint4* Ib;            // [panels * 64][D / 4]
     const float* thrf;          // [strips * 256]: thr - 3 eps; +inf for padding queries
     unsigned long long* pre;    // [strips * 256][kPreCap]: (item << 32) | bits(s~)
-    int* pre_cnt;               // [strips * 256][n_slices]
-    int strips, n_slices, cap_s;
+    int* pre_cnt;               // [strips * 256][n_slices][2]
+    int strips, n_slices, cap_s;   // cap_s: list slots per (query, slice), a power of two; half of it per half-wavefront
     int64_t panels_per_slice;
 };
 
@@ -63,53 +67,63 @@ __global__ __launch_bounds__(256) void topk_split_rows_kernel(int64_t n_rows, in
                                                               const uint32_t* __restrict__ thr, float* __restrict__ thrf,
                                                               float* __restrict__ epsv) {
     constexpr int LPR = D / 4, RPB = 256 / LPR;
+    __shared__ uint32_t blk_max[256 / MI_WAVE];
     const int li = threadIdx.x % LPR;
-    const int64_t r = (int64_t)blockIdx.x * RPB + threadIdx.x / LPR;
-    if (r >= n_pad) return;  // whole sub-groups leave together
-    float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (r < n_rows) {
-        const int64_t row = row_map ? row_map[r] : r;
-        x = *reinterpret_cast<const float4*>(T + row * ld + 4 * li);
-    }
-    const float xs[4] = {x.x, x.y, x.z, x.w};
-    uint32_t hb[4], lb[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        hb[c] = bf16_rn_bits(xs[c]);
-        lb[c] = bf16_rn_bits(xs[c] - __uint_as_float(hb[c] << 16));   // exact difference
-    }
-    out[r * (D / 2) + li] = make_uint2(hb[0] | (hb[1] << 16), hb[2] | (hb[3] << 16));
-    out[r * (D / 2) + D / 4 + li] = make_uint2(lb[0] | (lb[1] << 16), lb[2] | (lb[3] << 16));
-    float n2 = x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w;
-#pragma unroll
-    for (int m = LPR / 2; m > 0; m >>= 1) n2 += __shfl_xor(n2, m, LPR);
-    if (li != 0) return;
-    if (thr) {  // queries
+    uint32_t mx = 0u;   // bits of the largest |row|^2 this thread has seen (n2 >= 0: the bit patterns order like the values; NaN wins)
+    // grid-stride over groups of RPB rows; every thread of a sub-group takes the same trips
+    for (int64_t r = (int64_t)blockIdx.x * RPB + threadIdx.x / LPR; r < n_pad; r += (int64_t)gridDim.x * RPB) {
+        float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
         if (r < n_rows) {
-            const float eps = kPreC * 1.01f * sqrtf(n2) * sqrtf(__uint_as_float(*n2_max));
-            epsv[r] = eps;
-            thrf[r] = key_score(thr[r]) - 3.f * eps;   // NaN / -inf: everything passes, the row overflows -> exact path
-        } else {
-            thrf[r] = INFINITY;
+            const int64_t row = row_map ? row_map[r] : r;
+            x = *reinterpret_cast<const float4*>(T + row * ld + 4 * li);
         }
-    } else if (r < n_rows) {
-        atomicMax(n2_max, __float_as_uint(n2));        // n2 >= 0: the bit patterns order like the values; NaN wins
+        const float xs[4] = {x.x, x.y, x.z, x.w};
+        uint32_t hb[4], lb[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            hb[c] = bf16_rn_bits(xs[c]);
+            lb[c] = bf16_rn_bits(xs[c] - __uint_as_float(hb[c] << 16));   // exact difference
+        }
+        out[r * (D / 2) + li] = make_uint2(hb[0] | (hb[1] << 16), hb[2] | (hb[3] << 16));
+        out[r * (D / 2) + D / 4 + li] = make_uint2(lb[0] | (lb[1] << 16), lb[2] | (lb[3] << 16));
+        float n2 = x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w;
+#pragma unroll
+        for (int m = LPR / 2; m > 0; m >>= 1) n2 += __shfl_xor(n2, m, LPR);
+        if (thr) {  // queries
+            if (li == 0) {
+                if (r < n_rows) {
+                    const float eps = kPreC * 1.01f * sqrtf(n2) * sqrtf(__uint_as_float(*n2_max));
+                    epsv[r] = eps;
+                    thrf[r] = key_score(thr[r]) - 3.f * eps;   // NaN / -inf: everything passes, the row overflows -> exact path
+                } else {
+                    thrf[r] = INFINITY;
+                }
+            }
+        } else if (r < n_rows) {
+            mx = max(mx, __float_as_uint(n2));
+        }
+    }
+    if (thr) return;   // kernel-uniform
+    // items: one atomic per workgroup (one per row serialised 10^5 of them on one address: 570 us)
+#pragma unroll
+    for (int m = MI_WAVE / 2; m > 0; m >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, m, MI_WAVE));
+    if ((threadIdx.x & (MI_WAVE - 1)) == 0) blk_max[threadIdx.x / MI_WAVE] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t b = blk_max[0];
+        for (int w = 1; w < 256 / MI_WAVE; ++w) b = max(b, blk_max[w]);
+        atomicMax(n2_max, b);
     }
 }
 
-// One vote of the previous panel: accumulator register e of `prev` against its query's threshold; the lanes that pass
-// write (item, s~) to their query's slice region.  cnt[ub] is the lane's copy of its query's fill (lanes r and r + 32
-// hold the same query and count each other's hits).
-// The count runs on past cap_s: that is how the refine step sees an overflow.
-__device__ __forceinline__ void pre_hit(unsigned long long hm, float v, uint32_t item, int lane, int& cnt, int cap_s,
-                                        unsigned long long* __restrict__ region) {
-    const int r = lane & 31;
-    const int lo_hit = (int)((hm >> r) & 1ull), hi_hit = (int)((hm >> (r + 32)) & 1ull);
-    if ((hm >> lane) & 1ull) {
-        const int slot = cnt + ((lane >> 5) & lo_hit);
-        if (slot < cap_s) region[slot] = ((unsigned long long)item << 32) | (unsigned long long)__float_as_uint(v);
-    }
-    cnt += lo_hit + hi_hit;
+// One score of the previous panel that reached its query's threshold: (item, s~) goes to the lane's own region — the
+// (query, item slice, half-wavefront) part of the query's list, which no other lane writes, so the fill is a register
+// counter.  Slots wrap (cap is a power of two): a region that overflows loses entries but its count runs on, which is
+// how the refine step sees it.
+__device__ __forceinline__ void pre_put(bool p, float v, uint32_t item, int& cnt, unsigned long long* __restrict__ region,
+                                        int mask) {
+    if (p) region[cnt & mask] = ((unsigned long long)item << 32) | (unsigned long long)__float_as_uint(v);
+    cnt += p ? 1 : 0;
 }
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -143,9 +157,10 @@ void topk_prefilter_bf16_kernel(PreArgs a) {
     const int64_t p0 = slice * a.panels_per_slice;
     const int64_t p1 = min(a.panels, p0 + a.panels_per_slice);
     const int64_t u0 = (int64_t)strip * 256 + wave * 64;   // this wavefront's 64 queries
-    int* my_cnt_out = a.pre_cnt + (u0 + r) * a.n_slices + slice;
+    int* my_cnt_out = a.pre_cnt + ((u0 + r) * a.n_slices + slice) * 2 + h;   // [query][slice][half]
     if (p0 >= p1) {  // block-uniform: an empty slice still owns its counters
-        if (h == 0) { my_cnt_out[0] = 0; my_cnt_out[32 * (int64_t)a.n_slices] = 0; }
+        my_cnt_out[0] = 0;
+        my_cnt_out[64 * (int64_t)a.n_slices] = 0;
         return;
     }
     // queries: fragments of the B operand, lane (r, h) holds k = 8 h .. 8 h + 7 of k-step s for query 32 ub + r
@@ -164,7 +179,7 @@ void topk_prefilter_bf16_kernel(PreArgs a) {
 #pragma unroll
     for (int ub = 0; ub < 2; ++ub) {
         const int64_t q = u0 + 32 * ub + r;   // (padding queries have rows of their own: they pass only on NaN scores)
-        region[ub] = a.pre + q * kPreCap + slice * a.cap_s;
+        region[ub] = a.pre + q * kPreCap + slice * a.cap_s + h * (a.cap_s / 2);
     }
     int cnt[2] = {0, 0};
     // item panels: a panel is one contiguous block of the split table; chunk (row, c) lives at row * ROWB + ((c ^ (row & 15)) << 4)
@@ -186,7 +201,8 @@ void topk_prefilter_bf16_kernel(PreArgs a) {
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int e = 0; e < 16; ++e) { acc0[i][e] = 0.f; acc1[i][e] = 0.f; }
-    unsigned long long prev_ok = 0ull;   // no previous panel yet
+    float tqv[2] = {INFINITY, INFINITY};   // no previous panel yet: nothing passes
+    const int cmask = a.cap_s / 2 - 1;
     uint32_t item_prev = 0;
     const uint32_t row4 = 4u * (uint32_t)h;
     uint32_t cur = 0, nxt = PANELB;
@@ -202,19 +218,32 @@ void topk_prefilter_bf16_kernel(PreArgs a) {
         }                                                                                                               \
     }
     MI_PRE_READ(fr[0], 0u, 0)
-#define MI_PRE_VOTE(prev, e)                                                                                            \
+    // Votes on the previous panel, FOUR accumulator registers at a time (rows 8 j' .. 8 j' + 3 of one 32x32 block: group g
+    // = block g >> 2, j' = g & 3): one wave-uniform branch per group instead of one per register — the chain compare ->
+    // scalar and -> scalar compare -> branch is latency a lone wavefront per SIMD cannot hide (one branch per register:
+    // 304 us per 4 096-query chunk with empty hit bodies, against 125 us of MFMAs).
+#define MI_PRE_VOTE4(prev, g)                                                                                           \
     {                                                                                                                   \
-        const int ai_ = (e) >> 4, reg_ = (e) & 15;                                                                      \
-        const float v_ = prev[ai_][reg_];                                                                               \
-        const unsigned long long hm_ = __ballot(!(v_ < tq[ai_ & 1])) & prev_ok;                                         \
-        if (hm_)                                                                                                        \
-            pre_hit(hm_, v_, item_prev + (uint32_t)((ai_ >> 1) * 32 + (reg_ & 3) + 8 * (reg_ >> 2)) + row4, lane,      \
-                    cnt[ai_ & 1], a.cap_s, region[ai_ & 1]);                                                      \
+        const int ai_ = (g) >> 2, rb_ = 4 * ((g) & 3);                                                                  \
+        const float v0_ = prev[ai_][rb_], v1_ = prev[ai_][rb_ + 1], v2_ = prev[ai_][rb_ + 2], v3_ = prev[ai_][rb_ + 3]; \
+        const float t_ = tqv[ai_ & 1];                                                                                  \
+        const bool p0_ = !(v0_ < t_), p1_ = !(v1_ < t_), p2_ = !(v2_ < t_), p3_ = !(v3_ < t_);                          \
+        if (MI_PRE_PROBE == 2) cnt[ai_ & 1] += (int)p0_ + (int)p1_ + (int)p2_ + (int)p3_;                               \
+        else if (__builtin_expect(__ballot(p0_ | p1_ | p2_ | p3_) != 0ull, 0)) {   /* out of line */                    \
+            if (MI_PRE_PROBE == 1) cnt[ai_ & 1] += 1;                                                                   \
+            else {                                                                                                      \
+                const uint32_t it_ = item_prev + (uint32_t)((ai_ >> 1) * 32 + 2 * rb_) + row4;                          \
+                pre_put(p0_, v0_, it_, cnt[ai_ & 1], region[ai_ & 1], cmask);                                           \
+                pre_put(p1_, v1_, it_ + 1, cnt[ai_ & 1], region[ai_ & 1], cmask);                                       \
+                pre_put(p2_, v2_, it_ + 2, cnt[ai_ & 1], region[ai_ & 1], cmask);                                       \
+                pre_put(p3_, v3_, it_ + 3, cnt[ai_ & 1], region[ai_ & 1], cmask);                                       \
+            }                                                                                                           \
+        }                                                                                                               \
     }
 #define MI_PRE_PANEL(acc, prev, p)                                                                                      \
     {                                                                                                                   \
-        if ((p) + 1 < p1) pre_commit<PIECES>(g, pre_ring + nxt, woff);   /* panel p + 1: loaded one panel ago */        \
-        if ((p) + 2 < p1) pre_issue<PIECES>(g, a.Ib + ((p) + 2) * (64 * CH) + tid);                                     \
+        if ((p) + 1 < p1) pre_commit<PIECES>(g, pre_ring + nxt, woff);   /* panel p + 1: loaded one panel ago */ \
+        if ((p) + 2 < p1) pre_issue<PIECES>(g, a.Ib + ((p) + 2) * (64 * CH) + tid);                \
         _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                   \
             _Pragma("unroll") for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;                                             \
         _Pragma("unroll") for (int s = 0; s < S; ++s) {                                                                 \
@@ -225,11 +254,12 @@ void topk_prefilter_bf16_kernel(PreArgs a) {
                     acc[ai] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[s & 1][2 * ib + (term == 2 ? 1 : 0)],         \
                                                                       term == 1 ? ul[ub][s] : uh[ub][s], acc[ai], 0, 0, 0); \
                     const int m = s * 12 + term * 4 + ai;                                                               \
-                    _Pragma("unroll") for (int e = m * 64 / NS; e < (m + 1) * 64 / NS; ++e) MI_PRE_VOTE(prev, e)        \
+                    if ((m + 1) % (NS / 16) == 0) MI_PRE_VOTE4(prev, m / (NS / 16))                                     \
                 }                                                                                                       \
         }                                                                                                               \
         item_prev = (uint32_t)((p) * 64);                                                                               \
-        prev_ok = ~0ull;                                                                                                \
+        tqv[0] = tq[0];                                                                                                 \
+        tqv[1] = tq[1];                                                                                                 \
         cur = nxt;                                                                                                      \
         nxt = nxt + PANELB == 3 * PANELB ? 0u : nxt + PANELB;                                                           \
         __syncthreads();  /* panel p + 1 is in LDS and everybody is done with panel p */                                \
@@ -249,19 +279,16 @@ void topk_prefilter_bf16_kernel(PreArgs a) {
     // the last panel's votes
     if (last_in_acc0) {
 #pragma unroll
-        for (int e = 0; e < 64; ++e) MI_PRE_VOTE(acc0, e)
+        for (int g = 0; g < 16; ++g) MI_PRE_VOTE4(acc0, g)
     } else {
 #pragma unroll
-        for (int e = 0; e < 64; ++e) MI_PRE_VOTE(acc1, e)
+        for (int g = 0; g < 16; ++g) MI_PRE_VOTE4(acc1, g)
     }
 #undef MI_PRE_PANEL
 #undef MI_PRE_READ
-#undef MI_PRE_VOTE
-    if (h == 0) {
+#undef MI_PRE_VOTE4
 #pragma unroll
-        for (int ub = 0; ub < 2; ++ub)
-            my_cnt_out[32 * ub * (int64_t)a.n_slices] = cnt[ub];
-    }
+    for (int ub = 0; ub < 2; ++ub) my_cnt_out[64 * ub * (int64_t)a.n_slices] = cnt[ub];
 }
 
 // The kk-th largest score key among the n composites in sh.cand (n >= kk): 4-pass radix select in LDS.
@@ -294,8 +321,10 @@ __global__ __launch_bounds__(kBlock) void topk_refine_finalize_kernel(FusedArgs 
                                                                       int64_t* __restrict__ out_idx,
                                                                       float* __restrict__ out_score) {
     __shared__ SelectShared sh;
-    __shared__ uint32_t surv[kPreSurv];
     __shared__ __align__(16) float urow[FKC];
+    // the survivors' ids live in the last quarter of sh.cand (lists longer than kPreList take the exact path): 34 KB of LDS
+    // per workgroup = four of them per CU instead of three
+    uint32_t* surv = reinterpret_cast<uint32_t*>(sh.cand + kPreList);
     __shared__ int bad;
     const int64_t q = blockIdx.x;
     if (q >= a.n_q) return;
@@ -306,27 +335,27 @@ __global__ __launch_bounds__(kBlock) void topk_refine_finalize_kernel(FusedArgs 
     for (int c = tid; c < a.d; c += kBlock) urow[c] = u[c];
     __syncthreads();
     {   // gather: tps threads per slice region
-        const int n_sl = pa.n_slices;               // <= 256
-        const int tps = max(1, kBlock / n_sl);
-        const int* cq = pa.pre_cnt + q * n_sl;
+        const int n_reg = 2 * pa.n_slices, cap = pa.cap_s / 2;   // regions: [slice][half-wavefront]
+        const int tps = max(1, kBlock / n_reg);
+        const int* cq = pa.pre_cnt + q * n_reg;
         const unsigned long long* pq = pa.pre + q * kPreCap;
-        for (int sl = tid / tps; sl < n_sl; sl += kBlock / tps) {
+        for (int sl = tid / tps; sl < n_reg; sl += kBlock / tps) {
             const int n = cq[sl];
-            if (n > pa.cap_s) bad = 1;               // benign race: every writer stores 1
-            const unsigned long long* reg = pq + (int64_t)sl * pa.cap_s;
-            for (int i = tid % tps; i < min(n, pa.cap_s); i += tps) {
+            if (n > cap) bad = 1;                    // benign race: every writer stores 1
+            const unsigned long long* reg = pq + (int64_t)sl * cap;
+            for (int i = tid % tps; i < min(n, cap); i += tps) {
                 const unsigned long long e = reg[i];
                 const uint32_t item = (uint32_t)(e >> 32);
                 if (item >= (uint32_t)a.n_items) continue;                                          // table padding
                 if ((a.bitmap[q * a.words + (item >> 5)] >> (item & 31)) & 1u) continue;         // excluded
                 const int slot = atomicAdd(&sh.count, 1);
-                if (slot < kCand) sh.cand[slot] = composite(score_key(__uint_as_float((uint32_t)e)), item);
+                if (slot < kPreList) sh.cand[slot] = composite(score_key(__uint_as_float((uint32_t)e)), item);
             }
         }
     }
     __syncthreads();
     const int cnt = sh.count;
-    bool ok = !bad && cnt >= kk && cnt <= kCand;   // block-uniform
+    bool ok = !bad && cnt >= kk && cnt <= kPreList;   // block-uniform
     if (ok) {
         // t2: a lower bound of the kk-th largest approximate key
         uint32_t t2;
