@@ -80,6 +80,7 @@ def parse_args():
     ap.add_argument("--no-ranker", action="store_true", help="skip the ranker_c3 block (BASELINE configs[2])")
     ap.add_argument("--no-pinsage", action="store_true", help="skip the pinsage_c5 block (BASELINE configs[4] at N = 1)")
     ap.add_argument("--pinsage-iters", type=int, default=300)
+    ap.add_argument("--no-topk", action="store_true", help="skip the topk_a10 block (exact top-K with exclusion, users/s)")
     ap.add_argument("--ranker-steps", type=int, default=400)
     ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 --pmc passes (roofline.traffic falls back to profiles/traffic.json)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)  # the short run the PMC passes profile
@@ -455,6 +456,17 @@ def pinsage_block(args) -> dict:
     return mod.bench_line(iters=args.pinsage_iters)
 
 
+def topk_block(args) -> dict:
+    """SURVEY row a10 at C2's item count: users/s of the exact top-K with exclusion for k = 12 (evaluation) and k = 256 (the
+    matcher dump), default path (bf16x3 prefilter + exact rescoring) beside the f32 fused kernel, ids compared, and the
+    reference's per-user host loop (oracle, 64 users) — tools/bench_topk.py."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_topk", os.path.join(ROOT, "tools", "bench_topk.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.bench_line(full=True, n_q=16384)
+
+
 _T0 = time.perf_counter()
 _LEGS = {}   # wall seconds of each leg of this invocation (reported as "wall_s": where a default run's minutes go)
 
@@ -623,6 +635,10 @@ def main():
         if args.config == "c2" and not args.no_pinsage:
             out["pinsage_c5"] = pinsage_block(args)
             tl = _leg("pinsage_c5 (incl. graph generation)", tl)
+        if args.config == "c2" and not args.no_topk:
+            t.cuda.empty_cache()
+            out["topk_a10"] = topk_block(args)
+            tl = _leg("topk_a10 (incl. graph generation and the host loop)", tl)
     if rank == 0:
         _LEGS["total"] = round(time.perf_counter() - _T0, 1)
         out["wall_s"] = dict(_LEGS)

@@ -420,8 +420,14 @@ int mi_gemm_group_supported(const mi_gemm_problem* problems, int32_t n);
  * written: scores are compared in the MFMA epilogue with a per-row threshold taken from a 4 096-item sample and only the
  * survivors are kept; a row whose survivors are fewer than k or overflow its list recomputes its scores and takes
  * the exact multi-pass selection, so the result is the same as on the materialised path (smaller item sets).
+ * For d = 64 / 128 and k <= 256 the candidates are picked by a bf16x3 PREFILTER (csrc/topk_prefilter.hpp): both tables
+ * split into bf16 hi + lo parts, u_hi.i_hi + u_lo.i_hi + u_hi.i_lo on the bf16 MFMA, every score within a proven
+ * eps(u) = 2^-12 |u| max|i| of the f32 chain; the items that can still reach the answer under that bound are scored
+ * again with the exact fma chain and the answer is picked from those — ids and scores are the f32 path's bit for bit
+ * (environment LAPLACE_TOPK_PREFILTER=0, read per call, selects the f32 fused kernel: A/B and tests of both).
  * Workspace (mi_topk_workspace_bytes): address space for the [n_q, n_items] fp32 score block (touched only by
- * fallback rows on the fused path) + sample scores, exclusion bitmap, candidate lists: callers chunk n_q.
+ * fallback rows on the fused path) + sample scores, exclusion bitmap, candidate lists, the split tables: callers chunk
+ * n_q (multiples of 2 048 queries fill the prefilter's grid in whole rounds).
  * ---------------------------------------------------------------------------------- */
 size_t mi_topk_workspace_bytes(int64_t n_q, int64_t n_items, int64_t k);
 int    mi_topk_excl_f32(int64_t n_q, int64_t n_items, int64_t d, int64_t k,

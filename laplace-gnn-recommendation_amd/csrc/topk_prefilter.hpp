@@ -322,6 +322,7 @@ __global__ __launch_bounds__(kBlock) void topk_refine_finalize_kernel(FusedArgs 
                                                                       float* __restrict__ out_score) {
     __shared__ SelectShared sh;
     __shared__ __align__(16) float urow[FKC];
+    __shared__ int reg_off[2 * kBlock];
     // the survivors' ids live in the last quarter of sh.cand (lists longer than kPreList take the exact path): 34 KB of LDS
     // per workgroup = four of them per CU instead of three
     uint32_t* surv = reinterpret_cast<uint32_t*>(sh.cand + kPreList);
@@ -334,22 +335,49 @@ __global__ __launch_bounds__(kBlock) void topk_refine_finalize_kernel(FusedArgs 
     if (tid == 0) { sh.count = 0; bad = 0; }
     for (int c = tid; c < a.d; c += kBlock) urow[c] = u[c];
     __syncthreads();
-    {   // gather: tps threads per slice region
-        const int n_reg = 2 * pa.n_slices, cap = pa.cap_s / 2;   // regions: [slice][half-wavefront]
-        const int tps = max(1, kBlock / n_reg);
+    {   // gather.  The regions' fills first (one coalesced load) and their prefix sums, then the entries by FLAT index, four
+        // per thread and trip with the loads of a trip issued together: a thread walking "its" region entry by entry paid
+        // three dependent trips to memory (fill, entry, exclusion word) per entry
+        const int n_reg = 2 * pa.n_slices, cap = pa.cap_s / 2;   // regions: [slice][half-wavefront], <= 512
         const int* cq = pa.pre_cnt + q * n_reg;
         const unsigned long long* pq = pa.pre + q * kPreCap;
-        for (int sl = tid / tps; sl < n_reg; sl += kBlock / tps) {
-            const int n = cq[sl];
-            if (n > cap) bad = 1;                    // benign race: every writer stores 1
-            const unsigned long long* reg = pq + (int64_t)sl * cap;
-            for (int i = tid % tps; i < min(n, cap); i += tps) {
-                const unsigned long long e = reg[i];
-                const uint32_t item = (uint32_t)(e >> 32);
-                if (item >= (uint32_t)a.n_items) continue;                                          // table padding
-                if ((a.bitmap[q * a.words + (item >> 5)] >> (item & 31)) & 1u) continue;         // excluded
+        const int g0 = 2 * tid, g1 = 2 * tid + 1;
+        int c0 = g0 < n_reg ? cq[g0] : 0, c1 = g1 < n_reg ? cq[g1] : 0;
+        if (c0 > cap || c1 > cap) bad = 1;               // benign race: every writer stores 1
+        c0 = min(c0, cap);
+        c1 = min(c1, cap);
+        int total;
+        const int ex = block_excl_scan(c0 + c1, sh.scan_sh, &total);
+        reg_off[g0] = ex;                                // reg_off[g] = entries in front of region g
+        reg_off[g1] = ex + c0;
+        __syncthreads();
+        for (int base = 0; base < total; base += 4 * kBlock) {
+            unsigned long long e[4];
+            uint32_t w[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int i = base + tid + j * kBlock;
+                e[j] = ~0ull;
+                if (i < total) {
+                    int lo = 0, hi = n_reg;              // the last region whose offset is <= i (empty regions in between are skipped)
+                    while (hi - lo > 1) {
+                        const int mid = (lo + hi) >> 1;
+                        if (reg_off[mid] <= i) lo = mid; else hi = mid;
+                    }
+                    e[j] = pq[(int64_t)lo * cap + (i - reg_off[lo])];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t item = (uint32_t)(e[j] >> 32);
+                w[j] = item < (uint32_t)a.n_items ? a.bitmap[q * a.words + (item >> 5)] : ~0u;   // table padding (and the unused slots): dropped
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t item = (uint32_t)(e[j] >> 32);
+                if ((w[j] >> (item & 31)) & 1u) continue;                                        // excluded
                 const int slot = atomicAdd(&sh.count, 1);
-                if (slot < kPreList) sh.cand[slot] = composite(score_key(__uint_as_float((uint32_t)e)), item);
+                if (slot < kPreList) sh.cand[slot] = composite(score_key(__uint_as_float((uint32_t)e[j])), item);
             }
         }
     }

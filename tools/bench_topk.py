@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Throughput of the batched exact top-K with exclusion at C2's item count:
-users/s for k = 12 (evaluation) and k = 256 (the matcher dump of run_pipeline_lightgcn.py:212-221)."""
+users/s for k = 12 (evaluation) and k = 256 (the matcher dump of run_pipeline_lightgcn.py:212-221), on the default
+path (bf16x3 prefilter + exact rescoring, csrc/topk_prefilter.hpp) and on the f32 fused kernel (LAPLACE_TOPK_PREFILTER=0),
+with the ids of both compared."""
 import json
 import os
 import sys
@@ -10,24 +12,23 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def main():
+def bench_line(full: bool = True, n_q: int = 16384, pre_only: bool = False, cpu_loop: bool = True) -> dict:
     import torch as t
     from laplace_amd import ops, synthetic as S
     from laplace_amd.interactions import Interactions
     dev = "cuda"
-    spec = S.C2 if "--full" in sys.argv else S.SyntheticSpec(200_000, 100_000, 2_000_000, seed=1)
+    spec = S.C2 if full else S.SyntheticSpec(200_000, 100_000, 2_000_000, seed=1)
     ei = S.generate(spec).to(dev)
     inter = Interactions(ei, spec.num_users, spec.num_items)
     r = inter.csr()
     g = t.Generator(device=dev).manual_seed(0)
     ue = t.randn(spec.num_users, 128, device=dev, generator=g) * 0.1
     ie = t.randn(spec.num_items, 128, device=dev, generator=g) * 0.1
-    out = {"workload": f"top-K with exclusion, {spec.num_items} items, D=128, users' own edges excluded"}
-    n_q = int(sys.argv[sys.argv.index("--users") + 1]) if "--users" in sys.argv else 16384
+    out = {"workload": f"top-K with exclusion, {n_q} query users against {spec.num_items} items, D=128, users' own edges excluded"}
     uid = t.arange(n_q, device=dev)
     excl = ops.row_slice(r, 0, n_q)
+    kept = {}
     # default path first (bf16x3 prefilter + exact rescoring), then the f32 fused kernel (LAPLACE_TOPK_PREFILTER=0)
-    pre_only = "--pre-only" in sys.argv   # kernel-timing runs: the default path alone, no host loop
     for mode, tag in ((("1", ""),) if pre_only else (("1", ""), ("0", "_f32_path"))):
         os.environ["LAPLACE_TOPK_PREFILTER"] = mode
         for k in (12, 256):
@@ -43,15 +44,12 @@ def main():
             out[f"k{k}_users_per_s{tag}"] = n_q / best
             out[f"k{k}_ms_per_1k_users{tag}"] = 1e3 * best / (n_q / 1000)
             if mode == "1":
-                keep = out.setdefault("_ids", {})
-                keep[k] = ids
+                kept[k] = ids
             else:
-                out[f"k{k}_ids_equal_on_both_paths"] = bool(t.equal(ids, out["_ids"][k]))
-    out.pop("_ids", None)
+                out[f"k{k}_ids_equal_on_both_paths"] = bool(t.equal(ids, kept[k]))
     os.environ.pop("LAPLACE_TOPK_PREFILTER", None)
-    if pre_only:
-        print(json.dumps(out))
-        return
+    if pre_only or not cpu_loop:
+        return out
     # the reference's way, on the host: one GEMV + topk + setdiff per user (utils/metrics_lightgcn.py:125-142)
     from oracle import lightgcn_ref as R
     uec, iec = ue[:64].cpu(), ie.cpu()
@@ -62,7 +60,12 @@ def main():
         R.make_predictions_for_user(uec, iec, u, pos, 256)
     out["cpu_reference_loop_users_per_s_k256"] = 64 / (time.perf_counter() - t0)
     out["cpu_threads"] = t.get_num_threads()
-    print(json.dumps(out))
+    return out
+
+
+def main():
+    n_q = int(sys.argv[sys.argv.index("--users") + 1]) if "--users" in sys.argv else 16384
+    print(json.dumps(bench_line(full="--full" in sys.argv, n_q=n_q, pre_only="--pre-only" in sys.argv)))
 
 
 if __name__ == "__main__":
