@@ -867,10 +867,19 @@ __device__ __forceinline__ int32_t plan_find(const int32_t* __restrict__ prefix,
 
 // flags[t] = 1 when entry t of the long rows' entry list starts a work item: the first entry of a row, the
 // first entry of a band within the row, and every chunk-th entry after either.
+// min_per > 1 (A/B only, LAPLACE_SPMM_BAND_MIN_PER): a row cuts at multiples of band * 2^j instead, j the smallest for which a
+// cut of the row holds min_per entries on average.  The idea: every work item costs a 512-byte partial row written and read
+// back by the fix-up kernel, and a row with about one entry per band (C4's typical item: 10^3 entries over 990 bands) pays
+// that for EVERY entry — 11.3 M partial rows, 5.8 GB written + 6 GB read per launch, a quarter of the launch's traffic.
+// Measured on C4 at N = 1 (tools/ab_c4_band.sh, round 3): min_per 1 / 8 / 32 / 128 -> dense launch 9.78 / 11.89 / 14.85 /
+// 17.45 ms, step 57.2 / 66.1 / 80.9 / 94.1 ms (same loss to the last digit).  The band is not about a row reusing its own
+// gathers: the work items of one band run together on one XCD, and it is the OTHER rows' gathers of the same 8 192 user
+// rows that meet in that L2.  A thin row cut wider leaves that company and every gather goes to memory; the partial rows
+// are the cheaper evil.  Stays 1.
 __global__ void plan_seg_flags_kernel(int32_t nnz_long, int32_t n_long, const int32_t* __restrict__ lrows,
                                       const int32_t* __restrict__ lprefix, const int32_t* __restrict__ rowptr,
-                                      const int32_t* __restrict__ col, int32_t chunk, int32_t band,
-                                      int32_t* __restrict__ flags) {
+                                      const int32_t* __restrict__ col, int32_t chunk, int32_t band, int64_t n_cols,
+                                      int32_t min_per, int32_t* __restrict__ flags) {
     const int32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nnz_long) return;
     const int32_t i = plan_find(lprefix, n_long, t);
@@ -878,6 +887,10 @@ __global__ void plan_seg_flags_kernel(int32_t nnz_long, int32_t n_long, const in
     const int32_t p = rb + (t - lprefix[i]);
     int32_t run = rb;  // first entry of p's band within the row
     if (band > 0) {
+        if (min_per > 1) {
+            const int64_t deg = rowptr[lrows[i] + 1] - rb;
+            while ((int64_t)band * deg < (int64_t)min_per * n_cols && band < (1 << 29)) band <<= 1;
+        }
         const int32_t first_col = col[p] / band * band;
         int32_t lo = rb, hi = p;  // smallest index in [rb, p] whose column is >= first_col (columns ascend within a row)
         while (lo < hi) {
@@ -963,6 +976,15 @@ __global__ void plan_items_kernel(int32_t n_seg, int32_t banded, const uint64_t*
     const int32_t t_next = (s + 1 < n_seg) ? seg_start[s + 1] : INT32_MAX;
     const int32_t end = (t_next < lprefix[i + 1]) ? p + (t_next - t) : rowptr[r + 1];
     items[pos] = make_int4(r, p, end, s);
+}
+
+#ifndef MI_SPMM_BAND_MIN_PER
+#define MI_SPMM_BAND_MIN_PER 1   // entries a band cut of a split row should hold on average (plan_seg_flags_kernel); 1 = every row cuts at `band`
+#endif
+int32_t plan_band_min_per() {
+    const char* e = getenv("LAPLACE_SPMM_BAND_MIN_PER");   // A/B
+    const int v = e ? atoi(e) : MI_SPMM_BAND_MIN_PER;
+    return v < 1 ? 1 : v;
 }
 
 dim3 plan_grid(int64_t n) { return dim3((unsigned)mi_ceil_div(n > 0 ? n : 1, 256)); }
@@ -1147,7 +1169,7 @@ int mi_spmm_plan_count(int64_t n_rows, int64_t n_cols, const int32_t* rowptr, co
     hipLaunchKernelGGL(plan_long_rows_kernel, plan_grid(n1), dim3(256), 0, s, n_rows, w.is_long, w.long_off, w.lnz_off,
                        w.lrows, w.lprefix);
     hipLaunchKernelGGL(plan_seg_flags_kernel, plan_grid(nnz_long), dim3(256), 0, s, nnz_long, n_long, w.lrows, w.lprefix,
-                       rowptr, col, chunk, band, w.flags);
+                       rowptr, col, chunk, band, n_cols, plan_band_min_per(), w.flags);
     tb = w.tmp_bytes;
     MI_HIP(rocprim::exclusive_scan(w.tmp, tb, w.flags, w.seg_of, 0, (size_t)nnz_long, rocprim::plus<int32_t>(), s));
     int32_t last[2] = {0, 0};
