@@ -438,6 +438,18 @@ int    mi_topk_excl_f32(int64_t n_q, int64_t n_items, int64_t d, int64_t k,
                         int64_t* out_idx, float* out_score /* nullable */,
                         void* ws, size_t ws_bytes, mi_stream_t stream);
 
+/* Diagnostic of K10's bf16x3 prefilter (csrc/topk_prefilter.hpp), d = 64 / 128: scores[q, i] = the APPROXIMATE score the
+ * prefilter compares with its thresholds, eps[q] = the bound it assumes, |scores[q, i] - exact fma chain| <= eps[q] for
+ * every item (tests/test_gpu_topk_gemm.py asserts it on adversarial tables).  Not on any product path: the candidates'
+ * exact scores are what mi_topk_excl_f32 returns. */
+size_t mi_topk_prefilter_scores_workspace_bytes(int64_t n_q, int64_t n_items);
+int    mi_topk_prefilter_scores_f32(int64_t n_q, int64_t n_items, int64_t d,
+                                    const int64_t* uid /* nullable */,
+                                    const float* user_emb, int64_t ldu,
+                                    const float* item_emb, int64_t ldi,
+                                    float* scores /* [n_q, n_items] */, float* eps /* [n_q] */,
+                                    void* ws, size_t ws_bytes, mi_stream_t stream);
+
 /* ------------------------------------------------------------------------------------
  * K5  SAGEConv message passing.
  * replaces: SAGEConv.propagate -> torch_scatter.scatter(x_j, index, reduce=aggr) reached from

@@ -205,6 +205,8 @@ _PROTOTYPES = {
     "mi_topk_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int64]),
     "mi_topk_excl_f32": (c_int32, [c_int64, c_int64, c_int64, c_int64, P, P, c_int64, P, c_int64, P, P, P, P, P,
                                    c_size_t, P]),
+    "mi_topk_prefilter_scores_workspace_bytes": (c_size_t, [c_int64, c_int64]),
+    "mi_topk_prefilter_scores_f32": (c_int32, [c_int64, c_int64, c_int64, P, P, c_int64, P, c_int64, P, P, P, c_size_t, P]),
     "mi_segment_max_f32": (c_int32, [c_int64, c_int64, P, P, P, c_int64, P, c_int64, P, P]),
     "mi_segment_max_bwd_f32": (c_int32, [c_int64, c_int64, P, P, P, P, c_int64, P, c_int64, P]),
     "mi_embed_concat_f32": (c_int32, [c_int64, c_int32, P, POINTER(c_void_p), POINTER(c_int64), POINTER(c_int32),

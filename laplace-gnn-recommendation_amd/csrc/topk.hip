@@ -564,7 +564,8 @@ __global__ __launch_bounds__(kBlock) void threshold_kernel(int64_t n_q, int64_t 
                                                            const int32_t* __restrict__ excl_ptr,
                                                            const int32_t* __restrict__ excl_idx,
                                                            uint32_t* __restrict__ bitmap, int64_t words,
-                                                           uint32_t* __restrict__ thr, int* __restrict__ cnt) {
+                                                           uint32_t* __restrict__ thr, int* __restrict__ cnt,
+                                                           const float* __restrict__ epsv, float* __restrict__ thrf) {
     __shared__ SelectShared sh;
     const int64_t q = blockIdx.x;
     if (q >= n_q) return;
@@ -593,7 +594,13 @@ __global__ __launch_bounds__(kBlock) void threshold_kernel(int64_t n_q, int64_t 
 #else
     const uint32_t t_lo = sample_threshold_small(skey, sample_rank((int)min((int64_t)k, n_items), n_items), sh, skey + kSample);
 #endif
-    if (threadIdx.x == 0) thr[q] = t_lo;
+    if (threadIdx.x == 0) {
+        thr[q] = t_lo;
+        // prefilter (topk_prefilter.hpp): the sample was scored in bf16x3 as well, so t_lo - eps bounds the exact sample score
+        // it stands for, and the list is kept complete down to 3 eps below that.  NaN / -inf: everything passes, the row
+        // overflows and takes the exact path
+        if (thrf) thrf[q] = key_score(t_lo) - 4.f * epsv[q];
+    }
 }
 
 // 64 x FKC panel rows [row0, row0 + 64) of a K-contiguous operand into registers / LDS (zero beyond n_rows and d).
@@ -1198,7 +1205,7 @@ static int mi_cu_count() {
 static size_t topk_prefilter_bytes(int64_t n_q, int64_t n_items) {
     const size_t q_pad = (size_t)mi_ceil_div(n_q, 256) * 256, i_pad = (size_t)mi_ceil_div(n_items, 64) * 64;
     return mi_align_up(i_pad * 128 * sizeof(float), 256) + mi_align_up(q_pad * 128 * sizeof(float), 256) +
-           2 * mi_align_up(q_pad * sizeof(float), 256) + 256 +
+           mi_align_up((size_t)kSample * 128 * sizeof(float), 256) + 2 * mi_align_up(q_pad * sizeof(float), 256) + 256 +
            mi_align_up(q_pad * kPreCap * sizeof(unsigned long long), 256) + mi_align_up(q_pad * 512 * sizeof(int), 256);
 }
 
@@ -1207,41 +1214,27 @@ static bool topk_prefilter_on() {
     return !(e && e[0] == '0');
 }
 
-template <int D>
-static int topk_prefilter_launch(const FusedArgs& a, MiArena& ar, int k, int kpow2, float* scores, int64_t* out_idx,
-                                 float* out_score, int n_cu, hipStream_t s) {
-    const int64_t strips = mi_ceil_div(a.n_q, 256), q_pad = strips * 256;
-    const int64_t panels = mi_ceil_div(a.n_items, 64), i_pad = panels * 64;
-    uint2* Ib = reinterpret_cast<uint2*>(ar.take<float>((size_t)i_pad * 128));
-    uint2* Ub = reinterpret_cast<uint2*>(ar.take<float>((size_t)q_pad * 128));
-    float* thrf = ar.take<float>((size_t)q_pad);
-    float* epsv = ar.take<float>((size_t)q_pad);
-    uint32_t* n2max = ar.take<uint32_t>(64);
-    unsigned long long* pre = ar.take<unsigned long long>((size_t)q_pad * kPreCap);
-    int* pre_cnt = ar.take<int>((size_t)q_pad * 512);
-    if (!Ib || !Ub || !thrf || !epsv || !n2max || !pre || !pre_cnt) return MI_ERR_WORKSPACE;
-    // One workgroup per CU (its LDS ring), 8 XCDs: the workgroups of an XCD run ceil(strips * sl / per_xcd) rounds of
-    // panels / (8 sl) panels each (+ the prologue, ~2 panels' worth)
+// Grid of the bf16 kernel: `strips` groups of 256 register-side rows x 8 sl slices of the panel axis.  One workgroup per CU
+// (its LDS ring), 8 XCDs: the workgroups of an XCD run ceil(strips * sl / per_xcd) rounds of panels / (8 sl) panels each
+// (+ the prologue, ~2 panels' worth).
+static int64_t topk_pre_slices_per_xcd(int64_t strips, int64_t panels, int n_cu) {
     const int64_t per_xcd = std::max(1, n_cu / 8);
     int64_t sl = 1, best = INT64_MAX;
     for (int64_t l = 1; l <= 32; ++l) {
         const int64_t cost = mi_ceil_div(strips * l, per_xcd) * (mi_ceil_div(panels, 8 * l) + 2);
         if (cost < best) { best = cost; sl = l; }
     }
-    PreArgs pa;
-    pa.n_q = a.n_q; pa.n_items = a.n_items; pa.panels = panels;
-    pa.Ub = reinterpret_cast<const uint4*>(Ub); pa.Ib = reinterpret_cast<const uint4*>(Ib);
-    pa.thrf = thrf; pa.pre = pre; pa.pre_cnt = pre_cnt;
+    return sl;
+}
+
+template <int D, bool STORE>
+static int topk_pre_kernel_launch(PreArgs& pa, int64_t strips, int64_t panels, int n_cu, hipStream_t s) {
+    const int64_t sl = topk_pre_slices_per_xcd(strips, panels, n_cu);
+    pa.panels = panels;
     pa.strips = (int)strips; pa.n_slices = (int)(8 * sl); pa.cap_s = 2;
     while (pa.cap_s * 2 * pa.n_slices <= kPreCap) pa.cap_s *= 2;
     pa.panels_per_slice = mi_ceil_div(panels, pa.n_slices);
-    MI_HIP(hipMemsetAsync(n2max, 0, sizeof(uint32_t), s));
-    constexpr int RPB = 256 / (D / 4);
-    hipLaunchKernelGGL(topk_split_rows_kernel<D>, dim3((unsigned)std::min<int64_t>(mi_ceil_div(i_pad, RPB), 4 * n_cu)), dim3(256), 0, s, a.n_items, i_pad,
-                       a.I, a.ldi, (const int64_t*)nullptr, Ib, n2max, (const uint32_t*)nullptr, (float*)nullptr, (float*)nullptr);
-    hipLaunchKernelGGL(topk_split_rows_kernel<D>, dim3((unsigned)mi_ceil_div(q_pad, RPB)), dim3(256), 0, s, a.n_q, q_pad,
-                       a.U, a.ldu, a.uid, Ub, n2max, a.thr, thrf, epsv);
-    auto kern = topk_prefilter_bf16_kernel<D>;
+    auto kern = topk_prefilter_bf16_kernel<D, STORE>;
     constexpr int lds = 3 * 64 * (D / 4) * 16;
     static bool attr_set = false;  // per instantiation; idempotent
     if (!attr_set) {
@@ -1250,8 +1243,82 @@ static int topk_prefilter_launch(const FusedArgs& a, MiArena& ar, int k, int kpo
         attr_set = true;
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)(8 * sl * strips)), dim3(256), lds, s, pa);
+    return 0;
+}
+
+template <int D>
+static void topk_split_launch(int64_t n_rows, int64_t n_pad, const float* T, int64_t ld, const int64_t* row_map, uint2* out,
+                              uint32_t* n2max, int mode, float* thrf, float* epsv, int n_cu, hipStream_t s) {
+    constexpr int RPB = 256 / (D / 4);
+    hipLaunchKernelGGL(topk_split_rows_kernel<D>, dim3((unsigned)std::min<int64_t>(mi_ceil_div(n_pad, RPB), 4 * n_cu)), dim3(256),
+                       0, s, n_rows, n_pad, T, ld, row_map, out, n2max, mode, thrf, epsv);
+}
+
+// The whole prefilter path after the sample rows have been gathered (Is: [kSample, d] f32): split tables, sample scores in
+// bf16x3 (the STORE form of the kernel: panel side = the queries, register side = the sample), thresholds, lists, refine.
+template <int D>
+static int topk_prefilter_launch(FusedArgs& a, MiArena& ar, const float* Is, float* sample_scores, uint32_t* thr,
+                                 const int32_t* excl_ptr, const int32_t* excl_idx, int k, int kpow2, float* scores,
+                                 int64_t* out_idx, float* out_score, int n_cu, hipStream_t s) {
+    const int64_t strips = mi_ceil_div(a.n_q, 256), q_pad = strips * 256;
+    const int64_t panels = mi_ceil_div(a.n_items, 64), i_pad = panels * 64;
+    uint2* Ib = reinterpret_cast<uint2*>(ar.take<float>((size_t)i_pad * 128));
+    uint2* Ub = reinterpret_cast<uint2*>(ar.take<float>((size_t)q_pad * 128));
+    uint2* Sb = reinterpret_cast<uint2*>(ar.take<float>((size_t)kSample * 128));
+    float* thrf = ar.take<float>((size_t)q_pad);
+    float* epsv = ar.take<float>((size_t)q_pad);
+    uint32_t* n2max = ar.take<uint32_t>(64);
+    unsigned long long* pre = ar.take<unsigned long long>((size_t)q_pad * kPreCap);
+    int* pre_cnt = ar.take<int>((size_t)q_pad * 512);
+    if (!Ib || !Ub || !Sb || !thrf || !epsv || !n2max || !pre || !pre_cnt) return MI_ERR_WORKSPACE;
+    MI_HIP(hipMemsetAsync(n2max, 0, sizeof(uint32_t), s));
+    topk_split_launch<D>(a.n_items, i_pad, a.I, a.ldi, nullptr, Ib, n2max, kSplitItems, nullptr, nullptr, n_cu, s);
+    topk_split_launch<D>(a.n_q, q_pad, a.U, a.ldu, a.uid, Ub, n2max, kSplitQueries, thrf, epsv, n_cu, s);
+    topk_split_launch<D>(kSample, kSample, Is, D, nullptr, Sb, n2max, kSplitPlain, nullptr, nullptr, n_cu, s);
+    PreArgs pa;
+    memset(&pa, 0, sizeof(pa));
+    pa.n_q = a.n_q; pa.n_items = a.n_items;
+    // sample scores: out[query][sample]
+    pa.Ub = reinterpret_cast<const uint4*>(Sb); pa.Ib = reinterpret_cast<const uint4*>(Ub);
+    pa.out = sample_scores; pa.ldo = kSample; pa.n_a = a.n_q; pa.n_b = kSample;
+    int rc = topk_pre_kernel_launch<D, true>(pa, kSample / 256, q_pad / 64, n_cu, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(threshold_kernel, dim3((unsigned)a.n_q), dim3(kBlock), 0, s, a.n_q, a.n_items, k, sample_scores,
+                       excl_ptr, excl_idx, const_cast<uint32_t*>(a.bitmap), a.words, thr, a.cnt, epsv, thrf);
+    a.thr = thr;
+    // candidate lists
+    pa.Ub = reinterpret_cast<const uint4*>(Ub); pa.Ib = reinterpret_cast<const uint4*>(Ib);
+    pa.thrf = thrf; pa.pre = pre; pa.pre_cnt = pre_cnt;
+    pa.out = nullptr;
+    rc = topk_pre_kernel_launch<D, false>(pa, strips, panels, n_cu, s);
+    if (rc) return rc;
     hipLaunchKernelGGL(topk_refine_finalize_kernel, dim3((unsigned)a.n_q), dim3(kBlock), 0, s, a, pa, epsv, k, kpow2, scores,
                        out_idx, out_score);
+    return mi_launch_status();
+}
+
+// Diagnostic of the prefilter (mi_topk_prefilter_scores_f32): the approximate scores and the bound they come with.
+template <int D>
+static int topk_prefilter_scores(int64_t n_q, int64_t n_items, const int64_t* uid, const float* U, int64_t ldu, const float* I,
+                                 int64_t ldi, float* out, float* eps_out, MiArena& ar, int n_cu, hipStream_t s) {
+    const int64_t strips = mi_ceil_div(n_items, 256), i_pad = strips * 256;    // register side: the items
+    const int64_t panels = mi_ceil_div(n_q, 64), q_pad = panels * 64;          // panel side: the queries
+    uint2* Ib = reinterpret_cast<uint2*>(ar.take<float>((size_t)i_pad * 128));
+    uint2* Ub = reinterpret_cast<uint2*>(ar.take<float>((size_t)q_pad * 128));
+    float* epsv = ar.take<float>((size_t)q_pad);
+    uint32_t* n2max = ar.take<uint32_t>(64);
+    if (!Ib || !Ub || !epsv || !n2max) return MI_ERR_WORKSPACE;
+    MI_HIP(hipMemsetAsync(n2max, 0, sizeof(uint32_t), s));
+    topk_split_launch<D>(n_items, i_pad, I, ldi, nullptr, Ib, n2max, kSplitItems, nullptr, nullptr, n_cu, s);
+    topk_split_launch<D>(n_q, q_pad, U, ldu, uid, Ub, n2max, kSplitQueries, nullptr, epsv, n_cu, s);
+    PreArgs pa;
+    memset(&pa, 0, sizeof(pa));
+    pa.n_q = n_q; pa.n_items = n_items;
+    pa.Ub = reinterpret_cast<const uint4*>(Ib); pa.Ib = reinterpret_cast<const uint4*>(Ub);
+    pa.out = out; pa.ldo = n_items; pa.n_a = n_q; pa.n_b = n_items;
+    const int rc = topk_pre_kernel_launch<D, true>(pa, strips, panels, n_cu, s);
+    if (rc) return rc;
+    MI_HIP(hipMemcpyAsync(eps_out, epsv, (size_t)n_q * sizeof(float), hipMemcpyDeviceToDevice, s));
     return mi_launch_status();
 }
 
@@ -1305,6 +1372,16 @@ int mi_topk_excl_f32(int64_t n_q, int64_t n_items, int64_t d, int64_t k, const i
         FusedArgs a;
         a.n_q = n_q; a.n_items = n_items; a.d = (int)d; a.uid = uid;
         a.U = user_emb; a.ldu = ldu; a.I = item_emb; a.ldi = ldi;
+        if (topk_prefilter_on() && (d == 128 || d == 64) && k <= kPreMaxK) {
+            // bf16x3 prefilter (topk_prefilter.hpp): sample scores, thresholds, lists and the exact finish all in there
+            MI_HIP(hipMemsetAsync(bitmap, 0, (size_t)n_q * words * sizeof(uint32_t), s));
+            a.thr = thr; a.bitmap = bitmap; a.words = words; a.cand = cand; a.cnt = cnt;
+            if (d == 128)
+                return topk_prefilter_launch<128>(a, ar, Is, sample_scores, thr, excl_ptr, excl_idx, (int)k, kpow2, scores, out_idx,
+                                                  out_score, mi_cu_count(), s);
+            return topk_prefilter_launch<64>(a, ar, Is, sample_scores, thr, excl_ptr, excl_idx, (int)k, kpow2, scores, out_idx,
+                                             out_score, mi_cu_count(), s);
+        }
         const int64_t strips = mi_ceil_div(n_q, FM);
         const int64_t capacity = 2 * (int64_t)mi_cu_count();
         if (MI_TOPK_DMA && (d == 128 || d == 64)) {
@@ -1330,12 +1407,8 @@ int mi_topk_excl_f32(int64_t n_q, int64_t n_items, int64_t d, int64_t k, const i
         }
         MI_HIP(hipMemsetAsync(bitmap, 0, (size_t)n_q * words * sizeof(uint32_t), s));
         hipLaunchKernelGGL(threshold_kernel, dim3((unsigned)n_q), dim3(kBlock), 0, s, n_q, n_items, (int)k, sample_scores,
-                           excl_ptr, excl_idx, bitmap, words, thr, cnt);
+                           excl_ptr, excl_idx, bitmap, words, thr, cnt, (const float*)nullptr, (float*)nullptr);
         a.thr = thr; a.bitmap = bitmap; a.words = words; a.cand = cand; a.cnt = cnt;
-        if (topk_prefilter_on() && (d == 128 || d == 64) && k <= kPreMaxK) {
-            if (d == 128) return topk_prefilter_launch<128>(a, ar, (int)k, kpow2, scores, out_idx, out_score, mi_cu_count(), s);
-            return topk_prefilter_launch<64>(a, ar, (int)k, kpow2, scores, out_idx, out_score, mi_cu_count(), s);
-        }
         const int64_t n_tiles = mi_ceil_div(n_items, FN);
         // Every workgroup does the same work and two fit on a CU, so the launch runs in ceil(grid / (2 * CUs)) rounds of
         // tiles_per_slice panels each: a grid one workgroup over a multiple of the chip's capacity (the old rule,
@@ -1370,6 +1443,26 @@ int mi_topk_excl_f32(int64_t n_q, int64_t n_items, int64_t d, int64_t k, const i
     hipLaunchKernelGGL(select_kernel, dim3((unsigned)n_q), dim3(kBlock), 0, s, n_q, n_items, (int)k, kpow2, scores,
                        out_idx, out_score, MI_TOPK_ONE_PASS);
     return mi_launch_status();
+}
+
+size_t mi_topk_prefilter_scores_workspace_bytes(int64_t n_q, int64_t n_items) {
+    const size_t i_pad = (size_t)mi_ceil_div(n_items > 0 ? n_items : 1, 256) * 256, q_pad = (size_t)mi_ceil_div(n_q > 0 ? n_q : 1, 64) * 64;
+    return mi_align_up(i_pad * 128 * sizeof(float), 256) + mi_align_up(q_pad * 128 * sizeof(float), 256) +
+           mi_align_up(q_pad * sizeof(float), 256) + 256;
+}
+
+int mi_topk_prefilter_scores_f32(int64_t n_q, int64_t n_items, int64_t d, const int64_t* uid, const float* user_emb,
+                                 int64_t ldu, const float* item_emb, int64_t ldi, float* scores, float* eps, void* ws,
+                                 size_t ws_bytes, mi_stream_t stream) {
+    MI_CHECK_ARG(n_q > 0 && n_items > 0 && user_emb && item_emb && scores && eps && ws);
+    if (d != 64 && d != 128) return MI_ERR_UNSUPPORTED;
+    if (n_items >= INT32_MAX) return MI_ERR_TOO_LARGE;
+    MI_CHECK_ARG(ldu >= d && ldi >= d && ldu % 4 == 0 && ldi % 4 == 0 && mi_aligned16(user_emb) && mi_aligned16(item_emb));
+    if (ws_bytes < mi_topk_prefilter_scores_workspace_bytes(n_q, n_items)) return MI_ERR_WORKSPACE;
+    MiArena ar(ws, ws_bytes);
+    hipStream_t s = (hipStream_t)stream;
+    if (d == 128) return topk_prefilter_scores<128>(n_q, n_items, uid, user_emb, ldu, item_emb, ldi, scores, eps, ar, mi_cu_count(), s);
+    return topk_prefilter_scores<64>(n_q, n_items, uid, user_emb, ldu, item_emb, ldi, scores, eps, ar, mi_cu_count(), s);
 }
 
 }  // extern "C"

@@ -50,6 +50,10 @@ struct PreArgs {
     int* pre_cnt;               // [strips * 256][n_slices][2]
     int strips, n_slices, cap_s;   // cap_s: list slots per (query, slice), a power of two; half of it per half-wavefront
     int64_t panels_per_slice;
+    // STORE form (topk_prefilter_bf16_kernel<D, true>): no votes — the approximate scores themselves are written,
+    // out[a_row * ldo + b_row] for the panel-side rows a_row < n_a (Ib) and the register-side rows b_row < n_b (Ub)
+    float* out;
+    int64_t ldo, n_a, n_b;
 };
 
 __device__ __forceinline__ uint32_t bf16_rn_bits(float x) {
@@ -58,13 +62,15 @@ __device__ __forceinline__ uint32_t bf16_rn_bits(float x) {
     return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
 }
 
-// Rows of T (through row_map when given) -> [hi | lo] bf16 rows; rows in [n_rows, n_pad) are zero.  |row|^2 goes to
-// n2_max (items: the largest) or, with thr given (queries), into thrf / epsv.
+// Rows of T (through row_map when given) -> [hi | lo] bf16 rows; rows in [n_rows, n_pad) are zero.
+// mode 0 (items): the largest |row|^2 -> n2_max.  mode 1 (queries): eps(u) -> epsv, +inf -> thrf of the padding rows (the
+// real rows' thresholds come from threshold_kernel).  mode 2: the split alone.
+enum { kSplitItems = 0, kSplitQueries = 1, kSplitPlain = 2 };
 template <int D>
 __global__ __launch_bounds__(256) void topk_split_rows_kernel(int64_t n_rows, int64_t n_pad, const float* __restrict__ T,
                                                               int64_t ld, const int64_t* __restrict__ row_map,
                                                               uint2* __restrict__ out, uint32_t* __restrict__ n2_max,
-                                                              const uint32_t* __restrict__ thr, float* __restrict__ thrf,
+                                                              int mode, float* __restrict__ thrf,
                                                               float* __restrict__ epsv) {
     constexpr int LPR = D / 4, RPB = 256 / LPR;
     __shared__ uint32_t blk_max[256 / MI_WAVE];
@@ -89,21 +95,16 @@ __global__ __launch_bounds__(256) void topk_split_rows_kernel(int64_t n_rows, in
         float n2 = x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w;
 #pragma unroll
         for (int m = LPR / 2; m > 0; m >>= 1) n2 += __shfl_xor(n2, m, LPR);
-        if (thr) {  // queries
+        if (mode == kSplitQueries) {
             if (li == 0) {
-                if (r < n_rows) {
-                    const float eps = kPreC * 1.01f * sqrtf(n2) * sqrtf(__uint_as_float(*n2_max));
-                    epsv[r] = eps;
-                    thrf[r] = key_score(thr[r]) - 3.f * eps;   // NaN / -inf: everything passes, the row overflows -> exact path
-                } else {
-                    thrf[r] = INFINITY;
-                }
+                if (r < n_rows) epsv[r] = kPreC * 1.01f * sqrtf(n2) * sqrtf(__uint_as_float(*n2_max));
+                else if (thrf) thrf[r] = INFINITY;
             }
-        } else if (r < n_rows) {
+        } else if (mode == kSplitItems && r < n_rows) {
             mx = max(mx, __float_as_uint(n2));
         }
     }
-    if (thr) return;   // kernel-uniform
+    if (mode != kSplitItems) return;   // kernel-uniform
     // items: one atomic per workgroup (one per row serialised 10^5 of them on one address: 570 us)
 #pragma unroll
     for (int m = MI_WAVE / 2; m > 0; m >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, m, MI_WAVE));
@@ -138,7 +139,7 @@ __device__ __forceinline__ void pre_commit(const u32x4 (&g)[PIECES], unsigned ch
     for (int j = 0; j < PIECES; ++j) *reinterpret_cast<u32x4*>(buf + woff[j]) = g[j];
 }
 
-template <int D>
+template <int D, bool STORE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void topk_prefilter_bf16_kernel(PreArgs a) {
     constexpr int S = D / 16;                  // k-steps per part
@@ -157,10 +158,12 @@ void topk_prefilter_bf16_kernel(PreArgs a) {
     const int64_t p0 = slice * a.panels_per_slice;
     const int64_t p1 = min(a.panels, p0 + a.panels_per_slice);
     const int64_t u0 = (int64_t)strip * 256 + wave * 64;   // this wavefront's 64 queries
-    int* my_cnt_out = a.pre_cnt + ((u0 + r) * a.n_slices + slice) * 2 + h;   // [query][slice][half]
+    int* my_cnt_out = STORE ? nullptr : a.pre_cnt + ((u0 + r) * a.n_slices + slice) * 2 + h;   // [query][slice][half]
     if (p0 >= p1) {  // block-uniform: an empty slice still owns its counters
-        my_cnt_out[0] = 0;
-        my_cnt_out[64 * (int64_t)a.n_slices] = 0;
+        if (!STORE) {
+            my_cnt_out[0] = 0;
+            my_cnt_out[64 * (int64_t)a.n_slices] = 0;
+        }
         return;
     }
     // queries: fragments of the B operand, lane (r, h) holds k = 8 h .. 8 h + 7 of k-step s for query 32 ub + r
@@ -174,12 +177,12 @@ void topk_prefilter_bf16_kernel(PreArgs a) {
             ul[ub][s] = __builtin_bit_cast(bf16x8, up[CH / 2 + 2 * s]);
         }
     }
-    const float tq[2] = {a.thrf[u0 + r], a.thrf[u0 + 32 + r]};
+    const float tq[2] = {STORE ? 0.f : a.thrf[u0 + r], STORE ? 0.f : a.thrf[u0 + 32 + r]};
     unsigned long long* region[2];
 #pragma unroll
     for (int ub = 0; ub < 2; ++ub) {
         const int64_t q = u0 + 32 * ub + r;   // (padding queries have rows of their own: they pass only on NaN scores)
-        region[ub] = a.pre + q * kPreCap + slice * a.cap_s + h * (a.cap_s / 2);
+        region[ub] = STORE ? nullptr : a.pre + q * kPreCap + slice * a.cap_s + h * (a.cap_s / 2);
     }
     int cnt[2] = {0, 0};
     // item panels: a panel is one contiguous block of the split table; chunk (row, c) lives at row * ROWB + ((c ^ (row & 15)) << 4)
@@ -254,7 +257,15 @@ void topk_prefilter_bf16_kernel(PreArgs a) {
                     acc[ai] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[s & 1][2 * ib + (term == 2 ? 1 : 0)],         \
                                                                       term == 1 ? ul[ub][s] : uh[ub][s], acc[ai], 0, 0, 0); \
                     const int m = s * 12 + term * 4 + ai;                                                               \
-                    if ((m + 1) % (NS / 16) == 0) MI_PRE_VOTE4(prev, m / (NS / 16))                                     \
+                    if (!STORE && (m + 1) % (NS / 16) == 0) MI_PRE_VOTE4(prev, m / (NS / 16))                           \
+                }                                                                                                       \
+        }                                                                                                               \
+        if (STORE) {   /* out[a_row][b_row]: for one register the 32 lanes of a half write 128 consecutive bytes */      \
+            _Pragma("unroll") for (int ai = 0; ai < 4; ++ai)                                                            \
+                _Pragma("unroll") for (int reg = 0; reg < 16; ++reg) {                                                  \
+                    const int64_t ar_ = (p) * 64 + (ai >> 1) * 32 + (reg & 3) + 8 * (reg >> 2) + (int64_t)row4;         \
+                    const int64_t br_ = u0 + 32 * (ai & 1) + r;                                                         \
+                    if (ar_ < a.n_a && br_ < a.n_b) a.out[ar_ * a.ldo + br_] = acc[ai][reg];                            \
                 }                                                                                                       \
         }                                                                                                               \
         item_prev = (uint32_t)((p) * 64);                                                                               \
@@ -276,6 +287,7 @@ void topk_prefilter_bf16_kernel(PreArgs a) {
         MI_PRE_PANEL(acc0, acc1, p)
         last_in_acc0 = true;
     }
+    if (STORE) return;
     // the last panel's votes
     if (last_in_acc0) {
 #pragma unroll

@@ -18,8 +18,14 @@ from . import _lib
 from ._lib import SpmmExStruct, SpmmPlanStruct, SpmmSweepStruct, check
 
 DEFAULT_CHUNK = 256  # max nnz per work item of a split (hub) row
-DEFAULT_BAND = 8192  # columns per band of a banded plan: 8192 rows x 128 floats = the 4 MB L2 of one XCD
-MIN_BANDS = 16       # narrower adjacencies keep the row-major plan (nothing to block for)
+# columns per band of a banded work-item plan (the adjacencies the SWEEP form does not take: C4's 8 M x 100 K graph on one GPU).
+# The work items of a band run together on one XCD and meet in its L2.  A/B on C4 at N = 1, round 3 (tools/ab_c4_bandwidth.sh,
+# profiles/r03_c4_band_width.txt; ms per step / dense launch / sparse-operand launch): 2 048: 73.5 / 12.38 / 9.90, 4 096: 65.3 /
+# 11.00 / 8.50, 8 192 (rounds 1-2: "the 4 MB L2"): 58.3 / 9.98 / 7.27, 16 384: 54.3 / 9.39 / 6.39, 32 768: 56.2 / 9.98 / 6.24,
+# 65 536: 58.6 / 10.62 / 6.16, 131 072: 60.4 / 11.06 / 6.29 — fewer, longer work items (half the partial rows) outweigh the
+# band outgrowing one L2 up to 8 MB of rows.  Widening only the THIN rows' bands is slower (csrc/spmm.hip, plan_seg_flags_kernel).
+DEFAULT_BAND = int(_os_environ.get("LAPLACE_SPMM_BAND", 16384))
+MIN_BANDED_COLS = 131072  # narrower adjacencies keep the row-major plan (nothing to block for)
 
 # bench.py sets this to a list to collect (start, end, kind) HIP events around every propagate launch,
 # recorded on the stream the kernels are launched on.  None = no timing overhead.
@@ -363,7 +369,7 @@ SWEEP_PACE = int(_os.environ.get("LAPLACE_SWEEP_PACE", SWEEP_PACE))
 
 def build_spmm_plan(a: DeviceCSR, chunk: int = DEFAULT_CHUNK, band: Optional[int] = None, sweep: Optional[bool] = None) -> SpmmPlan:
     """Split-row plan of an adjacency.  band = columns per band of a banded plan (see include/laplace_hip.h),
-    0 = row-major, None = DEFAULT_BAND when the adjacency spans at least MIN_BANDS of them.  sweep (default: the
+    0 = row-major, None = DEFAULT_BAND when the adjacency has at least MIN_BANDED_COLS columns.  sweep (default: the
     module switch SWEEP, and only when band is not given): the SWEEP form when the adjacency qualifies."""
     if (SWEEP if sweep is None else sweep) and band is None:
         plan = build_sweep_plan(a, chunk, band=SWEEP_BAND)
@@ -371,7 +377,7 @@ def build_spmm_plan(a: DeviceCSR, chunk: int = DEFAULT_CHUNK, band: Optional[int
             return plan
     L = _lib.lib()
     if band is None:
-        band = DEFAULT_BAND if a.n_cols >= MIN_BANDS * DEFAULT_BAND else 0
+        band = DEFAULT_BAND if a.n_cols >= MIN_BANDED_COLS else 0
     dev = a.device
     ws = _ws(L.mi_spmm_plan_workspace_bytes(a.n_rows, a.nnz), dev)
     info = _lib.SpmmPlanInfo()
@@ -692,6 +698,26 @@ def topk_excl(uid: Tensor, user_emb: Tensor, item_emb: Tensor, k: int, excl: Opt
                                  out_idx[q0:q1].data_ptr(), out_sc[q0:q1].data_ptr() if want_scores else None,
                                  ws.data_ptr(), ws.numel(), _stream()), "mi_topk_excl_f32")
     return (out_idx, out_sc) if want_scores else out_idx
+
+
+def topk_prefilter_scores(uid: Optional[Tensor], user_emb: Tensor, item_emb: Tensor) -> Tuple[Tensor, Tensor]:
+    """Diagnostic of the bf16x3 prefilter behind topk_excl (csrc/topk_prefilter.hpp): the approximate scores [n_q, n_items]
+    it compares with its thresholds and the per-query bound eps it assumes for |approximate - exact fma chain|."""
+    ldu = _rows_ok(user_emb, "user_emb")
+    ldi = _rows_ok(item_emb, "item_emb")
+    n_q = uid.numel() if uid is not None else user_emb.shape[0]
+    n_items, d = item_emb.shape
+    if uid is not None:
+        _need(uid, t.int64, "uid")
+    dev = item_emb.device
+    sc = t.empty(n_q, n_items, dtype=t.float32, device=dev)
+    eps = t.empty(n_q, dtype=t.float32, device=dev)
+    L = _lib.lib()
+    ws = _ws(L.mi_topk_prefilter_scores_workspace_bytes(n_q, n_items), dev)
+    check(L.mi_topk_prefilter_scores_f32(n_q, n_items, d, _ptr(uid), user_emb.data_ptr(), ldu, item_emb.data_ptr(), ldi,
+                                         sc.data_ptr(), eps.data_ptr(), ws.data_ptr(), ws.numel(), _stream()),
+          "mi_topk_prefilter_scores_f32")
+    return sc, eps
 
 
 def segment_max(a: DeviceCSR, X: Tensor, want_arg: bool = True):

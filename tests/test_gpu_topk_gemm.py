@@ -185,6 +185,38 @@ def test_topk_bf16_prefilter_equals_the_f32_path(D, n_q, k, monkeypatch):
     assert t.equal(sc_b[:m].cpu()[valid], exact.gather(1, want.clamp(min=0))[valid])
 
 
+@pytest.mark.parametrize("D", [64, 128])
+@pytest.mark.parametrize("kind", ["gaussian", "wide_range", "cancelling", "constant_sign"])
+def test_topk_prefilter_error_bound_holds(D, kind):
+    """|bf16x3 score - exact fma chain| <= eps(u) = 2^-12 |u| max|i| — the bound the candidate selection rests on
+    (csrc/topk_prefilter.hpp) — measured through the diagnostic entry on tables built to stress it: components over six
+    decades, rows whose terms cancel to ~0 (all of the bound is rounding), rows of one sign (the largest sums).  The
+    worst case observed must also stay well inside the bound (the derivation leaves a factor ~2.3)."""
+    from laplace_amd import ops
+    g = t.Generator().manual_seed(7 * D + len(kind))
+    n_q, n_items = 200, 3000
+    if kind == "gaussian":
+        ue, ie = t.randn(n_q, D, generator=g), t.randn(n_items, D, generator=g)
+    elif kind == "wide_range":
+        ue = t.randn(n_q, D, generator=g) * 10.0 ** t.randint(-3, 4, (n_q, D), generator=g).float()
+        ie = t.randn(n_items, D, generator=g) * 10.0 ** t.randint(-3, 4, (n_items, D), generator=g).float()
+    elif kind == "cancelling":
+        half = t.randn(n_q, D // 2, generator=g)
+        ue = t.cat([half, half], 1)
+        ih = t.randn(n_items, D // 2, generator=g)
+        ie = t.cat([ih, -ih * (1.0 + t.randint(-2, 3, ih.shape, generator=g).float() * 2.0 ** -20)], 1)
+    else:
+        ue, ie = t.rand(n_q, D, generator=g) + 0.5, t.rand(n_items, D, generator=g) + 0.5
+    approx, eps = ops.topk_prefilter_scores(None, ue.to(DEV), ie.to(DEV))
+    exact = R.scores_fma(ue, ie)
+    err = (approx.cpu().double() - exact.double()).abs()
+    bound = eps.cpu().double()[:, None]
+    want_eps = 2.0 ** -12 * ue.double().norm(dim=1) * ie.double().norm(dim=1).max()
+    assert t.all(eps.cpu().double() >= want_eps) and t.all(eps.cpu().double() <= 1.03 * want_eps)
+    assert t.all(err <= bound)
+    assert float((err / bound).max()) < 0.6
+
+
 def test_pipeline_end_to_end_small():
     from laplace_amd import synthetic as S
     from laplace_amd.config import LightGCNConfig
