@@ -464,7 +464,7 @@ def topk_block(args) -> dict:
     spec = importlib.util.spec_from_file_location("bench_topk", os.path.join(ROOT, "tools", "bench_topk.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    return mod.bench_line(full=True, n_q=16384)
+    return mod.bench_line(full=True, n_q=16384, cpu_loop=not args.no_cpu_baseline)
 
 
 _T0 = time.perf_counter()

@@ -34,6 +34,9 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #ifndef MI_PRE_PROBE
 #define MI_PRE_PROBE 0   // timing probes (wrong results): 1 = vote branches with empty hit bodies, 2 = compares only (no branch)
 #endif
+#ifndef MI_PRE_ONE_PUT
+#define MI_PRE_ONE_PUT 1   // a vote group's hits as one predicated store when no lane has two of the four (A/B)
+#endif
 constexpr float kPreC = 2.44140625e-4f;   // 2^-12, see above
 constexpr int kPreCap = 8192;             // list slots per query in global memory, divided among the item slices
 constexpr int kPreMaxK = 256;             // beyond: the f32 path (the survivors of a row must fit the finish step)
@@ -236,10 +239,18 @@ void topk_prefilter_bf16_kernel(PreArgs a) {
             if (MI_PRE_PROBE == 1) cnt[ai_ & 1] += 1;                                                                   \
             else {                                                                                                      \
                 const uint32_t it_ = item_prev + (uint32_t)((ai_ >> 1) * 32 + 2 * rb_) + row4;                          \
-                pre_put(p0_, v0_, it_, cnt[ai_ & 1], region[ai_ & 1], cmask);                                           \
-                pre_put(p1_, v1_, it_ + 1, cnt[ai_ & 1], region[ai_ & 1], cmask);                                       \
-                pre_put(p2_, v2_, it_ + 2, cnt[ai_ & 1], region[ai_ & 1], cmask);                                       \
-                pre_put(p3_, v3_, it_ + 3, cnt[ai_ & 1], region[ai_ & 1], cmask);                                       \
+                const bool two_ = (p0_ & (p1_ | p2_ | p3_)) | (p1_ & (p2_ | p3_)) | (p2_ & p3_);                        \
+                if (MI_PRE_ONE_PUT && __builtin_expect(__ballot(two_) == 0ull, 1)) {                                    \
+                    /* no lane has two of the four (the usual case): ONE predicated store for the group */              \
+                    const float v_ = p0_ ? v0_ : (p1_ ? v1_ : (p2_ ? v2_ : v3_));                                       \
+                    const uint32_t o_ = p0_ ? 0u : (p1_ ? 1u : (p2_ ? 2u : 3u));                                        \
+                    pre_put(p0_ | p1_ | p2_ | p3_, v_, it_ + o_, cnt[ai_ & 1], region[ai_ & 1], cmask);                 \
+                } else {                                                                                                \
+                    pre_put(p0_, v0_, it_, cnt[ai_ & 1], region[ai_ & 1], cmask);                                       \
+                    pre_put(p1_, v1_, it_ + 1, cnt[ai_ & 1], region[ai_ & 1], cmask);                                   \
+                    pre_put(p2_, v2_, it_ + 2, cnt[ai_ & 1], region[ai_ & 1], cmask);                                   \
+                    pre_put(p3_, v3_, it_ + 3, cnt[ai_ & 1], region[ai_ & 1], cmask);                                   \
+                }                                                                                                       \
             }                                                                                                           \
         }                                                                                                               \
     }

@@ -668,6 +668,22 @@ TOPK_CHUNK_QUANTUM = 2048  # chunks are multiples of this when they can be: the 
 # sized to fill the chip in whole rounds; a second one beside it breaks the rounds of both.)
 
 
+# streams the chunks of one topk_excl call alternate over (each with its own workspace).  A/B, 65 536 queries against 100 K items
+# (tools/bench_topk.py --streams N): 1: 8.45 M / 6.17 M users/s (k = 12 / 256), 2: 8.87 M / 6.70 M, 3: 8.55 M / 6.65 M — one
+# chunk's side kernels (split, sample scores, threshold, refine) run beside the other's prefilter kernel, which holds one
+# wavefront per SIMD and 96 KB of LDS per CU.  (The same switch was slower for the f32 fused kernel, whose grid fills the chip
+# in whole rounds of two workgroups per CU.)
+TOPK_STREAMS = int(_os_environ.get("LAPLACE_TOPK_STREAMS", 2))
+_TOPK_SIDE = {}
+
+
+def _topk_side_streams(dev, n: int):
+    key = (t.device(dev).index if t.device(dev).index is not None else t.cuda.current_device(), n)
+    if key not in _TOPK_SIDE:
+        _TOPK_SIDE[key] = [t.cuda.Stream(device=dev) for _ in range(n)]
+    return _TOPK_SIDE[key]
+
+
 def topk_excl(uid: Tensor, user_emb: Tensor, item_emb: Tensor, k: int, excl: Optional[DeviceCSR] = None,
               want_scores: bool = False):
     """K10 — for each query user uid[q]: the k best item ids by (score desc, id asc) among items not in
@@ -687,8 +703,11 @@ def topk_excl(uid: Tensor, user_emb: Tensor, item_emb: Tensor, k: int, excl: Opt
     chunk = max(1, min(n_q, TOPK_WS_BYTES // max(4 * n_items, 1)))
     if n_q > chunk >= TOPK_CHUNK_QUANTUM:
         chunk -= chunk % TOPK_CHUNK_QUANTUM
-    ws = _ws(L.mi_topk_workspace_bytes(chunk, n_items, k), dev)
-    for q0 in range(0, n_q, chunk):
+    n_chunks = (n_q + chunk - 1) // chunk
+    lanes = TOPK_STREAMS if (TOPK_STREAMS > 1 and n_chunks > 1) else 1
+    wss = [_ws(L.mi_topk_workspace_bytes(chunk, n_items, k), dev) for _ in range(lanes)]
+
+    def launch(q0: int, ws: Tensor):
         q1 = min(n_q, q0 + chunk)
         # rowptr keeps absolute offsets into excl.col, so a chunk is just a slice of rowptr
         ep = excl.rowptr[q0:q1 + 1] if excl is not None else None
@@ -697,6 +716,28 @@ def topk_excl(uid: Tensor, user_emb: Tensor, item_emb: Tensor, k: int, excl: Opt
                                  item_emb.data_ptr(), ldi, _ptr(ep), _ptr(ei),
                                  out_idx[q0:q1].data_ptr(), out_sc[q0:q1].data_ptr() if want_scores else None,
                                  ws.data_ptr(), ws.numel(), _stream()), "mi_topk_excl_f32")
+
+    if lanes == 1:
+        for q0 in range(0, n_q, chunk):
+            launch(q0, wss[0])
+    else:
+        # chunks alternate over `lanes` streams, each with its own workspace: one chunk's side kernels (split, sample scores,
+        # threshold, refine: ~30 % of its time) run beside the other's prefilter kernel, which holds one wavefront per SIMD
+        cur = t.cuda.current_stream()
+        side = _topk_side_streams(dev, lanes)
+        for st in side:
+            st.wait_stream(cur)
+        for i, q0 in enumerate(range(0, n_q, chunk)):
+            with t.cuda.stream(side[i % lanes]):
+                launch(q0, wss[i % lanes])
+        for st, ws in zip(side, wss):
+            cur.wait_stream(st)
+            ws.record_stream(st)
+        for x in (uid, user_emb, item_emb, out_idx, out_sc, excl.rowptr if excl is not None else None,
+                  excl.col if excl is not None else None):
+            if x is not None:
+                for st in side:
+                    x.record_stream(st)
     return (out_idx, out_sc) if want_scores else out_idx
 
 

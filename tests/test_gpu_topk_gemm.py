@@ -178,6 +178,16 @@ def test_topk_bf16_prefilter_equals_the_f32_path(D, n_q, k, monkeypatch):
     ids_f, sc_f = ops.topk_excl(*args, want_scores=True)
     assert t.equal(ids_b, ids_f)
     assert t.equal(sc_b, sc_f)
+    if n_q > 600:   # the same call cut into chunks of 512 queries that alternate over two streams and two workspaces
+        monkeypatch.setenv("LAPLACE_TOPK_PREFILTER", "1")
+        monkeypatch.setattr(ops, "TOPK_WS_BYTES", 4 * n_items * 512)
+        monkeypatch.setattr(ops, "TOPK_CHUNK_QUANTUM", 512)
+        monkeypatch.setattr(ops, "TOPK_STREAMS", 2)
+        ids_c, sc_c = ops.topk_excl(*args, want_scores=True)
+        assert t.equal(ids_c, ids_b) and t.equal(sc_c, sc_b)
+        monkeypatch.setattr(ops, "TOPK_STREAMS", 1)
+        ids_d, _ = ops.topk_excl(*args, want_scores=True)
+        assert t.equal(ids_d, ids_b)
     m = min(n_q, 40)
     want = R.topk_excl_exact(exact, excl[:m], k)
     assert t.equal(ids_b[:m].cpu(), want)

@@ -12,9 +12,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def bench_line(full: bool = True, n_q: int = 16384, pre_only: bool = False, cpu_loop: bool = True) -> dict:
+def bench_line(full: bool = True, n_q: int = 16384, pre_only: bool = False, cpu_loop: bool = True, streams: int = 0) -> dict:
     import torch as t
     from laplace_amd import ops, synthetic as S
+    if streams:
+        ops.TOPK_STREAMS = streams   # A/B: chunks alternating over this many streams
     from laplace_amd.interactions import Interactions
     dev = "cuda"
     spec = S.C2 if full else S.SyntheticSpec(200_000, 100_000, 2_000_000, seed=1)
@@ -24,7 +26,8 @@ def bench_line(full: bool = True, n_q: int = 16384, pre_only: bool = False, cpu_
     g = t.Generator(device=dev).manual_seed(0)
     ue = t.randn(spec.num_users, 128, device=dev, generator=g) * 0.1
     ie = t.randn(spec.num_items, 128, device=dev, generator=g) * 0.1
-    out = {"workload": f"top-K with exclusion, {n_q} query users against {spec.num_items} items, D=128, users' own edges excluded"}
+    out = {"workload": f"top-K with exclusion, {n_q} query users against {spec.num_items} items, D=128, users' own edges excluded",
+           "chunk_streams": ops.TOPK_STREAMS}
     uid = t.arange(n_q, device=dev)
     excl = ops.row_slice(r, 0, n_q)
     kept = {}
@@ -65,7 +68,8 @@ def bench_line(full: bool = True, n_q: int = 16384, pre_only: bool = False, cpu_
 
 def main():
     n_q = int(sys.argv[sys.argv.index("--users") + 1]) if "--users" in sys.argv else 16384
-    print(json.dumps(bench_line(full="--full" in sys.argv, n_q=n_q, pre_only="--pre-only" in sys.argv)))
+    streams = int(sys.argv[sys.argv.index("--streams") + 1]) if "--streams" in sys.argv else 0
+    print(json.dumps(bench_line(full="--full" in sys.argv, n_q=n_q, pre_only="--pre-only" in sys.argv, streams=streams)))
 
 
 if __name__ == "__main__":
