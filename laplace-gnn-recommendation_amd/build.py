@@ -28,6 +28,14 @@ CXXFLAGS = [
 ]
 
 
+# per-file additions.  topk.hip: the bf16 prefilter kernel (csrc/topk_prefilter.hpp) compares its accumulators with per-lane
+# thresholds; with the accumulators in AGPRs (the allocator's default for an MFMA result when the kernel needs > 256 registers)
+# every compared value costs a v_accvgpr_read first — 85 per item panel beside 96 MFMAs.  The VGPR form of the MFMA keeps the
+# accumulators in VGPRs and the query fragments (MFMA operands only) in AGPRs: 480 -> 372 registers, no copies.  The other
+# kernels of the file fit 256 VGPRs and compile to the same code either way.
+EXTRA_FLAGS = {"topk.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+
+
 def _sources() -> list[str]:
     return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
 
@@ -42,7 +50,7 @@ def _compile(src: str, force: bool) -> str:
     stale = force or not os.path.exists(obj) or os.path.getmtime(obj) < max(
         os.path.getmtime(src), _deps_mtime())
     if stale:
-        cmd = [HIPCC, *CXXFLAGS, "-c", src, "-o", obj]
+        cmd = [HIPCC, *CXXFLAGS, *EXTRA_FLAGS.get(os.path.basename(src), []), "-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src}:\n{r.stdout}\n{r.stderr}")

@@ -34,6 +34,9 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #ifndef MI_PRE_PROBE
 #define MI_PRE_PROBE 0   // timing probes (wrong results): 1 = vote branches with empty hit bodies, 2 = compares only (no branch)
 #endif
+#ifndef MI_PRE_Q_IN_AGPR
+#define MI_PRE_Q_IN_AGPR 1   // the query fragments (128 registers, MFMA operands only) are steered into AGPRs so that the
+#endif                       // accumulators — which the votes compare — can stay in VGPRs: no v_accvgpr_read per vote (A/B)
 #ifndef MI_PRE_ONE_PUT
 #define MI_PRE_ONE_PUT 1   // a vote group's hits as one predicated store when no lane has two of the four (A/B)
 #endif
@@ -178,6 +181,10 @@ void topk_prefilter_bf16_kernel(PreArgs a) {
         for (int s = 0; s < S; ++s) {
             uh[ub][s] = __builtin_bit_cast(bf16x8, up[2 * s]);
             ul[ub][s] = __builtin_bit_cast(bf16x8, up[CH / 2 + 2 * s]);
+            if (MI_PRE_Q_IN_AGPR) {   // see the note at the macro
+                asm volatile("" : "+a"(uh[ub][s]));
+                asm volatile("" : "+a"(ul[ub][s]));
+            }
         }
     }
     const float tq[2] = {STORE ? 0.f : a.thrf[u0 + r], STORE ? 0.f : a.thrf[u0 + 32 + r]};

@@ -18,11 +18,13 @@ fs = glob.glob("$out/mfma/**/*counter_collection.csv", recursive=True)
 if fs:
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(fs[0])):
-        if "topk_scores_filter" in r["Kernel_Name"]:
+        if "topk_scores_filter" in r["Kernel_Name"] or "topk_prefilter_bf16" in r["Kernel_Name"]:
             acc[r["Kernel_Name"][:60]][r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, v in acc.items():
         m = {c: sum(x) / len(x) for c, x in v.items()}
         print(k, {c: round(x) for c, x in m.items()})
+        if m.get("SQ_BUSY_CU_CYCLES"):
+            print("   MFMA busy / (4 SIMDs x CU-busy cycles) =", round(m["SQ_VALU_MFMA_BUSY_CYCLES"] / (4 * m["SQ_BUSY_CU_CYCLES"]), 3))
 EOF2
 find $out -name "*_kernel_trace.csv" -delete 2>/dev/null || true
 find $out -name "*agent_info.csv" -delete 2>/dev/null || true
