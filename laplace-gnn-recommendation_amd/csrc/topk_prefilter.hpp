@@ -234,7 +234,10 @@ void topk_prefilter_bf16_kernel(PreArgs a) {
     // Votes on the previous panel, FOUR accumulator registers at a time (rows 8 j' .. 8 j' + 3 of one 32x32 block: group g
     // = block g >> 2, j' = g & 3): one wave-uniform branch per group instead of one per register — the chain compare ->
     // scalar and -> scalar compare -> branch is latency a lone wavefront per SIMD cannot hide (one branch per register:
-    // 304 us per 4 096-query chunk with empty hit bodies, against 125 us of MFMAs).
+    // 304 us per 4 096-query chunk with empty hit bodies, against 125 us of MFMAs).  The group's "any" is formed on the
+    // LANES' booleans (v_cndmask / v_or / one v_cmp_ne: 128 more vector instructions per panel than or-ing the four
+    // compare masks with s_or_b64) on purpose: the scalar form was measured 307 -> 356 us per chunk at k = 12 — vector
+    // instructions pipeline behind the MFMAs, the dependent scalar chain does not.
 #define MI_PRE_VOTE4(prev, g)                                                                                           \
     {                                                                                                                   \
         const int ai_ = (g) >> 2, rb_ = 4 * ((g) & 3);                                                                  \
