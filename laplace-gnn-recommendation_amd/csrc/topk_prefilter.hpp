@@ -37,6 +37,11 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #ifndef MI_PRE_Q_IN_AGPR
 #define MI_PRE_Q_IN_AGPR 1   // the query fragments (128 registers, MFMA operands only) are steered into AGPRs so that the
 #endif                       // accumulators — which the votes compare — can stay in VGPRs: no v_accvgpr_read per vote (A/B)
+#ifndef MI_PRE_MAX_TEST
+#define MI_PRE_MAX_TEST 0   // a vote group's wave-level test on the largest of its four scores (v_max3 + v_max + one compare: 144 fewer
+                            // vector instructions per panel).  A/B: 318 / 363 -> 320 / 368 us per chunk (k = 12 / 256), 9.66 M -> 9.27 M
+                            // users/s — the loop is not bound by its vector-instruction count.  Off.
+#endif
 #ifndef MI_PRE_ONE_PUT
 #define MI_PRE_ONE_PUT 1   // a vote group's hits as one predicated store when no lane has two of the four (A/B)
 #endif
@@ -243,9 +248,15 @@ void topk_prefilter_bf16_kernel(PreArgs a) {
         const int ai_ = (g) >> 2, rb_ = 4 * ((g) & 3);                                                                  \
         const float v0_ = prev[ai_][rb_], v1_ = prev[ai_][rb_ + 1], v2_ = prev[ai_][rb_ + 2], v3_ = prev[ai_][rb_ + 3]; \
         const float t_ = tqv[ai_ & 1];                                                                                  \
-        const bool p0_ = !(v0_ < t_), p1_ = !(v1_ < t_), p2_ = !(v2_ < t_), p3_ = !(v3_ < t_);                          \
-        if (MI_PRE_PROBE == 2) cnt[ai_ & 1] += (int)p0_ + (int)p1_ + (int)p2_ + (int)p3_;                               \
-        else if (__builtin_expect(__ballot(p0_ | p1_ | p2_ | p3_) != 0ull, 0)) {   /* out of line */                    \
+        /* the group's test on the LARGEST of the four (v_max3 + v_max + one compare).  A NaN score would slip through  \
+           fmaxf, but NaN / inf anywhere in the tables make eps and with it thrf NaN or -inf for every query (the norms),  \
+           and then this test passes everything: those calls end on the exact path regardless */                       \
+        const float mx_ = MI_PRE_MAX_TEST ? fmaxf(fmaxf(v0_, v1_), fmaxf(v2_, v3_)) : 0.f;                              \
+        const bool pq0_ = !(v0_ < t_), pq1_ = !(v1_ < t_), pq2_ = !(v2_ < t_), pq3_ = !(v3_ < t_);                      \
+        const bool any_ = MI_PRE_MAX_TEST ? !(mx_ < t_) : (pq0_ | pq1_ | pq2_ | pq3_);                                  \
+        if (MI_PRE_PROBE == 2) cnt[ai_ & 1] += (int)pq0_ + (int)pq1_ + (int)pq2_ + (int)pq3_;                           \
+        else if (__builtin_expect(__ballot(any_) != 0ull, 0)) {   /* out of line */                                     \
+            const bool p0_ = pq0_, p1_ = pq1_, p2_ = pq2_, p3_ = pq3_;                                                  \
             if (MI_PRE_PROBE == 1) cnt[ai_ & 1] += 1;                                                                   \
             else {                                                                                                      \
                 const uint32_t it_ = item_prev + (uint32_t)((ai_ >> 1) * 32 + 2 * rb_) + row4;                          \
