@@ -1234,7 +1234,8 @@ static int topk_pre_kernel_launch(PreArgs& pa, int64_t strips, int64_t panels, i
     pa.strips = (int)strips; pa.n_slices = (int)(8 * sl); pa.cap_s = 2;
     while (pa.cap_s * 2 * pa.n_slices <= kPreCap) pa.cap_s *= 2;
     pa.panels_per_slice = mi_ceil_div(panels, pa.n_slices);
-    auto kern = topk_prefilter_bf16_kernel<D, STORE>;
+    constexpr int UB = STORE ? 2 : MI_PRE_UB;   // (the STORE form spills at two wavefronts per SIMD)
+    auto kern = topk_prefilter_bf16_kernel<D, STORE, UB>;
     constexpr int lds = 3 * 64 * (D / 4) * 16;
     static bool attr_set = false;  // per instantiation; idempotent
     if (!attr_set) {
@@ -1242,7 +1243,7 @@ static int topk_pre_kernel_launch(PreArgs& pa, int64_t strips, int64_t panels, i
             return MI_ERR_UNSUPPORTED;
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)(8 * sl * strips)), dim3(256), lds, s, pa);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(8 * sl * strips)), dim3(512 / UB), lds, s, pa);
     return 0;
 }
 

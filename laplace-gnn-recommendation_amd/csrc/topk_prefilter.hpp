@@ -37,6 +37,9 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #ifndef MI_PRE_Q_IN_AGPR
 #define MI_PRE_Q_IN_AGPR 1   // the query fragments (128 registers, MFMA operands only) are steered into AGPRs so that the
 #endif                       // accumulators — which the votes compare — can stay in VGPRs: no v_accvgpr_read per vote (A/B)
+#ifndef MI_PRE_UB
+#define MI_PRE_UB 2   // 32-query blocks per wavefront of the prefilter kernel: 2 = one wavefront per SIMD, 1 = two (A/B)
+#endif
 #ifndef MI_PRE_MAX_TEST
 #define MI_PRE_MAX_TEST 0   // a vote group's wave-level test on the largest of its four scores (v_max3 + v_max + one compare: 144 fewer
                             // vector instructions per panel).  A/B: 318 / 363 -> 320 / 368 us per chunk (k = 12 / 256), 9.66 M -> 9.27 M
@@ -139,10 +142,10 @@ __device__ __forceinline__ void pre_put(bool p, float v, uint32_t item, int& cnt
 }
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-template <int PIECES>
+template <int PIECES, int THREADS>
 __device__ __forceinline__ void pre_issue(u32x4 (&g)[PIECES], const uint4* __restrict__ src) {
 #pragma unroll
-    for (int j = 0; j < PIECES; ++j) g[j] = *reinterpret_cast<const u32x4*>(src + 256 * j);
+    for (int j = 0; j < PIECES; ++j) g[j] = *reinterpret_cast<const u32x4*>(src + THREADS * j);
 }
 template <int PIECES>
 __device__ __forceinline__ void pre_commit(const u32x4 (&g)[PIECES], unsigned char* buf, const uint32_t (&woff)[PIECES]) {
@@ -150,15 +153,20 @@ __device__ __forceinline__ void pre_commit(const u32x4 (&g)[PIECES], unsigned ch
     for (int j = 0; j < PIECES; ++j) *reinterpret_cast<u32x4*>(buf + woff[j]) = g[j];
 }
 
-template <int D, bool STORE>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+// UB = 32-query blocks per wavefront: 2 = four wavefronts per workgroup, one per SIMD (372 registers); 1 = eight wavefronts,
+// two per SIMD (<= 256 registers each), so that one's barrier / LDS commit / hit bodies run under the other's MFMAs.
+template <int D, bool STORE, int UB>
+__global__ __launch_bounds__(512 / UB) __attribute__((amdgpu_waves_per_eu(2 / UB, 2 / UB)))
 void topk_prefilter_bf16_kernel(PreArgs a) {
+    constexpr int THREADS = 512 / UB;
+    constexpr int NACC = 2 * UB;               // 32x32 accumulator blocks per wavefront: [item block ib][query block ub]
     constexpr int S = D / 16;                  // k-steps per part
     constexpr int CH = D / 4;                  // 16-byte chunks per row
     constexpr int ROWB = CH * 16;
     constexpr int PANELB = 64 * ROWB;
-    constexpr int PIECES = PANELB / 16 / 256;  // chunks a thread moves per panel
-    constexpr int NS = 12 * S;                 // MFMAs per panel and wavefront
+    constexpr int PIECES = PANELB / 16 / THREADS;  // chunks a thread moves per panel
+    constexpr int NS = 3 * NACC * S;           // MFMAs per panel and wavefront
+    constexpr int NG = 4 * NACC;               // vote groups per panel and wavefront
     extern __shared__ __align__(16) unsigned char pre_ring[];   // 3 panels
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -168,19 +176,19 @@ void topk_prefilter_bf16_kernel(PreArgs a) {
     const int64_t slice = (int64_t)(bj / a.strips) * 8 + bx;
     const int64_t p0 = slice * a.panels_per_slice;
     const int64_t p1 = min(a.panels, p0 + a.panels_per_slice);
-    const int64_t u0 = (int64_t)strip * 256 + wave * 64;   // this wavefront's 64 queries
+    const int64_t u0 = (int64_t)strip * 256 + wave * (32 * UB);   // this wavefront's 32 UB queries
     int* my_cnt_out = STORE ? nullptr : a.pre_cnt + ((u0 + r) * a.n_slices + slice) * 2 + h;   // [query][slice][half]
     if (p0 >= p1) {  // block-uniform: an empty slice still owns its counters
         if (!STORE) {
-            my_cnt_out[0] = 0;
-            my_cnt_out[64 * (int64_t)a.n_slices] = 0;
+#pragma unroll
+            for (int ub = 0; ub < UB; ++ub) my_cnt_out[64 * ub * (int64_t)a.n_slices] = 0;
         }
         return;
     }
     // queries: fragments of the B operand, lane (r, h) holds k = 8 h .. 8 h + 7 of k-step s for query 32 ub + r
-    bf16x8 uh[2][S], ul[2][S];
+    bf16x8 uh[UB][S], ul[UB][S];
 #pragma unroll
-    for (int ub = 0; ub < 2; ++ub) {
+    for (int ub = 0; ub < UB; ++ub) {
         const uint4* up = a.Ub + (u0 + 32 * ub + r) * CH + h;
 #pragma unroll
         for (int s = 0; s < S; ++s) {
@@ -192,34 +200,38 @@ void topk_prefilter_bf16_kernel(PreArgs a) {
             }
         }
     }
-    const float tq[2] = {STORE ? 0.f : a.thrf[u0 + r], STORE ? 0.f : a.thrf[u0 + 32 + r]};
-    unsigned long long* region[2];
+    float tq[UB];
+    unsigned long long* region[UB];
+    int cnt[UB];
 #pragma unroll
-    for (int ub = 0; ub < 2; ++ub) {
+    for (int ub = 0; ub < UB; ++ub) {
         const int64_t q = u0 + 32 * ub + r;   // (padding queries have rows of their own: they pass only on NaN scores)
+        tq[ub] = STORE ? 0.f : a.thrf[q];
         region[ub] = STORE ? nullptr : a.pre + q * kPreCap + slice * a.cap_s + h * (a.cap_s / 2);
+        cnt[ub] = 0;
     }
-    int cnt[2] = {0, 0};
     // item panels: a panel is one contiguous block of the split table; chunk (row, c) lives at row * ROWB + ((c ^ (row & 15)) << 4)
     u32x4 g[PIECES];
     uint32_t woff[PIECES];
 #pragma unroll
     for (int j = 0; j < PIECES; ++j) {
-        const int idx = tid + 256 * j, row = idx / CH, c = idx % CH;
+        const int idx = tid + THREADS * j, row = idx / CH, c = idx % CH;
         woff[j] = (uint32_t)(row * ROWB + ((c ^ (row & 15)) << 4));
     }
-    pre_issue<PIECES>(g, a.Ib + p0 * (64 * CH) + tid);
+    pre_issue<PIECES, THREADS>(g, a.Ib + p0 * (64 * CH) + tid);
     pre_commit<PIECES>(g, pre_ring, woff);
-    if (p0 + 1 < p1) pre_issue<PIECES>(g, a.Ib + (p0 + 1) * (64 * CH) + tid);
+    if (p0 + 1 < p1) pre_issue<PIECES, THREADS>(g, a.Ib + (p0 + 1) * (64 * CH) + tid);
     // read offsets: item block ib, row 32 ib + r, chunk (part * CH / 2 + 2 s + h) ^ (r & 15) — one xor with a constant per read
     const uint32_t rx[2] = {(uint32_t)(r * ROWB) ^ (uint32_t)((h ^ (r & 15)) << 4),
                             (uint32_t)((32 + r) * ROWB) ^ (uint32_t)((h ^ (r & 15)) << 4)};
-    f32x16 acc0[4], acc1[4];
+    f32x16 acc0[NACC], acc1[NACC];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NACC; ++i)
 #pragma unroll
         for (int e = 0; e < 16; ++e) { acc0[i][e] = 0.f; acc1[i][e] = 0.f; }
-    float tqv[2] = {INFINITY, INFINITY};   // no previous panel yet: nothing passes
+    float tqv[UB];   // no previous panel yet: nothing passes
+#pragma unroll
+    for (int ub = 0; ub < UB; ++ub) tqv[ub] = INFINITY;
     const int cmask = a.cap_s / 2 - 1;
     uint32_t item_prev = 0;
     const uint32_t row4 = 4u * (uint32_t)h;
@@ -247,30 +259,30 @@ void topk_prefilter_bf16_kernel(PreArgs a) {
     {                                                                                                                   \
         const int ai_ = (g) >> 2, rb_ = 4 * ((g) & 3);                                                                  \
         const float v0_ = prev[ai_][rb_], v1_ = prev[ai_][rb_ + 1], v2_ = prev[ai_][rb_ + 2], v3_ = prev[ai_][rb_ + 3]; \
-        const float t_ = tqv[ai_ & 1];                                                                                  \
+        const float t_ = tqv[ai_ % UB]; \
         /* the group's test on the LARGEST of the four (v_max3 + v_max + one compare).  A NaN score would slip through  \
            fmaxf, but NaN / inf anywhere in the tables make eps and with it thrf NaN or -inf for every query (the norms),  \
            and then this test passes everything: those calls end on the exact path regardless */                       \
         const float mx_ = MI_PRE_MAX_TEST ? fmaxf(fmaxf(v0_, v1_), fmaxf(v2_, v3_)) : 0.f;                              \
         const bool pq0_ = !(v0_ < t_), pq1_ = !(v1_ < t_), pq2_ = !(v2_ < t_), pq3_ = !(v3_ < t_);                      \
         const bool any_ = MI_PRE_MAX_TEST ? !(mx_ < t_) : (pq0_ | pq1_ | pq2_ | pq3_);                                  \
-        if (MI_PRE_PROBE == 2) cnt[ai_ & 1] += (int)pq0_ + (int)pq1_ + (int)pq2_ + (int)pq3_;                           \
+        if (MI_PRE_PROBE == 2) cnt[ai_ % UB] += (int)pq0_ + (int)pq1_ + (int)pq2_ + (int)pq3_;                           \
         else if (__builtin_expect(__ballot(any_) != 0ull, 0)) {   /* out of line */                                     \
             const bool p0_ = pq0_, p1_ = pq1_, p2_ = pq2_, p3_ = pq3_;                                                  \
-            if (MI_PRE_PROBE == 1) cnt[ai_ & 1] += 1;                                                                   \
+            if (MI_PRE_PROBE == 1) cnt[ai_ % UB] += 1;                                                                   \
             else {                                                                                                      \
-                const uint32_t it_ = item_prev + (uint32_t)((ai_ >> 1) * 32 + 2 * rb_) + row4;                          \
+                const uint32_t it_ = item_prev + (uint32_t)((ai_ / UB) * 32 + 2 * rb_) + row4; \
                 const bool two_ = (p0_ & (p1_ | p2_ | p3_)) | (p1_ & (p2_ | p3_)) | (p2_ & p3_);                        \
                 if (MI_PRE_ONE_PUT && __builtin_expect(__ballot(two_) == 0ull, 1)) {                                    \
                     /* no lane has two of the four (the usual case): ONE predicated store for the group */              \
                     const float v_ = p0_ ? v0_ : (p1_ ? v1_ : (p2_ ? v2_ : v3_));                                       \
                     const uint32_t o_ = p0_ ? 0u : (p1_ ? 1u : (p2_ ? 2u : 3u));                                        \
-                    pre_put(p0_ | p1_ | p2_ | p3_, v_, it_ + o_, cnt[ai_ & 1], region[ai_ & 1], cmask);                 \
+                    pre_put(p0_ | p1_ | p2_ | p3_, v_, it_ + o_, cnt[ai_ % UB], region[ai_ % UB], cmask);                 \
                 } else {                                                                                                \
-                    pre_put(p0_, v0_, it_, cnt[ai_ & 1], region[ai_ & 1], cmask);                                       \
-                    pre_put(p1_, v1_, it_ + 1, cnt[ai_ & 1], region[ai_ & 1], cmask);                                   \
-                    pre_put(p2_, v2_, it_ + 2, cnt[ai_ & 1], region[ai_ & 1], cmask);                                   \
-                    pre_put(p3_, v3_, it_ + 3, cnt[ai_ & 1], region[ai_ & 1], cmask);                                   \
+                    pre_put(p0_, v0_, it_, cnt[ai_ % UB], region[ai_ % UB], cmask);                                       \
+                    pre_put(p1_, v1_, it_ + 1, cnt[ai_ % UB], region[ai_ % UB], cmask);                                   \
+                    pre_put(p2_, v2_, it_ + 2, cnt[ai_ % UB], region[ai_ % UB], cmask);                                   \
+                    pre_put(p3_, v3_, it_ + 3, cnt[ai_ % UB], region[ai_ % UB], cmask);                                   \
                 }                                                                                                       \
             }                                                                                                           \
         }                                                                                                               \
@@ -278,31 +290,30 @@ void topk_prefilter_bf16_kernel(PreArgs a) {
 #define MI_PRE_PANEL(acc, prev, p)                                                                                      \
     {                                                                                                                   \
         if ((p) + 1 < p1) pre_commit<PIECES>(g, pre_ring + nxt, woff);   /* panel p + 1: loaded one panel ago */ \
-        if ((p) + 2 < p1) pre_issue<PIECES>(g, a.Ib + ((p) + 2) * (64 * CH) + tid);                \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                   \
+        if ((p) + 2 < p1) pre_issue<PIECES, THREADS>(g, a.Ib + ((p) + 2) * (64 * CH) + tid); \
+        _Pragma("unroll") for (int i = 0; i < NACC; ++i) \
             _Pragma("unroll") for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;                                             \
         _Pragma("unroll") for (int s = 0; s < S; ++s) {                                                                 \
             if (s + 1 < S) MI_PRE_READ(fr[(s + 1) & 1], cur, s + 1)   /* a k-step ahead: the votes' branches pin it here */ \
             _Pragma("unroll") for (int term = 0; term < 3; ++term)                                                      \
-                _Pragma("unroll") for (int ai = 0; ai < 4; ++ai) {                                                      \
-                    const int ib = ai >> 1, ub = ai & 1;                                                                \
+                _Pragma("unroll") for (int ai = 0; ai < NACC; ++ai) { \
+                    const int ib = ai / UB, ub = ai % UB; \
                     acc[ai] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[s & 1][2 * ib + (term == 2 ? 1 : 0)],         \
                                                                       term == 1 ? ul[ub][s] : uh[ub][s], acc[ai], 0, 0, 0); \
-                    const int m = s * 12 + term * 4 + ai;                                                               \
-                    if (!STORE && (m + 1) % (NS / 16) == 0) MI_PRE_VOTE4(prev, m / (NS / 16))                           \
+                    const int m = s * (3 * NACC) + term * NACC + ai; \
+                    if (!STORE && (m + 1) % (NS / NG) == 0) MI_PRE_VOTE4(prev, m / (NS / NG)) \
                 }                                                                                                       \
         }                                                                                                               \
         if (STORE) {   /* out[a_row][b_row]: for one register the 32 lanes of a half write 128 consecutive bytes */      \
-            _Pragma("unroll") for (int ai = 0; ai < 4; ++ai)                                                            \
+            _Pragma("unroll") for (int ai = 0; ai < NACC; ++ai) \
                 _Pragma("unroll") for (int reg = 0; reg < 16; ++reg) {                                                  \
-                    const int64_t ar_ = (p) * 64 + (ai >> 1) * 32 + (reg & 3) + 8 * (reg >> 2) + (int64_t)row4;         \
-                    const int64_t br_ = u0 + 32 * (ai & 1) + r;                                                         \
+                    const int64_t ar_ = (p) * 64 + (ai / UB) * 32 + (reg & 3) + 8 * (reg >> 2) + (int64_t)row4; \
+                    const int64_t br_ = u0 + 32 * (ai % UB) + r; \
                     if (ar_ < a.n_a && br_ < a.n_b) a.out[ar_ * a.ldo + br_] = acc[ai][reg];                            \
                 }                                                                                                       \
         }                                                                                                               \
         item_prev = (uint32_t)((p) * 64);                                                                               \
-        tqv[0] = tq[0];                                                                                                 \
-        tqv[1] = tq[1];                                                                                                 \
+        _Pragma("unroll") for (int ub = 0; ub < UB; ++ub) tqv[ub] = tq[ub]; \
         cur = nxt;                                                                                                      \
         nxt = nxt + PANELB == 3 * PANELB ? 0u : nxt + PANELB;                                                           \
         __syncthreads();  /* panel p + 1 is in LDS and everybody is done with panel p */                                \
@@ -323,16 +334,16 @@ void topk_prefilter_bf16_kernel(PreArgs a) {
     // the last panel's votes
     if (last_in_acc0) {
 #pragma unroll
-        for (int g = 0; g < 16; ++g) MI_PRE_VOTE4(acc0, g)
+        for (int g = 0; g < NG; ++g) MI_PRE_VOTE4(acc0, g)
     } else {
 #pragma unroll
-        for (int g = 0; g < 16; ++g) MI_PRE_VOTE4(acc1, g)
+        for (int g = 0; g < NG; ++g) MI_PRE_VOTE4(acc1, g)
     }
 #undef MI_PRE_PANEL
 #undef MI_PRE_READ
 #undef MI_PRE_VOTE4
 #pragma unroll
-    for (int ub = 0; ub < 2; ++ub) my_cnt_out[64 * ub * (int64_t)a.n_slices] = cnt[ub];
+    for (int ub = 0; ub < UB; ++ub) my_cnt_out[64 * ub * (int64_t)a.n_slices] = cnt[ub];
 }
 
 // The kk-th largest score key among the n composites in sh.cand (n >= kk): 4-pass radix select in LDS.
