@@ -38,7 +38,11 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #define MI_PRE_Q_IN_AGPR 1   // the query fragments (128 registers, MFMA operands only) are steered into AGPRs so that the
 #endif                       // accumulators — which the votes compare — can stay in VGPRs: no v_accvgpr_read per vote (A/B)
 #ifndef MI_PRE_UB
-#define MI_PRE_UB 2   // 32-query blocks per wavefront of the prefilter kernel: 2 = one wavefront per SIMD, 1 = two (A/B)
+#define MI_PRE_UB 1   // 32-query blocks per wavefront of the prefilter kernel: 2 = four wavefronts of 64 queries, one per SIMD (372
+                      // registers), 1 = eight of 32 queries, two per SIMD (212 registers).  A/B per 4 096-query chunk: 314 / 355 us
+                      // (k = 12 / 256) -> 264 / 305; 65 536 queries: 9.63 M / 8.07 M -> 10.56 M / 8.48 M users/s.  The lone
+                      // wavefront spent a quarter of its cycles parked at the per-panel barrier and its LDS commit
+                      // (SQ_WAIT_ANY, profiles/r03_topk_prefilter.md); now the SIMD's other wavefront issues MFMAs meanwhile
 #endif
 #ifndef MI_PRE_MAX_TEST
 #define MI_PRE_MAX_TEST 0   // a vote group's wave-level test on the largest of its four scores (v_max3 + v_max + one compare: 144 fewer
