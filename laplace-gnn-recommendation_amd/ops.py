@@ -658,7 +658,9 @@ def gemm_group(problems) -> bool:
     return True
 
 
-TOPK_WS_BYTES = 2 << 30  # score block per launch; queries are processed in chunks of this size
+TOPK_WS_BYTES = 2 << 30  # score block per launch; queries are processed in chunks of this size.  A/B at 100 K items, 65 536 queries
+                         # (tools/bench_topk.py --ws-gib): 1 GiB (2 048 queries per chunk): 10.02 M / 8.03 M users/s (k = 12 / 256),
+                         # 2 GiB (4 096): 10.63 M / 8.60 M, 4 GiB (8 192): 10.29 M / 8.09 M, 8 GiB (20 480): 10.69 M / 8.14 M
 TOPK_CHUNK_QUANTUM = 2048  # chunks are multiples of this when they can be: the bf16 prefilter kernel (csrc/topk_prefilter.hpp)
                            # keeps 256 queries per workgroup and deals the workgroups of an item slice to one XCD's 32 CUs —
                            # 2 048 / 4 096 queries fill the chip in one round (100 K items: 4 096 per chunk)

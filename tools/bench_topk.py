@@ -12,11 +12,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def bench_line(full: bool = True, n_q: int = 16384, pre_only: bool = False, cpu_loop: bool = True, streams: int = 0) -> dict:
+def bench_line(full: bool = True, n_q: int = 16384, pre_only: bool = False, cpu_loop: bool = True, streams: int = 0, ws_gib: float = 0.0) -> dict:
     import torch as t
     from laplace_amd import ops, synthetic as S
     if streams:
         ops.TOPK_STREAMS = streams   # A/B: chunks alternating over this many streams
+    if ws_gib:
+        ops.TOPK_WS_BYTES = int(ws_gib * (1 << 30))   # A/B: queries per chunk = this / (4 n_items), rounded down to 2 048s
     from laplace_amd.interactions import Interactions
     dev = "cuda"
     spec = S.C2 if full else S.SyntheticSpec(200_000, 100_000, 2_000_000, seed=1)
@@ -69,7 +71,8 @@ def bench_line(full: bool = True, n_q: int = 16384, pre_only: bool = False, cpu_
 def main():
     n_q = int(sys.argv[sys.argv.index("--users") + 1]) if "--users" in sys.argv else 16384
     streams = int(sys.argv[sys.argv.index("--streams") + 1]) if "--streams" in sys.argv else 0
-    print(json.dumps(bench_line(full="--full" in sys.argv, n_q=n_q, pre_only="--pre-only" in sys.argv, streams=streams)))
+    ws_gib = float(sys.argv[sys.argv.index("--ws-gib") + 1]) if "--ws-gib" in sys.argv else 0.0
+    print(json.dumps(bench_line(full="--full" in sys.argv, n_q=n_q, pre_only="--pre-only" in sys.argv, streams=streams, ws_gib=ws_gib)))
 
 
 if __name__ == "__main__":
