@@ -12,7 +12,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def bench_line(full: bool = True, n_q: int = 16384, pre_only: bool = False, cpu_loop: bool = True, streams: int = 0, ws_gib: float = 0.0) -> dict:
+def bench_line(full: bool = True, n_q: int = 16384, pre_only: bool = False, cpu_loop: bool = True, streams: int = 0, ws_gib: float = 0.0,
+               dim: int = 128) -> dict:
     import torch as t
     from laplace_amd import ops, synthetic as S
     if streams:
@@ -26,9 +27,9 @@ def bench_line(full: bool = True, n_q: int = 16384, pre_only: bool = False, cpu_
     inter = Interactions(ei, spec.num_users, spec.num_items)
     r = inter.csr()
     g = t.Generator(device=dev).manual_seed(0)
-    ue = t.randn(spec.num_users, 128, device=dev, generator=g) * 0.1
-    ie = t.randn(spec.num_items, 128, device=dev, generator=g) * 0.1
-    out = {"workload": f"top-K with exclusion, {n_q} query users against {spec.num_items} items, D=128, users' own edges excluded",
+    ue = t.randn(spec.num_users, dim, device=dev, generator=g) * 0.1
+    ie = t.randn(spec.num_items, dim, device=dev, generator=g) * 0.1
+    out = {"workload": f"top-K with exclusion, {n_q} query users against {spec.num_items} items, D={dim}, users' own edges excluded",
            "chunk_streams": ops.TOPK_STREAMS}
     uid = t.arange(n_q, device=dev)
     excl = ops.row_slice(r, 0, n_q)
@@ -72,7 +73,8 @@ def main():
     n_q = int(sys.argv[sys.argv.index("--users") + 1]) if "--users" in sys.argv else 16384
     streams = int(sys.argv[sys.argv.index("--streams") + 1]) if "--streams" in sys.argv else 0
     ws_gib = float(sys.argv[sys.argv.index("--ws-gib") + 1]) if "--ws-gib" in sys.argv else 0.0
-    print(json.dumps(bench_line(full="--full" in sys.argv, n_q=n_q, pre_only="--pre-only" in sys.argv, streams=streams, ws_gib=ws_gib)))
+    print(json.dumps(bench_line(full="--full" in sys.argv, n_q=n_q, pre_only="--pre-only" in sys.argv, streams=streams, ws_gib=ws_gib,
+                                dim=int(sys.argv[sys.argv.index("--dim") + 1]) if "--dim" in sys.argv else 128)))
 
 
 if __name__ == "__main__":

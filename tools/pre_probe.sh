@@ -7,7 +7,7 @@ P=$GRAFT_REPO_ROOT/laplace-gnn-recommendation_amd
 for v in now "$@"; do
   if [ "$v" = now ]; then export LAPLACE_HIP_LIB=$P/liblaplace_hip.so; else export LAPLACE_HIP_LIB=$P/liblaplace_hip_$v.so; fi
   rm -rf /tmp/pp_$v
-  timeout -k 10 120 rocprofv3 --kernel-trace --stats -d /tmp/pp_$v --output-format csv -- python3 tools/bench_topk.py --full --pre-only --users 32768 > /tmp/pp_$v.log 2>&1
+  timeout -k 10 120 rocprofv3 --kernel-trace --stats -d /tmp/pp_$v --output-format csv -- python3 tools/bench_topk.py --full --pre-only --users 32768 $PRE_PROBE_ARGS > /tmp/pp_$v.log 2>&1
   grep -h '"workload"' /tmp/pp_$v.log | cut -c1-400
   python3 - <<EOF2
 import csv, glob
