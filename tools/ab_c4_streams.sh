@@ -1,0 +1,15 @@
+#!/bin/bash
+# A/B of the propagate's stream mode on BASELINE configs[3] at N = 1: tools/ab_c4_streams.sh 0 1 2
+for v in "$@"; do
+  LAPLACE_SPMM_TWO_STREAMS=$v timeout -k 10 240 python3 bench.py --config c4 --steps 10 --warmup 3 --no-cpu-baseline --no-pmc --no-map \
+      --no-plain-leg --no-ranker --no-pinsage --no-topk > /tmp/ab_c4s_$v.log 2>&1
+  python3 - <<EOF2
+import json
+line = [l for l in open("/tmp/ab_c4s_$v.log") if l.startswith("{")]
+if not line:
+    print("two_streams=$v: no line", open("/tmp/ab_c4s_$v.log").read()[-600:])
+else:
+    d = json.loads(line[-1]); r = d["roofline"]
+    print(f"two_streams=$v: {d['ms_per_step']:.2f} ms/step, dense launch {r['avg_launch_ms']:.3f} ms, sparse {r['sparse_launch_avg_ms']:.3f} ms, with Adam {r['dense_with_adam_epilogue_avg_ms']:.3f} ms, loss {d['loss']:.6f}")
+EOF2
+done
