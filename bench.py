@@ -5,16 +5,18 @@ A "step" is one pass of the hot path over one batch: K-layer propagate forward, 
 sampling of B positive edges + negatives, fused BPR forward/backward, K-layer propagate backward,
 dense Adam over the whole table (run_pipeline_lightgcn.py:117-159).
 
-  --config c2 (default)  BASELINE.json configs[1]: synthetic bipartite 1M users x 100K items, 10M edges, LightGCN
+  --config c4 (default)  BASELINE.json configs[3], the configuration the metric is quoted on ("H&M-scale graph"; it fits
+                         one GPU): ONE fixed graph, 8M users x 100K items, 100M edges (seed 3), sharded by
+                         user_id // ceil(U/N) over the N ranks (items replicated, one RCCL all-reduce of the item
+                         rows per layer), global batch 131072: total work fixed, "scaling": "strong".
+  --config c2            BASELINE.json configs[1]: synthetic bipartite 1M users x 100K items, 10M edges, LightGCN
                          3-layer D=128 (SURVEY 8d "C2": symmetric adjacency nnz=20M, B=16384).  At N>1 every rank
                          owns its own 1M-user / 10M-edge shard of a weak-scaled graph: "scaling": "weak".
-  --config c4            BASELINE.json configs[3]: ONE fixed graph, 8M users x 100K items, 100M edges (seed 3), sharded
-                         by user_id // ceil(U/N) over the N ranks (items replicated, one RCCL all-reduce of the item
-                         rows per layer), global batch 131072: total work fixed, "scaling": "strong".
 
 The default N=1 run carries, after the timed region, the metric's other configurations as blocks of the same JSON line:
-  "c4_n1"      BASELINE configs[3] on one GPU (ms/step, positive-edges/s, roofline with live PMC traffic, cpu_baseline
-               from ONE CPU step)                                                            [--no-c4 to skip]
+  "c2"         BASELINE configs[1] on one GPU (--steps/--warmup as the headline; ms/step, positive-edges/s, roofline with
+               live PMC traffic, plain_step_ms, cpu_baseline); with --config c2 the side block is "c4_n1"
+                                                                                             [--no-side to skip]
   "ranker_c3"  BASELINE configs[2]: the encoder-decoder ranker's training loop at the full H&M shape, 24 users per
                batch, on-device 2-hop sampling (tools/bench_ranker.py's bench line)          [--no-ranker to skip]
   pinsage_c5   BASELINE configs[4] at N = 1: PinSAGE item-item training at the H&M shape, the reference's batch of 32
@@ -60,7 +62,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--config", choices=("c2", "c4"), default="c2")
+    ap.add_argument("--config", choices=("c2", "c4"), default="c4")
     ap.add_argument("--users", type=int, default=None)
     ap.add_argument("--items", type=int, default=None)
     ap.add_argument("--edges", type=int, default=None)
@@ -68,15 +70,15 @@ def parse_args():
     ap.add_argument("--layers", type=int, default=3)
     ap.add_argument("--batch", type=int, default=None, help="positive edges per GPU (c2) / per job (c4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-baseline", action="store_true", help="time the CPU port when --config c4 is the headline too")
+    ap.add_argument("--plain-leg", action="store_true", help="time the straightforward step as plain_step_ms for --config c4 too")
     ap.add_argument("--plain-step", action="store_true",
                     help="A/B: time the straightforward step (full final, dense gradient buffer) as the headline instead of the byte-saving one")
     ap.add_argument("--no-plain-leg", action="store_true", help="skip the extra plain-step timing (plain_step_ms)")
     ap.add_argument("--no-map", action="store_true", help="skip the MAP@12 leg")
     ap.add_argument("--map-steps", type=int, default=100, help="train steps on the planted-structure graph before MAP@12 is scored")
     ap.add_argument("--map-users", type=int, default=20000)
-    ap.add_argument("--no-c4", action="store_true", help="skip the c4_n1 block (BASELINE configs[3] on one GPU)")
-    ap.add_argument("--c4-steps", type=int, default=10)
+    ap.add_argument("--no-side", "--no-c4", dest="no_side", action="store_true",
+                    help="skip the LightGCN side block (the other of configs[1] / configs[3] on one GPU)")
     ap.add_argument("--no-ranker", action="store_true", help="skip the ranker_c3 block (BASELINE configs[2])")
     ap.add_argument("--no-pinsage", action="store_true", help="skip the pinsage_c5 block (BASELINE configs[4] at N = 1)")
     ap.add_argument("--pinsage-iters", type=int, default=300)
@@ -260,11 +262,15 @@ def roofline_block(events, nnz: int, n_rows: int, D: int, steps: int, traffic, t
     comp_gbs = compulsory / (avg_ms * 1e-3) / 1e9 if spmm_ms else 0.0
     if traffic:
         achieved = traffic / (avg_ms * 1e-3) / 1e9
-        basis = "measured L2-miss traffic (PMC) / HIP-event launch time"
+        basis = ("L2-miss (fabric) traffic, incl. Infinity-Cache hits (PMC FETCH_SIZE / WRITE_SIZE) / HIP-event launch time: an UPPER "
+                 "bound on HBM bytes, not HBM bytes (the HBM side of the Infinity Cache has no counter on this pool)")
     else:  # no counter figure for this workload: the compulsory bytes are the only physically meaningful numerator
         achieved = comp_gbs
         basis = "compulsory bytes (every operand once) / HIP-event launch time; no PMC traffic figure for this workload"
-    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    # "bound" keeps the bench contract's vocabulary (hbm | mfma): the launch is memory-side bound.  What `achieved` measures is
+    # named by `measured_level` / `basis`: traffic that left the L2s, whether the Infinity Cache or HBM served it.
+    return {"bound": "hbm", "measured_level": "L2-miss (fabric) traffic, incl. Infinity-Cache hits" if traffic else "compulsory bytes",
+            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "basis": basis, "traffic_source": traffic_src,
             "frac_of_measured_random_gather_ceiling": achieved / 5650.0,
             "ceiling_note": "MI355X_MICROARCH.md measures 5.5-5.8 TB/s for random whole rows gathered from beyond the caches (6.0-6.1 "
@@ -408,31 +414,67 @@ def map_leg(args, dev) -> dict:
     return out
 
 
-def c4_block(args, dev, traffic, traffic_src) -> dict:
-    """BASELINE configs[3] on ONE GPU: the 8M x 100K, 100M-edge graph, global batch 131072."""
+def plain_step_leg(model, adj, inter, B: int, steps: int, warmup: int) -> float:
+    """ms per step of the straightforward step shape (full `final`, dense gradient buffer, 6 dense propagates, separate
+    Adam): same parameters to rounding (tests/test_gpu_lightgcn.py::test_sparse_batch_step_equals_plain_step), more
+    bytes.  Quote this figure whenever the number is compared with a reference-shaped step."""
     import torch as t
-    w = build_workload("c4", args, 1, 0, dev, want_table0=not args.no_cpu_baseline)
+    from laplace_amd.trainer import LightGCNTrainer
+    plain = LightGCNTrainer(model, adj, inter, lr=1e-3, Lambda=1e-6, batch_size=B, seed=11, sparse_batch=False)
+    for _ in range(max(warmup, 1)):
+        plain.step()
+    t.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(steps):
+        plain.step()
+    t.cuda.synchronize()
+    ms = 1e3 * (time.perf_counter() - t1) / steps
+    plain.finish()
+    return ms
+
+
+def side_block(config: str, args, dev, traffic, traffic_src) -> dict:
+    """The OTHER LightGCN configuration on one GPU, as a block of the line: "c2" (BASELINE configs[1]) under the default
+    headline, "c4_n1" (configs[3]) under --config c2.  Same --steps / --warmup, same roofline fields, own cpu_baseline."""
+    import torch as t
+    want_cpu = not args.no_cpu_baseline
+    w = build_workload(config, args, 1, 0, dev, want_table0=want_cpu)
     trainer = w["trainer"]
     sync = t.cuda.synchronize
     sync()
-    elapsed, per_step, events, loss = timed_steps(trainer, args.c4_steps, 3, sync)
+    steps, warmup = args.steps, max(args.warmup, 3)
+    elapsed, per_step, events, loss = timed_steps(trainer, steps, warmup, sync)
     nnz, n_rows = trainer.adj_fwd.nnz, trainer.adj_fwd.n_rows
     spec, B = w["spec"], w["B"]
-    block = {"metric": "positive-edges/sec (train step)", "value": B * args.c4_steps / elapsed, "unit": "positive-edges/s",
-             "n_gpus": 1, "steps": args.c4_steps, "warmup": 3, "ms_per_step": 1e3 * elapsed / args.c4_steps,
+    ref = "BASELINE.json configs[3] at N=1" if config == "c4" else "BASELINE.json configs[1]"
+    block = {"metric": "positive-edges/sec (train step)", "value": B * steps / elapsed, "unit": "positive-edges/s",
+             "n_gpus": 1, "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * elapsed / steps,
              "ms_per_step_p10_p50_p90": [round(per_step[min(len(per_step) - 1, int(q * len(per_step)))], 4) for q in (0.1, 0.5, 0.9)],
              "workload": (f"LightGCN train step, ONE synthetic bipartite graph {spec.num_users}x{w['I']} users x items, {spec.num_edges} edges "
                           f"(seed {spec.seed}), all of it on one GPU (symmetric adjacency nnz={nnz}), {w['K']}-layer D={w['D']}, batch {B} "
-                          f"positive edges, on-device sampling, BPR + dense Adam; BASELINE.json configs[3] at N=1"),
-             "roofline": roofline_block(events, nnz, n_rows, w["D"], args.c4_steps, traffic, traffic_src),
+                          f"positive edges, on-device sampling, BPR + dense Adam; {ref}"),
+             "roofline": roofline_block(events, nnz, n_rows, w["D"], steps, traffic, traffic_src),
+             "node_order": "locality (items by popularity, users by coldest item)" if getattr(trainer, "order", None) is not None else "generator ids",
              "loss": float(loss), "graph_gen_s": round(w["t_gen"], 1)}
+    if config == "c2" and not args.no_plain_leg:
+        trainer.to_original_order()  # the second trainer relabels the table itself
+        block["plain_step_ms"] = plain_step_leg(w["model"], w["adj"], w["inter"], B, steps, warmup)
+        block["plain_step_positive_edges_per_s"] = B * 1e3 / block["plain_step_ms"]
     trainer.finish()
     ei, U, I, K, table0 = w["ei"], w["U"], w["I"], w["K"], w["table0"]
     del trainer, w, events
     t.cuda.empty_cache()
     if table0 is not None:
-        block["cpu_baseline"] = cpu_baseline(ei, U, I, K, B, table0, steps=1, warm=False, faithful=False)
+        block["cpu_baseline"] = cpu_baseline_for(config, args, ei, U, I, K, B, table0)
     return block
+
+
+def cpu_baseline_for(config: str, args, ei, U, I, K, B, table0) -> dict:
+    """The bounded CPU sample of a configuration: C2 = one warm-up + --cpu-steps timed steps (~2.4 s each on 128 cores)
+    + one draw of the reference's O(E) sampler; C4 = one warm-up + ONE timed step (~20 s each)."""
+    if config == "c4":
+        return cpu_baseline(ei, U, I, K, B, table0, steps=1, warm=True, faithful=False)
+    return cpu_baseline(ei, U, I, K, B, table0, steps=args.cpu_steps, warm=True, faithful=not args.no_cpu_faithful)
 
 
 def ranker_block(args) -> dict:
@@ -487,7 +529,9 @@ def main():
 
     # ---- live PMC passes: children first, while this process has not touched the GPU ----------------------------------
     pmc = {}
-    want_c4_leg = world_env == 1 and args.config == "c2" and not args.no_c4 and not args.pmc_child
+    side = "c2" if args.config == "c4" else "c4"     # the other LightGCN configuration rides as a block at N = 1
+    custom_size = any(v is not None for v in (args.users, args.items, args.edges, args.batch)) or args.uniform
+    want_side = world_env == 1 and not args.no_side and not args.pmc_child and not args.plain_step and not custom_size
     if world_env == 1 and not args.no_pmc and not args.pmc_child and not args.plain_step:
         passthrough = []
         for flag, val in (("--users", args.users), ("--items", args.items), ("--edges", args.edges), ("--batch", args.batch)):
@@ -501,9 +545,9 @@ def main():
         tl = time.perf_counter()
         pmc[args.config] = pmc_traffic(args.config, passthrough)
         tl = _leg("pmc_children_" + args.config, tl)
-        if want_c4_leg:
-            pmc["c4"] = pmc_traffic("c4", ["--dim", str(args.dim), "--layers", str(args.layers)] + (["--no-reorder"] if args.no_reorder else []))
-            _leg("pmc_children_c4", tl)
+        if want_side:
+            pmc[side] = pmc_traffic(side, ["--dim", str(args.dim), "--layers", str(args.layers)] + (["--no-reorder"] if args.no_reorder else []))
+            _leg("pmc_children_" + side, tl)
 
     import torch as t
     import torch.distributed as dist
@@ -522,14 +566,13 @@ def main():
 
     if os.environ.get("LAPLACE_SPMM_TWO_STREAMS") is not None:  # A/B switch
         ops.SPMM_TWO_STREAMS = int(os.environ["LAPLACE_SPMM_TWO_STREAMS"] or 0)   # 1: short rows enqueued first, 2: split rows first
-    want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline and not args.pmc_child and (args.config == "c2" or args.cpu_baseline)
+    want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline and not args.pmc_child
     tl = time.perf_counter()
     w = build_workload(args.config, args, world, rank, dev, plain=args.plain_step, want_table0=want_cpu)
     tl = _leg("import_and_graph_setup", tl)
     spec, ei, U, I, D, K, B = w["spec"], w["ei"], w["U"], w["I"], w["D"], w["K"], w["B"]
     model, inter, adj, trainer, strong = w["model"], w["inter"], w["adj"], w["trainer"], w["strong"]
-    default_workload = (args.config == "c2" and (spec.num_users, I, spec.num_edges, D, K) == (1_000_000, 100_000, 10_000_000, 128, 3)
-                        and not args.uniform)
+    default_workload = args.config == "c2" and not custom_size and (D, K) == (128, 3)
     nnz, n_rows = trainer.adj_fwd.nnz, trainer.adj_fwd.n_rows
     t.cuda.synchronize()
 
@@ -591,51 +634,38 @@ def main():
 
     # ---- extra legs, N=1 only, after the timed region ------------------------------------------------
     tl = time.perf_counter()
-    if world == 1 and not args.plain_step and not args.no_plain_leg:
-        # the straightforward step shape (full `final`, dense gradient buffer, separate Adam): same parameters to
-        # rounding (tests/test_gpu_lightgcn.py::test_sparse_batch_step_equals_plain_step), more bytes.  Quote the
-        # plain figure whenever the number is compared with a reference-shaped step.
+    if world == 1 and not args.plain_step and not args.no_plain_leg and (args.config == "c2" or args.plain_leg):
         trainer.to_original_order()  # the second trainer relabels the table itself
-        plain = LightGCNTrainer(model, adj, inter, lr=1e-3, Lambda=1e-6, batch_size=B, seed=11, sparse_batch=False)
-        for _ in range(max(args.warmup, 1)):
-            plain.step()
-        t.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            plain.step()
-        t.cuda.synchronize()
-        out["plain_step_ms"] = 1e3 * (time.perf_counter() - t1) / args.steps
+        out["plain_step_ms"] = plain_step_leg(model, adj, inter, B, args.steps, args.warmup)
         out["plain_step_positive_edges_per_s"] = B * 1e3 / out["plain_step_ms"]
-        plain.finish()
-        del plain
         tl = _leg("plain_step_leg", tl)
     if rank == 0 and want_cpu:
         trainer.finish()
-        out["cpu_baseline"] = cpu_baseline(ei, U, I, K, B, w["table0"], steps=args.cpu_steps, warm=True,
-                                           faithful=not args.no_cpu_faithful and args.config == "c2")
+        out["cpu_baseline"] = cpu_baseline_for(args.config, args, ei, U, I, K, B, w["table0"])
         tl = _leg("cpu_baseline", tl)
     if world == 1 and rank == 0:
         # free the headline's state before the other configurations
         del trainer, model, inter, adj, w, events
         t.cuda.empty_cache()
-        if not args.no_map and not strong and not args.uniform:
+        extras = not custom_size and not args.plain_step
+        if want_side:
+            s_traffic, _, s_src = pmc.get(side, (None, None, "live PMC passes off (--no-pmc)"))
+            if s_traffic is None:
+                s_src = f"no live figure ({s_src})"
+            out["c2" if side == "c2" else "c4_n1"] = side_block(side, args, dev, s_traffic, s_src)
+            tl = _leg(f"{side} side block (incl. its CPU baseline)", tl)
+        if extras and not args.no_map:
             out["map_at_12"] = map_leg(args, dev)
             t.cuda.empty_cache()
             tl = _leg("map_at_12", tl)
-        if want_c4_leg:
-            c4_traffic, _, c4_src = pmc.get("c4", (None, None, "live PMC passes off (--no-pmc)"))
-            if c4_traffic is None:
-                c4_src = f"no live figure ({c4_src})"
-            out["c4_n1"] = c4_block(args, dev, c4_traffic, c4_src)
-            tl = _leg("c4_n1 (incl. its one-step CPU baseline)", tl)
-        if args.config == "c2" and not args.no_ranker:
+        if extras and not args.no_ranker:
             out["ranker_c3"] = ranker_block(args)
             t.cuda.empty_cache()
             tl = _leg("ranker_c3 (incl. graph generation and the CPU twin)", tl)
-        if args.config == "c2" and not args.no_pinsage:
+        if extras and not args.no_pinsage:
             out["pinsage_c5"] = pinsage_block(args)
             tl = _leg("pinsage_c5 (incl. graph generation)", tl)
-        if args.config == "c2" and not args.no_topk:
+        if extras and not args.no_topk:
             t.cuda.empty_cache()
             out["topk_a10"] = topk_block(args)
             tl = _leg("topk_a10 (incl. graph generation and the host loop)", tl)

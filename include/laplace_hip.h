@@ -148,6 +148,13 @@ size_t mi_spmm_plan_workspace_bytes(int64_t n_rows, int64_t nnz);
 int    mi_spmm_plan_count(int64_t n_rows, int64_t n_cols, const int32_t* rowptr, const int32_t* col,
                           int32_t chunk, int32_t band, void* ws, size_t ws_bytes,
                           mi_spmm_plan_info* info, mi_stream_t stream);
+/* The same analysis restricted to the rows with chunk < degree <= max_deg (round 4): the banded half of a HYBRID plan whose
+ * rows above max_deg are laid out in SWEEP form (mi_spmm_sweep) by the host.  The host merges the two: long_rows / item_ptr
+ * concatenated, the work items' slots shifted behind the sweep's 8 * n_slots partial rows, n_items = the sum; passing both
+ * `items` and a sweep to mi_spmm_csr_ex_f32 runs both split-row kernels and ONE fix-up. */
+int    mi_spmm_plan_count_range(int64_t n_rows, int64_t n_cols, const int32_t* rowptr, const int32_t* col,
+                                int32_t chunk, int32_t max_deg, int32_t band, void* ws, size_t ws_bytes,
+                                mi_spmm_plan_info* info, mi_stream_t stream);
 int    mi_spmm_plan_fill(int64_t n_rows, const int32_t* rowptr, const mi_spmm_plan_info* info,
                          mi_spmm_plan* plan, void* ws, size_t ws_bytes, mi_stream_t stream);
 /* Bytes of partial-sum workspace mi_spmm_csr_f32 needs for this plan and width. */
@@ -649,6 +656,10 @@ int64_t mi_ranker_sizeof(int32_t which);  /* sizeof of: 0 model, 1 batch, 2 conv
 size_t mi_ranker_step_workspace_bytes(const mi_ranker_model* model, const mi_ranker_batch* batch);
 int    mi_ranker_step_f32(const mi_ranker_model* model, const mi_ranker_batch* batch, void* ws, size_t ws_bytes,
                           mi_stream_t stream);
+/* The validation pass of mi_ranker_step_f32 alone: 0 when the call would be taken, MI_ERR_UNSUPPORTED / MI_ERR_ARG when it
+ * would be declined.  Enqueues nothing and reads no device memory (host-side walk of the two descriptors), so data-parallel
+ * callers can agree on taking or declining a batch BEFORE any rank enters the gradient all-reduce (round 4). */
+int    mi_ranker_step_check(const mi_ranker_model* model, const mi_ranker_batch* batch, void* ws, size_t ws_bytes);
 /* The update alone, for data-parallel callers: run mi_ranker_step_f32 with apply_adam = 0, all-reduce(sum) the gradient
  * buffers (params[i].g; the host side keeps them in ONE flat allocation so that is one collective), then this:
  * Adam (a9's arithmetic, model->lr/beta/eps/step) over model->params with every gradient multiplied by grad_scale
@@ -869,6 +880,8 @@ int64_t mi_pinsage_step_sizeof(int32_t which);  /* sizeof of: 0 model, 1 batch, 
 size_t mi_pinsage_step_workspace_bytes(const mi_pinsage_model* model, const mi_pinsage_step_batch* batch);
 int    mi_pinsage_step_f32(const mi_pinsage_model* model, const mi_pinsage_step_batch* batch, void* ws, size_t ws_bytes,
                            mi_stream_t stream);
+/* The validation pass of mi_pinsage_step_f32 alone (see mi_ranker_step_check): nothing enqueued, no device memory read. */
+int    mi_pinsage_step_check(const mi_pinsage_model* model, const mi_pinsage_step_batch* batch, void* ws, size_t ws_bytes);
 /* The update of a data-parallel iteration: the lists of every rank (exchanged by the caller: an all-gather of a few hundred
  * KB instead of an all-reduce of the dense 27 MB table gradient), in rank order, are added into the zero-kept dense
  * buffers — projector rows times grad_scale (1 / world), bias entries as they are; lists are applied one after the other,

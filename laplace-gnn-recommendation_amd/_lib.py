@@ -181,6 +181,7 @@ _PROTOTYPES = {
     "mi_scale_csr_f32": (c_int32, [c_int64, c_int64, P, P, P, P, P, P, P]),
     "mi_spmm_plan_workspace_bytes": (c_size_t, [c_int64, c_int64]),
     "mi_spmm_plan_count": (c_int32, [c_int64, c_int64, P, P, c_int32, c_int32, P, c_size_t, POINTER(SpmmPlanInfo), P]),
+    "mi_spmm_plan_count_range": (c_int32, [c_int64, c_int64, P, P, c_int32, c_int32, c_int32, P, c_size_t, POINTER(SpmmPlanInfo), P]),
     "mi_spmm_plan_fill": (c_int32, [c_int64, P, POINTER(SpmmPlanInfo), POINTER(SpmmPlanStruct), P, c_size_t, P]),
     "mi_spmm_workspace_bytes": (c_size_t, [POINTER(SpmmPlanStruct), c_int64]),
     "mi_spmm_csr_f32": (c_int32, [c_int64, c_int64, P, P, P, P, c_int64, P, c_int64, P, c_int64, P, c_int64,
@@ -229,6 +230,7 @@ _PROTOTYPES = {
     "mi_ranker_sizeof": (c_int64, [c_int32]),
     "mi_ranker_step_workspace_bytes": (c_size_t, [POINTER(RankerModel), POINTER(RankerBatch)]),
     "mi_ranker_step_f32": (c_int32, [POINTER(RankerModel), POINTER(RankerBatch), P, c_size_t, P]),
+    "mi_ranker_step_check": (c_int32, [POINTER(RankerModel), POINTER(RankerBatch), P, c_size_t]),
     "mi_ranker_adam_f32": (c_int32, [POINTER(RankerModel), ctypes.c_float, P]),
     "mi_match_same_location_i32": (c_int32, [c_int64, P, P, P, P, P, P, c_int32, P, P, P]),
     "mi_sampler_workspace_bytes": (c_size_t, [POINTER(SamplerDesc)]),
@@ -245,6 +247,7 @@ _PROTOTYPES = {
     "mi_pinsage_step_sizeof": (c_int64, [c_int32]),
     "mi_pinsage_step_workspace_bytes": (c_size_t, [POINTER(PinsageModel), POINTER(PinsageStepBatch)]),
     "mi_pinsage_step_f32": (c_int32, [POINTER(PinsageModel), POINTER(PinsageStepBatch), P, c_size_t, P]),
+    "mi_pinsage_step_check": (c_int32, [POINTER(PinsageModel), POINTER(PinsageStepBatch), P, c_size_t]),
     "mi_pinsage_apply_f32": (c_int32, [POINTER(PinsageModel), POINTER(PinsageGradList), c_int32, ctypes.c_float, P]),
     "mi_adam_dense_f32": (c_int32, [c_int64, c_int64, P, c_int64, P, c_int64, P, P, P,
                                     c_double, c_double, c_double, c_double, c_int64, P]),

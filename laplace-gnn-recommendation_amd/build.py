@@ -77,6 +77,55 @@ def build_hip(force: bool = False, verbose: bool = False) -> str:
     return LIB_PATH
 
 
+# ---- host-side sanitizer build ("-fsanitize=address host build of the C++ layer") --------------------------------
+# The HOST half of every csrc/*.hip — the C ABI, the native executors' descriptor walks (COUNT / CHECK / LAUNCH passes), the
+# plan builders' host code — compiled with AddressSanitizer + UndefinedBehaviorSanitizer (-Xarch_host: the gfx950 device code
+# is compiled as in the product; GPU sanitizers are not available on this pool).  A separate library, never loaded by the
+# product; tests/test_host_sanitizers.py runs tests/asan_driver.py against it on the CPU (LD_PRELOAD = the ASan runtime).
+ASAN_OBJ_DIR = os.path.join(PKG_DIR, "build", "asan")
+ASAN_LIB_PATH = os.path.join(PKG_DIR, "build", "liblaplace_hip_asan.so")
+ASAN_FLAGS = [f"--offload-arch={ARCH}", "-O1", "-g", "-std=c++17", "-fPIC", "-Wno-unused-result", "-DNDEBUG",
+              "-Xarch_host", "-fsanitize=address,undefined", "-Xarch_host", "-fno-omit-frame-pointer"]
+
+
+def asan_runtime() -> str:
+    """Path of the shared ASan runtime of hipcc's clang (to LD_PRELOAD into the python that loads the library)."""
+    clang = os.path.join(os.path.dirname(os.path.realpath(HIPCC)), "..", "lib", "llvm", "bin", "clang")
+    if not os.path.exists(clang):
+        clang = "/opt/rocm/lib/llvm/bin/clang"
+    r = subprocess.run([clang, "-print-file-name=libclang_rt.asan-x86_64.so"], capture_output=True, text=True)
+    path = r.stdout.strip()
+    if r.returncode != 0 or not os.path.isabs(path) or not os.path.exists(path):
+        raise RuntimeError(f"ASan runtime not found ({clang}: {r.stdout} {r.stderr})")
+    return path
+
+
+def build_asan(force: bool = False, verbose: bool = False) -> str:
+    """liblaplace_hip_asan.so: host code under ASan + UBSan, device code as in the product.  Returns its path."""
+    os.makedirs(ASAN_OBJ_DIR, exist_ok=True)
+    dep = _deps_mtime()
+
+    def one(src: str) -> str:
+        obj = os.path.join(ASAN_OBJ_DIR, os.path.basename(src)[:-4] + ".o")
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), dep):
+            cmd = [HIPCC, *ASAN_FLAGS, *EXTRA_FLAGS.get(os.path.basename(src), []), "-c", src, "-o", obj]
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError(f"hipcc (asan) failed on {src}:\n{r.stdout}\n{r.stderr}")
+        return obj
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        objs = list(ex.map(one, _sources()))
+    if force or not os.path.exists(ASAN_LIB_PATH) or any(os.path.getmtime(o) > os.path.getmtime(ASAN_LIB_PATH) for o in objs):
+        cmd = [HIPCC, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-fsanitize=address,undefined", "-shared-libsan",
+               "-o", ASAN_LIB_PATH, *objs]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link (asan) failed:\n{r.stdout}\n{r.stderr}")
+    if verbose:
+        print(f"[build] {ASAN_LIB_PATH} ({os.path.getsize(ASAN_LIB_PATH)} bytes; host side under ASan + UBSan)")
+    return ASAN_LIB_PATH
+
+
 def build_oracle(verbose: bool = False) -> None:
     """Compile oracle/'s C restatement (test infrastructure, never loaded by the product)."""
     r = subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle")], capture_output=True, text=True)
@@ -89,3 +138,5 @@ def build_oracle(verbose: bool = False) -> None:
 if __name__ == "__main__":
     build_hip(force="--force" in sys.argv, verbose=True)
     build_oracle(verbose=True)
+    if "--asan" in sys.argv:
+        build_asan(force="--force" in sys.argv, verbose=True)

@@ -314,7 +314,7 @@ int PinExec::run() {
     const int H = M.hidden, h4 = H / 4;
     if (NL < 1 || NL > MI_PINSAGE_MAX_LAYERS || B.n_blocks != NL || M.n_params < 0 || M.n_params > MI_PINSAGE_MAX_PARAMS)
         return MI_ERR_UNSUPPORTED;   // every pass: the loops below index fixed-size arrays
-    if (mode == CHECK) {
+    {   // ... and so is the rest of the header (round 4, with the ranker's: the counting pass sizes buffers from these counts)
         if (NL < 1 || NL > MI_PINSAGE_MAX_LAYERS || B.n_blocks != NL) return MI_ERR_UNSUPPORTED;
         if (H < 4 || H % 4 != 0 || H > 128) return MI_ERR_UNSUPPORTED;
         if (!(M.p_dropout >= 0.f && M.p_dropout < 1.f)) return MI_ERR_BAD_ARG;
@@ -334,8 +334,17 @@ int PinExec::run() {
             if (M.n_ones < b.n_src) return MI_ERR_BAD_ARG;
             const mi_pinsage_conv& cv = M.conv[l];
             if (!cv.q_w || !cv.q_b || !cv.w_w || !cv.w_b || !cv.g_q_w || !cv.g_q_b || !cv.g_w_w || !cv.g_w_b) return MI_ERR_BAD_ARG;
+            if (!mi_aligned16(cv.q_w) || !mi_aligned16(cv.w_w) || !mi_aligned16(cv.g_q_w) || !mi_aligned16(cv.g_w_w) ||
+                !mi_aligned16(cv.q_b) || !mi_aligned16(cv.w_b) || !mi_aligned16(cv.g_q_b) || !mi_aligned16(cv.g_w_b))
+                return MI_ERR_UNSUPPORTED;
         }
         if (want_dst != B.n_seeds) return MI_ERR_BAD_ARG;
+        if (M.n_items < 1 || !mi_aligned16(M.proj) || !mi_aligned16(M.g_proj) || !mi_aligned16(M.m_proj) || !mi_aligned16(M.v_proj))
+            return MI_ERR_UNSUPPORTED;
+        for (int i = 0; i < M.n_params; ++i) {
+            const mi_ranker_param& q = M.params[i];
+            if (!q.p || !q.g || !q.m || !q.v || q.n < 0) return MI_ERR_BAD_ARG;
+        }
     }
     const float p = M.p_dropout, scale = p > 0.f ? 1.0f / (1.0f - p) : 1.f;
     const uint32_t k0 = (uint32_t)B.seed, k1 = (uint32_t)(B.seed >> 32), st = (uint32_t)B.step;
@@ -510,8 +519,14 @@ extern "C" int64_t mi_pinsage_step_sizeof(int32_t which) {
 extern "C" size_t mi_pinsage_step_workspace_bytes(const mi_pinsage_model* model, const mi_pinsage_step_batch* batch) {
     if (!model || !batch) return 0;
     PinExec e(*model, *batch, reinterpret_cast<void*>((uintptr_t)4096), (size_t)1 << 46, COUNT, nullptr);
-    e.run();
+    if (e.run() != 0) return 0;   // a descriptor the executor does not take has no workspace size
     return e.ar.off + 4096;
+}
+
+extern "C" int mi_pinsage_step_check(const mi_pinsage_model* model, const mi_pinsage_step_batch* batch, void* ws, size_t ws_bytes) {
+    MI_CHECK_ARG(model && batch && ws && mi_aligned16(ws));
+    PinExec chk(*model, *batch, ws, ws_bytes, CHECK, nullptr);   // validates every operand; enqueues nothing, touches no memory
+    return chk.run();
 }
 
 extern "C" int mi_pinsage_step_f32(const mi_pinsage_model* model, const mi_pinsage_step_batch* batch, void* ws, size_t ws_bytes,

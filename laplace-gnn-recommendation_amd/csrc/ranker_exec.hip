@@ -192,7 +192,11 @@ int Exec::run() {
     const int32_t* bptr[2] = {B.by_customer_ptr, B.by_article_ptr};
     const int32_t* bcol[2] = {B.by_customer_col, B.by_article_col};
 
-    if (mode == CHECK) {
+    // The header is validated in EVERY mode: the walk below indexes the descriptor's fixed arrays with these counts, so the
+    // counting pass must not run on a descriptor that names 9 layers or 40 columns either (round 4: found by the host
+    // sanitizer build, tests/test_host_sanitizers.py — mi_ranker_step_workspace_bytes divided by a zero width read from
+    // beyond conv[]).  mi_ranker_step_workspace_bytes returns 0 for such descriptors.
+    {
         if (L < 1 || L > MI_RANKER_MAX_LAYERS || LD < 1 || LD > MI_RANKER_MAX_LAYERS) return MI_ERR_UNSUPPORTED;
         if (M.aggr != 0 && M.aggr != 1) return MI_ERR_UNSUPPORTED;
         if (!(M.p_dropout >= 0.f && M.p_dropout < 1.f)) return MI_ERR_BAD_ARG;
@@ -201,9 +205,28 @@ int Exec::run() {
         if (n[0] <= 0 || n[1] <= 0 || nl <= 0 || nnz < 0) return MI_ERR_UNSUPPORTED;
         if (M.n_ones < std::max(std::max(n[0], n[1]), nl) || !M.ones4) return MI_ERR_BAD_ARG;
         if (M.n_params < 0 || M.n_params > MI_RANKER_MAX_PARAMS) return MI_ERR_BAD_ARG;
-        for (int t = 0; t < kTypes; ++t)
+        for (int t = 0; t < kTypes; ++t) {
             if (M.n_cols[t] < 1 || M.n_cols[t] > MI_RANKER_MAX_COLS || !B.x[t]) return MI_ERR_UNSUPPORTED;
+            for (int c = 0; c < M.n_cols[t]; ++c)
+                if (M.dims[t][c] < 1 || M.dims[t][c] > 4096 || M.table_rows[t][c] < 1 || !M.tables[t][c]) return MI_ERR_BAD_ARG;
+        }
         if (!B.by_customer_ptr || !B.by_article_ptr || !B.label_row || !B.label_col || (!B.label && !B.label_f32) || !B.loss) return MI_ERR_BAD_ARG;
+        if (nnz > 0 && (!B.by_customer_col || !B.by_article_col)) return MI_ERR_BAD_ARG;
+        for (int l = 0; l < L; ++l)
+            for (int r = 0; r < 2; ++r) {
+                const mi_ranker_conv& cv = M.conv[l][r];
+                if (cv.c_src < 1 || cv.c_dst < 1 || cv.c_out < 1 || cv.c_src > 4096 || cv.c_dst > 4096 || cv.c_out > 4096) return MI_ERR_UNSUPPORTED;
+                if (!cv.w_l || !cv.w_r || !cv.gw_l || !cv.gw_r || (cv.b_l && !cv.gb_l)) return MI_ERR_BAD_ARG;
+            }
+        for (int j = 0; j < LD; ++j) {
+            const mi_ranker_linear& ln = M.dec[j];
+            if (ln.in < 1 || ln.out < 1 || ln.in > 4096 || ln.out > 4096 || !ln.w || !ln.gw || (ln.b && !ln.gb)) return MI_ERR_BAD_ARG;
+        }
+        for (int i = 0; i < M.n_params; ++i) {
+            const mi_ranker_param& q = M.params[i];
+            if (!q.p || !q.g || !q.m || !q.v || q.n < 0 || !mi_aligned16(q.p) || !mi_aligned16(q.g) || !mi_aligned16(q.m) || !mi_aligned16(q.v))
+                return MI_ERR_UNSUPPORTED;
+        }
     }
 
     // ---- embeddings (K7) ------------------------------------------------------------------------------------------
@@ -530,8 +553,14 @@ extern "C" size_t mi_ranker_step_workspace_bytes(const mi_ranker_model* model, c
     if (!model || !batch) return 0;
     // counting pass over a fictitious base: only offsets matter
     Exec e(*model, *batch, reinterpret_cast<void*>((uintptr_t)4096), (size_t)1 << 46, COUNT, nullptr);
-    e.run();
+    if (e.run() != 0) return 0;   // a descriptor the executor does not take has no workspace size
     return e.ar.off + 4096;
+}
+
+extern "C" int mi_ranker_step_check(const mi_ranker_model* model, const mi_ranker_batch* batch, void* ws, size_t ws_bytes) {
+    MI_CHECK_ARG(model && batch && ws && mi_aligned16(ws));
+    Exec chk(*model, *batch, ws, ws_bytes, CHECK, nullptr);   // validates every operand; enqueues nothing, touches no memory
+    return chk.run();
 }
 
 extern "C" int mi_ranker_step_f32(const mi_ranker_model* model, const mi_ranker_batch* batch, void* ws, size_t ws_bytes,

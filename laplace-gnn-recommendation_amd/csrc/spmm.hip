@@ -830,12 +830,12 @@ bool plan_carve(MiArena& ar, int64_t n_rows, int64_t nnz_total, int64_t n_long, 
     return w.seg_start && w.keys0 && w.keys1;
 }
 
-__global__ void plan_flags_kernel(int64_t n_rows, const int32_t* __restrict__ rowptr, int32_t chunk,
+__global__ void plan_flags_kernel(int64_t n_rows, const int32_t* __restrict__ rowptr, int32_t chunk, int32_t max_deg,
                                   int32_t* __restrict__ is_long, int32_t* __restrict__ ldeg) {
     int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r > n_rows) return;
     const int32_t deg = (r < n_rows) ? rowptr[r + 1] - rowptr[r] : 0;
-    const bool lg = deg > chunk;
+    const bool lg = deg > chunk && deg <= max_deg;  // rows above max_deg belong to another plan (the SWEEP half of a hybrid)
     is_long[r] = lg ? 1 : 0;
     ldeg[r] = lg ? deg : 0;
 }
@@ -1026,7 +1026,10 @@ int launch_spmm_mode(int64_t n_rows, int d4, const int32_t* rowptr, const int32_
         } else {
             return MI_ERR_UNSUPPORTED;
         }
-    } else if (do_split && plan && plan->n_items > 0) {  // row_list mode still reduces every split row: hubs are few and almost always wanted
+    }
+    // HYBRID plan (round 4): the hub rows in SWEEP form AND the remaining split rows as banded work items — `items` is
+    // then non-null beside the sweep, its slots are absolute (they start behind the sweep's 8 * n_slots partial rows)
+    if (do_split && plan && plan->n_items > 0 && (!sweep || plan->items)) {  // row_list mode still reduces every split row: hubs are few and almost always wanted
         const int64_t n_launch = plan->n_launch;
         dim3 gi((unsigned)mi_ceil_div(n_launch, SG * ITEMS_RPS));
         hipLaunchKernelGGL((spmm_items_kernel<LPR, VPL, UNROLL, ITEMS_RPS, SPARSE>), gi, dim3(kBlock), 0, s, n_launch,
@@ -1131,7 +1134,13 @@ size_t mi_spmm_plan_workspace_bytes(int64_t n_rows, int64_t nnz) {
 int mi_spmm_plan_count(int64_t n_rows, int64_t n_cols, const int32_t* rowptr, const int32_t* col,
                        int32_t chunk, int32_t band, void* ws, size_t ws_bytes, mi_spmm_plan_info* info,
                        mi_stream_t stream) {
-    MI_CHECK_ARG(n_rows >= 0 && n_cols >= 0 && rowptr && chunk > 0 && band >= 0 && ws && info);
+    return mi_spmm_plan_count_range(n_rows, n_cols, rowptr, col, chunk, INT32_MAX, band, ws, ws_bytes, info, stream);
+}
+
+int mi_spmm_plan_count_range(int64_t n_rows, int64_t n_cols, const int32_t* rowptr, const int32_t* col,
+                             int32_t chunk, int32_t max_deg, int32_t band, void* ws, size_t ws_bytes,
+                             mi_spmm_plan_info* info, mi_stream_t stream) {
+    MI_CHECK_ARG(n_rows >= 0 && n_cols >= 0 && rowptr && chunk > 0 && max_deg >= chunk && band >= 0 && ws && info);
     if (n_rows >= INT32_MAX || n_cols >= INT32_MAX) return MI_ERR_TOO_LARGE;
     hipStream_t s = (hipStream_t)stream;
     memset(info, 0, sizeof(*info));
@@ -1149,7 +1158,7 @@ int mi_spmm_plan_count(int64_t n_rows, int64_t n_cols, const int32_t* rowptr, co
         if (!plan_carve(ar, n_rows, nnz, -1, -1, -1, w)) return MI_ERR_WORKSPACE;
     }
     const int64_t n1 = n_rows + 1;
-    hipLaunchKernelGGL(plan_flags_kernel, plan_grid(n1), dim3(256), 0, s, n_rows, rowptr, chunk, w.is_long, w.ldeg);
+    hipLaunchKernelGGL(plan_flags_kernel, plan_grid(n1), dim3(256), 0, s, n_rows, rowptr, chunk, max_deg, w.is_long, w.ldeg);
     size_t tb = w.tmp_bytes;
     MI_HIP(rocprim::exclusive_scan(w.tmp, tb, w.is_long, w.long_off, 0, (size_t)n1, rocprim::plus<int32_t>(), s));
     tb = w.tmp_bytes;
@@ -1294,16 +1303,20 @@ int mi_spmm_csr_ex_f32(int64_t n_rows, int64_t d, const int32_t* rowptr, const i
     if (sweep) {
         MI_CHECK_ARG(sweep->col && sweep->val && sweep->stream_ptr && sweep->slot_of);
         MI_CHECK_ARG(sweep->n_streams > 0 && sweep->n_streams % 32 == 0 && sweep->n_streams <= 32 * 32);
-        MI_CHECK_ARG(sweep->n_slots > 0 && plan->n_items == 8 * sweep->n_slots && n_cols_ok(sweep));
+        // plain sweep plan: every partial row is the sweep's; hybrid: work items (plan->items) own the slots behind them
+        MI_CHECK_ARG(sweep->n_slots > 0 && n_cols_ok(sweep) &&
+                     (plan->items ? plan->n_items > 8 * sweep->n_slots : plan->n_items == 8 * sweep->n_slots));
         MI_CHECK_ARG(sweep->slack >= 0);
         if (d > 128) return MI_ERR_UNSUPPORTED;
     }
     float4* partial = nullptr;
     if (plan && plan->n_items > 0) {
-        MI_CHECK_ARG(plan->item_ptr && plan->long_rows && (sweep || (plan->items && plan->n_launch >= plan->n_items)));
-        MI_CHECK_ARG(sweep || plan->band == 0 || plan->n_launch % (8 * kPlanGroup) == 0);
+        const int64_t own_items = (int64_t)plan->n_items - (sweep ? 8 * (int64_t)sweep->n_slots : 0);  // the work items' partial rows
+        MI_CHECK_ARG(plan->item_ptr && plan->long_rows && (sweep || plan->items));
+        MI_CHECK_ARG(!plan->items || plan->n_launch >= own_items);
+        MI_CHECK_ARG(!plan->items || plan->band == 0 || plan->n_launch % (8 * kPlanGroup) == 0);
         if (!ws || ws_bytes < mi_spmm_workspace_bytes(plan, d)) return MI_ERR_WORKSPACE;
-        MI_CHECK_ARG(mi_aligned16(ws) && (sweep || mi_aligned16(plan->items)));
+        MI_CHECK_ARG(mi_aligned16(ws) && (!plan->items || mi_aligned16(plan->items)));
         partial = reinterpret_cast<float4*>(ws);
     }
     Epilogue ep;

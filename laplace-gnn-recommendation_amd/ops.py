@@ -261,10 +261,12 @@ SWEEP_PACE = 0        # pacing of the sweep: ticks (10 ns) per band of the time 
 
 
 def build_sweep_plan(a: DeviceCSR, chunk: int = DEFAULT_CHUNK, band: int = SWEEP_BAND,
-                     n_streams: int = SWEEP_STREAMS) -> Optional[SpmmPlan]:
+                     n_streams: int = SWEEP_STREAMS, min_deg: Optional[int] = None) -> Optional[SpmmPlan]:
     """SWEEP-form split-row plan (include/laplace_hip.h, mi_spmm_sweep), or None when the adjacency does not qualify
     (no long rows, fewer than SWEEP_MIN_BANDS bands, more row parts than the 8 * n_streams accumulators of an XCD,
-    columns >= 2^28, no values yet).  Set-up: a few device sorts and one host pass over the long rows' degrees."""
+    columns >= 2^28, no values yet).  Set-up: a few device sorts and one host pass over the long rows' degrees.
+    min_deg (default: chunk): only the rows with MORE entries than this are laid out — the hub half of a hybrid plan
+    (build_hybrid_plan), whose remaining split rows are banded work items."""
     import heapq
     if a.val is None or a.nnz == 0 or a.n_cols >= (1 << 27) or a.n_cols < SWEEP_MIN_BANDS * band:
         return None
@@ -282,7 +284,7 @@ def build_sweep_plan(a: DeviceCSR, chunk: int = DEFAULT_CHUNK, band: int = SWEEP
         pp = [max(1, -(-d // target)) for d in host]
         return rows, host, tot, pp, sum(pp)
 
-    long_rows, dl_host, total, parts, n_slots = slots_for(chunk)
+    long_rows, dl_host, total, parts, n_slots = slots_for(chunk if min_deg is None else max(int(min_deg), chunk))
     if long_rows.numel() == 0:
         return None
     if n_slots > 8 * n_streams:
@@ -359,6 +361,97 @@ def build_sweep_plan(a: DeviceCSR, chunk: int = DEFAULT_CHUNK, band: int = SWEEP
     sw = SpmmSweepStruct(col_s.data_ptr(), val_s.data_ptr(), stream_ptr.data_ptr(), slot_of_t.data_ptr(), n_streams, n_slots,
                          None, int(n_t), max(SWEEP_PACE, 0))
     return SpmmPlan(st, long_rows32, item_ptr, None, long_index, sweep=sw, sweep_t=(col_s, val_s, stream_ptr, slot_of_t))
+
+
+def sweep_degree_threshold(a: DeviceCSR, chunk: int, n_streams: int = SWEEP_STREAMS, fill: float = 1.0) -> Optional[int]:
+    """The smallest degree T such that the rows with MORE than T entries fit the sweep form's 8 * n_streams row-part
+    accumulators (build_sweep_plan's own part count: ceil(deg / max(chunk, total / (3 n_streams))) per row); None when even
+    the single longest row does not, or no row is longer than chunk.  One host pass over the long rows' degrees."""
+    import numpy as np
+    deg = (a.rowptr[1:] - a.rowptr[:-1])
+    dl = deg[deg > chunk]
+    if dl.numel() == 0:
+        return None
+    ds = np.sort(dl.cpu().numpy().astype(np.int64))[::-1]           # descending
+    cum = np.cumsum(ds)
+    cap = int(8 * n_streams * fill)
+
+    def slots(h):   # row parts of the h longest rows
+        target = max(chunk, int(cum[h - 1]) // (3 * n_streams))
+        return int(np.sum(-(-ds[:h] // target)))
+    if slots(1) > cap:
+        return None
+    lo, hi = 1, len(ds)                                                # largest h with slots(h) <= cap (monotone in practice: checked)
+    while lo < hi:
+        mid = (lo + hi + 1) // 2
+        if slots(mid) <= cap:
+            lo = mid
+        else:
+            hi = mid - 1
+    h = lo
+    if h == len(ds):
+        return int(chunk)
+    T = int(ds[h])                                                     # rows with deg > T: a prefix of the h longest (ties cut)
+    while True:
+        hh = int(np.searchsorted(-ds, -T, side="left"))                # number of rows with deg > T
+        if hh == 0:
+            return None
+        if slots(hh) <= cap:
+            return T
+        T = int(ds[hh - 1])                                            # not monotone here: drop the shortest kept degree
+
+
+def build_hybrid_plan(a: DeviceCSR, chunk: int = DEFAULT_CHUNK, band: Optional[int] = None, tail_whole: bool = False,
+                      sweep_band: Optional[int] = None, n_streams: int = SWEEP_STREAMS) -> Optional[SpmmPlan]:
+    """HYBRID split-row plan (round 4) for adjacencies whose typical row is long (C4's item rows: 100 K rows of ~10^3 entries):
+    the hub rows — as many of the longest as the sweep form's 8 192 row-part accumulators hold, ~80 % of the entries on a
+    Zipf graph — in SWEEP form (every row of X fetched into ONE XCD's L2 about once, 8 partial rows per row part), the
+    remaining split rows either as banded work items (tail_whole=False) or, with the split threshold raised to the hub
+    rows' degree, whole in the short-row kernel (tail_whole=True).  None when the adjacency does not qualify."""
+    T = sweep_degree_threshold(a, chunk, n_streams)
+    if T is None:
+        return None
+    sb = SWEEP_BAND if sweep_band is None else sweep_band
+    if tail_whole or T <= chunk:
+        return build_sweep_plan(a, chunk=max(T, chunk), band=sb, n_streams=n_streams)
+    sw = build_sweep_plan(a, chunk=chunk, band=sb, n_streams=n_streams, min_deg=T)
+    if sw is None:
+        return None
+    # the banded half: rows with chunk < degree <= T
+    L = _lib.lib()
+    if band is None:
+        band = HYBRID_TAIL_BAND if a.n_cols >= MIN_BANDED_COLS else 0
+    dev = a.device
+    ws = _ws(L.mi_spmm_plan_workspace_bytes(a.n_rows, a.nnz), dev)
+    info = _lib.SpmmPlanInfo()
+    check(L.mi_spmm_plan_count_range(a.n_rows, a.n_cols, _ptr(a.rowptr), _ptr(a.col), chunk, T, band, ws.data_ptr(), ws.numel(),
+                                     ctypes.byref(info), _stream()), "mi_spmm_plan_count_range")
+    nl, nlaunch = int(info.n_long_rows), int(info.n_launch)
+    if nl == 0:
+        return sw
+    long_rows_b = t.empty(nl, dtype=t.int32, device=dev)
+    item_ptr_b = t.empty(nl + 1, dtype=t.int32, device=dev)
+    items = t.empty(4 * max(nlaunch, 1), dtype=t.int32, device=dev)
+    st_b = SpmmPlanStruct()
+    st_b.long_rows, st_b.item_ptr, st_b.items, st_b.long_index = long_rows_b.data_ptr(), item_ptr_b.data_ptr(), items.data_ptr(), None
+    check(L.mi_spmm_plan_fill(a.n_rows, _ptr(a.rowptr), ctypes.byref(info), ctypes.byref(st_b), ws.data_ptr(), ws.numel(),
+                              _stream()), "mi_spmm_plan_fill")
+    off = int(sw.struct.n_items)                                     # 8 * n_slots partial rows of the sweep come first
+    it = items.view(-1, 4)
+    it[:, 3] += (it[:, 3] >= 0).to(t.int32) * off                    # padding slots stay negative
+    long_rows = t.cat([sw.long_rows, long_rows_b]).contiguous()
+    item_ptr = t.cat([sw.item_ptr[:-1], item_ptr_b + off]).contiguous()
+    long_index = t.full((max(a.n_rows, 1),), -1, dtype=t.int32, device=dev)
+    long_index[long_rows.long()] = t.arange(long_rows.numel(), dtype=t.int32, device=dev)
+    st = SpmmPlanStruct()
+    st.chunk, st.n_long_rows = chunk, int(long_rows.numel())
+    st.n_items, st.n_launch = off + int(info.n_items), nlaunch
+    st.long_rows, st.item_ptr, st.items, st.long_index = long_rows.data_ptr(), item_ptr.data_ptr(), items.data_ptr(), long_index.data_ptr()
+    st.band, st.n_bands = int(info.band), int(info.n_bands)
+    return SpmmPlan(st, long_rows, item_ptr, items, long_index, sweep=sw.sweep, sweep_t=sw.sweep_t)
+
+
+HYBRID_TAIL_BAND = int(_os_environ.get("LAPLACE_HYBRID_TAIL_BAND", 16384))  # columns per band of a hybrid plan's banded tail
 
 
 import os as _os

@@ -157,9 +157,9 @@ def train_epoch(model: PinSAGEModel, optimizer: t.optim.Optimizer, sampler, batc
             if loss is not None:
                 losses.append(loss[0])
                 continue
-            if native is not None and multi:
-                # a declined batch in a data-parallel run would leave the ranks on different collective sequences
-                raise RuntimeError(f"NativePinSAGEStep declined a batch in a data-parallel run: {native.declined}")
+            # a declined batch: in a data-parallel run the executor's decline is collective (one all-reduce(MIN) of a flag before
+            # anything is enqueued, pinsage/native.py), so EVERY rank is here with its own batch and the autograd iteration
+            # below — with its dense all-reduce — runs on all of them
             loss = model(b["seeds"], b["pos"], b["neg"], b["blocks"]).mean()
             optimizer.zero_grad()
             loss.backward()

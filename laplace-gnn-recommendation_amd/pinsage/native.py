@@ -159,11 +159,10 @@ class NativePinSAGEStep:
         return i == d.n_params
 
     # ------------------------------------------------------------------------------------------
-    def step(self, batch: dict) -> Optional[Tensor]:
-        """One iteration on a PinSAGESampler batch; the loss as a 1-element device tensor, or None when declined (nothing
-        has been enqueued then)."""
+    def _prepare(self, batch: dict):
+        """Everything up to (not including) the launch, the executor's own validation pass included (mi_pinsage_step_check).
+        Returns (d, b, loss, keep-alive) or None with self.declined set; nothing has been enqueued either way."""
         model = self.model
-        self.declined = None
         if not model.training:
             self.declined = "model in eval mode"
             return None
@@ -222,11 +221,39 @@ class NativePinSAGEStep:
         need = int(L.mi_pinsage_step_workspace_bytes(ctypes.byref(d), ctypes.byref(b)))
         if self._ws is None or self._ws.numel() < need:
             self._ws = t.empty(int(need * 1.25) + (1 << 20), dtype=t.uint8, device=seeds.device)
-        rc = L.mi_pinsage_step_f32(ctypes.byref(d), ctypes.byref(b), self._ws.data_ptr(), self._ws.numel(), _lib.current_stream())
+        rc = L.mi_pinsage_step_check(ctypes.byref(d), ctypes.byref(b), self._ws.data_ptr(), self._ws.numel())
         if rc == _lib.MI_ERR_UNSUPPORTED:
             self.declined = "mi_pinsage_step_f32: MI_ERR_UNSUPPORTED (shape outside the executor's)"
             self._desc = None      # the caller's own step may leave anything in the gradient buffers: start clean next time
             return None
+        _lib.check(rc, "mi_pinsage_step_check")
+        return d, b, loss, (keep, ones, seeds, pu, pv, nv)
+
+    def step(self, batch: dict) -> Optional[Tensor]:
+        """One iteration on a PinSAGESampler batch; the loss as a 1-element device tensor, or None when declined (nothing
+        has been enqueued then).  Data-parallel with more than one rank: the decline is COLLECTIVE — one all-reduce(MIN) of
+        a 1-int flag before anything is enqueued, so that a rank whose batch lies outside the executor's shapes does not
+        leave its peers waiting in the row exchange; every rank returns None together."""
+        import torch.distributed as dist
+        self.declined = None
+        prep = self._prepare(batch)
+        world = dist.get_world_size(self.group) if (self.data_parallel and dist.is_initialized()) else 1
+        if world > 1:
+            flag = t.tensor([1 if prep is not None else 0], dtype=t.int32, device=self.model.proj.weight.device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+            if not int(flag.item()):
+                if prep is not None:
+                    self.declined = "a peer rank declined its batch (collective decision: every rank takes the fallback)"
+                    self._desc = None
+                return None
+        elif prep is None:
+            return None
+        d, b, loss, _keep = prep
+        group = self.optimizer.param_groups[0]
+        L = _lib.lib()
+        rc = L.mi_pinsage_step_f32(ctypes.byref(d), ctypes.byref(b), self._ws.data_ptr(), self._ws.numel(), _lib.current_stream())
+        if rc == _lib.MI_ERR_UNSUPPORTED:      # cannot happen: mi_pinsage_step_check took the same descriptors
+            raise _lib.MiError("mi_pinsage_step_f32 declined a batch its own validation pass had accepted")
         _lib.check(rc, "mi_pinsage_step_f32")
         self.iteration += 1
         if self.data_parallel:

@@ -220,11 +220,11 @@ class NativeRankerStep:
         return True
 
     # ------------------------------------------------------------------------------------------
-    def step(self, x_dict: Dict[str, Tensor], edge_index_dict: dict, edge_label_index: Tensor, labels: Tensor) -> Optional[Tensor]:
-        """One iteration; the loss as a 1-element device tensor, or None when the executor declines this batch (nothing
-        has been enqueued then; the caller runs FusedRankerStep / autograd)."""
+    def _prepare(self, x_dict: Dict[str, Tensor], edge_index_dict: dict, edge_label_index: Tensor, labels: Tensor):
+        """Everything up to (not including) the launch: descriptors built, workspace sized, the executor's own validation
+        pass run (mi_ranker_step_check).  Returns (d, b, loss, steps, keep-alive) or None with self.declined set; nothing has
+        been enqueued either way."""
         model = self.model
-        self.declined = None       # why the last call returned None (diagnostics)
         if not model.training:
             self.declined = "model in eval mode"
             return None
@@ -289,10 +289,47 @@ class NativeRankerStep:
         need = int(L.mi_ranker_step_workspace_bytes(ctypes.byref(d), ctypes.byref(b)))
         if self._ws is None or self._ws.numel() < need:
             self._ws = t.empty(int(need * 1.25) + (1 << 20), dtype=t.uint8, device=xc.device)
-        rc = L.mi_ranker_step_f32(ctypes.byref(d), ctypes.byref(b), self._ws.data_ptr(), self._ws.numel(), _lib.current_stream())
+        rc = L.mi_ranker_step_check(ctypes.byref(d), ctypes.byref(b), self._ws.data_ptr(), self._ws.numel())
         if rc == _lib.MI_ERR_UNSUPPORTED:
             self.declined = "mi_ranker_step_f32: MI_ERR_UNSUPPORTED (shape outside the executor's)"
             return None
+        _lib.check(rc, "mi_ranker_step_check")
+        return d, b, loss, steps, (xc, xa, row, col, labels, ones, by_c, by_a)
+
+    def _world(self) -> int:
+        import torch.distributed as dist
+        return dist.get_world_size(self.group) if (self.data_parallel and dist.is_initialized()) else 1
+
+    def _all_ranks_take_it(self, mine: bool, device) -> bool:
+        """Data-parallel only: the decline is COLLECTIVE.  A rank whose batch lies outside the executor's shapes must not
+        leave its peers alone in the gradient all-reduce (they would wait for the collective's timeout, or reduce against
+        the fallback path's differently sized buffer): one all-reduce(MIN) of a 1-int flag BEFORE anything is enqueued, and
+        every rank takes the same branch."""
+        import torch.distributed as dist
+        flag = t.tensor([1 if mine else 0], dtype=t.int32, device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+        return bool(int(flag.item()))
+
+    def step(self, x_dict: Dict[str, Tensor], edge_index_dict: dict, edge_label_index: Tensor, labels: Tensor) -> Optional[Tensor]:
+        """One iteration; the loss as a 1-element device tensor, or None when the executor declines this batch (nothing
+        has been enqueued then; the caller runs FusedRankerStep / autograd).  With data_parallel=True and more than one
+        rank the decision is collective: every rank returns None when ANY rank's batch is declined, so all of them take the
+        caller's fallback together (`declined` then names the local reason, or says that a peer declined)."""
+        self.declined = None       # why the last call returned None (diagnostics)
+        prep = self._prepare(x_dict, edge_index_dict, edge_label_index, labels)
+        if self._world() > 1:
+            if not self._all_ranks_take_it(prep is not None, next(self.model.parameters()).device):
+                if prep is not None:
+                    self.declined = "a peer rank declined its batch (collective decision: every rank takes the fallback)"
+                return None
+        elif prep is None:
+            return None
+        d, b, loss, steps, _keep = prep
+        group = self.optimizer.param_groups[0]
+        L = _lib.lib()
+        rc = L.mi_ranker_step_f32(ctypes.byref(d), ctypes.byref(b), self._ws.data_ptr(), self._ws.numel(), _lib.current_stream())
+        if rc == _lib.MI_ERR_UNSUPPORTED:      # cannot happen: mi_ranker_step_check took the same descriptors
+            raise _lib.MiError("mi_ranker_step_f32 declined a batch its own validation pass had accepted")
         _lib.check(rc, "mi_ranker_step_f32")
         self.iteration += 1
         if self.before_step is not None:       # gradients are in param.grad: exchange them, then torch's own update

@@ -179,3 +179,76 @@ def test_c3_full_size_device_sampler_bit_exact_and_ranker_logits(hm_graph):
         want_logits = ref({k: v.clone() for k, v in xc.items()}, ec, elic).view(-1)
     assert got_logits.shape == want_logits.shape == (int(y.numel()),)
     assert float((got_logits - want_logits).abs().max()) <= 1e-4
+
+
+# ------------------------------------------------------------------------------------------ configs[4], full H&M shape
+@pytest.mark.parametrize("walk_length", [2, 3])
+def test_c5_full_size_pinsage_batches_bit_exact_and_native_step_vs_twin(hm_graph, walk_length):
+    """BASELINE configs[4] (PinSage item-item link prediction on the H&M graph) at its workload: the 1 371 980 x 105 542 x
+    31.8 M graph of bench.py's pinsage_c5 block, the reference's batch of 32 pairs, 10 walks, restart 0.5, T = 3, 2 layers,
+    hidden 16 (pinsage/model.py:143-148), walk length 2 (the reference's default) and 3 (BASELINE's "3-hop").
+    (1) the batch built on the device by ONE C call (mi_pinsage_sample_batch: pairs, seeds, both blocks) against the numpy
+    mirror of pinsage/sampler.py:16-106, bit for bit, on three steps; (2) ONE mi_pinsage_step_f32 iteration on such a
+    batch — loss and every parameter gradient, the dense 105 543 x 16 projector table's included — directly against the
+    torch-only twin (oracle/pinsage_ref.py) evaluated on the MIRROR's batch, dropout off."""
+    from oracle import pinsage_ref as PR
+    from laplace_amd.pinsage.model import PinSAGEModel
+    from laplace_amd.pinsage.native import NativePinSAGEStep
+    from laplace_amd.pinsage.sampler import PinSAGESampler
+    graph, users, articles = hm_graph
+    U, I, H, LAYERS, SEED = 1_371_980, 105_542, 16, 2, 13
+    ucsr, icsr = PR.Csr(users.ptr, users.idx), PR.Csr(articles.ptr, articles.idx)
+    smp = PinSAGESampler(users, articles, U, I, batch_size=32, random_walk_length=walk_length, random_walk_restart_prob=0.5,
+                         num_random_walks=10, num_neighbors=3, num_layers=LAYERS, seed=SEED)
+    batches = {}
+    for step in (0, 7, 12345):
+        got = smp._sample_batch_device(step)
+        assert got is not None                                          # the reference's sizes are inside the device builder's
+        wh, wt, wn = PR.item_pairs(32, I, icsr, ucsr, SEED, step)
+        want = PR.sample_from_item_pairs(wh, wt, wn, icsr, ucsr, LAYERS, walk_length, 0.5, 10, 3, SEED, step)
+        assert 20 <= len(wh) <= 32 and len(want["seeds"]) > 32
+        assert np.array_equal(got["seeds"].cpu().numpy(), want["seeds"]), step
+        for a, b in zip(got["pos"] + got["neg"], want["pos"] + want["neg"]):
+            assert np.array_equal(a.cpu().numpy(), b), step
+        assert len(got["blocks"]) == LAYERS
+        for gb, wb in zip(got["blocks"], want["blocks"]):
+            assert gb["n_dst"] == wb["n_dst"]
+            for key in ("src_ids", "edge_src", "edge_dst", "weights"):
+                assert np.array_equal(gb[key].cpu().numpy(), wb[key]), (step, key)
+        batches[step] = (got, want)
+    # walks of 3 traversals visit more distinct items than walks of 2: the two settings really are different samplers
+    assert bool((smp._pos32 == -1).all())
+    t.manual_seed(3)
+    model = PinSAGEModel(I, H, LAYERS).to(DEV)
+    with t.no_grad():
+        model.bias.normal_(0, 0.1)
+    for cv in model.convs:
+        cv.dropout.p = 0.0
+    ref = PR.PinSAGERef(I, H, LAYERS)
+    ref.load_state_dict({k: v.detach().cpu().clone() for k, v in model.state_dict().items()})
+    for cv in ref.convs:
+        cv.dropout.p = 0.0
+    opt = t.optim.Adam(model.parameters(), lr=3e-5)                     # pinsage/model.py:153
+    probe = NativePinSAGEStep(model, opt, keep_grads=True)
+    model.train(); ref.train()
+    for step in (7, 12345):
+        got, want = batches[step]
+        loss = probe.step(got)
+        assert loss is not None, probe.declined
+        tb = PR.to_torch_blocks(want["blocks"])
+        ref.zero_grad()
+        out = ref(t.from_numpy(want["seeds"]), tuple(t.from_numpy(x) for x in want["pos"]),
+                  tuple(t.from_numpy(x) for x in want["neg"]), tb)
+        loss_ref = out.mean()
+        loss_ref.backward()
+        assert abs(float(loss) - float(loss_ref)) <= 1e-5 * max(1.0, abs(float(loss_ref))), step
+        for (n, p), (_, pr) in zip(model.named_parameters(), ref.named_parameters()):
+            scale = float(pr.grad.abs().max()) + 1e-12
+            assert float((p.grad.cpu() - pr.grad).abs().max()) <= 2e-4 * scale + 1e-8, (step, n)
+        # the dense table gradients are non-zero exactly on the batch's rows
+        rows = t.nonzero(model.proj.weight.grad.abs().sum(1) > 0).view(-1).cpu()
+        rows_ref = t.nonzero(ref.proj.weight.grad.abs().sum(1) > 0).view(-1)
+        assert t.equal(rows, rows_ref) and 0 < rows.numel() <= len(want["blocks"][0]["src_ids"])
+        model.proj.weight.grad.zero_(); model.bias.grad.zero_()         # what the probe left behind
+    del model, probe
+    t.cuda.empty_cache()

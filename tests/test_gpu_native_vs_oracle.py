@@ -1,0 +1,255 @@
+"""GPU: the two native executors — the paths bench.py times for BASELINE configs[2] (mi_ranker_step_f32) and configs[4]
+(mi_pinsage_step_f32) — compared DIRECTLY with the oracle's torch-only twins (oracle/ranker_ref.py, oracle/pinsage_ref.py),
+not through the product's own fused / autograd forms: loss, every parameter gradient, the BatchNorm statistics, and the
+Adam update wherever the gradient is above rounding noise (training.py:19-34; pinsage/model.py:118-131)."""
+import copy
+
+import numpy as np
+import pytest
+import torch as t
+
+from oracle import pinsage_ref as PR
+from oracle import ranker_ref as RR
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.mark.parametrize("aggr", ["add", "mean"])
+def test_native_ranker_step_against_the_oracle_twin(aggr):
+    from test_gpu_ranker import _hetero_setup
+    from laplace_amd.ranker_native import NativeRankerStep
+    from laplace_amd.utils.get_info import select_properties
+    model, loader, first = _hetero_setup(seed=7, aggr=aggr, embedding=True, p_drop=0.0)
+    ref = RR.ref_from_product(model, first.x_dict)
+    opt = t.optim.Adam(model.parameters(), lr=0.01)                     # training.py / run_pipeline.py:75
+    opt_ref = t.optim.Adam(ref.parameters(), lr=0.01)
+    assert NativeRankerStep.unsupported_reason(model, opt) is None
+    native = NativeRankerStep(model, opt)
+    crit = t.nn.BCEWithLogitsLoss()
+    model.train(); ref.train()
+    names = [n for n, _ in model.named_parameters()]
+    assert names == [n for n, _ in ref.named_parameters()]
+    for step, batch in enumerate(loader):
+        if step == 4:
+            break
+        x, ei, eli, y = select_properties(batch)                         # the host batch feeds the oracle ...
+        before = {n: p.detach().cpu().clone() for n, p in model.named_parameters()}
+        opt_ref.zero_grad()
+        out_ref = ref({k: v.clone() for k, v in x.items()}, ei, eli)
+        loss_ref = crit(out_ref, y.float())
+        loss_ref.backward()
+        xg, eig, elig, yg = select_properties(batch.to(DEV))             # ... its device copy the executor
+        loss = native.step({k: v.clone() for k, v in xg.items()}, eig, elig, yg)
+        assert loss is not None, native.declined
+        assert abs(float(loss) - float(loss_ref)) <= 1e-5, step
+        grads_ref = {n: p.grad.detach().clone() for n, p in ref.named_parameters()}
+        for n, p in model.named_parameters():
+            g = grads_ref[n]
+            scale = float(g.abs().max()) + 1e-8
+            assert float((p.grad.cpu() - g).abs().max()) <= 2e-4 * scale + 1e-6, (step, n)
+        for bn in ("encoder_layer_norm_customer", "encoder_layer_norm_article"):
+            assert t.allclose(getattr(model, bn).running_mean.cpu(), getattr(ref, bn).running_mean, atol=1e-5)
+            assert t.allclose(getattr(model, bn).running_var.cpu(), getattr(ref, bn).running_var, atol=1e-5, rtol=1e-5)
+            assert int(getattr(model, bn).num_batches_tracked) == int(getattr(ref, bn).num_batches_tracked) == step + 1
+        # the executor's multi-tensor Adam against torch.optim.Adam on the oracle's gradients.  Adam normalises: in its first
+        # steps a gradient entry at rounding-noise level moves its weight by up to lr whichever sign the noise takes, so the
+        # update is compared where the oracle's gradient is clear of the noise floor of the comparison above.
+        opt_ref.step()
+        checked = 0
+        for n, p in model.named_parameters():
+            g, q = grads_ref[n], dict(ref.named_parameters())[n].detach()
+            big = g.abs() > 1e-3 * (float(g.abs().max()) + 1e-8) + 1e-5
+            checked += int(big.sum())
+            moved = p.detach().cpu() - before[n]
+            assert t.allclose(moved[big], (q - before[n])[big], rtol=5e-2, atol=2e-5), (step, n)
+            assert float(moved.abs().max()) <= 0.01 * 1.001 * (step + 1) ** 0  # |Adam step| <= lr
+        assert checked > 1000
+        model.load_state_dict({k: v.to(DEV) for k, v in ref.state_dict().items()})   # cut the chain at rounding level
+        for p, q in zip(model.parameters(), ref.parameters()):
+            for k in ("exp_avg", "exp_avg_sq"):
+                opt.state[p][k].copy_(opt_ref.state[q][k].to(DEV))
+
+
+def _pin_graph(seed, U, I, E):
+    from laplace_amd import synthetic as S
+    from laplace_amd.data.dataset import AdjList
+    ei = S.generate(S.SyntheticSpec(U, I, E, seed=seed, deg_min=1, deg_max=60, zipf_s=0.9))
+    u, a = ei[0].numpy(), ei[1].numpy()
+    return AdjList.from_edges(u, a, U), AdjList.from_edges(a, u, I)
+
+
+@pytest.mark.parametrize("hidden,layers,walk", [(16, 2, 2), (64, 2, 3), (32, 3, 2)])
+def test_native_pinsage_step_against_the_oracle_twin(hidden, layers, walk):
+    """mi_pinsage_step_f32 on device-built batches against PinSAGERef on the MIRROR's batches (the mirror builds them from
+    the same Philox draws, so this also ties the device batch to the oracle's): loss, every gradient; then the full step's
+    update against torch.optim.Adam on the oracle's gradients."""
+    from laplace_amd.pinsage.model import PinSAGEModel
+    from laplace_amd.pinsage.native import NativePinSAGEStep
+    from laplace_amd.pinsage.sampler import PinSAGESampler
+    U, I, SEED, B = 2500, 800, 31, 48
+    users, items = _pin_graph(5, U, I, 40000)
+    ucsr, icsr = PR.Csr(users.ptr, users.idx), PR.Csr(items.ptr, items.idx)
+    smp = PinSAGESampler(users, items, U, I, batch_size=B, random_walk_length=walk, num_layers=layers, seed=SEED)
+    t.manual_seed(hidden + layers)
+    model = PinSAGEModel(I, hidden, layers).to(DEV)
+    with t.no_grad():
+        model.bias.normal_(0, 0.1)
+    for cv in model.convs:
+        cv.dropout.p = 0.0
+    ref = PR.PinSAGERef(I, hidden, layers)
+    for cv in ref.convs:
+        cv.dropout.p = 0.0
+    lr = 3e-3
+    opt, opt_ref = t.optim.Adam(model.parameters(), lr=lr), t.optim.Adam(ref.parameters(), lr=lr)
+    probe, full = NativePinSAGEStep(model, opt, keep_grads=True), None
+    model.train(); ref.train()
+    for step in range(3):
+        ref.load_state_dict({k: v.detach().cpu().clone() for k, v in model.state_dict().items()})
+        got = smp.sample_batch(step)
+        wh, wt, wn = PR.item_pairs(B, I, icsr, ucsr, SEED, step)
+        want = PR.sample_from_item_pairs(wh, wt, wn, icsr, ucsr, layers, walk, 0.5, 10, 3, SEED, step)
+        assert np.array_equal(got["seeds"].cpu().numpy(), want["seeds"])
+        la = probe.step(got)
+        assert la is not None, probe.declined
+        opt_ref.zero_grad()
+        lb = ref(t.from_numpy(want["seeds"]), tuple(t.from_numpy(x) for x in want["pos"]),
+                 tuple(t.from_numpy(x) for x in want["neg"]), PR.to_torch_blocks(want["blocks"])).mean()
+        lb.backward()
+        assert abs(float(la) - float(lb)) <= 1e-5 * max(1.0, abs(float(lb))), step
+        grads_ref = [p.grad.detach().clone() for p in ref.parameters()]
+        for (n, p), g in zip(model.named_parameters(), grads_ref):
+            scale = float(g.abs().max()) + 1e-12
+            assert float((p.grad.cpu() - g).abs().max()) <= 2e-4 * scale + 1e-8, (step, n)
+        model.proj.weight.grad.zero_(); model.bias.grad.zero_()          # what the probe left behind
+        # the full iteration (gradients + dense Adam over every tensor) from the same weights
+        before = [p.detach().cpu().clone() for p in model.parameters()]
+        if full is None:
+            full = NativePinSAGEStep(model, opt)
+        assert full.step(got) is not None, full.declined
+        opt_ref.step()
+        for (n, p), q, g, b in zip(model.named_parameters(), ref.parameters(), grads_ref, before):
+            big = g.abs() > 1e-3 * (float(g.abs().max()) + 1e-12) + 1e-7
+            assert bool(big.any()), n
+            assert t.allclose((p.detach().cpu() - b)[big], (q.detach() - b)[big], rtol=5e-2, atol=2e-6), (step, n)
+            assert t.equal(p.detach().cpu()[g == 0], b[g == 0]) or step > 0   # rows never touched do not move on the first step
+
+
+# ---- data-parallel decline is collective: no rank is left alone in a collective ------------------------------
+
+def _decline_worker(rank, world, port, ret):
+    import os
+    import torch.distributed as dist
+    import datetime
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
+    try:
+        from test_gpu_ranker import _hetero_setup
+        from laplace_amd.dist_ranker import broadcast_parameters, fused_step, native_step
+        from laplace_amd.utils.get_info import select_properties
+        t.manual_seed(70 + rank)
+        model, loader, first = _hetero_setup(seed=3, aggr="add", embedding=True, p_drop=0.0)
+        broadcast_parameters(model)
+        for tabs in model.embedding_layers.values():
+            for tb in tabs:
+                dist.broadcast(tb.data, src=0)
+        opt = t.optim.Adam(model.parameters(), lr=0.01)
+        step, fallback = native_step(model, opt, seed=1), fused_step(model, opt)
+        model.train()
+        batches = [b for i, b in zip(range(2 * world), loader)]
+        out = []
+        for it in range(3):
+            x, ei, eli, y = select_properties(batches[rank + it].to(DEV))
+            if it == 1 and rank == 1:
+                y = y.to(t.float64)        # a label dtype the executor does not take: THIS rank's batch is declined
+            loss = step.step({k: v.clone() for k, v in x.items()}, ei, eli, y)
+            out.append((loss is not None, step.declined))
+            if loss is None:               # every rank is here together: the op-by-op step with its own gradient all-reduce
+                loss = fallback.step({k: v.clone() for k, v in x.items()}, ei, eli, y.float())
+                assert loss is not None
+        t.cuda.synchronize()
+        ret[rank] = {"taken": out, "params": [p.detach().cpu() for p in model.parameters()]}
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_data_parallel_ranker_decline_is_collective():
+    """Two ranks on the card; in iteration 1 rank 1's batch is outside the executor's shapes.  Both ranks must return None
+    from that call (rank 0 with the 'peer declined' reason) and take the fallback together; iterations 0 and 2 run on the
+    executor; the replicas end bitwise identical and nobody waits for a collective's timeout."""
+    import socket
+    import time
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ret = mp.Manager().dict()
+    t0 = time.time()
+    mp.spawn(_decline_worker, args=(2, port, ret), nprocs=2, join=True)
+    assert time.time() - t0 < 55
+    a, b = ret[0], ret[1]
+    assert [x[0] for x in a["taken"]] == [x[0] for x in b["taken"]] == [True, False, True]
+    assert "peer rank declined" in a["taken"][1][1] and "labels" in b["taken"][1][1]
+    for x, y in zip(a["params"], b["params"]):
+        assert t.equal(x, y)
+
+
+def _pin_decline_worker(rank, world, port, ret):
+    import os
+    import torch.distributed as dist
+    import datetime
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
+    try:
+        from laplace_amd.dist_ranker import broadcast_parameters
+        from laplace_amd.pinsage.model import PinSAGEModel, train_epoch
+        from laplace_amd.pinsage.sampler import PinSAGESampler
+        U, I = 2500, 800
+        users, items = _pin_graph(11, U, I, 40000)
+        # rank 1 draws batches of 64 pairs against an exchange capacity sized for 32 (the capacity comes from the sampler's
+        # own batch_size attribute, which this test overrides below): its batches do not fit and are declined there
+        smp = PinSAGESampler(users, items, U, I, batch_size=64 if rank == 1 else 32, seed=200 + rank)
+        if rank == 1:
+            smp_bs = smp.batch_size
+
+            class Lying:   # the sampler under a wrapper that reports the other rank's bounds
+                batch_size, T, n_layers = 32, smp.T, smp.n_layers
+
+                def batches(self, n):
+                    return smp.batches(n)
+            source = Lying()
+        else:
+            source = smp
+        t.manual_seed(50 + rank)
+        model = PinSAGEModel(I, 32, 2).to("cuda")
+        for cv in model.convs:
+            cv.dropout.p = 0.0
+        broadcast_parameters(model)
+        opt = t.optim.Adam(model.parameters(), lr=3e-3)
+        losses = train_epoch(model, opt, source, 4)
+        t.cuda.synchronize()
+        ret[rank] = {"losses": losses, "params": [p.detach().cpu() for p in model.parameters()]}
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_data_parallel_pinsage_decline_is_collective():
+    """Rank 1's batches exceed the exchange capacity: the executor's decline is voted on before anything is enqueued, both
+    ranks run the autograd iteration with the dense all-reduce instead, and the replicas stay identical (to rounding of the
+    mean: the dense path divides after the sum on both ranks alike, so bitwise)."""
+    import socket
+    import time
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ret = mp.Manager().dict()
+    t0 = time.time()
+    mp.spawn(_pin_decline_worker, args=(2, port, ret), nprocs=2, join=True)
+    assert time.time() - t0 < 55
+    a, b = ret[0], ret[1]
+    assert len(a["losses"]) == len(b["losses"]) == 4 and all(np.isfinite(a["losses"] + b["losses"]))
+    for x, y in zip(a["params"], b["params"]):
+        assert t.equal(x, y)

@@ -90,8 +90,7 @@ def run(args):
             loss = native.step(b)
             if loss is not None:
                 return loss, b
-            if world > 1:
-                raise RuntimeError(f"data-parallel native step declined a batch: {native.declined}")
+            # (data-parallel: the decline is collective, every rank takes the autograd iteration below together)
         loss = model(b["seeds"], b["pos"], b["neg"], b["blocks"]).mean()
         opt.zero_grad()
         loss.backward()
