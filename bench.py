@@ -21,6 +21,9 @@ The default N=1 run carries, after the timed region, the metric's other configur
                batch, on-device 2-hop sampling (tools/bench_ranker.py's bench line)          [--no-ranker to skip]
   pinsage_c5   BASELINE configs[4] at N = 1: PinSAGE item-item training at the H&M shape, the reference's batch of 32
                pairs (tools/bench_pinsage.py)                                               [--no-pinsage to skip]
+  "e2e_c3"     BASELINE configs[3]'s "candidate-gen + ranker end-to-end" at the H&M shape on one GPU: per-stage seconds of LightGCN
+               steps -> top-100 dump -> matchers -> ranker iterations -> device-built evaluation, MAP@12 on held-out purchases
+               (tools/e2e_hm_scale.py)                                                        [--no-e2e to skip]
   "map_at_12"  ranking quality on a PLANTED-structure graph (synthetic.SyntheticSpec.communities), layer-0 predictor vs
                propagated embeddings vs popularity                                           [--no-map to skip]
 
@@ -82,6 +85,9 @@ def parse_args():
     ap.add_argument("--no-ranker", action="store_true", help="skip the ranker_c3 block (BASELINE configs[2])")
     ap.add_argument("--no-pinsage", action="store_true", help="skip the pinsage_c5 block (BASELINE configs[4] at N = 1)")
     ap.add_argument("--pinsage-iters", type=int, default=300)
+    ap.add_argument("--no-e2e", action="store_true", help="skip the e2e_c3 block (configs[3]: candidate generation -> ranker, H&M shape)")
+    ap.add_argument("--e2e-lightgcn-steps", type=int, default=300)
+    ap.add_argument("--e2e-ranker-iters", type=int, default=300)
     ap.add_argument("--no-topk", action="store_true", help="skip the topk_a10 block (exact top-K with exclusion, users/s)")
     ap.add_argument("--ranker-steps", type=int, default=400)
     ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 --pmc passes (roofline.traffic falls back to profiles/traffic.json)")
@@ -488,14 +494,30 @@ def ranker_block(args) -> dict:
 
 
 def pinsage_block(args) -> dict:
-    """BASELINE configs[4] at N = 1: PinSAGE item-item training at the H&M shape, the reference's defaults (32 pairs per batch,
-    10 walks of length 2, T = 3, 2 layers) — tools/bench_pinsage.py; the iteration is one C call (mi_pinsage_step_f32) with the
-    next batch sampled on a side stream."""
+    """BASELINE configs[4] at N = 1: PinSAGE item-item training at the H&M shape with the reference's settings (32 pairs per batch,
+    10 walks, restart 0.5, T = 3, 2 layers, hidden 16, lr 3e-5: pinsage/model.py:143-153) — tools/bench_pinsage.py; the
+    iteration is one C call (mi_pinsage_step_f32) with the next batch sampled on a side stream.  The headline of the block is
+    the "3-hop random-walk sampler" BASELINE names (walks of 3 traversals); the reference's own default (walks of 2) rides
+    beside it, measured on the same graph."""
     import importlib.util
     spec = importlib.util.spec_from_file_location("bench_pinsage", os.path.join(ROOT, "tools", "bench_pinsage.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    return mod.bench_line(iters=args.pinsage_iters)
+    out = mod.bench_line(iters=args.pinsage_iters, walk_length=3)
+    out["reference_default_walk_length_2"] = mod.bench_line(iters=args.pinsage_iters, walk_length=2)
+    mod._GRAPH_CACHE.clear()
+    return out
+
+
+def e2e_block(args) -> dict:
+    """BASELINE configs[3]'s "LightGCN candidate-gen + GNN ranker end-to-end" at the H&M shape on one GPU, per-stage seconds and
+    MAP@12 on held-out purchases of a planted-structure graph (tools/e2e_hm_scale.py::run): LightGCN steps -> top-100 dump ->
+    matchers -> ranker iterations -> device-built evaluation."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("e2e_hm_scale", os.path.join(ROOT, "tools", "e2e_hm_scale.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.run(lightgcn_steps=args.e2e_lightgcn_steps, ranker_iters=args.e2e_ranker_iters)
 
 
 def topk_block(args) -> dict:
@@ -665,6 +687,10 @@ def main():
         if extras and not args.no_pinsage:
             out["pinsage_c5"] = pinsage_block(args)
             tl = _leg("pinsage_c5 (incl. graph generation)", tl)
+        if extras and not args.no_e2e:
+            t.cuda.empty_cache()
+            out["e2e_c3"] = e2e_block(args)
+            tl = _leg("e2e_c3 (incl. graph generation)", tl)
         if extras and not args.no_topk:
             t.cuda.empty_cache()
             out["topk_a10"] = topk_block(args)

@@ -233,16 +233,19 @@ typedef struct mi_spmm_ex {
     int32_t        parts;           /* 0 = the whole product; else a mask: MI_SPMM_SHORT_ROWS computes the rows of at most
                                        plan->chunk entries, MI_SPMM_SPLIT_ROWS the split rows (work items + fix-up).  The two
                                        halves touch disjoint output rows, so a caller may enqueue them on two streams */
-    int32_t        hot_rows;        /* Short rows of a dense launch with a plan (d <= 256) run as a PERSISTENT, software-
-                                       pipelined launch: the grid is what the chip holds at once, wavefronts stride over the
-                                       row pairs and fetch the next rows' pointers and (col, val) entries under the current
-                                       gathers.  hot_rows > 0 adds an LDS cache: rows [hot_base, hot_base + hot_rows) of X are
-                                       staged once per workgroup and gathers of them are served from LDS instead of L2 (a
-                                       recommendation graph under the locality order keeps its most popular items in the first
-                                       item rows: 64 rows take ~46 %, 300 rows ~59 % of all user-row gathers); clipped to the
-                                       workgroup's LDS share.  0 = no cache.  < 0 = the plain one-workgroup-per-8-rows launch
-                                       (A/B).  Hints for speed only: same values summed in the same order, bitwise the same
-                                       result in all three forms */
+    int32_t        hot_rows;        /* 0 (the default, also of a null mi_spmm_ex and of mi_spmm_csr_f32): the plain
+                                       one-workgroup-per-8-rows short-row launch — the measured best (profiles/
+                                       r03_spmm_rows_persistent.md, r04_c4_item_rows_experiments.md).  != 0 (opt-in, dense launches
+                                       with a plan, d <= 256): the short rows run as a PERSISTENT, software-pipelined launch — the
+                                       grid is what the chip holds at once, wavefronts stride over the row pairs and fetch the next
+                                       rows' pointers and (col, val) entries under the current gathers; hot_rows > 0 adds an LDS
+                                       cache: rows [hot_base, hot_base + hot_rows) of X are staged once per workgroup and gathers
+                                       of them are served from LDS instead of L2 (a recommendation graph under the locality order
+                                       keeps its most popular items in the first item rows: 64 rows take ~46 %, 300 rows ~59 % of
+                                       all user-row gathers), clipped to the workgroup's LDS share; hot_rows < 0 = persistent
+                                       without a cache.  Hints for speed only: same values summed in the same order, bitwise the
+                                       same result in all three forms.  (Round 3 had 0 = persistent and < 0 = plain: a zero-
+                                       initialised struct silently chose the slower form.) */
     const mi_spmm_sweep* sweep;     /* nullable: the split rows run in SWEEP form (plan->items is then unused) */
     int32_t        hot_base;        /* first cached row of X (see hot_rows) */
     int32_t        hot_threads;     /* tuning of the hot-row launch, 0 = defaults: bits 0..11 workgroup size (256 / 512 / 1024),

@@ -6,6 +6,7 @@
 // sums, and every workgroup of the second kernel re-reduces those few partials itself (32 x C doubles from L2) instead
 // of paying a third launch — forward = 2 launches, backward = 2 launches.
 #include "common.hpp"
+#include "pairs.hpp"
 
 namespace {
 
@@ -72,13 +73,13 @@ __global__ __launch_bounds__(kBlock) void bn_partial_kernel(int64_t n, int c, co
 // xor tree over the wave's row groups, then the block's waves in order: deterministic, a different association from
 // the scalar walk (both within rounding of the exact double sum).
 template <bool BWD>
-__global__ __launch_bounds__(kBlock) void bn_partial4_kernel(int64_t n, int c, const float* __restrict__ X, int64_t ldx,
-                                                             const float* __restrict__ dY, int64_t ldy,
-                                                             const float* __restrict__ mean,
-                                                             const float* __restrict__ invstd,
-                                                             double* __restrict__ part /* [kBnParts, 2, c] */) {
+__device__ __forceinline__ void bn_partial4_body(int p, int64_t n, int c, const float* __restrict__ X, int64_t ldx,
+                                                 const float* __restrict__ dY, int64_t ldy,
+                                                 const float* __restrict__ mean,
+                                                 const float* __restrict__ invstd,
+                                                 double* __restrict__ part /* [kBnParts, 2, c] */) {
     __shared__ double red[kWaves][2][256];
-    const int lane = mi_lane(), wave = threadIdx.x / MI_WAVE, p = blockIdx.x;
+    const int lane = mi_lane(), wave = threadIdx.x / MI_WAVE;
     const int lpr = c >> 2, rpw = MI_WAVE / lpr;
     const int sub = lane / lpr, q = lane - sub * lpr;
     double a[4] = {0.0, 0.0, 0.0, 0.0}, b[4] = {0.0, 0.0, 0.0, 0.0};
@@ -128,6 +129,21 @@ __global__ __launch_bounds__(kBlock) void bn_partial4_kernel(int64_t n, int c, c
         part[((int64_t)p * 2 + 0) * c + ch] = sa;
         part[((int64_t)p * 2 + 1) * c + ch] = sb;
     }
+}
+template <bool BWD>
+__global__ __launch_bounds__(kBlock) void bn_partial4_kernel(int64_t n, int c, const float* __restrict__ X, int64_t ldx,
+                                                             const float* __restrict__ dY, int64_t ldy,
+                                                             const float* __restrict__ mean,
+                                                             const float* __restrict__ invstd, double* __restrict__ part) {
+    bn_partial4_body<BWD>(blockIdx.x, n, c, X, ldx, dY, ldy, mean, invstd, part);
+}
+// twin launch (mi_pairs): workgroups [0, kBnParts) take problem 0, [kBnParts, 2 kBnParts) problem 1
+struct BnPart4 { int64_t n; const float* X; const float* dY; const float* mean; const float* invstd; double* part; };
+template <bool BWD>
+__global__ __launch_bounds__(kBlock) void bn_partial4_pair_kernel(BnPart4 a, BnPart4 b, int c) {
+    const bool first = blockIdx.x < kBnParts;
+    const BnPart4& q = first ? a : b;
+    bn_partial4_body<BWD>(first ? blockIdx.x : blockIdx.x - kBnParts, q.n, c, q.X, c, q.dY, c, q.mean, q.invstd, q.part);
 }
 
 // Sum of the kBnParts partials of every channel, by the whole block: G = kBlock / cp groups of cp threads (cp = c rounded
@@ -187,13 +203,13 @@ __device__ __forceinline__ void bn_sum_parts(const double* __restrict__ part, in
 // in part order); block 0 also stores them for the backward and updates the running statistics (momentum, unbiased
 // variance) exactly as torch.nn.BatchNorm1d does.  Eval: mean / var are the running statistics.
 template <bool TRAIN>
-__global__ __launch_bounds__(kBlock) void bn_apply_kernel(int64_t n, int c, const float* __restrict__ X, int64_t ldx,
-                                                          const double* __restrict__ part,
-                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                          float* __restrict__ run_mean, float* __restrict__ run_var,
-                                                          float momentum, float eps, float* __restrict__ save_mean,
-                                                          float* __restrict__ save_invstd, float* __restrict__ Y,
-                                                          int64_t ldy, int vec4) {
+__device__ __forceinline__ void bn_apply_body(unsigned bid, unsigned nblocks, int64_t n, int c, const float* __restrict__ X, int64_t ldx,
+                                              const double* __restrict__ part,
+                                              const float* __restrict__ gamma, const float* __restrict__ beta,
+                                              float* __restrict__ run_mean, float* __restrict__ run_var,
+                                              float momentum, float eps, float* __restrict__ save_mean,
+                                              float* __restrict__ save_invstd, float* __restrict__ Y,
+                                              int64_t ldy, int vec4) {
     __shared__ float s_scale[kBnMaxC], s_shift[kBnMaxC];
     __shared__ double s_tmp[kBlock / 64][2][256];
     __shared__ double s_sa[kBnMaxC], s_sb[kBnMaxC];
@@ -207,7 +223,7 @@ __global__ __launch_bounds__(kBlock) void bn_apply_kernel(int64_t n, int c, cons
             if (var < 0.0) var = 0.0;
             mu = (float)m;
             is = (float)(1.0 / sqrt(var + (double)eps));
-            if (blockIdx.x == 0) {
+            if (bid == 0) {
                 save_mean[ch] = mu;
                 save_invstd[ch] = is;
                 if (run_mean) {
@@ -228,7 +244,7 @@ __global__ __launch_bounds__(kBlock) void bn_apply_kernel(int64_t n, int c, cons
     if (vec4) {  // c, ldx, ldy multiples of 4 and 16-byte aligned bases (checked by the launcher): the same fma, four at a time
         const int c4 = c >> 2;
         const int64_t total4 = n * (int64_t)c4;
-        for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total4; i += (int64_t)gridDim.x * kBlock) {
+        for (int64_t i = (int64_t)bid * kBlock + threadIdx.x; i < total4; i += (int64_t)nblocks * kBlock) {
             const int64_t r = i / c4;
             const int ch = (int)(i - r * c4) * 4;
             const float4 x = *reinterpret_cast<const float4*>(X + r * ldx + ch);
@@ -242,29 +258,49 @@ __global__ __launch_bounds__(kBlock) void bn_apply_kernel(int64_t n, int c, cons
         return;
     }
     const int64_t total = n * (int64_t)c;
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
+    for (int64_t i = (int64_t)bid * kBlock + threadIdx.x; i < total; i += (int64_t)nblocks * kBlock) {
         const int64_t r = i / c;
         const int ch = (int)(i - r * c);
         Y[r * ldy + ch] = fmaf(X[r * ldx + ch], s_scale[ch], s_shift[ch]);
     }
 }
 
+template <bool TRAIN>
+__global__ __launch_bounds__(kBlock) void bn_apply_kernel(int64_t n, int c, const float* __restrict__ X, int64_t ldx,
+                                                          const double* __restrict__ part,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          float* __restrict__ run_mean, float* __restrict__ run_var,
+                                                          float momentum, float eps, float* __restrict__ save_mean,
+                                                          float* __restrict__ save_invstd, float* __restrict__ Y,
+                                                          int64_t ldy, int vec4) {
+    bn_apply_body<TRAIN>(blockIdx.x, gridDim.x, n, c, X, ldx, part, gamma, beta, run_mean, run_var, momentum, eps, save_mean,
+                         save_invstd, Y, ldy, vec4);
+}
+struct BnApply { int64_t n; const float* X; const double* part; const float *gamma, *beta; float *run_mean, *run_var;
+                 float momentum, eps; float *save_mean, *save_invstd; float* Y; };
+__global__ __launch_bounds__(kBlock) void bn_apply_pair_kernel(BnApply a, BnApply b, int c, unsigned split, int vec4) {
+    const bool first = blockIdx.x < split;
+    const BnApply& q = first ? a : b;
+    bn_apply_body<true>(first ? blockIdx.x : blockIdx.x - split, first ? split : gridDim.x - split, q.n, c, q.X, c, q.part, q.gamma,
+                        q.beta, q.run_mean, q.run_var, q.momentum, q.eps, q.save_mean, q.save_invstd, q.Y, c, vec4);
+}
+
 // dx = gamma * invstd * (dy - mean(dy) - xhat * mean(dy * xhat)); block 0 writes dgamma = sum dy*xhat, dbeta = sum dy.
-__global__ __launch_bounds__(kBlock) void bn_bwd_apply_kernel(int64_t n, int c, const float* __restrict__ X, int64_t ldx,
-                                                              const float* __restrict__ dY, int64_t ldy,
-                                                              const double* __restrict__ part,
-                                                              const float* __restrict__ gamma,
-                                                              const float* __restrict__ mean,
-                                                              const float* __restrict__ invstd, float* __restrict__ dX,
-                                                              int64_t lddx, float* __restrict__ dgamma,
-                                                              float* __restrict__ dbeta, int vec4) {
+__device__ __forceinline__ void bn_bwd_apply_body(unsigned bid, unsigned nblocks, int64_t n, int c, const float* __restrict__ X, int64_t ldx,
+                                                  const float* __restrict__ dY, int64_t ldy,
+                                                  const double* __restrict__ part,
+                                                  const float* __restrict__ gamma,
+                                                  const float* __restrict__ mean,
+                                                  const float* __restrict__ invstd, float* __restrict__ dX,
+                                                  int64_t lddx, float* __restrict__ dgamma,
+                                                  float* __restrict__ dbeta, int vec4) {
     __shared__ float s_a[kBnMaxC], s_b[kBnMaxC], s_mu[kBnMaxC], s_is[kBnMaxC], s_g[kBnMaxC];
     __shared__ double s_tmp[kBlock / 64][2][256];
     __shared__ double s_sa[kBnMaxC], s_sb[kBnMaxC];
     bn_sum_parts(part, c, s_tmp, s_sa, s_sb);
     for (int ch = threadIdx.x; ch < c; ch += kBlock) {
         const double sa = s_sa[ch], sb = s_sb[ch];
-        if (blockIdx.x == 0) {
+        if (bid == 0) {
             if (dbeta) dbeta[ch] = (float)sa;
             if (dgamma) dgamma[ch] = (float)sb;
         }
@@ -279,7 +315,7 @@ __global__ __launch_bounds__(kBlock) void bn_bwd_apply_kernel(int64_t n, int c, 
     if (vec4) {
         const int c4 = c >> 2;
         const int64_t total4 = n * (int64_t)c4;
-        for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total4; i += (int64_t)gridDim.x * kBlock) {
+        for (int64_t i = (int64_t)bid * kBlock + threadIdx.x; i < total4; i += (int64_t)nblocks * kBlock) {
             const int64_t r = i / c4;
             const int ch = (int)(i - r * c4) * 4;
             const float4 x = *reinterpret_cast<const float4*>(X + r * ldx + ch);
@@ -293,12 +329,31 @@ __global__ __launch_bounds__(kBlock) void bn_bwd_apply_kernel(int64_t n, int c, 
         return;
     }
     const int64_t total = n * (int64_t)c;
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
+    for (int64_t i = (int64_t)bid * kBlock + threadIdx.x; i < total; i += (int64_t)nblocks * kBlock) {
         const int64_t r = i / c;
         const int ch = (int)(i - r * c);
         const float xh = (X[r * ldx + ch] - s_mu[ch]) * s_is[ch];
         dX[r * lddx + ch] = s_g[ch] * (dY[r * ldy + ch] - s_a[ch] - xh * s_b[ch]);
     }
+}
+
+__global__ __launch_bounds__(kBlock) void bn_bwd_apply_kernel(int64_t n, int c, const float* __restrict__ X, int64_t ldx,
+                                                              const float* __restrict__ dY, int64_t ldy,
+                                                              const double* __restrict__ part,
+                                                              const float* __restrict__ gamma,
+                                                              const float* __restrict__ mean,
+                                                              const float* __restrict__ invstd, float* __restrict__ dX,
+                                                              int64_t lddx, float* __restrict__ dgamma,
+                                                              float* __restrict__ dbeta, int vec4) {
+    bn_bwd_apply_body(blockIdx.x, gridDim.x, n, c, X, ldx, dY, ldy, part, gamma, mean, invstd, dX, lddx, dgamma, dbeta, vec4);
+}
+struct BnBwdApply { int64_t n; const float* X; const float* dY; const double* part; const float *gamma, *mean, *invstd; float* dX;
+                    float *dgamma, *dbeta; };
+__global__ __launch_bounds__(kBlock) void bn_bwd_apply_pair_kernel(BnBwdApply a, BnBwdApply b, int c, unsigned split, int vec4) {
+    const bool first = blockIdx.x < split;
+    const BnBwdApply& q = first ? a : b;
+    bn_bwd_apply_body(first ? blockIdx.x : blockIdx.x - split, first ? split : gridDim.x - split, q.n, c, q.X, c, q.dY, c, q.part,
+                      q.gamma, q.mean, q.invstd, q.dX, c, q.dgamma, q.dbeta, vec4);
 }
 
 // out[e, 0:cu] = Zu[row[e], :], out[e, cu:cu+ci] = Zi[col[e], :]; one wavefront per label edge
@@ -324,10 +379,9 @@ __global__ __launch_bounds__(kBlock) void gather_cat_kernel(int64_t n_e, int cu,
 // (a user's ~45 label edges are consecutive, and only a few dozen wavefronts own a row on the customer side: the walk is a
 // chain of load latencies — 4 rows in flight: 27 us per launch at 24 users / batch, round 3)
 constexpr int kGcbRows = 16;
-__global__ __launch_bounds__(kBlock) void gather_cat_bwd_kernel(int64_t n_e, int c, int off, const int64_t* __restrict__ idx,
-                                                                const float* __restrict__ dOut, int64_t ldo,
-                                                                float* __restrict__ dZ, int64_t ldz) {
-    const int64_t e = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / MI_WAVE;
+__device__ __forceinline__ void gather_cat_bwd_body(int64_t e, int64_t n_e, int c, int off, const int64_t* __restrict__ idx,
+                                                    const float* __restrict__ dOut, int64_t ldo,
+                                                    float* __restrict__ dZ, int64_t ldz) {
     if (e >= n_e) return;
     const int lane = mi_lane();
     const int64_t v = idx[e];
@@ -357,6 +411,21 @@ __global__ __launch_bounds__(kBlock) void gather_cat_bwd_kernel(int64_t n_e, int
         }
         if (k < c) dZ[v * ldz + k] = acc;
     }
+}
+__global__ __launch_bounds__(kBlock) void gather_cat_bwd_kernel(int64_t n_e, int c, int off, const int64_t* __restrict__ idx,
+                                                                const float* __restrict__ dOut, int64_t ldo,
+                                                                float* __restrict__ dZ, int64_t ldz) {
+    gather_cat_bwd_body(((int64_t)blockIdx.x * kBlock + threadIdx.x) / MI_WAVE, n_e, c, off, idx, dOut, ldo, dZ, ldz);
+}
+// twin launch (mi_pairs): the first `split` workgroups sum the customer half (columns [0, c) by idx0), the rest the article half
+__global__ __launch_bounds__(kBlock) void gather_cat_bwd_pair_kernel(int64_t n_e, int c, const int64_t* __restrict__ idx0,
+                                                                     const int64_t* __restrict__ idx1, const float* __restrict__ dOut,
+                                                                     int64_t ldo, float* __restrict__ dZ0, float* __restrict__ dZ1,
+                                                                     unsigned split) {
+    const bool first = blockIdx.x < split;
+    const unsigned bid = first ? blockIdx.x : blockIdx.x - split;
+    gather_cat_bwd_body(((int64_t)bid * kBlock + threadIdx.x) / MI_WAVE, n_e, c, first ? 0 : c, first ? idx0 : idx1, dOut, ldo,
+                        first ? dZ0 : dZ1, c);
 }
 
 // BCEWithLogitsLoss(reduction="mean") and its gradient in one launch, one workgroup: loss = mean(max(x, 0) - x*y +
@@ -533,3 +602,56 @@ int mi_gather_cat_bwd_f32(int64_t n_edges, int64_t c, int64_t off, const int64_t
 }
 
 }  // extern "C"
+
+// ---- twin launchers (pairs.hpp) ---------------------------------------------------------------------------------------------
+namespace mi_pairs {
+
+static bool bn_pair_ok(const BnSide& a, const BnSide& b, int64_t c) {
+    // the single launches' fast path on both sides: power-of-two channel count, float4-addressable rows (ld = c)
+    return bn_pow2_rows(c) && a.n > 0 && b.n > 0 && a.X && b.X && a.ws && b.ws && a.save_mean && a.save_invstd && b.save_mean &&
+           b.save_invstd && mi_aligned16(a.X) && mi_aligned16(b.X) && mi_aligned16(a.save_mean) && mi_aligned16(a.save_invstd) &&
+           mi_aligned16(b.save_mean) && mi_aligned16(b.save_invstd);
+}
+static unsigned bn_grid(int64_t n, int64_t c) {
+    const unsigned g = (unsigned)std::min<int64_t>(1024, mi_ceil_div(n * c, kBlock * 4));   // mi_batchnorm_*_f32's own grid
+    return g ? g : 1u;
+}
+
+int batchnorm_fwd_pair(const BnSide& a, const BnSide& b, int64_t c, hipStream_t s) {
+    if (!bn_pair_ok(a, b, c) || !a.Y || !b.Y || !mi_aligned16(a.Y) || !mi_aligned16(b.Y)) return MI_ERR_UNSUPPORTED;
+    if ((a.running_mean == nullptr) != (a.running_var == nullptr) || (b.running_mean == nullptr) != (b.running_var == nullptr))
+        return MI_ERR_UNSUPPORTED;
+    BnPart4 pa{a.n, a.X, nullptr, nullptr, nullptr, reinterpret_cast<double*>(a.ws)};
+    BnPart4 pb{b.n, b.X, nullptr, nullptr, nullptr, reinterpret_cast<double*>(b.ws)};
+    hipLaunchKernelGGL(bn_partial4_pair_kernel<false>, dim3(2 * kBnParts), dim3(kBlock), 0, s, pa, pb, (int)c);
+    BnApply qa{a.n, a.X, pa.part, a.gamma, a.beta, a.running_mean, a.running_var, a.momentum, a.eps, a.save_mean, a.save_invstd, a.Y};
+    BnApply qb{b.n, b.X, pb.part, b.gamma, b.beta, b.running_mean, b.running_var, b.momentum, b.eps, b.save_mean, b.save_invstd, b.Y};
+    const unsigned ga = bn_grid(a.n, c), gb = bn_grid(b.n, c);
+    hipLaunchKernelGGL(bn_apply_pair_kernel, dim3(ga + gb), dim3(kBlock), 0, s, qa, qb, (int)c, ga, 1);
+    return mi_launch_status();
+}
+
+int batchnorm_bwd_pair(const BnSide& a, const BnSide& b, int64_t c, hipStream_t s) {
+    if (!bn_pair_ok(a, b, c) || !a.dY || !b.dY || !a.dX || !b.dX || !mi_aligned16(a.dY) || !mi_aligned16(b.dY) || !mi_aligned16(a.dX) ||
+        !mi_aligned16(b.dX))
+        return MI_ERR_UNSUPPORTED;
+    BnPart4 pa{a.n, a.X, a.dY, a.save_mean, a.save_invstd, reinterpret_cast<double*>(a.ws)};
+    BnPart4 pb{b.n, b.X, b.dY, b.save_mean, b.save_invstd, reinterpret_cast<double*>(b.ws)};
+    hipLaunchKernelGGL(bn_partial4_pair_kernel<true>, dim3(2 * kBnParts), dim3(kBlock), 0, s, pa, pb, (int)c);
+    BnBwdApply qa{a.n, a.X, a.dY, pa.part, a.gamma, a.save_mean, a.save_invstd, a.dX, a.dgamma, a.dbeta};
+    BnBwdApply qb{b.n, b.X, b.dY, pb.part, b.gamma, b.save_mean, b.save_invstd, b.dX, b.dgamma, b.dbeta};
+    const unsigned ga = bn_grid(a.n, c), gb = bn_grid(b.n, c);
+    hipLaunchKernelGGL(bn_bwd_apply_pair_kernel, dim3(ga + gb), dim3(kBlock), 0, s, qa, qb, (int)c, ga, 1);
+    return mi_launch_status();
+}
+
+int gather_cat_bwd_pair(int64_t n_edges, int64_t c, const int64_t* idx0, const int64_t* idx1, const float* dOut, int64_t ldo,
+                        float* dZ0, float* dZ1, hipStream_t s) {
+    if (n_edges <= 0 || n_edges > mi_gather_cat_bwd_max_edges() || c <= 0 || !idx0 || !idx1 || !dOut || !dZ0 || !dZ1 || ldo < 2 * c)
+        return MI_ERR_UNSUPPORTED;
+    const unsigned g = (unsigned)mi_ceil_div(n_edges * MI_WAVE, kBlock);
+    hipLaunchKernelGGL(gather_cat_bwd_pair_kernel, dim3(2 * g), dim3(kBlock), 0, s, n_edges, (int)c, idx0, idx1, dOut, ldo, dZ0, dZ1, g);
+    return mi_launch_status();
+}
+
+}  // namespace mi_pairs

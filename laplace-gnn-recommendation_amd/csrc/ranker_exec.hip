@@ -12,6 +12,7 @@
 // The body runs three times over the same code: COUNT (workspace size), CHECK (every operand of every product is
 // validated against the kernels' requirements — nothing has been enqueued if it returns MI_ERR_UNSUPPORTED), LAUNCH.
 #include "common.hpp"
+#include "pairs.hpp"
 #include <algorithm>
 
 extern "C" int mi_gemm_group_supported(const mi_gemm_problem* problems, int32_t n);
@@ -35,8 +36,11 @@ __global__ __launch_bounds__(kBlock) void ranker_prep_kernel(int64_t nnz, int64_
                                                              float* __restrict__ v_cus, float* __restrict__ vt_cus,
                                                              float* __restrict__ v_art, float* __restrict__ vt_art,
                                                              int64_t n_label, const int64_t* __restrict__ label,
-                                                             float* __restrict__ label_f) {
+                                                             float* __restrict__ label_f, float4* __restrict__ zero4, int64_t n_zero4) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    // round 4: the zero-fill of the gather-cat backward's outputs (rows no label edge names must read zero) rides here,
+    // long before its consumer, instead of two fillBuffer launches in the middle of the backward
+    for (int64_t z = i; z < n_zero4; z += (int64_t)gridDim.x * kBlock) zero4[z] = mi_f4_zero();
     if (label && i < n_label) label_f[i] = (float)label[i];
     if (!mean) {
         if (i < nnz) v_cus[i] = vt_cus[i] = v_art[i] = vt_art[i] = 1.f;
@@ -166,6 +170,44 @@ struct Exec {
         ok(mi_launch_status());
     }
 
+    // Twin launches (csrc/pairs.hpp, round 4): the customer-side and the article-side twin of a step as ONE launch.  Only without
+    // an auxiliary stream (the twins then run side by side anyway); MI_ERR_UNSUPPORTED from a pair launcher = the pair does not
+    // share a kernel instantiation: the two single launches are issued instead.  Same device code per element either way.
+    bool twin() const { return s2 == s; }
+    bool paired(int prc) {   // true: the pair launch took the work
+        if (prc == 0) return true;
+        if (prc != MI_ERR_UNSUPPORTED) ok(prc);
+        return prc != MI_ERR_UNSUPPORTED;
+    }
+    void dropout2(const float* xa, float* ya, int64_t na, uint32_t site_a, const float* xb, float* yb, int64_t nb, uint32_t site_b) {
+        if (mode == CHECK && (na % 4 != 0 || nb % 4 != 0)) fail(MI_ERR_UNSUPPORTED);
+        if (!go()) return;
+        if (!twin() || na == 0 || nb == 0) {
+            on(0); dropout(xa, ya, na, site_a);
+            on(1); dropout(xb, yb, nb, site_b);
+            return;
+        }
+        const float p = M.p_dropout;
+        const DropSeg a{na / 4, reinterpret_cast<const float4*>(xa), reinterpret_cast<float4*>(ya), site_a};
+        const DropSeg b{nb / 4, reinterpret_cast<const float4*>(xb), reinterpret_cast<float4*>(yb), site_b};
+        const unsigned ga = (unsigned)mi_ceil_div(a.n4, kBlock), gb = (unsigned)mi_ceil_div(b.n4, kBlock);
+        hipLaunchKernelGGL(dropout_pair_kernel, dim3(ga + gb), dim3(kBlock), 0, s, a, b, ga, p, 1.0f / (1.0f - p), (uint32_t)B.seed,
+                           (uint32_t)(B.seed >> 32), (uint32_t)B.step);
+        ok(mi_launch_status());
+    }
+    // two plan-less products (rows = destinations of relation r); in place: S = addend + acc
+    void spmm2(const mi_pairs::SpmmSide (&q)[2], const int (&stream_of)[2]) {
+        for (int r = 0; r < 2; ++r)
+            if (mode == CHECK && (q[r].d % 4 != 0 || q[r].d > 512)) fail(MI_ERR_UNSUPPORTED);
+        if (!go()) return;
+        if (twin() && paired(mi_pairs::spmm_planless_pair(q[0], q[1], s))) return;
+        for (int r = 0; r < 2; ++r) {
+            on(stream_of[r]);
+            ok(mi_spmm_csr_ex_f32(q[r].n_rows, q[r].d, q[r].rowptr, q[r].col, q[r].val, q[r].X, q[r].d, q[r].Y, q[r].d, q[r].addend, q[r].d,
+                                  q[r].S, q[r].d, 1.0f, nullptr, nullptr, nullptr, 0, (mi_stream_t)cur));
+        }
+    }
+
     static mi_gemm_problem prob(int ta, int tb, int64_t m, int64_t n, int64_t k, const float* A, int64_t lda, const float* Bm,
                                 int64_t ldb, float* C, int64_t ldc, const float* mask = nullptr, const float* bias = nullptr,
                                 int act = 0) {
@@ -238,14 +280,26 @@ int Exec::run() {
     // gather_cat — three launches fewer, ~15 us — made the producers compute a Philox block per ELEMENT instead of one per
     // four: embed_concat 5.7 + 11 -> 19 + 33 us, gather_cat 4.8 -> 16 us, iteration 0.545 -> 0.62 ms.)
     fork();
-    for (int t = 0; t < kTypes; ++t) {
-        x0[t] = take(n[t], width[t]);
-        on(t);
-        if (go())
-            ok(mi_embed_concat_f32(n[t], M.n_cols[t], B.x[t], M.tables[t], M.table_rows[t], M.dims[t], M.max_norm, x0[t], width[t],
-                                   (mi_stream_t)cur));
+    for (int t = 0; t < kTypes; ++t) x0[t] = take(n[t], width[t]);
+    {
+        bool done = false;
+        if (go() && twin()) {
+            const mi_pairs::EmbedSide ea{n[0], M.n_cols[0], B.x[0], M.tables[0], M.table_rows[0], M.dims[0], x0[0], width[0]};
+            const mi_pairs::EmbedSide eb{n[1], M.n_cols[1], B.x[1], M.tables[1], M.table_rows[1], M.dims[1], x0[1], width[1]};
+            done = paired(mi_pairs::embed_concat_pair(ea, eb, M.max_norm, s));
+        }
+        for (int t = 0; t < kTypes && !done; ++t) {
+            on(t);
+            if (go())
+                ok(mi_embed_concat_f32(n[t], M.n_cols[t], B.x[t], M.tables[t], M.table_rows[t], M.dims[t], M.max_norm, x0[t], width[t],
+                                       (mi_stream_t)cur));
+        }
     }
     on(1);
+    // the gather-cat backward's outputs: allocated here so that the prep launch below can zero-fill them (rows no label edge
+    // names must read zero); C = the encoder's output width (both relations': checked below)
+    const int64_t C0 = M.conv[L - 1][0].c_out;
+    float* dz_early[2] = {take(n[0], C0), take(n[1], C0)};
     // ---- aggregation weights + labels
     float* v_cus = take(nnz, 1);
     float* vt_cus = take(nnz, 1);
@@ -256,7 +310,8 @@ int Exec::run() {
         const int64_t span = std::max(std::max(nnz, nl), std::max(n[0], n[1]));
         hipLaunchKernelGGL(ranker_prep_kernel, dim3((unsigned)mi_ceil_div(span, kBlock)), dim3(kBlock), 0, s, nnz, n[0], n[1],
                            M.aggr == 1 ? 1 : 0, B.by_customer_ptr, B.by_customer_col, B.by_article_ptr, B.by_article_col, v_cus,
-                           vt_cus, v_art, vt_art, nl, B.label_f32 ? nullptr : B.label, label_f);
+                           vt_cus, v_art, vt_art, nl, B.label_f32 ? nullptr : B.label, label_f, reinterpret_cast<float4*>(dz_early[0]),
+                           (int64_t)((dz_early[1] + n[1] * C0) - dz_early[0]) / 4);
         ok(mi_launch_status());
     }
     const float* fval[2] = {v_art, v_cus};     // forward values of relation r (CSR by destination)
@@ -274,16 +329,15 @@ int Exec::run() {
         if (l > 0) fork();
         for (int t = 0; t < kTypes; ++t) {
             xin[l][t] = xcur[t];
-            if (!last && drop) {
-                xin[l][t] = take(n[t], cw[t]);
-                on(t);
-                dropout(xcur[t], xin[l][t], n[t] * cw[t], (uint32_t)(l * 2 + t));
-            }
+            if (!last && drop) xin[l][t] = take(n[t], cw[t]);
         }
+        if (!last && drop)
+            dropout2(xcur[0], xin[l][0], n[0] * cw[0], (uint32_t)(l * 2 + 0), xcur[1], xin[l][1], n[1] * cw[1], (uint32_t)(l * 2 + 1));
         on(1);
         join();    // each aggregation reads the OTHER type's input
         fork();
         mi_gemm_problem pr[2];
+        mi_pairs::SpmmSide fq[2];
         for (int r = 0; r < 2; ++r) {
             const mi_ranker_conv& cv = M.conv[l][r];
             const int st = src_of[r], dt = dst_of[r];
@@ -292,12 +346,12 @@ int Exec::run() {
                 return MI_ERR_UNSUPPORTED;
             agg[l][r] = take(n[dt], cv.c_src);
             out[l][r] = take(n[dt], cv.c_out);
-            on(dt);   // relation 1 (destination: customers) is the small one
-            spmm(n[dt], cv.c_src, fptr[r], fcol[r], fval[r], xin[l][st], agg[l][r], nullptr, nullptr);
+            fq[r] = mi_pairs::SpmmSide{n[dt], cv.c_src, fptr[r], fcol[r], fval[r], xin[l][st], agg[l][r], nullptr, nullptr};
             pr[r] = prob(0, 1, n[dt], cv.c_out, cv.c_src, agg[l][r], cv.c_src, cv.w_l, cv.c_src, out[l][r], cv.c_out, nullptr,
                          cv.b_l, last ? 0 : 1);
             pr[r].k2 = cv.c_dst; pr[r].A2 = xin[l][dt]; pr[r].lda2 = cv.c_dst; pr[r].B2 = cv.w_r; pr[r].ldb2 = cv.c_dst;
         }
+        spmm2(fq, dst_of);   // relation 1 (destination: customers) is the small one
         on(1);
         join();
         products(pr, 2);
@@ -306,7 +360,7 @@ int Exec::run() {
             cw[dst_of[r]] = M.conv[l][r].c_out;
         }
     }
-    if (mode == CHECK && cw[0] != cw[1]) return MI_ERR_UNSUPPORTED;
+    if (mode == CHECK && (cw[0] != cw[1] || cw[0] != C0)) return MI_ERR_UNSUPPORTED;
     const int64_t C = cw[0];
     // ---- BatchNorm (K8) -------------------------------------------------------------------------------------------
     float* z[2] = {xcur[0], xcur[1]};
@@ -324,6 +378,20 @@ int Exec::run() {
             z[t] = take(n[t], C);
             bn_mean[t] = take(C, 1);
             bn_inv[t] = take(C, 1);
+        }
+        bool done = false;
+        if (go() && twin()) {
+            mi_pairs::BnSide q[2];
+            for (int t = 0; t < kTypes; ++t) {
+                const mi_ranker_norm& bn = M.norm[t];
+                q[t] = mi_pairs::BnSide{n[t], zpre[t], bn.gamma, bn.beta, bn.running_mean, bn.running_var, bn.momentum, bn.eps,
+                                        bn_mean[t], bn_inv[t], z[t], nullptr, nullptr, nullptr, nullptr, bn_ws[t]};
+            }
+            done = paired(mi_pairs::batchnorm_fwd_pair(q[0], q[1], C, s));
+        }
+        for (int t = 0; t < kTypes && !done; ++t) {
+            const mi_ranker_norm& bn = M.norm[t];
+            on(t);
             if (go())
                 ok(mi_batchnorm_fwd_f32(n[t], C, zpre[t], C, bn.gamma, bn.beta, bn.running_mean, bn.running_var, bn.momentum, bn.eps,
                                         1, bn_mean[t], bn_inv[t], z[t], C, bn_ws[t], bn_ws_bytes, (mi_stream_t)cur));
@@ -399,33 +467,45 @@ int Exec::run() {
         if (!last && drop) dropout(dx, dx, nl * ln.in, (uint32_t)(64 + j));   // the forward's mask, regenerated
     }
     // ---- gather-cat backward
-    float* dz[2];
+    float* dz[2] = {dz_early[0], dz_early[1]};   // zero-filled by the prep launch
     fork();
-    for (int t = 0; t < kTypes; ++t) {
-        dz[t] = take(n[t], C);
-        on(t);
-        if (go()) {
-            ok((int)hipMemsetAsync(dz[t], 0, (size_t)n[t] * C * sizeof(float), cur));
-            ok(mi_gather_cat_bwd_f32(nl, C, t == 0 ? 0 : C, t == 0 ? B.label_row : B.label_col, dh, 2 * C, dz[t], C, (mi_stream_t)cur));
+    {
+        const bool done = go() && twin() && paired(mi_pairs::gather_cat_bwd_pair(nl, C, B.label_row, B.label_col, dh, 2 * C, dz[0], dz[1], s));
+        for (int t = 0; t < kTypes && !done; ++t) {
+            on(t);
+            if (go())
+                ok(mi_gather_cat_bwd_f32(nl, C, t == 0 ? 0 : C, t == 0 ? B.label_row : B.label_col, dh, 2 * C, dz[t], C, (mi_stream_t)cur));
         }
     }
     on(1);
     // ---- BatchNorm backward
     if (M.batch_normalize) {   // still inside the fork: each type's chain is gather-cat backward -> BatchNorm backward
+        float* dxb[2] = {take(n[0], C), take(n[1], C)};
+        bool done = false;
+        if (go() && twin()) {
+            mi_pairs::BnSide q[2];
+            for (int t = 0; t < kTypes; ++t) {
+                const mi_ranker_norm& bn = M.norm[t];
+                q[t] = mi_pairs::BnSide{n[t], zpre[t], bn.gamma, nullptr, nullptr, nullptr, 0.f, 0.f, bn_mean[t], bn_inv[t], nullptr,
+                                        dz[t], dxb[t], bn.gamma ? bn.g_gamma : nullptr, bn.gamma ? bn.g_beta : nullptr, bn_ws[t]};
+            }
+            done = paired(mi_pairs::batchnorm_bwd_pair(q[0], q[1], C, s));
+        }
         for (int t = 0; t < kTypes; ++t) {
             const mi_ranker_norm& bn = M.norm[t];
-            float* dx = take(n[t], C);
             on(t);
-            if (go())
-                ok(mi_batchnorm_bwd_f32(n[t], C, zpre[t], C, dz[t], C, bn.gamma, bn_mean[t], bn_inv[t], dx, C, bn.gamma ? bn.g_gamma : nullptr,
+            if (go() && !done)
+                ok(mi_batchnorm_bwd_f32(n[t], C, zpre[t], C, dz[t], C, bn.gamma, bn_mean[t], bn_inv[t], dxb[t], C, bn.gamma ? bn.g_gamma : nullptr,
                                         bn.gamma ? bn.g_beta : nullptr, bn_ws[t], bn_ws_bytes, (mi_stream_t)cur));
-            dz[t] = dx;
+            dz[t] = dxb[t];
         }
         on(1);
     }
     join();
     // ---- encoder backward -----------------------------------------------------------------------------------------
     float* dxs[2] = {dz[0], dz[1]};
+    mi_wgrad_problem wq_all[4];
+    int n_wq = 0;
     for (int l = L - 1; l >= 0; --l) {
         const bool last = l == L - 1, need_x = l > 0;   // layer 0 reads frozen embeddings
         const float* dy[2];
@@ -450,12 +530,13 @@ int Exec::run() {
             }
             products(pr, np);
             fork();
+            mi_pairs::SpmmSide bq[2];
             for (int r = 0; r < 2; ++r) {   // dX_src += A^T dAgg, in the epilogue
                 const mi_ranker_conv& cv = M.conv[l][r];
                 const int st = src_of[r];
-                on(st);
-                spmm(n[st], cv.c_src, bptr[r], bcol[r], bval[r], dagg[r], nullptr, dxn[st], dxn[st]);
+                bq[r] = mi_pairs::SpmmSide{n[st], cv.c_src, bptr[r], bcol[r], bval[r], dagg[r], nullptr, dxn[st], dxn[st]};
             }
+            spmm2(bq, src_of);
             on(1);
         }
         // the weight gradients need nothing of the aggregations above: they run beside them.  Round 3: both relations'
@@ -472,9 +553,14 @@ int Exec::run() {
             wq[r].gw1 = cv.gw_l; wq[r].gb = cv.b_l ? cv.gb_l : nullptr; wq[r].gw2 = cv.gw_r;
         }
         if (mi_sage_wgrad_supported(wq, 2)) {   // depends on the dimensions and on pointers being non-null only: same answer in every pass
-            const size_t need = mi_sage_wgrad_workspace_bytes(wq, 2);
-            char* w = take_bytes(need);
-            if (go()) ok(mi_sage_wgrad_f32(wq, 2, w, need, (mi_stream_t)s));
+            if (L <= 2) {   // round 4: nothing but Adam reads the weight gradients — both layers' products go out as ONE launch at the end
+                wq_all[n_wq++] = wq[0];
+                wq_all[n_wq++] = wq[1];
+            } else {
+                const size_t need = mi_sage_wgrad_workspace_bytes(wq, 2);
+                char* w = take_bytes(need);
+                if (go()) ok(mi_sage_wgrad_f32(wq, 2, w, need, (mi_stream_t)s));
+            }
             if (need_x) {
                 for (int t = 0; t < kTypes; ++t) {
                     dxs[t] = dxn[t];
@@ -510,6 +596,11 @@ int Exec::run() {
             on(1);
             join();
         }
+    }
+    if (n_wq > 0) {
+        const size_t need = mi_sage_wgrad_workspace_bytes(wq_all, n_wq);
+        char* w = take_bytes(need);
+        if (go()) ok(mi_sage_wgrad_f32(wq_all, n_wq, w, need, (mi_stream_t)s));
     }
     if (oom) return MI_ERR_WORKSPACE;
     if (rc) return rc;

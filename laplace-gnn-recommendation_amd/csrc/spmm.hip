@@ -25,6 +25,7 @@
 // of each going to HBM.  Measured on C2 (tools/ab_band.py, round 1): 1.20 -> 1.04 ms per launch with
 // one wavefront per item; see DESIGN.md for the final figures.
 #include "common.hpp"
+#include "pairs.hpp"
 #include <algorithm>
 #include <rocprim/rocprim.hpp>
 
@@ -101,7 +102,7 @@ struct Ex {
     const int32_t* n_list_dev;  // device count of valid row_list entries (<= the launch bound), or null
     const int32_t* long_index;  // [n_rows]: index into the plan's long rows, -1 for short rows (row_list mode)
     int32_t parts;              // mask of MI_SPMM_SHORT_ROWS / MI_SPMM_SPLIT_ROWS (host side only)
-    int32_t hot_base, hot_rows, hot_threads;  // LDS hot-row cache of the short-row half (host side only); hot_rows 0 = off
+    int32_t hot_base, hot_rows, hot_threads;  // persistent short-row launch (host side only): hot_rows 0 = plain launch, > 0 = LDS cache rows, < 0 = no cache
 };
 
 // Largest n over the sub-groups of the wavefront (loop bounds must be wave-uniform around __shfl).
@@ -210,12 +211,12 @@ __device__ __forceinline__ void load_addend(const Epilogue& ep, int64_t ar, int 
                               // row was still a 60 us serial walk inside a 31 us average launch, profiles/r2_ranker_v4.md)
 #endif
 template <int LPR, int VPL, int UNROLL, int RPS, bool SPARSE, bool ADAM>
-__global__ __launch_bounds__(kBlock) void spmm_rows_kernel(int64_t n_out, int d4,
-                                                           const int32_t* __restrict__ rowptr,
-                                                           const int32_t* __restrict__ col,
-                                                           const float* __restrict__ val,
-                                                           const float4* __restrict__ X4, int64_t ldx4,
-                                                           Epilogue ep, int32_t chunk, Ex ex, int32_t coop) {
+__device__ __forceinline__ void spmm_rows_body(const int64_t block_id, const int64_t n_blocks, int64_t n_out, int d4,
+                                               const int32_t* __restrict__ rowptr,
+                                               const int32_t* __restrict__ col,
+                                               const float* __restrict__ val,
+                                               const float4* __restrict__ X4, int64_t ldx4,
+                                               const Epilogue& ep, int32_t chunk, const Ex& ex, int32_t coop) {
     constexpr int NB = MI_WAVE / LPR, SG = NB * kWavesPerBlock;
     // coop (plan-less dense launches only: the per-batch subgraphs of the ranker, which cannot afford a plan's host
     // read-backs): a hub row of such a graph — an article bought by thousands of the batch's users — used to be one
@@ -240,10 +241,10 @@ __global__ __launch_bounds__(kBlock) void spmm_rows_kernel(int64_t n_out, int d4
     // instead of block w: under the locality order neighbouring rows share their cold gathers, which then meet in one L2.
     // A/B on C2, round 2 (tools/exp_locality.py --reorder cold): traffic 4.27 -> 4.16 GB but 808 -> 1 491 us — the eighths
     // are unequal work (the item rows and the high-degree users sit at the end of the order).  Off.
-    int64_t blk = blockIdx.x;
+    int64_t blk = block_id;
     if (MI_SPMM_XCD_RANGES && !listed) {
-        const int64_t per = gridDim.x / 8;  // the launcher rounds the grid up to a multiple of 8
-        blk = (int64_t)(blockIdx.x & 7) * per + (blockIdx.x >> 3);
+        const int64_t per = n_blocks / 8;  // the launcher rounds the grid up to a multiple of 8
+        blk = (int64_t)(block_id & 7) * per + (block_id >> 3);
     }
     const int64_t base = blk * (SG * RPS);
     if (kCoop && coop) {
@@ -309,6 +310,43 @@ __global__ __launch_bounds__(kBlock) void spmm_rows_kernel(int64_t n_out, int d4
             __syncthreads();
         }
     }
+}
+template <int LPR, int VPL, int UNROLL, int RPS, bool SPARSE, bool ADAM>
+__global__ __launch_bounds__(kBlock) void spmm_rows_kernel(int64_t n_out, int d4,
+                                                           const int32_t* __restrict__ rowptr,
+                                                           const int32_t* __restrict__ col,
+                                                           const float* __restrict__ val,
+                                                           const float4* __restrict__ X4, int64_t ldx4,
+                                                           Epilogue ep, int32_t chunk, Ex ex, int32_t coop) {
+    spmm_rows_body<LPR, VPL, UNROLL, RPS, SPARSE, ADAM>(blockIdx.x, gridDim.x, n_out, d4, rowptr, col, val, X4, ldx4, ep, chunk, ex, coop);
+}
+// Twin launch (pairs.hpp): two plan-less dense products in one grid — the first `split` workgroups take product a, the rest
+// product b.  The same body as the single launch (same instantiation), so each product's rows are bitwise the single launch's.
+struct RowsSide {
+    int64_t n_out; int d4;
+    const int32_t* rowptr; const int32_t* col; const float* val;
+    const float4* X4; int64_t ldx4;
+    Epilogue ep;
+};
+template <int LPR, int UNROLL>
+__global__ __launch_bounds__(kBlock) void spmm_rows_pair_kernel(RowsSide a, RowsSide b, unsigned split) {
+    // every field picked on its own (scalar selects of kernel arguments): a reference chosen between the two structs makes
+    // the compiler copy both into scratch (376 bytes per lane, 94 us instead of 22 for the pair — measured, round 4)
+    const bool first = blockIdx.x < split;
+#define MI_PICK(f) (first ? a.f : b.f)
+    Epilogue ep;
+    ep.Y = MI_PICK(ep.Y);           ep.ldy4 = MI_PICK(ep.ldy4);
+    ep.addend = MI_PICK(ep.addend); ep.lda4 = MI_PICK(ep.lda4);
+    ep.S = MI_PICK(ep.S);           ep.lds4 = MI_PICK(ep.lds4);
+    ep.scale = MI_PICK(ep.scale);
+    ep.streaming = MI_PICK(ep.streaming);
+    ep.p = nullptr; ep.ldp4 = 0; ep.m = nullptr; ep.v = nullptr; ep.reg_w = nullptr;
+    ep.adam = MiAdamConsts{};
+    const Ex ex = {nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0};
+    spmm_rows_body<LPR, 1, UNROLL, MI_SPMM_ROWS_RPS, false, false>(first ? blockIdx.x : blockIdx.x - split, first ? split : gridDim.x - split,
+                                                                  MI_PICK(n_out), MI_PICK(d4), MI_PICK(rowptr), MI_PICK(col), MI_PICK(val),
+                                                                  MI_PICK(X4), MI_PICK(ldx4), ep, INT32_MAX, ex, 1);
+#undef MI_PICK
 }
 
 
@@ -1039,7 +1077,7 @@ int launch_spmm_mode(int64_t n_rows, int d4, const int32_t* rowptr, const int32_
     const int64_t n_out = listed ? n_list : n_rows;
     bool short_done = false;
     if constexpr (!SPARSE && VPL == 1) {
-        if (do_short && n_out > 0 && plan && ex.hot_rows >= 0) {
+        if (do_short && n_out > 0 && plan && ex.hot_rows != 0) {
             // persistent pipelined launch, optionally with the hot rows of X in LDS; falls through to the plain launch
             // when the device query fails
             auto kern = spmm_rows_hot_kernel<LPR, UNROLL, ADAM>;
@@ -1067,7 +1105,7 @@ int launch_spmm_mode(int64_t n_rows, int d4, const int32_t* rowptr, const int32_
                 // hot rows — a small cache loses little (Zipf: 64 rows serve 46 % of the gathers, 304 rows 59 %)
                 int wg_per_cu = std::max(1, (waves_arg > 0 ? waves_arg : MI_SPMM_HOT_WAVES) / (threads / MI_WAVE));
                 const size_t share = (hl.lds_cap / (size_t)wg_per_cu) - 512;
-                const int hot_n = (int)std::min<size_t>((size_t)ex.hot_rows, share / row_bytes);
+                const int hot_n = (int)std::min<size_t>((size_t)std::max(ex.hot_rows, 0), share / row_bytes);
                 const size_t lds = (size_t)hot_n * row_bytes;
                 const int key = threads * 4 + (hot_n > 0 ? 1 : 0);  // occupancy depends on the registers, and on the LDS only via wg_per_cu
                 if (hl.occ_key != key) {
@@ -1287,7 +1325,7 @@ int mi_spmm_csr_ex_f32(int64_t n_rows, int64_t d, const int32_t* rowptr, const i
         if (!ex.x_map && !ex.row_list && d <= 256) {  // hints: ignored where the persistent launch does not apply
             MI_CHECK_ARG(exh->hot_base >= 0 && exh->hot_threads >= 0);
             ex.hot_base = exh->hot_base;
-            ex.hot_rows = exh->hot_rows;   // the caller's contract: hot_base + hot_rows <= rows of X
+            ex.hot_rows = exh->hot_rows;   // the caller's contract: hot_base + max(hot_rows, 0) <= rows of X
             ex.hot_threads = exh->hot_threads;
         }
         if (ex.row_list) {
@@ -1358,3 +1396,50 @@ int mi_spmm_csr_f32(int64_t n_rows, int64_t d, const int32_t* rowptr, const int3
 }
 
 }  // extern "C"
+
+// ---- twin launcher (pairs.hpp) ----------------------------------------------------------------------------------------------
+namespace mi_pairs {
+
+static int lpr_class(int d4) { return d4 <= 8 ? 8 : d4 <= 16 ? 16 : d4 <= 32 ? 32 : d4 <= 64 ? 64 : 0; }
+
+static bool rows_side(const SpmmSide& q, RowsSide& r) {
+    if (q.n_rows <= 0 || q.d <= 0 || q.d % 4 != 0 || q.n_rows >= INT32_MAX || !q.rowptr || !q.X || (!q.Y && !q.S)) return false;
+    if (!mi_aligned16(q.X) || (q.Y && (!mi_aligned16(q.Y) || q.Y == q.X)) || (q.S && (!mi_aligned16(q.S) || q.S == q.X)) ||
+        (q.addend && !mi_aligned16(q.addend)))
+        return false;
+    r.n_out = q.n_rows; r.d4 = (int)(q.d / 4);
+    r.rowptr = q.rowptr; r.col = q.col ? q.col : q.rowptr; r.val = q.val ? q.val : reinterpret_cast<const float*>(q.rowptr);
+    r.X4 = reinterpret_cast<const float4*>(q.X); r.ldx4 = q.d / 4;
+    Epilogue& ep = r.ep;
+    ep.Y = reinterpret_cast<float4*>(q.Y);                 ep.ldy4 = q.d / 4;
+    ep.addend = reinterpret_cast<const float4*>(q.addend); ep.lda4 = q.d / 4;
+    ep.S = reinterpret_cast<float4*>(q.S);                 ep.lds4 = q.d / 4;
+    ep.scale = 1.0f;
+    ep.streaming = (size_t)q.n_rows * (size_t)q.d * sizeof(float) >= ((size_t)64 << 20);   // mi_spmm_csr_ex_f32's own rule
+    ep.p = nullptr; ep.ldp4 = 0; ep.m = nullptr; ep.v = nullptr; ep.reg_w = nullptr;
+    ep.adam = MiAdamConsts{};
+    return true;
+}
+
+template <int LPR>
+static int launch_rows_pair(const RowsSide& a, const RowsSide& b, hipStream_t s) {
+    constexpr int SG = (MI_WAVE / LPR) * kWavesPerBlock;
+    const unsigned ga = (unsigned)mi_ceil_div(a.n_out, SG * MI_SPMM_ROWS_RPS), gb = (unsigned)mi_ceil_div(b.n_out, SG * MI_SPMM_ROWS_RPS);
+    hipLaunchKernelGGL((spmm_rows_pair_kernel<LPR, MI_SPMM_UNROLL>), dim3(ga + gb), dim3(kBlock), 0, s, a, b, ga);
+    return mi_launch_status();
+}
+
+int spmm_planless_pair(const SpmmSide& a, const SpmmSide& b, hipStream_t s) {
+    RowsSide ra, rb;
+    if (MI_SPMM_XCD_RANGES || !rows_side(a, ra) || !rows_side(b, rb)) return MI_ERR_UNSUPPORTED;
+    const int ca = lpr_class(ra.d4), cb = lpr_class(rb.d4);
+    if (ca == 0 || ca != cb) return MI_ERR_UNSUPPORTED;   // different instantiations (or the two-register rows of d > 256)
+    switch (ca) {
+        case 8: return launch_rows_pair<8>(ra, rb, s);
+        case 16: return launch_rows_pair<16>(ra, rb, s);
+        case 32: return launch_rows_pair<32>(ra, rb, s);
+        default: return launch_rows_pair<64>(ra, rb, s);
+    }
+}
+
+}  // namespace mi_pairs

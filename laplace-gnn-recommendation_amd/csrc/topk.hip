@@ -410,6 +410,41 @@ __device__ __forceinline__ void finish_candidates(int cnt, int k, int kk, int kp
         }
         __syncthreads();   // massive ties at the bound: the sort below
     }
+    if (kRankFinish && kk > 64 && cnt <= 2 * kBlock) {
+        // Large k with a SHORT list (round 4: the prefilter path's survivors at k = 256 are kk + a few, ~270-350): no radix
+        // select and no sort at all — every candidate counts the candidates that beat it (composites are unique: the item id
+        // is part of them) and those of rank < kk write themselves to their place.  Two candidates per thread, the list read
+        // as pairs from LDS: cnt^2 / 256 ~ 500 64-bit compares per thread against the 12 barrier stages of the 4-pass radix
+        // select plus the 36 of the 256-entry bitonic sort.
+        const int tid = threadIdx.x;
+        if (tid == 0 && (cnt & 1)) sh.cand[cnt] = 0ull;                   // the pair reads see a pad that beats nobody
+        __syncthreads();
+        const int i0 = tid, i1 = tid + kBlock;
+        const unsigned long long m0 = i0 < cnt ? sh.cand[i0] : ~0ull, m1 = i1 < cnt ? sh.cand[i1] : ~0ull;
+        int r0 = 0, r1 = 0;
+        const ulonglong2* c2 = reinterpret_cast<const ulonglong2*>(sh.cand);
+#pragma unroll 4
+        for (int j = 0; j < (cnt + 1) / 2; ++j) {
+            const ulonglong2 o = c2[j];
+            r0 += (o.x > m0 ? 1 : 0) + (o.y > m0 ? 1 : 0);
+            r1 += (o.x > m1 ? 1 : 0) + (o.y > m1 ? 1 : 0);
+        }
+#define MI_RANK_WRITE(me, rank, idx)                                                        \
+        if ((idx) < cnt && (rank) < kk) {                                                   \
+            const float sc = key_score((uint32_t)((me) >> 32));                             \
+            const bool live = sc != -INFINITY;                                              \
+            out_idx[q * k + (rank)] = live ? (int64_t)(0xFFFFFFFFu - (uint32_t)(me)) : -1;  \
+            if (out_score) out_score[q * k + (rank)] = live ? sc : -INFINITY;               \
+        }
+        MI_RANK_WRITE(m0, r0, i0)
+        MI_RANK_WRITE(m1, r1, i1)
+#undef MI_RANK_WRITE
+        for (int j = kk + tid; j < k; j += kBlock) {                      // k > n_items: the tail of the row
+            out_idx[q * k + j] = -1;
+            if (out_score) out_score[q * k + j] = -INFINITY;
+        }
+        return;
+    }
     if (kRankFinish && kk > 64 && cnt > kpow2 && cnt <= kCand / 2) {
         // Large k (the matcher dump's k = 256 with ~750 candidates): instead of sorting the list padded to 1 024 (55 barrier
         // stages over 512 pairs), find the kk-th largest score key by a 4-pass radix select over the candidates in LDS, keep
@@ -1227,6 +1262,27 @@ static int64_t topk_pre_slices_per_xcd(int64_t strips, int64_t panels, int n_cu)
     return sl;
 }
 
+// The prefilter kernel needs 96 KB (D = 128) of dynamic LDS: an opt-in attribute of the kernel, PER DEVICE.  Queried and set
+// before anything of a call is enqueued (a failure used to surface after the memset and split kernels were in
+// the stream, and one process-wide flag covered every device); on failure the caller takes the f32 fused path.
+template <int D, bool STORE>
+static bool topk_pre_attr_ok() {
+    constexpr int UB = STORE ? 2 : MI_PRE_UB;
+    constexpr int lds = 3 * 64 * (D / 4) * 16;
+    static unsigned char state[64] = {};   // per device: 0 = not tried, 1 = set, 2 = refused (idempotent: a race sets it twice)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+    if (state[dev] == 0) {
+        auto kern = topk_prefilter_bf16_kernel<D, STORE, UB>;
+        state[dev] = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess ? 1 : 2;
+    }
+    return state[dev] == 1;
+}
+static bool topk_prefilter_usable(int64_t d) {
+    return d == 128 ? (topk_pre_attr_ok<128, true>() && topk_pre_attr_ok<128, false>())
+                    : (d == 64 && topk_pre_attr_ok<64, true>() && topk_pre_attr_ok<64, false>());
+}
+
 template <int D, bool STORE>
 static int topk_pre_kernel_launch(PreArgs& pa, int64_t strips, int64_t panels, int n_cu, hipStream_t s) {
     const int64_t sl = topk_pre_slices_per_xcd(strips, panels, n_cu);
@@ -1237,12 +1293,7 @@ static int topk_pre_kernel_launch(PreArgs& pa, int64_t strips, int64_t panels, i
     constexpr int UB = STORE ? 2 : MI_PRE_UB;   // (the STORE form spills at two wavefronts per SIMD)
     auto kern = topk_prefilter_bf16_kernel<D, STORE, UB>;
     constexpr int lds = 3 * 64 * (D / 4) * 16;
-    static bool attr_set = false;  // per instantiation; idempotent
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-            return MI_ERR_UNSUPPORTED;
-        attr_set = true;
-    }
+    if (!topk_pre_attr_ok<D, STORE>()) return MI_ERR_UNSUPPORTED;   // callers have asked topk_prefilter_usable() before enqueuing anything
     hipLaunchKernelGGL(kern, dim3((unsigned)(8 * sl * strips)), dim3(512 / UB), lds, s, pa);
     return 0;
 }
@@ -1373,7 +1424,7 @@ int mi_topk_excl_f32(int64_t n_q, int64_t n_items, int64_t d, int64_t k, const i
         FusedArgs a;
         a.n_q = n_q; a.n_items = n_items; a.d = (int)d; a.uid = uid;
         a.U = user_emb; a.ldu = ldu; a.I = item_emb; a.ldi = ldi;
-        if (topk_prefilter_on() && (d == 128 || d == 64) && k <= kPreMaxK) {
+        if (topk_prefilter_on() && (d == 128 || d == 64) && k <= kPreMaxK && topk_prefilter_usable(d)) {
             // bf16x3 prefilter (topk_prefilter.hpp): sample scores, thresholds, lists and the exact finish all in there
             MI_HIP(hipMemsetAsync(bitmap, 0, (size_t)n_q * words * sizeof(uint32_t), s));
             a.thr = thr; a.bitmap = bitmap; a.words = words; a.cand = cand; a.cnt = cnt;

@@ -91,7 +91,12 @@ class UsersWithCommonItemsMatcher(Matcher):
 
     def matches_for_all_device(self, num_users: int, device) -> Tensor:
         from .. import ops
-        if getattr(self, "_dev", None) is None or self._dev[0].device != t.device(device):
+        dev = t.device(device)
+        if dev.type == "cuda" and dev.index is None:       # "cuda" and "cuda:0" are the same place: compare normalised devices
+            dev = t.device("cuda", t.cuda.current_device())
+        if num_users > self.location_for_user.size:
+            raise IndexError(f"{num_users} query users but location_for_user has {self.location_for_user.size} entries")
+        if getattr(self, "_dev", None) is None or self._dev[0].device != dev:
             to32 = lambda a: t.from_numpy(np.ascontiguousarray(a.astype(np.int32))).to(device)
             self._dev = (to32(self.users.ptr), to32(self.users.idx), to32(self.articles.ptr), to32(self.articles.idx))
         out, _ = ops.match_common_items(*self._dev, self.k, n_queries=num_users)
@@ -127,6 +132,12 @@ class UsersSameLocationMatcher(Matcher):
         n_loc = max([int(loc.max()) + 1 if loc.size else 0] + [int(l) + 1 for l in customers_per_location])
         self.customers = AdjList({int(l): list(v) for l, v in customers_per_location.items()}, n_loc)
         self.k = int(k)
+        # the device kernel indexes the customers' purchase lists and the location table with these ids unchecked: validate once
+        idx = np.asarray(self.customers.idx)
+        if idx.size and (int(idx.min()) < 0 or int(idx.max()) >= n_users):
+            raise IndexError(f"customers_per_location names customer {int(idx.max())} but there are {n_users} customers")
+        if loc.size and int(loc.max()) >= n_loc:
+            raise IndexError("location_for_user names a location beyond customers_per_location")
 
     def get_matches(self, user_id: int) -> Tensor:
         loc = int(self.location_for_user[user_id])
@@ -143,8 +154,13 @@ class UsersSameLocationMatcher(Matcher):
 
     def matches_for_all_device(self, num_users: int, device) -> Tensor:
         from .. import ops
-        if getattr(self, "_dev", None) is None or self._dev[0].device != t.device(device):
-            to32 = lambda a: t.from_numpy(np.ascontiguousarray(np.asarray(a).astype(np.int32))).to(device)
+        dev = t.device(device)
+        if dev.type == "cuda" and dev.index is None:       # "cuda" and "cuda:0" are the same place: compare normalised devices
+            dev = t.device("cuda", t.cuda.current_device())
+        if num_users > self.location_for_user.size:
+            raise IndexError(f"{num_users} query users but location_for_user has {self.location_for_user.size} entries")
+        if getattr(self, "_dev", None) is None or self._dev[0].device != dev:
+            to32 = lambda a: t.from_numpy(np.ascontiguousarray(np.asarray(a).astype(np.int32))).to(dev)
             self._dev = (to32(self.location_for_user), to32(self.customers.ptr), to32(self.customers.idx),
                          to32(self.users.ptr), to32(self.users.idx))
         out, _ = ops.match_same_location(*self._dev, self.k, n_queries=num_users)

@@ -569,11 +569,13 @@ def spmm(a: DeviceCSR, X: Tensor, *, Y: Optional[Tensor] = None, addend: Optiona
         ev = (t.cuda.Event(enable_timing=True), t.cuda.Event(enable_timing=True))
         ev[0].record()
     sweep = plan.sweep if (plan is not None and plan.sweep is not None) else None
-    hot_base, hot_rows = 0, (0 if PERSISTENT_ROWS else -1)
+    hot_base, hot_rows = 0, (-1 if PERSISTENT_ROWS else 0)   # mi_spmm_ex.hot_rows: 0 = the plain launch, < 0 = persistent without a cache
     if (a.hot is not None and plan is not None and x_map is None and row_list is None and d <= 256 and HOT_ROWS > 0
             and PERSISTENT_ROWS):
         hot_base, hot_rows = int(a.hot[0]), int(a.hot[1])
-        if hot_base < 0 or hot_rows < 0 or hot_base + hot_rows > X.shape[0]:
+        if hot_rows == 0:
+            hot_rows = -1       # an empty range: still the persistent form the switch asks for
+        if hot_base < 0 or hot_rows < -1 or hot_base + max(hot_rows, 0) > X.shape[0]:
             raise ValueError(f"hot rows [{hot_base}, {hot_base + hot_rows}) lie outside X ({X.shape[0]} rows)")
 
     def launch(parts: int, stream: int) -> None:
@@ -757,10 +759,9 @@ TOPK_WS_BYTES = 2 << 30  # score block per launch; queries are processed in chun
 TOPK_CHUNK_QUANTUM = 2048  # chunks are multiples of this when they can be: the bf16 prefilter kernel (csrc/topk_prefilter.hpp)
                            # keeps 256 queries per workgroup and deals the workgroups of an item slice to one XCD's 32 CUs —
                            # 2 048 / 4 096 queries fill the chip in one round (100 K items: 4 096 per chunk)
-# (Round 3, measured and not kept: alternating the chunks of one call over two streams, each with its own workspace, so that
-# one chunk's side kernels — sample scores, bitmap, threshold, finalize, ~18 % of its time — run under the other's fused
-# score + filter kernel: 3.50-3.55 M -> 2.95-3.02 M users/s at k = 12, unchanged at k = 256.  The fused kernel's grid is
-# sized to fill the chip in whole rounds; a second one beside it breaks the rounds of both.)
+# (Two-stream chunking: slower for the f32 fused kernel — 3.50-3.55 M -> 2.95-3.02 M users/s at k = 12, its grid fills the chip
+# in whole rounds and a second one beside it breaks the rounds of both — but a gain for the bf16 prefilter path, which is the
+# default: see TOPK_STREAMS below.)
 
 
 # streams the chunks of one topk_excl call alternate over (each with its own workspace).  A/B, 65 536 queries against 100 K items
@@ -800,7 +801,16 @@ def topk_excl(uid: Tensor, user_emb: Tensor, item_emb: Tensor, k: int, excl: Opt
         chunk -= chunk % TOPK_CHUNK_QUANTUM
     n_chunks = (n_q + chunk - 1) // chunk
     lanes = TOPK_STREAMS if (TOPK_STREAMS > 1 and n_chunks > 1) else 1
-    wss = [_ws(L.mi_topk_workspace_bytes(chunk, n_items, k), dev) for _ in range(lanes)]
+    # transient footprint = lanes x workspace (~2.2 GiB each at the default chunk): fall back to one lane, then to smaller
+    # chunks, when the device does not have that much free
+    ws_bytes = int(L.mi_topk_workspace_bytes(chunk, n_items, k))
+    free = t.cuda.mem_get_info(dev)[0] + t.cuda.memory_reserved(dev) - t.cuda.memory_allocated(dev)
+    if lanes > 1 and lanes * ws_bytes > 0.8 * free:
+        lanes = 1
+    while ws_bytes > 0.8 * free and chunk > 256:
+        chunk = max(256, chunk // 2)
+        ws_bytes = int(L.mi_topk_workspace_bytes(chunk, n_items, k))
+    wss = [_ws(ws_bytes, dev) for _ in range(lanes)]
 
     def launch(q0: int, ws: Tensor):
         q1 = min(n_q, q0 + chunk)

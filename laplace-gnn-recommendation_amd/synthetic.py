@@ -218,11 +218,15 @@ HM_ARTICLE_CARDS = (47_224, 132, 30, 50)        # product_code, product_type_no,
 C3 = SyntheticSpec(1_371_980, 105_542, 31_800_000, seed=2, deg_max=2000, zipf_s=1.0)
 
 
-def generate_hetero(spec: SyntheticSpec, customer_cards=HM_CUSTOMER_CARDS, article_cards=HM_ARTICLE_CARDS):
+def generate_hetero(spec: SyntheticSpec, customer_cards=HM_CUSTOMER_CARDS, article_cards=HM_ARTICLE_CARDS,
+                    feature_signal: bool = False):
     """Returns (graph, users_adj, articles_adj) in the shapes the reference's preprocessing writes
     (train_graph.pt / edges_train.pt / rev_edges_train.pt; run_preprocessing.py:176-195): a HeteroData with
     int64 categorical `x` per node type and the `buys` edge_index, plus the two adjacency lists (as CSR
-    AdjList objects — a dict of Python lists does not scale to 31.8 M edges)."""
+    AdjList objects — a dict of Python lists does not scale to 31.8 M edges).
+    feature_signal (with spec.communities > 1): the features say something about the planted structure, as a real
+    dataset's do — the first customer column and the first article column wide enough hold the node's latent group
+    (the other columns stay noise).  Without it the ranker has nothing but graph structure to learn from."""
     from .data.dataset import AdjList
     from .hetero import HeteroData
     from .utils.constants import Constants
@@ -230,6 +234,12 @@ def generate_hetero(spec: SyntheticSpec, customer_cards=HM_CUSTOMER_CARDS, artic
     rng = np.random.default_rng(spec.seed + 7919)
     cx = np.stack([rng.integers(0, min(c, spec.num_users) if c > 1000 else c, size=spec.num_users) for c in customer_cards], 1)
     ax = np.stack([rng.integers(0, min(c, spec.num_items) if c > 1000 else c, size=spec.num_items) for c in article_cards], 1)
+    if feature_signal and spec.communities > 1:
+        for x, cards, group in ((cx, customer_cards, user_community(spec)), (ax, article_cards, item_community(spec))):
+            wide = [j for j, c in enumerate(cards) if spec.communities <= c <= 1000]
+            if not wide:
+                raise ValueError("feature_signal needs a categorical column with at least `communities` values")
+            x[:, wide[0]] = group
     g = HeteroData()
     g[Constants.node_user].x = t.from_numpy(cx.astype(np.int64))
     g[Constants.node_item].x = t.from_numpy(ax.astype(np.int64))

@@ -126,3 +126,33 @@ def test_candidate_generation_feeds_the_ranker():
     from laplace_amd.utils.metrics import MAPatK
     gt = [t.from_numpy(np.asarray(test_users[u])) for u in range(U)]
     assert 0.0 <= MAPatK(gt, preds, k=cfg.k) <= 1.0
+
+
+def test_configs3_chain_at_one_tenth_scale_keeps_its_ranking_quality_across_the_hand_off():
+    """BASELINE configs[3] ("LightGCN candidate-gen + GNN ranker end-to-end") — the chain bench.py's `e2e_c3` block runs at the
+    full H&M shape (tools/e2e_hm_scale.py::run), here at 1/10 of it (137 198 x 10 554 x 3.18 M, planted structure, one held-out
+    purchase per evaluation user): LightGCN steps -> top-100 dump -> matchers -> ranker iterations on device-sampled batches ->
+    device-built evaluation samples -> top-12.  The hand-off must keep what the candidate generator learned: the matchers'
+    candidates contain the held-out purchase far more often than popularity alone would put it there, and the ranker's
+    re-ranking of ~150 candidates scores well above a shuffle of the same candidates."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("e2e_hm_scale", os.path.join(root, "tools", "e2e_hm_scale.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    out = mod.run(users=137_198, items=10_554, edges=3_180_000, lightgcn_steps=300, ranker_iters=400, ranker_batch=128,
+                  eval_users=4_000, top_n=100, popular_n=50)
+    m = out["map_at_12"]
+    print(out)
+    assert out["eval_users"] >= 3_900
+    for key in ("generate_s", "lightgcn_train_s", "topn_dump_s", "matchers_s", "ranker_train_s", "eval_inference_s"):
+        assert out["stage_s"][key] >= 0.0
+    assert out["lightgcn_positive_edges_per_s"] > 1e5 and out["ranker_positive_edges_per_s"] > 1e4
+    # a uniformly shuffled list of ~150 candidates that contains the item puts it into the top 12 with p ~ 12 / 150 at a mean
+    # reciprocal rank of ~0.26: MAP ~ 0.02 x recall
+    shuffled = 0.02 * m["candidate_recall"]
+    assert m["candidate_recall"] >= 0.15, m
+    assert m["candidate_generator_alone"] >= 3 * shuffled, m
+    assert m["ranker_reranked_candidates"] >= 3 * shuffled, m
+    assert m["ranker_reranked_candidates"] <= m["candidate_recall"] + 1e-6     # it can only rank what was proposed

@@ -261,6 +261,81 @@ def test_spmm_sweep_plan_equals_work_item_plan(d, n_streams):
     want = (vv[b:e, None] * Xw.cpu().double()[cc[b:e]]).sum(0)
     assert (Yw[r].cpu().double() - want).abs().max() <= 1e-3
 
+@pytest.mark.parametrize("tail_whole", [False, True])
+@pytest.mark.parametrize("d", [32, 128])
+def test_hybrid_plan_equals_the_banded_plan(d, tail_whole):
+    """HYBRID split-row plan (round 4, ops.build_hybrid_plan): an adjacency with MORE long rows than the sweep form's
+    accumulators hold — the longest rows in SWEEP form, the other split rows as banded work items behind the sweep's partial
+    rows (one fix-up over both) or, tail_whole, whole in the short-row kernel.  Every form of the product against the banded
+    work-item plan of the same adjacency (same sums, another association) and float64; bitwise reproducible."""
+    ops = _ops()
+    g = t.Generator().manual_seed(d + int(tail_whole))
+    n, n_streams = 9000, 32                                   # 8 * 32 = 256 row-part accumulators per XCD
+    degs = t.cat([t.tensor([6000, 4100, 2500]), t.randint(300, 1500, (380,), generator=g)])    # 383 rows above chunk = 256
+    hub_rows = t.randperm(n, generator=g)[: degs.numel()]
+    row = t.cat([t.full((int(L),), int(r)) for r, L in zip(hub_rows, degs)] + [t.randint(0, n, (40000,), generator=g)])
+    col = t.randint(0, n, (row.numel(),), generator=g)
+    a = ops.coo_to_csr(row.to(DEV), col.to(DEV), n, n, want_perm=False)
+    a.val = (t.rand(a.nnz, generator=g) + 0.5).to(DEV)
+    T = ops.sweep_degree_threshold(a, 256, n_streams)
+    assert T is not None and T > 256                          # not every long row fits the sweep form
+    assert ops.build_sweep_plan(a, chunk=256, band=64, n_streams=n_streams) is None
+    hyb = ops.build_hybrid_plan(a, chunk=256, band=64, tail_whole=tail_whole, sweep_band=64, n_streams=n_streams)
+    items = ops.build_spmm_plan(a, chunk=256, band=64)
+    assert hyb is not None and hyb.sweep is not None and items.sweep is None
+    deg = (a.rowptr[1:] - a.rowptr[:-1]).cpu()
+    n_hub = int((deg > T).sum())
+    assert 0 < n_hub < items.n_long_rows and int(hyb.sweep.n_slots) <= 8 * n_streams
+    if tail_whole:
+        assert hyb.items is None and hyb.n_long_rows == n_hub and int(hyb.struct.chunk) == T
+    else:
+        assert hyb.items is not None and hyb.n_long_rows == items.n_long_rows and int(hyb.struct.chunk) == 256
+        assert hyb.n_items > 8 * int(hyb.sweep.n_slots)       # the work items' partial rows follow the sweep's
+        assert sorted(hyb.long_rows.cpu().tolist()) == sorted(items.long_rows.cpu().tolist())
+    X = t.randn(n, d, generator=g).to(DEV)
+    A = t.randn(n, d, generator=g).to(DEV)
+    out = {}
+    for name, plan in (("hybrid", hyb), ("items", items)):
+        a.plan = plan
+        Y, S = t.empty(n, d, device=DEV), t.empty(n, d, device=DEV)
+        ops.spmm(a, X, Y=Y, addend=A, S=S, scale=0.5)
+        out[name] = (Y, S)
+    scale = float(out["items"][0].abs().max())
+    assert (out["hybrid"][0] - out["items"][0]).abs().max() <= 1e-5 * scale
+    assert (out["hybrid"][1] - out["items"][1]).abs().max() <= 1e-5 * scale
+    rp, cc, vv, Xd = a.rowptr.cpu().long(), a.col.cpu().long(), a.val.cpu().double(), X.cpu().double()
+    for r in hub_rows[:12].tolist() + hub_rows[-12:].tolist() + [0, 1, n - 1]:
+        b, e = int(rp[r]), int(rp[r + 1])
+        want = (vv[b:e, None] * Xd[cc[b:e]]).sum(0)
+        tol = 1e-6 * float((vv[b:e, None] * Xd[cc[b:e]].abs()).sum(0).max()) + 1e-6
+        assert (out["hybrid"][0][r].cpu().double() - want).abs().max() <= tol, r
+    a.plan = hyb
+    Y2 = t.full((n, d), float("nan"), device=DEV)
+    ops.spmm(a, X, Y=Y2)
+    assert t.equal(Y2, out["hybrid"][0])                      # no float atomics: bitwise reproducible
+    # both halves on two streams = the whole product
+    saved = ops.SPMM_TWO_STREAMS
+    try:
+        ops.SPMM_TWO_STREAMS = 0
+        Y3 = t.empty(n, d, device=DEV)
+        ops.spmm(a, X, Y=Y3)
+    finally:
+        ops.SPMM_TWO_STREAMS = saved
+    assert t.equal(Y3, Y2)
+    # sparse-operand forms: compact X through x_map, a row list naming hub rows, tail rows and short rows
+    keep = t.rand(n, generator=g) < 0.3
+    xmap = t.full((n,), -1, dtype=t.int32)
+    xmap[keep] = t.arange(int(keep.sum()), dtype=t.int32)
+    Ys, Yd = t.empty(n, d, device=DEV), t.empty(n, d, device=DEV)
+    ops.spmm(a, X[keep.to(DEV)].contiguous(), Y=Ys, x_map=xmap.to(DEV))
+    ops.spmm(a, X * keep.to(DEV)[:, None], Y=Yd)
+    assert (Ys - Yd).abs().max() <= 1e-5 * scale
+    rl = t.cat([hub_rows[:3], hub_rows[-3:], t.tensor([2, 7])]).to(t.int32).to(DEV)
+    Yl = t.empty(rl.numel(), d, device=DEV)
+    ops.spmm(a, X, Y=Yl, row_list=rl)
+    assert (Yl - out["hybrid"][0][rl.long()]).abs().max() <= 1e-5 * scale
+
+
 
 @pytest.mark.parametrize("band,chunk", [(0, 256), (64, 256), (7, 50), (100, 1000), (1, 256)])
 def test_spmm_plan_structure(band, chunk):

@@ -63,7 +63,8 @@ def test_native_ranker_step_against_the_oracle_twin(aggr):
             checked += int(big.sum())
             moved = p.detach().cpu() - before[n]
             assert t.allclose(moved[big], (q - before[n])[big], rtol=5e-2, atol=2e-5), (step, n)
-            assert float(moved.abs().max()) <= 0.01 * 1.001 * (step + 1) ** 0  # |Adam step| <= lr
+            if step == 0:
+                assert float(moved.abs().max()) <= 0.01 * 1.001                    # Adam's first step: |delta| <= lr
         assert checked > 1000
         model.load_state_dict({k: v.to(DEV) for k, v in ref.state_dict().items()})   # cut the chain at rounding level
         for p, q in zip(model.parameters(), ref.parameters()):

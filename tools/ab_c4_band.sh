@@ -3,7 +3,7 @@
 # band cut of a split row should hold on average (csrc/spmm.hip, plan_seg_flags_kernel).  tools/ab_c4_band.sh 1 8 32 ...
 for v in "$@"; do
   LAPLACE_SPMM_BAND_MIN_PER=$v timeout -k 10 240 python3 bench.py --config c4 --steps 10 --warmup 3 --no-cpu-baseline --no-pmc --no-map \
-      --no-plain-leg --no-ranker --no-pinsage --no-topk > /tmp/ab_c4_$v.log 2>&1
+      --no-plain-leg --no-ranker --no-pinsage --no-e2e --no-topk > /tmp/ab_c4_$v.log 2>&1
   python3 - <<EOF2
 import json
 line = [l for l in open("/tmp/ab_c4_$v.log") if l.startswith("{")]

@@ -5,7 +5,7 @@ for spec in "$@"; do
   IFS='|' read -r label envs extra <<< "$spec"
   log=/tmp/ab_c4env_$$.log
   env $envs timeout -k 10 300 python3 bench.py --config c4 --steps 8 --warmup 3 --no-cpu-baseline --no-pmc --no-map \
-      --no-plain-leg --no-side --no-ranker --no-pinsage --no-topk $extra > $log 2>&1
+      --no-plain-leg --no-side --no-ranker --no-pinsage --no-e2e --no-topk $extra > $log 2>&1
   python3 - "$label" "$log" <<'EOF2'
 import json, sys
 label, log = sys.argv[1], sys.argv[2]

@@ -2,7 +2,7 @@
 # A/B of the propagate's stream mode on BASELINE configs[3] at N = 1: tools/ab_c4_streams.sh 0 1 2
 for v in "$@"; do
   LAPLACE_SPMM_TWO_STREAMS=$v timeout -k 10 240 python3 bench.py --config c4 --steps 10 --warmup 3 --no-cpu-baseline --no-pmc --no-map \
-      --no-plain-leg --no-ranker --no-pinsage --no-topk > /tmp/ab_c4s_$v.log 2>&1
+      --no-plain-leg --no-ranker --no-pinsage --no-e2e --no-topk > /tmp/ab_c4s_$v.log 2>&1
   python3 - <<EOF2
 import json
 line = [l for l in open("/tmp/ab_c4s_$v.log") if l.startswith("{")]

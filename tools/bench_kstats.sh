@@ -4,7 +4,7 @@ v=$1; pat=${2:-bpr}
 export TMPDIR=/tmp
 out=$GRAFT_REPO_ROOT/gpurun_out/bk_$v; rm -rf $out; mkdir -p $out
 if [ $v != now ]; then export LAPLACE_HIP_LIB=$GRAFT_REPO_ROOT/laplace-gnn-recommendation_amd/liblaplace_hip_$v.so; fi
-rocprofv3 --kernel-trace --stats -d $out/kt --output-format csv -- python3 bench.py --config c2 --no-pmc --no-c4 --no-ranker --no-pinsage --no-map --no-cpu-baseline --no-plain-leg > $out/kt.log 2>&1
+rocprofv3 --kernel-trace --stats -d $out/kt --output-format csv -- python3 bench.py --config c2 --no-pmc --no-c4 --no-ranker --no-pinsage --no-e2e --no-map --no-cpu-baseline --no-plain-leg > $out/kt.log 2>&1
 python3 - <<EOF2
 import csv, glob
 f = glob.glob("$out/kt/**/*kernel_stats.csv", recursive=True)[0]

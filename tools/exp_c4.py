@@ -17,9 +17,14 @@ ap.add_argument('--half', default='both')
 ap.add_argument('--n', type=int, default=5)
 ap.add_argument('--blocks', type=int, default=S.C4_BLOCKS, help='user blocks of C4 to generate (64 = all of it)')
 ap.add_argument('--chunk', type=int, default=ops.DEFAULT_CHUNK)
+ap.add_argument('--pace', type=int, default=0, help='sweep time table: ticks (10 ns) per band')
+ap.add_argument('--sweep-band', type=int, default=0)
 ap.add_argument('--hybrid', type=int, default=-1, help='>= 0: hybrid plan (sweep for the hub rows + tail mode: 0 banded, 1 whole rows)')
 args = ap.parse_args()
 ops.SPMM_TWO_STREAMS = 0
+ops.SWEEP_PACE = args.pace
+if args.sweep_band:
+    ops.SWEEP_BAND = args.sweep_band
 
 spec = S.C4
 ei = S.generate_blocks(spec, S.C4_BLOCKS, 0, args.blocks).to('cuda')
@@ -72,5 +77,5 @@ for _ in range(3):
     s_.record()
     for _ in range(args.n): product()
     e_.record(); t.cuda.synchronize(); ts.append(s_.elapsed_time(e_) / args.n)
-print(f'C4 half={args.half} slices={args.slices} band={args.band} chunk={args.chunk} hybrid={args.hybrid}: product ms min {min(ts):.4f} med {sorted(ts)[1]:.4f}  '
+print(f'C4 half={args.half} slices={args.slices} band={args.band} chunk={args.chunk} hybrid={args.hybrid} pace={args.pace} sweep_band={ops.SWEEP_BAND}: product ms min {min(ts):.4f} med {sorted(ts)[1]:.4f}  '
       f'max err vs f64 {err:.2e}', flush=True)
