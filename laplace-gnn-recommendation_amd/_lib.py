@@ -50,6 +50,7 @@ class SpmmExStruct(Structure):
 
 MI_SPMM_SHORT_ROWS, MI_SPMM_SPLIT_ROWS = 1, 2
 MI_ERR_UNSUPPORTED = -4
+MI_ERR_WORKSPACE = -3
 
 
 class GemmProblem(Structure):

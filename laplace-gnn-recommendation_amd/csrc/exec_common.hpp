@@ -22,20 +22,24 @@ __global__ __launch_bounds__(kBlock) void dropout_kernel(int64_t n4, const float
 // Two dropout launches as one (the customer-side and article-side inputs of an encoder layer): workgroups [0, split) take
 // segment a, the rest segment b; per element the same draw as dropout_kernel (counter = element / 4 of ITS segment, its site).
 struct DropSeg { int64_t n4; const float4* x; float4* y; uint32_t site; };
-__global__ __launch_bounds__(kBlock) void dropout_pair_kernel(DropSeg a, DropSeg b, unsigned split, float p, float scale, uint32_t k0,
-                                                              uint32_t k1, uint32_t step_lo) {
-    const bool first = blockIdx.x < split;
-    const DropSeg& q = first ? a : b;
-    const int64_t i = (int64_t)(first ? blockIdx.x : blockIdx.x - split) * kBlock + threadIdx.x;
-    if (i >= q.n4) return;
-    const MiPhilox r = mi_philox4x32((uint32_t)i, (uint32_t)((uint64_t)i >> 32), q.site, step_lo, k0, k1);
+__device__ __forceinline__ void dropout_segment(int64_t n4, const float4* __restrict__ x, float4* __restrict__ y, uint32_t site,
+                                                unsigned bid, float p, float scale, uint32_t k0, uint32_t k1, uint32_t step_lo) {
+    const int64_t i = (int64_t)bid * kBlock + threadIdx.x;
+    if (i >= n4) return;
+    const MiPhilox r = mi_philox4x32((uint32_t)i, (uint32_t)((uint64_t)i >> 32), site, step_lo, k0, k1);
     const uint32_t thr = (uint32_t)fminf(4294967040.f, p * 4294967296.f);
-    float4 v = q.x[i];
+    float4 v = x[i];
     v.x = r.c[0] >= thr ? v.x * scale : 0.f;
     v.y = r.c[1] >= thr ? v.y * scale : 0.f;
     v.z = r.c[2] >= thr ? v.z * scale : 0.f;
     v.w = r.c[3] >= thr ? v.w * scale : 0.f;
-    q.y[i] = v;
+    y[i] = v;
+}
+__global__ __launch_bounds__(kBlock) void dropout_pair_kernel(DropSeg a, DropSeg b, unsigned split, float p, float scale, uint32_t k0,
+                                                              uint32_t k1, uint32_t step_lo) {
+    const bool first = blockIdx.x < split;   // fields picked one by one (a reference chosen between two argument structs goes through scratch)
+    dropout_segment(first ? a.n4 : b.n4, first ? a.x : b.x, first ? a.y : b.y, first ? a.site : b.site,
+                    first ? blockIdx.x : blockIdx.x - split, p, scale, k0, k1, step_lo);
 }
 
 struct AdamTable {

@@ -428,6 +428,28 @@ __global__ __launch_bounds__(kBlock) void gather_cat_bwd_pair_kernel(int64_t n_e
                         first ? dZ0 : dZ1, c);
 }
 
+// gather + concat + Philox dropout (pairs.hpp: gather_cat_dropout).  32-bit Philox4x32-10 as exec_common.hpp's dropout_kernel:
+// counter (i lo, i hi, site, step), key (k0, k1), i = flat float4 index of the output matrix.
+__global__ __launch_bounds__(kBlock) void gather_cat_dropout_kernel(int64_t n_e, int cu4, int ci4, const int64_t* __restrict__ row,
+                                                                    const int64_t* __restrict__ col, const float4* __restrict__ Zu,
+                                                                    const float4* __restrict__ Zi, float4* __restrict__ out, float p,
+                                                                    float scale, uint32_t k0, uint32_t k1, uint32_t site,
+                                                                    uint32_t step_lo) {
+    const int w4 = cu4 + ci4;
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n_e * w4) return;
+    const int64_t e = i / w4;
+    const int c = (int)(i - e * w4);
+    float4 v = c < cu4 ? Zu[row[e] * cu4 + c] : Zi[col[e] * ci4 + (c - cu4)];
+    const MiPhilox r = mi_philox4x32((uint32_t)i, (uint32_t)((uint64_t)i >> 32), site, step_lo, k0, k1);
+    const uint32_t thr = (uint32_t)fminf(4294967040.f, p * 4294967296.f);  // keep when the draw is >= p * 2^32
+    v.x = r.c[0] >= thr ? v.x * scale : 0.f;
+    v.y = r.c[1] >= thr ? v.y * scale : 0.f;
+    v.z = r.c[2] >= thr ? v.z * scale : 0.f;
+    v.w = r.c[3] >= thr ? v.w * scale : 0.f;
+    out[i] = v;
+}
+
 // BCEWithLogitsLoss(reduction="mean") and its gradient in one launch, one workgroup: loss = mean(max(x, 0) - x*y +
 // log1p(exp(-|x|))) (torch's formulation), dx = (sigmoid(x) - y) / n.  Sums in double, fixed tree: reproducible.
 __global__ __launch_bounds__(1024) void bce_logits_kernel(int64_t n, const float* __restrict__ x, const float* __restrict__ y,
@@ -493,6 +515,53 @@ __global__ __launch_bounds__(kBlock) void linear1_bwd_reduce_kernel(int64_t band
     for (int64_t b = 0; b < bands; ++b) acc += part[b * (in + 1) + c];
     if (c < in) gw[c] = acc;
     else if (gb) gb[0] = acc;
+}
+
+// The two kernels above as one launch (pairs.hpp: linear1_bwd_lastblock): every workgroup writes its band's partial row, takes a
+// ticket, and the workgroup holding the last ticket reduces all bands in band order — the sums of linear1_bwd_reduce_kernel.
+// Release / acquire at agent scope around the ticket (the partial rows were written by workgroups on other XCDs, whose L2s are
+// not coherent with this one's): every thread fences after its stores, one thread adds, the last workgroup fences before it reads.
+__global__ __launch_bounds__(kBlock) void linear1_bwd_fused_kernel(int64_t n, int in, const float* __restrict__ dy,
+                                                                   const float* __restrict__ w, const float* __restrict__ x,
+                                                                   int64_t ldx, float* __restrict__ dx, int64_t lddx,
+                                                                   float* __restrict__ part, float* __restrict__ gw,
+                                                                   float* __restrict__ gb, int32_t* __restrict__ counter) {
+    __shared__ float sdy[kL1Rows];
+    __shared__ int s_last;
+    const int64_t r0 = (int64_t)blockIdx.x * kL1Rows;
+    const int rows = (int)min((int64_t)kL1Rows, n - r0);
+    if (threadIdx.x < kL1Rows) sdy[threadIdx.x] = (int)threadIdx.x < rows ? dy[r0 + threadIdx.x] : 0.f;
+    __syncthreads();
+    for (int c = threadIdx.x; c < in; c += kBlock) {
+        const float wc = w[c];
+        float acc = 0.f;
+#pragma unroll 8
+        for (int r = 0; r < rows; ++r) {
+            const float g = sdy[r];
+            acc = fmaf(g, x[(r0 + r) * ldx + c], acc);
+            if (dx) dx[(r0 + r) * lddx + c] = g * wc;
+        }
+        part[(int64_t)blockIdx.x * (in + 1) + c] = acc;
+    }
+    if (threadIdx.x == 0) {
+        float sb = 0.f;
+        for (int r = 0; r < rows; ++r) sb += sdy[r];
+        part[(int64_t)blockIdx.x * (in + 1) + in] = sb;
+    }
+    __threadfence();                       // release: this thread's partial-row stores, at agent scope
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = (atomicAdd(counter, 1) == (int)gridDim.x - 1) ? 1 : 0;
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();                       // acquire: the other workgroups' partial rows
+    const int64_t bands = gridDim.x;
+    for (int c = threadIdx.x; c <= in; c += kBlock) {
+        float acc = 0.f;
+        for (int64_t b = 0; b < bands; ++b) acc += part[b * (in + 1) + c];
+        if (c < in) gw[c] = acc;
+        else if (gb) gb[0] = acc;
+    }
+    if (threadIdx.x == 0) *counter = 0;    // ready for the next call
 }
 
 extern "C" {
@@ -651,6 +720,28 @@ int gather_cat_bwd_pair(int64_t n_edges, int64_t c, const int64_t* idx0, const i
         return MI_ERR_UNSUPPORTED;
     const unsigned g = (unsigned)mi_ceil_div(n_edges * MI_WAVE, kBlock);
     hipLaunchKernelGGL(gather_cat_bwd_pair_kernel, dim3(2 * g), dim3(kBlock), 0, s, n_edges, (int)c, idx0, idx1, dOut, ldo, dZ0, dZ1, g);
+    return mi_launch_status();
+}
+
+int gather_cat_dropout(int64_t n_edges, int64_t cu, int64_t ci, const int64_t* row, const int64_t* col, const float* Zu, const float* Zi,
+                       float* out, float p, uint64_t seed, uint32_t site, uint32_t step_lo, hipStream_t s) {
+    if (n_edges <= 0 || cu <= 0 || ci <= 0 || cu % 4 || ci % 4 || !row || !col || !Zu || !Zi || !out || !(p > 0.f && p < 1.f))
+        return MI_ERR_UNSUPPORTED;
+    if (!mi_aligned16(Zu) || !mi_aligned16(Zi) || !mi_aligned16(out)) return MI_ERR_UNSUPPORTED;
+    const int64_t total4 = n_edges * ((cu + ci) / 4);
+    hipLaunchKernelGGL(gather_cat_dropout_kernel, dim3((unsigned)mi_ceil_div(total4, kBlock)), dim3(kBlock), 0, s, n_edges, (int)(cu / 4),
+                       (int)(ci / 4), row, col, reinterpret_cast<const float4*>(Zu), reinterpret_cast<const float4*>(Zi),
+                       reinterpret_cast<float4*>(out), p, 1.0f / (1.0f - p), (uint32_t)seed, (uint32_t)(seed >> 32), site, step_lo);
+    return mi_launch_status();
+}
+
+int linear1_bwd_lastblock(int64_t n, int64_t in, const float* dy, const float* w, const float* x, float* dx, float* gw, float* gb,
+                          void* ws, size_t ws_bytes, int32_t* counter, hipStream_t s) {
+    if (n <= 0 || in <= 0 || !dy || !w || !x || !gw || !ws || !counter || ws_bytes < mi_linear1_bwd_workspace_bytes(n, in))
+        return MI_ERR_UNSUPPORTED;
+    const int64_t bands = mi_ceil_div(n, kL1Rows);
+    hipLaunchKernelGGL(linear1_bwd_fused_kernel, dim3((unsigned)bands), dim3(kBlock), 0, s, n, (int)in, dy, w, x, in, dx, in,
+                       static_cast<float*>(ws), gw, gb, counter);
     return mi_launch_status();
 }
 

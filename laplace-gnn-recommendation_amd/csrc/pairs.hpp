@@ -43,4 +43,16 @@ int batchnorm_bwd_pair(const BnSide& a, const BnSide& b, int64_t c, hipStream_t 
 int gather_cat_bwd_pair(int64_t n_edges, int64_t c, const int64_t* idx0, const int64_t* idx1, const float* dOut, int64_t ldo,
                         float* dZ0, float* dZ1, hipStream_t s);
 
+// mi_gather_cat_f32 with the decoder's Philox feature dropout applied on the way out (out = dropout(cat(Zu[row], Zi[col]))): one
+// launch instead of gather + dropout.  A lane owns one float4 of the concatenated row and draws ONE Philox block for it —
+// the counter (flat float4 index of the [n_edges, cu + ci] matrix, site, step) is exactly dropout_kernel's, so the backward's
+// regenerated mask matches.  cu, ci multiples of 4, 16-byte aligned rows; else MI_ERR_UNSUPPORTED.
+int gather_cat_dropout(int64_t n_edges, int64_t cu, int64_t ci, const int64_t* row, const int64_t* col, const float* Zu, const float* Zi,
+                       float* out, float p, uint64_t seed, uint32_t site, uint32_t step_lo, hipStream_t s);
+
+// mi_linear1_bwd_f32 as ONE launch: the band partials are reduced by the workgroup that finishes last (agent-scope ticket in
+// `counter`, which must be zero at entry and is zero again at exit), in band order — the same sums as the two-launch form.
+int linear1_bwd_lastblock(int64_t n, int64_t in, const float* dy, const float* w, const float* x, float* dx, float* gw, float* gb,
+                          void* ws, size_t ws_bytes, int32_t* counter, hipStream_t s);
+
 }  // namespace mi_pairs

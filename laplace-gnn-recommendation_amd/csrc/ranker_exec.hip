@@ -30,17 +30,19 @@ constexpr int kTypes = 2;  // 0 = customer, 1 = article
 //   vt_cus[p] (by_customer CSR, relation 0 backward): mean ? 1 / deg(article = column)     : 1
 //   vt_art[p] (by_article CSR, relation 1 backward):  mean ? 1 / deg(customer = column)    : 1
 // (BipartiteGraph.weights of model/layers.py: scale_csr(by_dst, inv) and scale_csr(by_src, col_scale = inv).)
-__global__ __launch_bounds__(kBlock) void ranker_prep_kernel(int64_t nnz, int64_t n_c, int64_t n_a, int mean,
+__device__ __forceinline__ void ranker_prep_body(const int64_t block_id, const int64_t n_blocks, int64_t nnz, int64_t n_c, int64_t n_a, int mean,
                                                              const int32_t* __restrict__ cptr, const int32_t* __restrict__ ccol,
                                                              const int32_t* __restrict__ aptr, const int32_t* __restrict__ acol,
                                                              float* __restrict__ v_cus, float* __restrict__ vt_cus,
                                                              float* __restrict__ v_art, float* __restrict__ vt_art,
                                                              int64_t n_label, const int64_t* __restrict__ label,
-                                                             float* __restrict__ label_f, float4* __restrict__ zero4, int64_t n_zero4) {
-    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+                                                             float* __restrict__ label_f, float4* __restrict__ zero4, int64_t n_zero4,
+                                                             int32_t* __restrict__ counters) {
+    const int64_t i = block_id * kBlock + threadIdx.x;
+    if (counters && i < 4) counters[i] = 0;   // tickets of the last-workgroup reductions further down the iteration
     // round 4: the zero-fill of the gather-cat backward's outputs (rows no label edge names must read zero) rides here,
     // long before its consumer, instead of two fillBuffer launches in the middle of the backward
-    for (int64_t z = i; z < n_zero4; z += (int64_t)gridDim.x * kBlock) zero4[z] = mi_f4_zero();
+    for (int64_t z = i; z < n_zero4; z += n_blocks * kBlock) zero4[z] = mi_f4_zero();
     if (label && i < n_label) label_f[i] = (float)label[i];
     if (!mean) {
         if (i < nnz) v_cus[i] = vt_cus[i] = v_art[i] = vt_art[i] = 1.f;
@@ -70,6 +72,32 @@ __global__ __launch_bounds__(kBlock) void ranker_prep_kernel(int64_t nnz, int64_
 }
 
 #include "exec_common.hpp"
+
+struct PrepArgs {
+    int64_t nnz, n_c, n_a; int mean;
+    const int32_t *cptr, *ccol, *aptr, *acol;
+    float *v_cus, *vt_cus, *v_art, *vt_art;
+    int64_t n_label; const int64_t* label; float* label_f;
+    float4* zero4; int64_t n_zero4; int32_t* counters;
+};
+__device__ __forceinline__ void ranker_prep_run(const PrepArgs& a, int64_t block_id, int64_t n_blocks) {
+    ranker_prep_body(block_id, n_blocks, a.nnz, a.n_c, a.n_a, a.mean, a.cptr, a.ccol, a.aptr, a.acol, a.v_cus, a.vt_cus, a.v_art, a.vt_art,
+                     a.n_label, a.label, a.label_f, a.zero4, a.n_zero4, a.counters);
+}
+__global__ __launch_bounds__(kBlock) void ranker_prep_kernel(PrepArgs a) { ranker_prep_run(a, blockIdx.x, gridDim.x); }
+// the prep work and the first encoder layer's two input dropouts (independent of each other) as ONE launch: workgroups
+// [0, gp) prepare, [gp, gp + ga) drop the customer features, the rest the article features (round 4)
+__global__ __launch_bounds__(kBlock) void ranker_prep_dropout_kernel(PrepArgs a, unsigned gp, DropSeg da, DropSeg db, unsigned ga, float p,
+                                                                     float scale, uint32_t k0, uint32_t k1, uint32_t step_lo) {
+    if (blockIdx.x < gp) {
+        ranker_prep_run(a, blockIdx.x, gp);
+        return;
+    }
+    const unsigned bid = blockIdx.x - gp;
+    const bool first = bid < ga;
+    dropout_segment(first ? da.n4 : db.n4, first ? da.x : db.x, first ? da.y : db.y, first ? da.site : db.site, first ? bid : bid - ga, p, scale,
+                    k0, k1, step_lo);
+}
 
 // ---- the iteration --------------------------------------------------------------------------------------------------------
 
@@ -306,12 +334,30 @@ int Exec::run() {
     float* v_art = take(nnz, 1);
     float* vt_art = take(nnz, 1);
     float* label_f = take(nl, 1);
+    int32_t* counters = reinterpret_cast<int32_t*>(take_bytes(64));   // tickets of the last-workgroup reductions; zeroed by the prep launch
+    // the first encoder layer's dropped inputs: with twin launches their two dropouts ride in the prep launch (independent work)
+    const bool drop0 = drop && L > 1;
+    float* xin0[2] = {nullptr, nullptr};
+    if (drop0)
+        for (int t = 0; t < kTypes; ++t) xin0[t] = take(n[t], width[t]);
+    if (mode == CHECK && drop0 && ((n[0] * width[0]) % 4 != 0 || (n[1] * width[1]) % 4 != 0)) fail(MI_ERR_UNSUPPORTED);
+    const bool merged0 = drop0 && twin();
     if (go()) {
         const int64_t span = std::max(std::max(nnz, nl), std::max(n[0], n[1]));
-        hipLaunchKernelGGL(ranker_prep_kernel, dim3((unsigned)mi_ceil_div(span, kBlock)), dim3(kBlock), 0, s, nnz, n[0], n[1],
-                           M.aggr == 1 ? 1 : 0, B.by_customer_ptr, B.by_customer_col, B.by_article_ptr, B.by_article_col, v_cus,
-                           vt_cus, v_art, vt_art, nl, B.label_f32 ? nullptr : B.label, label_f, reinterpret_cast<float4*>(dz_early[0]),
-                           (int64_t)((dz_early[1] + n[1] * C0) - dz_early[0]) / 4);
+        const PrepArgs pa{nnz, n[0], n[1], M.aggr == 1 ? 1 : 0, B.by_customer_ptr, B.by_customer_col, B.by_article_ptr, B.by_article_col,
+                          v_cus, vt_cus, v_art, vt_art, nl, B.label_f32 ? nullptr : B.label, label_f,
+                          reinterpret_cast<float4*>(dz_early[0]), (int64_t)((dz_early[1] + n[1] * C0) - dz_early[0]) / 4, counters};
+        const unsigned gp = (unsigned)mi_ceil_div(span, kBlock);
+        if (merged0) {
+            const float p = M.p_dropout;
+            const DropSeg da{n[0] * width[0] / 4, reinterpret_cast<const float4*>(x0[0]), reinterpret_cast<float4*>(xin0[0]), 0u};
+            const DropSeg db{n[1] * width[1] / 4, reinterpret_cast<const float4*>(x0[1]), reinterpret_cast<float4*>(xin0[1]), 1u};
+            const unsigned ga = (unsigned)mi_ceil_div(da.n4, kBlock), gb = (unsigned)mi_ceil_div(db.n4, kBlock);
+            hipLaunchKernelGGL(ranker_prep_dropout_kernel, dim3(gp + ga + gb), dim3(kBlock), 0, s, pa, gp, da, db, ga, p, 1.0f / (1.0f - p),
+                               (uint32_t)B.seed, (uint32_t)(B.seed >> 32), (uint32_t)B.step);
+        } else {
+            hipLaunchKernelGGL(ranker_prep_kernel, dim3(gp), dim3(kBlock), 0, s, pa);
+        }
         ok(mi_launch_status());
     }
     const float* fval[2] = {v_art, v_cus};     // forward values of relation r (CSR by destination)
@@ -329,9 +375,9 @@ int Exec::run() {
         if (l > 0) fork();
         for (int t = 0; t < kTypes; ++t) {
             xin[l][t] = xcur[t];
-            if (!last && drop) xin[l][t] = take(n[t], cw[t]);
+            if (!last && drop) xin[l][t] = l == 0 ? xin0[t] : take(n[t], cw[t]);
         }
-        if (!last && drop)
+        if (!last && drop && !(l == 0 && merged0))
             dropout2(xcur[0], xin[l][0], n[0] * cw[0], (uint32_t)(l * 2 + 0), xcur[1], xin[l][1], n[1] * cw[1], (uint32_t)(l * 2 + 1));
         on(1);
         join();    // each aggregation reads the OTHER type's input
@@ -401,7 +447,13 @@ int Exec::run() {
     }
     // ---- decoder forward (b7) -------------------------------------------------------------------------------------
     float* h = take(nl, 2 * C);
-    if (go()) ok(mi_gather_cat_f32(nl, C, C, B.label_row, B.label_col, z[0], C, z[1], C, h, 2 * C, (mi_stream_t)s));
+    // with dropout in front of the first decoder layer the gather writes the DROPPED rows directly (pairs.hpp: gather_cat_dropout;
+    // the undropped concatenation has no other reader): one launch instead of gather + dropout
+    bool gc_fused = false;
+    if (go() && drop && LD > 1)
+        gc_fused = paired(mi_pairs::gather_cat_dropout(nl, C, C, B.label_row, B.label_col, z[0], z[1], h, M.p_dropout, B.seed, 64u,
+                                                       (uint32_t)B.step, s));
+    if (go() && !gc_fused) ok(mi_gather_cat_f32(nl, C, C, B.label_row, B.label_col, z[0], C, z[1], C, h, 2 * C, (mi_stream_t)s));
     float* din[MI_RANKER_MAX_LAYERS];
     float* dout[MI_RANKER_MAX_LAYERS];
     int64_t hw = 2 * C;
@@ -412,7 +464,8 @@ int Exec::run() {
         din[j] = h;
         if (!last && drop) {
             din[j] = take(nl, hw);
-            dropout(h, din[j], nl * hw, (uint32_t)(64 + j));
+            if (j == 0 && mode == LAUNCH && gc_fused) din[j] = h;   // h already holds the dropped rows (the spare buffer stays unused)
+            else dropout(h, din[j], nl * hw, (uint32_t)(64 + j));
         }
         dout[j] = take(nl, ln.out);
         const size_t need = mi_gemm_workspace_bytes(nl, ln.out, hw);
@@ -447,7 +500,8 @@ int Exec::run() {
         if (last && ln.out == 1) {   // Linear(in, 1): mi_linear1_bwd_f32 (as FusedRankerStep does)
             const size_t need = mi_linear1_bwd_workspace_bytes(nl, ln.in);
             char* w = take_bytes(need);
-            if (go())
+            if (go() && !paired(mi_pairs::linear1_bwd_lastblock(nl, ln.in, dh, ln.w, din[j], dx, ln.gw, ln.b ? ln.gb : nullptr, w, need,
+                                                                 counters + 0, s)))
                 ok(mi_linear1_bwd_f32(nl, ln.in, dh, ln.w, din[j], ln.in, dx, ln.in, ln.gw, ln.b ? ln.gb : nullptr, w, need,
                                       (mi_stream_t)s));
             dh = dx;

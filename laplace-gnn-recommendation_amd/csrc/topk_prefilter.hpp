@@ -371,6 +371,53 @@ __device__ __forceinline__ uint32_t kth_key_of_cands(SelectShared& sh, int n, in
     return sh.prefix;
 }
 
+// A LOWER BOUND of the kk-th largest score key among the n composites in sh.cand (n >= kk) that at least kk of them reach —
+// all the refine step needs (round 4).  The 4-pass radix select above cost 55 of the refine kernel's ~200 us per 4 096-query
+// chunk at k = 256 (probe builds, profiles/r04_topk_refine.md): the keys of one row's list share sign, exponent and the top
+// mantissa bits, so the first passes put all ~750 entries on two or three LDS counters.  Here ONE histogram over the keys'
+// own range [min, max], 256 equal bins (the entries spread over all of them), the highest bin b* whose suffix count reaches
+// kk, and the smallest key in it: at least kk keys are >= that key, and it is at most a bin's width (~3 entries) below the
+// exact kk-th largest — a handful of extra survivors for the exact rescoring, a quarter of the barriers, no contention.
+__device__ __forceinline__ uint32_t kth_key_bound_of_cands(SelectShared& sh, int n, int kk) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint32_t lo = 0xFFFFFFFFu, hi = 0u;
+    for (int i = tid; i < n; i += kBlock) {
+        const uint32_t key = (uint32_t)(sh.cand[i] >> 32);
+        lo = min(lo, key);
+        hi = max(hi, key);
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        lo = min(lo, (uint32_t)__shfl_xor((int)lo, d, 64));
+        hi = max(hi, (uint32_t)__shfl_xor((int)hi, d, 64));
+    }
+    uint32_t* mm = reinterpret_cast<uint32_t*>(sh.scan_sh);   // kBlock / 64 + 1 = 5 words: min per wave, then reused
+    __shared__ uint32_t s_hi[kBlock / 64];
+    if (lane == 0) { mm[wave] = lo; s_hi[wave] = hi; }
+    sh.hist[tid] = 0;
+    if (tid == 0) sh.need = kk;
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < kBlock / 64; ++w) { lo = min(lo, mm[w]); hi = max(hi, s_hi[w]); }
+    if (hi == lo) return lo;                                   // block-uniform: every key equal
+    const float scale = 256.0f / ((float)(hi - lo) + 1.0f);
+    auto bin_of = [&](uint32_t key) { return min(255, (int)((float)(key - lo) * scale)); };   // monotone in key
+    __syncthreads();                                           // mm / s_hi read by everybody before scan_sh is reused
+    for (int i = tid; i < n; i += kBlock) atomicAdd(&sh.hist[bin_of((uint32_t)(sh.cand[i] >> 32))], 1);
+    __syncthreads();
+    radix_pick_bin(sh, 0u, 0);                                 // sh.prefix = b*: the highest bin with >= kk keys at or above it
+    const int b = (int)sh.prefix;
+    __syncthreads();
+    if (tid == 0) sh.prefix = 0xFFFFFFFFu;
+    __syncthreads();
+    for (int i = tid; i < n; i += kBlock) {
+        const uint32_t key = (uint32_t)(sh.cand[i] >> 32);
+        if (bin_of(key) == b) atomicMin(&sh.prefix, key);
+    }
+    __syncthreads();
+    return sh.prefix;
+}
+
 // One block per query: the slice regions of its list -> LDS (exclusions and table padding dropped here), the survivor
 // bound of step 2, exact scores of the survivors, finish_candidates().  Rows that cannot be decided this way (a region
 // or the list overflowed, fewer than kk candidates, the bound dips below the list's own) are recomputed exactly, as on
@@ -441,6 +488,9 @@ __global__ __launch_bounds__(kBlock) void topk_refine_finalize_kernel(FusedArgs 
         }
     }
     __syncthreads();
+#if defined(MI_REFINE_PROBE) && MI_REFINE_PROBE == 1   // timing probes (tools/pre_probe.sh): wrong results
+    return;
+#endif
     const int cnt = sh.count;
     bool ok = !bad && cnt >= kk && cnt <= kPreList;   // block-uniform
     if (ok) {
@@ -466,8 +516,15 @@ __global__ __launch_bounds__(kBlock) void topk_refine_finalize_kernel(FusedArgs 
             __syncthreads();
             t2 = sh.prefix;
         } else {
-            t2 = kth_key_of_cands(sh, cnt, kk);
+#if defined(MI_REFINE_RADIX_T2)
+            t2 = kth_key_of_cands(sh, cnt, kk);          // A/B: the exact kk-th largest by 4-pass radix select
+#else
+            t2 = kth_key_bound_of_cands(sh, cnt, kk);
+#endif
         }
+#if defined(MI_REFINE_PROBE) && MI_REFINE_PROBE == 2
+        if (t2 != 0x12345u) return;
+#endif
         const float eps = epsv[q];
         const float t_l = key_score(t2) - 2.f * eps;
         ok = t_l >= pa.thrf[q];                      // false on NaN as well
@@ -483,7 +540,65 @@ __global__ __launch_bounds__(kBlock) void topk_refine_finalize_kernel(FusedArgs 
             }
             __syncthreads();
             const int n2 = sh.need;                  // >= kk
+#if defined(MI_REFINE_PROBE) && MI_REFINE_PROBE == 3
+            if (n2 >= 0) return;
+#endif
             ok = n2 <= kPreSurv;
+#ifndef MI_REFINE_SLABS
+#define MI_REFINE_SLABS 0   // 1: the exact rescoring stages 64-byte row slabs through LDS, four lanes per row (A/B).  Measured at
+                            // k = 256, round 4 (tools/pre_probe.sh): refine kernel 186 us per 4 096-query chunk without, 192 with —
+                            // a thread reading ITS row issues all 32 sixteen-byte loads at once, and that depth of loads in
+                            // flight is worth more than the 4 x fewer L2 requests of the coalesced form (8 dependent slab steps)
+#endif
+            if (ok && MI_REFINE_SLABS && n2 <= 512 && a.d % 16 == 0) {
+                // exact scores, coalesced (A/B form, off: see MI_REFINE_SLABS): a wavefront stages its 64 rows' 64-byte slab (16 floats)
+                // with FOUR lanes per row — one 64-byte request per row and slab — into LDS (the candidate list's region is
+                // free by now; rows 80 bytes apart: conflict-free 16-byte reads), then every lane runs its row's 16 fma steps
+                // from LDS; the next slab's loads are in flight meanwhile.  Same k-ordered fma chain, same bits.
+                float* stage = reinterpret_cast<float*>(sh.cand) + 1024 + (tid >> 6) * (64 * 20);   // behind 512 result composites
+                const int lane = tid & 63, sub = lane >> 2, part = lane & 3;
+                const int n_slab = a.d / 16;
+                for (int base = 0; base < n2; base += kBlock) {
+                    const int my = base + tid;                       // the survivor this lane scores
+                    const float* rowp[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {                    // the rows this lane helps to load: sub + 16 j of the wavefront's 64
+                        const int r = base + (tid & ~63) + sub + 16 * j;
+                        rowp[j] = r < n2 ? a.I + (int64_t)surv[r] * a.ldi + 4 * part : nullptr;
+                    }
+                    float4 nxt[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) nxt[j] = rowp[j] ? *reinterpret_cast<const float4*>(rowp[j]) : mi_f4_zero();
+                    float acc = 0.f;
+                    for (int sl = 0; sl < n_slab; ++sl) {
+                        __builtin_amdgcn_wave_barrier();             // the previous slab's reads are done (same wavefront: program order)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) *reinterpret_cast<float4*>(stage + (sub + 16 * j) * 20 + 4 * part) = nxt[j];
+                        if (sl + 1 < n_slab) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                nxt[j] = rowp[j] ? *reinterpret_cast<const float4*>(rowp[j] + 16 * (sl + 1)) : mi_f4_zero();
+                        }
+                        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                        for (int c4 = 0; c4 < 4; ++c4) {
+                            const float4 w = *reinterpret_cast<const float4*>(stage + lane * 20 + 4 * c4);
+                            const float4 uu = *reinterpret_cast<const float4*>(urow + 16 * sl + 4 * c4);
+                            acc = fmaf(uu.x, w.x, acc);
+                            acc = fmaf(uu.y, w.y, acc);
+                            acc = fmaf(uu.z, w.z, acc);
+                            acc = fmaf(uu.w, w.w, acc);
+                        }
+                    }
+                    if (my < n2) sh.cand[my] = composite(score_key(acc), surv[my]);
+                }
+                __syncthreads();
+#if defined(MI_REFINE_PROBE) && MI_REFINE_PROBE == 4
+                if (n2 >= 0) { if (tid == 0) out_idx[q * k] = (int64_t)sh.cand[0]; return; }
+#endif
+                finish_candidates(n2, k, kk, kpow2, q, out_idx, out_score, sh);
+                return;
+            }
             if (ok) {
                 // exact scores: the k-ordered fma chain, bit for bit the f32 MFMA's and the oracle's
                 for (int i = tid; i < n2; i += kBlock) {
@@ -501,6 +616,9 @@ __global__ __launch_bounds__(kBlock) void topk_refine_finalize_kernel(FusedArgs 
                     sh.cand[i] = composite(score_key(acc), item);
                 }
                 __syncthreads();
+#if defined(MI_REFINE_PROBE) && MI_REFINE_PROBE == 4
+                if (n2 >= 0) { if (tid == 0) out_idx[q * k] = (int64_t)sh.cand[0]; return; }
+#endif
                 finish_candidates(n2, k, kk, kpow2, q, out_idx, out_score, sh);
                 return;
             }

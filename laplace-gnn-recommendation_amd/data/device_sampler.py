@@ -140,8 +140,10 @@ class DeviceGraphSampler:
                                  self._ws.data_ptr(), self._ws.numel(), totals, stream), "mi_sampler_count")
         return self._emit(seeds, desc, [int(x) for x in totals], stream, raw)
 
-    def _emit(self, seeds: Tensor, desc: SamplerDesc, totals, stream: int, raw: bool = False):
-        """Phase B on `stream` (the current torch stream must be that stream: the feature gathers follow it)."""
+    def _emit(self, seeds: Tensor, desc: SamplerDesc, totals, stream: int, raw: bool = False, ws: Optional[Tensor] = None):
+        """Phase B on `stream` (the current torch stream must be that stream: the feature gathers follow it).  ws: the
+        workspace phase A of this batch ran in (default: the sampler's own)."""
+        ws = self._ws if ws is None else ws
         nu, na, ne, nl = totals
         B = seeds.numel()
         L = _lib.lib()
@@ -154,7 +156,7 @@ class DeviceGraphSampler:
         labels = t.empty(nl, dtype=t.int64, device=dev)
         user_ptr = t.empty(B + 1, dtype=t.int64, device=dev)
         article_ptr = t.empty(B + 1, dtype=t.int64, device=dev)
-        check(L.mi_sampler_emit(ctypes.byref(desc), seeds.data_ptr(), self._ws.data_ptr(), self._ws.numel(), tot,
+        check(L.mi_sampler_emit(ctypes.byref(desc), seeds.data_ptr(), ws.data_ptr(), ws.numel(), tot,
                                 user_ids.data_ptr(), article_ids.data_ptr(), edge_index.data_ptr() if ne else None,
                                 label_index.data_ptr(), labels.data_ptr(), user_ptr.data_ptr(), article_ptr.data_ptr(),
                                 stream), "mi_sampler_emit")
@@ -165,7 +167,7 @@ class DeviceGraphSampler:
             a_rowptr = t.empty(na + 1, dtype=t.int32, device=dev)
             u_col, a_col = t.empty(ne, dtype=t.int32, device=dev), t.empty(ne, dtype=t.int32, device=dev)
             cursor = t.empty(max(na, 1), dtype=t.int32, device=dev)
-            check(L.mi_sampler_emit_csr(ctypes.byref(desc), self._ws.data_ptr(), self._ws.numel(), tot, u_rowptr.data_ptr(),
+            check(L.mi_sampler_emit_csr(ctypes.byref(desc), ws.data_ptr(), ws.numel(), tot, u_rowptr.data_ptr(),
                                         u_col.data_ptr() if ne else None, a_rowptr.data_ptr(), a_col.data_ptr() if ne else None,
                                         cursor.data_ptr(), stream), "mi_sampler_emit_csr")
             # (rows = customers, rows = articles): by-source and by-destination forms of the customer -> article relation
@@ -195,7 +197,7 @@ class DeviceGraphSampler:
 
     def __iter__(self) -> Iterator[HeteroData]:
         """One epoch: every user once, shuffled (DataLoader(shuffle=True) semantics).  With `prefetch` (default)
-        sampling runs two batches ahead on a side stream while the consumer trains on batch i: nothing of the
+        sampling runs three batches ahead on a side stream while the consumer trains on batch i: nothing of the
         sampler sits between two steps.  Same batches, same order, same Philox steps as the serial loop."""
         g = t.Generator(device="cpu").manual_seed(self.seed + self.step)
         order = t.randperm(self.num_users, generator=g) if self.shuffle else t.arange(self.num_users)
@@ -206,29 +208,38 @@ class DeviceGraphSampler:
             return
         L = _lib.lib()
         main = t.cuda.current_stream(self.device)
+        DEPTH = 3   # batches in flight: the walk of batch i + 3 is enqueued while the consumer trains on batch i (see below)
         if getattr(self, "_side", None) is None:
             self._side = t.cuda.Stream(device=self.device)
-            self._pinned = [t.empty(4, dtype=t.int32).pin_memory() for _ in range(2)]
+            self._pinned = [t.empty(4, dtype=t.int32).pin_memory() for _ in range(DEPTH)]
+            # a workspace per batch in flight: phase A of batch j + DEPTH may be enqueued before phase B of batch j + 1 ...
+            self._ws_ring = [self._ws] + [t.empty_like(self._ws) for _ in range(DEPTH - 1)]
         side = self._side
         step0 = self.step
 
-        def start(i: int):  # phase A of batch i, enqueued on the side stream, no host wait
-            with t.cuda.stream(side):
-                seeds = batches[i].to(self.device, t.int64).contiguous()
-                desc = self._desc if seeds.numel() == self.batch_size else self._make_desc(seeds.numel())
-                check(L.mi_sampler_count_async(ctypes.byref(desc), seeds.data_ptr(), self.seed & (2**64 - 1),
-                                               int(step0 + i) & (2**64 - 1), self._ws.data_ptr(), self._ws.numel(),
-                                               self._pinned[i % 2].data_ptr(), side.cuda_stream), "mi_sampler_count_async")
-                ev = t.cuda.Event()
-                ev.record(side)
+        # the epoch's seed order goes to the device ONCE (round 4: a 24-element host-to-device copy per batch was 40 us of the
+        # loop's host time — the loop is host-bound, tools/prof_host_native.py); a batch's seeds are a view of it
+        order_dev = order.to(self.device, t.int64)
+        batches_dev = [order_dev[b:b + self.batch_size] for b in range(0, self.num_users, self.batch_size)]
+
+        side_raw = side.cuda_stream
+
+        def start(i: int):  # phase A of batch i, enqueued on the side stream (raw handle: no torch op, no stream context), no host wait
+            seeds = batches_dev[i]
+            desc = self._desc if seeds.numel() == self.batch_size else self._make_desc(seeds.numel())
+            check(L.mi_sampler_count_async(ctypes.byref(desc), seeds.data_ptr(), self.seed & (2**64 - 1),
+                                           int(step0 + i) & (2**64 - 1), self._ws_ring[i % DEPTH].data_ptr(), self._ws_ring[i % DEPTH].numel(),
+                                           self._pinned[i % DEPTH].data_ptr(), side_raw), "mi_sampler_count_async")
+            ev = t.cuda.Event()
+            ev.record(side)
             return seeds, desc, ev
 
         def finish(i: int, pend):  # phase B of batch i on the side stream, once its four totals have landed
             seeds, desc, ev = pend
             ev.synchronize()
-            totals = self._pinned[i % 2].tolist()
+            totals = self._pinned[i % DEPTH].tolist()
             with t.cuda.stream(side):
-                data = self._emit(seeds, desc, totals, side.cuda_stream)
+                data = self._emit(seeds, desc, totals, side_raw, ws=self._ws_ring[i % DEPTH])
                 ready = t.cuda.Event()
                 ready.record(side)
             return data, ready
@@ -245,9 +256,13 @@ class DeviceGraphSampler:
                 c.col.record_stream(main)
             return data
 
-        # Two batches ahead: while the consumer trains on batch i, batch i+1 is complete (or being emitted) and the walk
-        # of batch i+2 is running; the wait in finish(i+1) is on work enqueued a whole training step earlier.  One
-        # workspace serves all of it because the side stream runs count(i+1), emit(i+1), count(i+2), ... in order.
+        # THREE batches ahead (round 4; two before): while the consumer trains on batch i, batch i+1 is being emitted and the
+        # walks of batches i+2 and i+3 are queued behind it.  With two, finish(i+2) waited for a walk that had been enqueued
+        # only one host-side step issue (~0.2 ms) earlier — the walk + emit chain of a batch is ~0.3 ms of side-stream kernels
+        # plus ~0.15 ms of host work, and the loop ran at THAT period (0.47 ms) although the step's kernels take 0.41 and the
+        # host issues an iteration in ~0.3 (tools/prof_host_native.py).  Now the wait is on work enqueued a whole iteration
+        # earlier.  Side-stream order: ... emit(i+1), count(i+3), emit(i+2), count(i+4) ...; batch j works in workspace j mod 3,
+        # so count(j+3) overwrites workspace j mod 3 only after emit(j) — same stream, enqueued earlier.
         side.wait_stream(main)
         nb = len(batches)
         if getattr(self, "prefetch", True) == "thread":
@@ -295,12 +310,13 @@ class DeviceGraphSampler:
                 sys.setswitchinterval(interval)
                 t.cuda.current_stream(self.device).wait_stream(side)
             return
-        cur = finish(0, start(0))
-        pend = start(1) if nb > 1 else None
+        pend = {j: start(j) for j in range(min(DEPTH, nb))}      # phase A of the first DEPTH batches
+        cur = finish(0, pend.pop(0))
         for i in range(nb):
             data, ready = cur
             if i + 1 < nb:
-                cur = finish(i + 1, pend)
-                pend = start(i + 2) if i + 2 < nb else None
+                cur = finish(i + 1, pend.pop(i + 1))
+                if i + DEPTH < nb:
+                    pend[i + DEPTH] = start(i + DEPTH)
             self.step = step0 + i + 1
             yield hand_out(data, ready)

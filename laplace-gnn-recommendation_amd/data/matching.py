@@ -94,10 +94,10 @@ class UsersWithCommonItemsMatcher(Matcher):
         dev = t.device(device)
         if dev.type == "cuda" and dev.index is None:       # "cuda" and "cuda:0" are the same place: compare normalised devices
             dev = t.device("cuda", t.cuda.current_device())
-        if num_users > self.location_for_user.size:
-            raise IndexError(f"{num_users} query users but location_for_user has {self.location_for_user.size} entries")
+        if num_users > len(self.users):
+            raise IndexError(f"{num_users} query users but the purchase lists cover {len(self.users)}")
         if getattr(self, "_dev", None) is None or self._dev[0].device != dev:
-            to32 = lambda a: t.from_numpy(np.ascontiguousarray(a.astype(np.int32))).to(device)
+            to32 = lambda a: t.from_numpy(np.ascontiguousarray(a.astype(np.int32))).to(dev)
             self._dev = (to32(self.users.ptr), to32(self.users.idx), to32(self.articles.ptr), to32(self.articles.idx))
         out, _ = ops.match_common_items(*self._dev, self.k, n_queries=num_users)
         return out.to(t.int64)

@@ -221,12 +221,15 @@ class NativePinSAGEStep:
         need = int(L.mi_pinsage_step_workspace_bytes(ctypes.byref(d), ctypes.byref(b)))
         if self._ws is None or self._ws.numel() < need:
             self._ws = t.empty(int(need * 1.25) + (1 << 20), dtype=t.uint8, device=seeds.device)
-        rc = L.mi_pinsage_step_check(ctypes.byref(d), ctypes.byref(b), self._ws.data_ptr(), self._ws.numel())
-        if rc == _lib.MI_ERR_UNSUPPORTED:
-            self.declined = "mi_pinsage_step_f32: MI_ERR_UNSUPPORTED (shape outside the executor's)"
-            self._desc = None      # the caller's own step may leave anything in the gradient buffers: start clean next time
-            return None
-        _lib.check(rc, "mi_pinsage_step_check")
+        import torch.distributed as dist
+        if self.data_parallel and dist.is_initialized() and dist.get_world_size(self.group) > 1:
+            # the validation pass on its own only where the ranks must agree before anything is enqueued
+            rc = L.mi_pinsage_step_check(ctypes.byref(d), ctypes.byref(b), self._ws.data_ptr(), self._ws.numel())
+            if rc == _lib.MI_ERR_UNSUPPORTED:
+                self.declined = "mi_pinsage_step_f32: MI_ERR_UNSUPPORTED (shape outside the executor's)"
+                self._desc = None      # the caller's own step may leave anything in the gradient buffers: start clean next time
+                return None
+            _lib.check(rc, "mi_pinsage_step_check")
         return d, b, loss, (keep, ones, seeds, pu, pv, nv)
 
     def step(self, batch: dict) -> Optional[Tensor]:
@@ -252,8 +255,12 @@ class NativePinSAGEStep:
         group = self.optimizer.param_groups[0]
         L = _lib.lib()
         rc = L.mi_pinsage_step_f32(ctypes.byref(d), ctypes.byref(b), self._ws.data_ptr(), self._ws.numel(), _lib.current_stream())
-        if rc == _lib.MI_ERR_UNSUPPORTED:      # cannot happen: mi_pinsage_step_check took the same descriptors
-            raise _lib.MiError("mi_pinsage_step_f32 declined a batch its own validation pass had accepted")
+        if rc == _lib.MI_ERR_UNSUPPORTED:
+            if world > 1:                      # cannot happen: mi_pinsage_step_check took the same descriptors
+                raise _lib.MiError("mi_pinsage_step_f32 declined a batch its own validation pass had accepted")
+            self.declined = "mi_pinsage_step_f32: MI_ERR_UNSUPPORTED (shape outside the executor's)"
+            self._desc = None      # the caller's own step may leave anything in the gradient buffers: start clean next time
+            return None
         _lib.check(rc, "mi_pinsage_step_f32")
         self.iteration += 1
         if self.data_parallel:

@@ -47,8 +47,10 @@ class NativeRankerStep:
         self.seed = int(t.initial_seed() if seed is None else seed) & ((1 << 64) - 1)
         self.iteration = 0
         self._desc: Optional[RankerModel] = None
+        self._snapshot = None      # the pointers the descriptor was built from, as Python ints (see _params_current)
         self._keep = []            # tensors the descriptor points into
         self._ws: Optional[Tensor] = None
+        self._ws_dims = None       # the largest (customers, articles, edges, label edges) the workspace was sized for
         self._adam_step = 0
         self.declined: Optional[str] = None
         # a second stream for the customer-side twins of independent launch pairs (mi_ranker_batch.aux_stream).  OFF by
@@ -200,24 +202,41 @@ class NativeRankerStep:
 
     def _params_current(self, d: RankerModel) -> bool:
         """The descriptor holds raw pointers: rebuilt when a parameter, gradient, optimizer-state, BatchNorm buffer or
-        embedding table was replaced (zero_grad(set_to_none=True), model.to(...), load of a new optimizer state, ...)."""
-        group = self.optimizer.param_groups[0]
-        if d.n_params != len(group["params"]):
+        embedding table was replaced (zero_grad(set_to_none=True), model.to(...), load of a new optimizer state, ...).
+        Compared against plain Python ints captured at build time: reading the pointers back out of the ctypes descriptor
+        (four fields x ~25 tensors) was 30 us of a host-bound 0.47 ms iteration (round 4, tools/prof_host_native.py)."""
+        snap = self._snapshot
+        if snap is None:
             return False
-        for i, p in enumerate(group["params"]):
-            st = self.optimizer.state.get(p)
-            if (p.grad is None or not st or d.params[i].p != p.data_ptr() or d.params[i].g != p.grad.data_ptr()
-                    or d.params[i].m != st["exp_avg"].data_ptr() or d.params[i].v != st["exp_avg_sq"].data_ptr()):
+        params = self.optimizer.param_groups[0]["params"]
+        if len(params) != len(snap[0]):
+            return False
+        state = self.optimizer.state
+        for p, (q, pp, gp, mp, vp) in zip(params, snap[0]):
+            g = p.grad
+            st = state.get(p)
+            if (p is not q or g is None or not st or p.data_ptr() != pp or g.data_ptr() != gp or st["exp_avg"].data_ptr() != mp
+                    or st["exp_avg_sq"].data_ptr() != vp):
                 return False
-        model = self.model
-        for ti, (key, bn) in enumerate(((Constants.node_user, model.encoder_layer_norm_customer),
-                                        (Constants.node_item, model.encoder_layer_norm_article))):
-            if bn.track_running_stats and d.norm[ti].running_mean != bn.running_mean.data_ptr():
+        for tensor_of, ptr in snap[1]:
+            if tensor_of().data_ptr() != ptr:
                 return False
-            for c, tb in enumerate(model.embedding_layers[key]):
-                if d.tables[ti][c] != tb.data_ptr():
-                    return False
         return True
+
+    def _take_snapshot(self) -> None:
+        params = self.optimizer.param_groups[0]["params"]
+        state = self.optimizer.state
+        rows = [(p, p.data_ptr(), p.grad.data_ptr(), state[p]["exp_avg"].data_ptr(), state[p]["exp_avg_sq"].data_ptr()) for p in params]
+        model = self.model
+        others = []
+        for key, name in ((Constants.node_user, "encoder_layer_norm_customer"), (Constants.node_item, "encoder_layer_norm_article")):
+            bn = getattr(model, name)
+            if bn.track_running_stats:
+                others.append((lambda bn=bn: bn.running_mean, bn.running_mean.data_ptr()))
+            tables = model.embedding_layers[key]
+            for c in range(len(tables)):
+                others.append((lambda tables=tables, c=c: tables[c], tables[c].data_ptr()))
+        self._snapshot = (rows, others)
 
     # ------------------------------------------------------------------------------------------
     def _prepare(self, x_dict: Dict[str, Tensor], edge_index_dict: dict, edge_label_index: Tensor, labels: Tensor):
@@ -255,6 +274,7 @@ class NativeRankerStep:
             by_a = ops.coo_to_csr(dst, src, n_a, n_c, want_perm=False)
         if self._desc is None or not self._params_current(self._desc):
             self._desc = self._build()
+            self._take_snapshot()
         d = self._desc
         p = model.encoder.p_dropout_features
         d.p_dropout = float(p) if p else 0.0
@@ -286,14 +306,23 @@ class NativeRankerStep:
         if self._aux is not None:
             b.aux_stream, b.ev_fork, b.ev_join = self._aux[0].cuda_stream, self._aux[1].cuda_event, self._aux[2].cuda_event
         L = _lib.lib()
-        need = int(L.mi_ranker_step_workspace_bytes(ctypes.byref(d), ctypes.byref(b)))
-        if self._ws is None or self._ws.numel() < need:
-            self._ws = t.empty(int(need * 1.25) + (1 << 20), dtype=t.uint8, device=xc.device)
-        rc = L.mi_ranker_step_check(ctypes.byref(d), ctypes.byref(b), self._ws.data_ptr(), self._ws.numel())
-        if rc == _lib.MI_ERR_UNSUPPORTED:
-            self.declined = "mi_ranker_step_f32: MI_ERR_UNSUPPORTED (shape outside the executor's)"
-            return None
-        _lib.check(rc, "mi_ranker_step_check")
+        dims = (n_c, n_a, int(by_c.nnz), n_lab, d.p_dropout > 0.0)
+        sized = self._ws_dims      # (dims of the largest batch the counting pass has seen, its byte count)
+        if self._ws is None or sized is None or dims[4] != sized[0][4] or any(x > y for x, y in zip(dims[:4], sized[0][:4])):
+            # the workspace is a sum of arrays proportional to these four counts, so a batch no larger in ANY of them than one the
+            # counting pass has sized needs no more than that one: the pass (a host walk of the whole iteration) is skipped for it
+            need = int(L.mi_ranker_step_workspace_bytes(ctypes.byref(d), ctypes.byref(b)))
+            if self._ws is None or self._ws.numel() < need:
+                self._ws = t.empty(int(need * 1.25) + (1 << 20), dtype=t.uint8, device=xc.device)
+            if sized is None or dims[4] != sized[0][4] or need >= sized[1]:
+                self._ws_dims = (dims, need)
+        if self._world() > 1:    # the validation pass on its own only where the ranks must agree BEFORE anything is enqueued;
+            #                      a single process lets mi_ranker_step_f32 run it (the loop is host-bound: every call counts)
+            rc = L.mi_ranker_step_check(ctypes.byref(d), ctypes.byref(b), self._ws.data_ptr(), self._ws.numel())
+            if rc == _lib.MI_ERR_UNSUPPORTED:
+                self.declined = "mi_ranker_step_f32: MI_ERR_UNSUPPORTED (shape outside the executor's)"
+                return None
+            _lib.check(rc, "mi_ranker_step_check")
         return d, b, loss, steps, (xc, xa, row, col, labels, ones, by_c, by_a)
 
     def _world(self) -> int:
@@ -328,8 +357,16 @@ class NativeRankerStep:
         group = self.optimizer.param_groups[0]
         L = _lib.lib()
         rc = L.mi_ranker_step_f32(ctypes.byref(d), ctypes.byref(b), self._ws.data_ptr(), self._ws.numel(), _lib.current_stream())
-        if rc == _lib.MI_ERR_UNSUPPORTED:      # cannot happen: mi_ranker_step_check took the same descriptors
-            raise _lib.MiError("mi_ranker_step_f32 declined a batch its own validation pass had accepted")
+        if rc == _lib.MI_ERR_WORKSPACE:        # (found by the validation pass: nothing enqueued) the skipped counting pass after all
+            need = int(L.mi_ranker_step_workspace_bytes(ctypes.byref(d), ctypes.byref(b)))
+            self._ws = t.empty(int(need * 1.25) + (1 << 20), dtype=t.uint8, device=self._ws.device)
+            self._ws_dims = None
+            rc = L.mi_ranker_step_f32(ctypes.byref(d), ctypes.byref(b), self._ws.data_ptr(), self._ws.numel(), _lib.current_stream())
+        if rc == _lib.MI_ERR_UNSUPPORTED:
+            if self._world() > 1:              # cannot happen: mi_ranker_step_check took the same descriptors
+                raise _lib.MiError("mi_ranker_step_f32 declined a batch its own validation pass had accepted")
+            self.declined = "mi_ranker_step_f32: MI_ERR_UNSUPPORTED (shape outside the executor's)"
+            return None
         _lib.check(rc, "mi_ranker_step_f32")
         self.iteration += 1
         if self.before_step is not None:       # gradients are in param.grad: exchange them, then torch's own update

@@ -13,7 +13,7 @@ sys.path.insert(0, ROOT)
 
 
 def bench_line(full: bool = True, n_q: int = 16384, pre_only: bool = False, cpu_loop: bool = True, streams: int = 0, ws_gib: float = 0.0,
-               dim: int = 128) -> dict:
+               dim: int = 128, ks=(12, 256)) -> dict:
     import torch as t
     from laplace_amd import ops, synthetic as S
     if streams:
@@ -37,7 +37,7 @@ def bench_line(full: bool = True, n_q: int = 16384, pre_only: bool = False, cpu_
     # default path first (bf16x3 prefilter + exact rescoring), then the f32 fused kernel (LAPLACE_TOPK_PREFILTER=0)
     for mode, tag in ((("1", ""),) if pre_only else (("1", ""), ("0", "_f32_path"))):
         os.environ["LAPLACE_TOPK_PREFILTER"] = mode
-        for k in (12, 256):
+        for k in ks:
             ops.topk_excl(uid[:4096], ue, ie, k, ops.row_slice(r, 0, 4096))
             t.cuda.synchronize()
             best = None
@@ -74,7 +74,8 @@ def main():
     streams = int(sys.argv[sys.argv.index("--streams") + 1]) if "--streams" in sys.argv else 0
     ws_gib = float(sys.argv[sys.argv.index("--ws-gib") + 1]) if "--ws-gib" in sys.argv else 0.0
     print(json.dumps(bench_line(full="--full" in sys.argv, n_q=n_q, pre_only="--pre-only" in sys.argv, streams=streams, ws_gib=ws_gib,
-                                dim=int(sys.argv[sys.argv.index("--dim") + 1]) if "--dim" in sys.argv else 128)))
+                                dim=int(sys.argv[sys.argv.index("--dim") + 1]) if "--dim" in sys.argv else 128,
+                                ks=tuple(int(x) for x in sys.argv[sys.argv.index("--ks") + 1].split(",")) if "--ks" in sys.argv else (12, 256))))
 
 
 if __name__ == "__main__":
