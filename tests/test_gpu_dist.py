@@ -104,3 +104,33 @@ def test_two_ranks_on_one_gpu_equal_the_single_process_reference(sparse_batch, r
     assert (r0["table"][U0:] - iw.detach()).abs().max() <= tol
     assert (r0["final"][:U0] - wu[:U0]).abs().max() <= tol and (r1["final"][:U1] - wu[U0:]).abs().max() <= tol
     assert (r0["final"][U0:] - wi).abs().max() <= tol and (r1["final"][U1:] - wi).abs().max() <= tol
+
+
+def test_bench_c4_four_ranks_on_one_card_smoke():
+    """`bench.py --gpus 4` (the default configuration: BASELINE configs[3], ONE graph sharded by user over the ranks, strong
+    scaling) rehearsed on this one-GPU box: the parent starts four fresh worker processes BEFORE anything touches the GPU (no
+    re-exec), the ranks share the card (LAPLACE_BENCH_ONE_GPU=1) and gloo carries the item-row exchanges.  A reduced graph
+    (64 000 x 2 000 x 640 000 in 64 user blocks, global batch 4 096), so that the line's bookkeeping is what is checked:
+    n_gpus, strong scaling, the global batch split four ways, the workload string.  Four ranks, not the eight the node run
+    uses: a GPU box of this pool allows at most six processes on the card at once (world sizes 4 and 8 of the sharded trainer
+    itself: tests/test_dist_world_sizes.py, gloo on the CPU)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, LAPLACE_BENCH_BACKEND="gloo", LAPLACE_BENCH_ONE_GPU="1", LAPLACE_BENCH_DEADLINE_S="300")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--users", "64000", "--items", "2000",
+                        "--edges", "640000", "--batch", "4096", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=420)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 4 and d["scaling"] == "strong" and d["steps"] == 3 and d["warmup"] == 1
+    assert d["unit"] == "positive-edges/s" and d["value"] > 0 and d["backend"] == "gloo"
+    w = d["config"]["workload"]
+    assert "sharded by user over 4 GPU(s)" in w and "16000 users" in w and "global batch 4096" in w and "configs[3]" in w
+    assert abs(d["value"] - 4096 * 3 / (d["ms_per_step"] * 3e-3)) / d["value"] < 1e-6      # whole-job edges / max-over-ranks time
+    assert d["roofline"]["dense_launches_per_step"] > 0 and "cpu_baseline" not in d
