@@ -754,6 +754,13 @@ int    mi_sampler_emit(const mi_sampler_desc* d, const int64_t* seed_users, void
                        const int64_t* totals_host, int64_t* user_ids, int64_t* article_ids,
                        int64_t* edge_index, int64_t* edge_label_index, int64_t* edge_label,
                        int64_t* user_ptr, int64_t* article_ptr, mi_stream_t stream);
+/* mi_sampler_emit with edge_index / edge_label_index written as [3, n] when three_rows != 0: row 2 repeats row 0, so rows 0..1
+ * are the `buys` relation's index and rows 1..2 the reversed relation's (`rev_buys`: data/dataset.py builds it with flip(0)) —
+ * two views of one buffer instead of two flip launches per batch (round 4). */
+int    mi_sampler_emit3(const mi_sampler_desc* d, const int64_t* seed_users, void* ws, size_t ws_bytes,
+                        const int64_t* totals_host, int64_t* user_ids, int64_t* article_ids,
+                        int64_t* edge_index, int64_t* edge_label_index, int64_t* edge_label,
+                        int64_t* user_ptr, int64_t* article_ptr, int32_t three_rows, mi_stream_t stream);
 int    mi_sampler_emit_csr(const mi_sampler_desc* d, void* ws, size_t ws_bytes, const int64_t* totals_host,
                            int32_t* customer_rowptr, int32_t* customer_col, int32_t* article_rowptr,
                            int32_t* article_col, int32_t* article_cursor, mi_stream_t stream);

@@ -238,6 +238,7 @@ _PROTOTYPES = {
     "mi_sampler_count": (c_int32, [POINTER(SamplerDesc), P, c_uint64, c_uint64, P, c_size_t, POINTER(c_int64), P]),
     "mi_sampler_count_async": (c_int32, [POINTER(SamplerDesc), P, c_uint64, c_uint64, P, c_size_t, P, P]),
     "mi_sampler_emit": (c_int32, [POINTER(SamplerDesc), P, P, c_size_t, POINTER(c_int64), P, P, P, P, P, P, P, P]),
+    "mi_sampler_emit3": (c_int32, [POINTER(SamplerDesc), P, P, c_size_t, POINTER(c_int64), P, P, P, P, P, P, P, c_int32, P]),
     "mi_sampler_emit_csr": (c_int32, [POINTER(SamplerDesc), P, c_size_t, POINTER(c_int64), P, P, P, P, P, P]),
     "mi_pinsage_item_pairs": (c_int32, [c_int64, c_int64, P, P, P, P, c_uint64, c_uint64, P, P, P, P]),
     "mi_pinsage_neighbors_workspace_bytes": (c_size_t, [c_int64, c_int32, c_int32]),

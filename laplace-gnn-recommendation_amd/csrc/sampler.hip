@@ -666,6 +666,7 @@ struct SmpOut {
     int64_t* label_index; int64_t n_labels;      // [2, n_labels]
     int64_t* labels;                             // [n_labels]
     int64_t* user_ptr; int64_t* article_ptr;     // [B+1]
+    int32_t three_rows;                          // edge_index / label_index are [3, n]: row 2 repeats row 0 (rows 1..2 = the reversed relation)
 };
 
 __device__ __forceinline__ int32_t article_rank(const Smp& p, int s, int32_t a) {
@@ -685,6 +686,7 @@ __global__ __launch_bounds__(256) void smp_emit_edges_kernel(Smp p, SmpOut o) {
             const int32_t a = q < np_ ? p.pos_items[(int64_t)s * p.max_pos + q] : p.neg_items[(int64_t)s * p.max_neg + q - np_];
             o.label_index[off_l + q] = off_u + seed_local;
             o.label_index[o.n_labels + off_l + q] = off_a + article_rank(p, s, a);
+            if (o.three_rows) o.label_index[2 * o.n_labels + off_l + q] = off_u + seed_local;
             o.labels[off_l + q] = q < np_ ? 1 : 0;
         }
         if (threadIdx.x == 0) {
@@ -706,6 +708,7 @@ __global__ __launch_bounds__(256) void smp_emit_edges_kernel(Smp p, SmpOut o) {
     for (int x = threadIdx.x; x < deg; x += blockDim.x) {
         o.edge_index[off_e + es + x] = off_u + ul;
         o.edge_index[o.n_edges + off_e + es + x] = off_a + article_rank(p, s, p.uidx[beg + x]);
+        if (o.three_rows) o.edge_index[2 * o.n_edges + off_e + es + x] = off_u + ul;
     }
 }
 
@@ -1012,6 +1015,14 @@ int mi_sampler_emit(const mi_sampler_desc* d, const int64_t* seed_users, void* w
                     const int64_t* totals_host, int64_t* user_ids, int64_t* article_ids, int64_t* edge_index,
                     int64_t* edge_label_index, int64_t* edge_label, int64_t* user_ptr, int64_t* article_ptr,
                     mi_stream_t stream) {
+    return mi_sampler_emit3(d, seed_users, ws, ws_bytes, totals_host, user_ids, article_ids, edge_index, edge_label_index, edge_label,
+                            user_ptr, article_ptr, 0, stream);
+}
+
+int mi_sampler_emit3(const mi_sampler_desc* d, const int64_t* seed_users, void* ws, size_t ws_bytes,
+                     const int64_t* totals_host, int64_t* user_ids, int64_t* article_ids, int64_t* edge_index,
+                     int64_t* edge_label_index, int64_t* edge_label, int64_t* user_ptr, int64_t* article_ptr,
+                     int32_t three_rows, mi_stream_t stream) {
     Smp p;
     int rc = fill_params(p, d);
     if (rc) return rc;
@@ -1025,6 +1036,7 @@ int mi_sampler_emit(const mi_sampler_desc* d, const int64_t* seed_users, void* w
     o.edge_index = edge_index; o.n_edges = totals_host[2];
     o.label_index = edge_label_index; o.n_labels = totals_host[3];
     o.labels = edge_label; o.user_ptr = user_ptr; o.article_ptr = article_ptr;
+    o.three_rows = three_rows ? 1 : 0;
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(smp_emit_edges_kernel, dim3(1 + p.H * p.n, p.B), dim3(256), 0, s, p, o);
     hipLaunchKernelGGL(smp_emit_articles_kernel, dim3((p.WA + 255) / 256, p.B), dim3(256), 0, s, p, o);

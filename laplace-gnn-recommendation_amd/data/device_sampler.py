@@ -149,29 +149,42 @@ class DeviceGraphSampler:
         L = _lib.lib()
         tot = (ctypes.c_int64 * 4)(nu, na, ne, nl)
         dev = self.device
-        user_ids = t.empty(nu, dtype=t.int64, device=dev)
-        article_ids = t.empty(na, dtype=t.int64, device=dev)
-        edge_index = t.empty(2, ne, dtype=t.int64, device=dev)
-        label_index = t.empty(2, nl, dtype=t.int64, device=dev)
-        labels = t.empty(nl, dtype=t.int64, device=dev)
-        user_ptr = t.empty(B + 1, dtype=t.int64, device=dev)
-        article_ptr = t.empty(B + 1, dtype=t.int64, device=dev)
-        check(L.mi_sampler_emit(ctypes.byref(desc), seeds.data_ptr(), ws.data_ptr(), ws.numel(), tot,
-                                user_ids.data_ptr(), article_ids.data_ptr(), edge_index.data_ptr() if ne else None,
-                                label_index.data_ptr(), labels.data_ptr(), user_ptr.data_ptr(), article_ptr.data_ptr(),
-                                stream), "mi_sampler_emit")
+        # ONE int64 block and ONE int32 block per batch, the outputs are views of them (round 4: 18 allocations per batch and
+        # 14 record_stream calls were a visible part of a host-bound loop).  edge_index / edge_label_index are written as
+        # [3, n] — row 2 repeats row 0 — so the reversed relation's index (data/dataset.py: flip(0)) is rows 1..2 of the same
+        # buffer: a view, not two flip launches.
+        r4 = lambda n: (n + 3) & ~3                      # every piece starts on a 32-byte (int64) / 16-byte (int32) boundary
+        sizes = (r4(nu), r4(na), r4(3 * ne), r4(3 * nl), r4(nl), r4(B + 1), r4(B + 1))
+        blk = t.empty(sum(sizes), dtype=t.int64, device=dev)
+        off, parts = 0, []
+        for n_alloc in sizes:
+            parts.append(off)
+            off += n_alloc
+        user_ids, article_ids = blk[parts[0]:parts[0] + nu], blk[parts[1]:parts[1] + na]
+        edge3 = blk[parts[2]:parts[2] + 3 * ne].view(3, ne)
+        label3 = blk[parts[3]:parts[3] + 3 * nl].view(3, nl)
+        labels = blk[parts[4]:parts[4] + nl]
+        user_ptr, article_ptr = blk[parts[5]:parts[5] + B + 1], blk[parts[6]:parts[6] + B + 1]
+        edge_index, label_index = edge3[0:2], label3[0:2]
+        check(L.mi_sampler_emit3(ctypes.byref(desc), seeds.data_ptr(), ws.data_ptr(), ws.numel(), tot,
+                                 user_ids.data_ptr(), article_ids.data_ptr(), edge3.data_ptr() if ne else None,
+                                 label3.data_ptr(), labels.data_ptr(), user_ptr.data_ptr(), article_ptr.data_ptr(), 1,
+                                 stream), "mi_sampler_emit3")
         csr = None
+        blocks = [blk]
         if getattr(self, "emit_csr", False):
             from .. import ops
-            u_rowptr = t.empty(nu + 1, dtype=t.int32, device=dev)
-            a_rowptr = t.empty(na + 1, dtype=t.int32, device=dev)
-            u_col, a_col = t.empty(ne, dtype=t.int32, device=dev), t.empty(ne, dtype=t.int32, device=dev)
-            cursor = t.empty(max(na, 1), dtype=t.int32, device=dev)
+            s32 = (r4(nu + 1), r4(na + 1), r4(ne), r4(ne), r4(max(na, 1)))
+            b32 = t.empty(sum(s32), dtype=t.int32, device=dev)
+            o0, o1, o2, o3 = s32[0], s32[0] + s32[1], s32[0] + s32[1] + s32[2], s32[0] + s32[1] + s32[2] + s32[3]
+            u_rowptr, a_rowptr = b32[0:nu + 1], b32[o0:o0 + na + 1]
+            u_col, a_col, cursor = b32[o1:o1 + ne], b32[o2:o2 + ne], b32[o3:o3 + max(na, 1)]
             check(L.mi_sampler_emit_csr(ctypes.byref(desc), ws.data_ptr(), ws.numel(), tot, u_rowptr.data_ptr(),
                                         u_col.data_ptr() if ne else None, a_rowptr.data_ptr(), a_col.data_ptr() if ne else None,
                                         cursor.data_ptr(), stream), "mi_sampler_emit_csr")
             # (rows = customers, rows = articles): by-source and by-destination forms of the customer -> article relation
             csr = (ops.DeviceCSR(nu, na, u_rowptr, u_col), ops.DeviceCSR(na, nu, a_rowptr, a_col))
+            blocks.append(b32)
         if raw:
             out = {"user_ids": user_ids, "article_ids": article_ids, "edge_index": edge_index,
                     "edge_label_index": label_index, "edge_label": labels, "user_ptr": user_ptr, "article_ptr": article_ptr}
@@ -179,8 +192,9 @@ class DeviceGraphSampler:
                 out["csr_by_customer"], out["csr_by_article"] = csr
             return out
         data = HeteroData()
-        data[Constants.node_user].x = self.user_x[user_ids]
-        data[Constants.node_item].x = self.article_x[article_ids]
+        xc, xa = self.user_x[user_ids], self.article_x[article_ids]
+        data[Constants.node_user].x = xc
+        data[Constants.node_item].x = xa
         data[Constants.node_user].n_id = user_ids
         data[Constants.node_item].n_id = article_ids
         if csr is not None:
@@ -188,11 +202,12 @@ class DeviceGraphSampler:
         data[Constants.edge_key].edge_index = edge_index
         data[Constants.edge_key].edge_label_index = label_index
         data[Constants.edge_key].edge_label = labels
-        rev = edge_index.flip(0)
-        rev._reverse_of = edge_index  # lets the encoder reuse the forward relation's sorted CSRs (model/layers.py)
+        rev = edge3[1:3]                  # = edge_index.flip(0): rows (article, customer)
+        rev._reverse_of = edge_index      # lets the encoder reuse the forward relation's sorted CSRs (model/layers.py)
         data[Constants.rev_edge_key].edge_index = rev
-        data[Constants.rev_edge_key].edge_label_index = label_index.flip(0)
+        data[Constants.rev_edge_key].edge_label_index = label3[1:3]
         data[Constants.rev_edge_key].edge_label = labels
+        data._blocks = blocks + [xc, xa]  # the storages behind every tensor of the batch (the iterator's record_stream calls)
         return data
 
     def __iter__(self) -> Iterator[HeteroData]:
@@ -246,14 +261,8 @@ class DeviceGraphSampler:
 
         def hand_out(data, ready):
             main.wait_event(ready)
-            for store in (data[Constants.node_user], data[Constants.node_item], data[Constants.edge_key],
-                          data[Constants.rev_edge_key]):
-                for v in store.values():
-                    if isinstance(v, Tensor):
-                        v.record_stream(main)
-            for c in getattr(data[Constants.edge_key].edge_index, "_sorted_csr", ()):
-                c.rowptr.record_stream(main)
-                c.col.record_stream(main)
+            for blk in data._blocks:      # every tensor of the batch is a view of one of these storages
+                blk.record_stream(main)
             return data
 
         # THREE batches ahead (round 4; two before): while the consumer trains on batch i, batch i+1 is being emitted and the
