@@ -112,7 +112,7 @@ class PinSAGESampler:
         host = t.empty(2 + 2 * NL, dtype=t.int32).pin_memory() if dev.type == "cuda" else t.empty(2 + 2 * NL, dtype=t.int32)
         return dict(out=out, seeds=seeds, pos_u=pos_u, pos_v=pos_v, neg_v=neg_v, counts=counts, bufs=bufs, ws=ws, host=host)
 
-    def _launch_batch(self, step: int, buf: Optional[dict] = None) -> Optional[dict]:
+    def _launch_batch(self, step: int, buf: Optional[dict] = None, pos32: Optional[Tensor] = None) -> Optional[dict]:
         """Enqueue the whole batch (one C call, six launches for two layers) and the copy of its counts to pinned host
         memory on the current stream; None when the sizes are outside the single-workgroup kernels'."""
         if self.n_layers > _lib.MI_PINSAGE_MAX_LAYERS:
@@ -120,7 +120,7 @@ class PinSAGESampler:
         buf = buf if buf is not None else self._batch_buffers()
         desc = _lib.PinsageBatchDesc(self.batch_size, self.num_items, self.iu_ptr.data_ptr(), self.iu_idx.data_ptr(),
                                      self.ui_ptr.data_ptr(), self.ui_idx.data_ptr(), self.L, self.W, self.T, self.n_layers, self.p,
-                                     self._pos32.data_ptr())
+                                     (self._pos32 if pos32 is None else pos32).data_ptr())
         rc = _lib.lib().mi_pinsage_sample_batch(ctypes.byref(desc), self.seed & (2**64 - 1), step, ctypes.byref(buf["out"]),
                                                 buf["ws"].data_ptr(), buf["ws"].numel(), self._stream())
         if rc == _lib.MI_ERR_UNSUPPORTED:
@@ -157,41 +157,48 @@ class PinSAGESampler:
         return self._finish_batch(buf)
 
     def batches(self, n: int):
-        """n training batches (steps self.step ...), batch i + 1 sampled on a side stream while the caller trains on batch
-        i: the walks, the block construction and the read-back of the counts leave the critical path (round 3: the
-        reference-default iteration 1.9 -> see profiles/r03_pinsage_n1.json).  Same batches as n calls of sample_batch().
-        Three rotating buffer sets: a batch's tensors stay valid until the caller has asked for the batch after the next."""
+        """n training batches (steps self.step ...), sampled AHEAD of the caller on two side streams: while the caller trains
+        on batch i, the chains of batches i + 1 and i + 2 are in flight, one per stream (round 4; one stream and one batch
+        ahead in round 3).  A batch is ~six dependent single-workgroup launches — a LATENCY chain of 0.25-0.33 ms that one
+        side stream runs back to back, so the loop ran at the sampler's period (0.318 ms at walk length 3 against ~0.2 ms of
+        step); two chains side by side do not compete for the chip (one workgroup each) and halve that period.  Each stream has
+        its own position scratch; four rotating buffer sets: a batch's tensors stay valid until the caller has asked for the
+        batch after the next.  Same batches as n calls of sample_batch()."""
         if not (self.device_batches and self.device.type == "cuda") or n <= 0:
             for _ in range(max(n, 0)):
                 yield self.sample_batch()
             return
         main = t.cuda.current_stream(self.device)
-        if getattr(self, "_side", None) is None:
-            self._side = t.cuda.Stream(device=self.device)
-            self._sets = [None, None, None]
-        side = self._side
+        LANES, SETS = 2, 4
+        if getattr(self, "_lanes", None) is None:
+            self._lanes = [t.cuda.Stream(device=self.device) for _ in range(LANES)]
+            self._lane_pos = [t.full_like(self._pos32, -1) for _ in range(LANES)]   # not the serial path's: an abandoned epoch's chains may still be running
+            self._sets = [None] * SETS
         first = self.step
 
         def launch(i: int):
-            k = i % 3
-            side.wait_stream(main)       # the set's previous batch (three back) has been consumed by then
-            with t.cuda.stream(side):
+            k, lane = i % SETS, self._lanes[i % LANES]
+            lane.wait_stream(main)       # the set's previous batch (four back) has been consumed by then
+            with t.cuda.stream(lane):
                 if self._sets[k] is None:
                     self._sets[k] = self._batch_buffers()
-                buf = self._launch_batch(first + i, self._sets[k])
+                buf = self._launch_batch(first + i, self._sets[k], pos32=self._lane_pos[i % LANES])
                 ev = t.cuda.Event()
-                ev.record(side)
+                ev.record(lane)
             return buf, ev
 
-        pending = launch(0)
+        pending = [launch(j) for j in range(min(LANES, n))]
         for i in range(n):
-            buf, ev = pending
+            buf, ev = pending.pop(0)
             if buf is None:              # sizes outside the device path: everything through sample_batch
                 self.step = first + i
+                for lane in self._lanes:
+                    lane.synchronize()
                 for _ in range(n - i):
                     yield self.sample_batch()
                 return
-            pending = launch(i + 1) if i + 1 < n else None
+            if i + LANES < n:
+                pending.append(launch(i + LANES))
             ev.synchronize()             # host: the counts are in pinned memory
             main.wait_event(ev)          # device: the batch's tensors are complete
             self.step = first + i + 1

@@ -336,7 +336,6 @@ def test_hybrid_plan_equals_the_banded_plan(d, tail_whole):
     assert (Yl - out["hybrid"][0][rl.long()]).abs().max() <= 1e-5 * scale
 
 
-
 @pytest.mark.parametrize("band,chunk", [(0, 256), (64, 256), (7, 50), (100, 1000), (1, 256)])
 def test_spmm_plan_structure(band, chunk):
     """The work items partition the entries of every split row, slots are contiguous per row, banded items stay

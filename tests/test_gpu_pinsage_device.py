@@ -97,7 +97,8 @@ def test_overlapped_batches_are_the_serial_batches():
             assert x.shape == y.shape and t.equal(x, y), i
         prev = batch
     assert b.step == a.step == 7
-    assert bool((b._pos32 == -1).all())
+    t.cuda.synchronize()
+    assert bool((b._pos32 == -1).all()) and all(bool((p == -1).all()) for p in b._lane_pos)   # every stream's scratch handed back clean
     again = [x for x in b.batches(2)]                                  # a second call continues the sequence
     want = [a.sample_batch() for _ in range(2)]
     for g, w in zip(again, want):

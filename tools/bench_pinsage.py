@@ -139,7 +139,7 @@ def run(args):
                                   f"T={args.neighbors}, {args.layers} layers, hidden {args.hidden}",
                       "iteration": ("native executor (mi_pinsage_step_f32)" + (" + compact-row exchange (mi_pinsage_apply_f32)" if world > 1 else ""))
                       if native is not None else "autograd, op by op",
-                      "sampling": "serial" if serial else "overlapped (side stream, one batch ahead)",
+                      "sampling": "serial" if serial else "overlapped (two side streams, two batches ahead)",
                       "ms_per_iteration": round(1e3 * dt / args.iters, 3), "positive_pairs_per_s": round(pairs / dt),
                       "sampler_ms_per_batch": round(1e3 * ds, 3), "loss": round(float(loss.detach()), 4)})
     if world > 1:
