@@ -448,6 +448,15 @@ int    mi_topk_excl_f32(int64_t n_q, int64_t n_items, int64_t d, int64_t k,
                         const int32_t* excl_ptr, const int32_t* excl_idx,
                         int64_t* out_idx, float* out_score /* nullable */,
                         void* ws, size_t ws_bytes, mi_stream_t stream);
+/* The same with flags.  MI_TOPK_ITEMS_PREPARED: `ws` still holds the ITEM side of the bf16 prefilter (the sampled item rows, the
+ * bf16 hi / lo split of the item table and of the sample, the largest |item|^2) from the previous call on this stream with
+ * the same item table, n_q, n_items, d and k — callers that cut one request into equal chunks of queries set it from the second
+ * chunk on (one split of a 100 K-item table is ~40 us of a ~550 us chunk).  Ignored on the paths without a prefilter. */
+#define MI_TOPK_ITEMS_PREPARED 1u
+int    mi_topk_excl_ex_f32(int64_t n_q, int64_t n_items, int64_t d, int64_t k, const int64_t* uid,
+                           const float* user_emb, int64_t ldu, const float* item_emb, int64_t ldi,
+                           const int32_t* excl_ptr, const int32_t* excl_idx, int64_t* out_idx,
+                           float* out_score, void* ws, size_t ws_bytes, uint32_t flags, mi_stream_t stream);
 
 /* Diagnostic of K10's bf16x3 prefilter (csrc/topk_prefilter.hpp), d = 64 / 128: scores[q, i] = the APPROXIMATE score the
  * prefilter compares with its thresholds, eps[q] = the bound it assumes, |scores[q, i] - exact fma chain| <= eps[q] for

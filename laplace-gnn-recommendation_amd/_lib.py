@@ -3,7 +3,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int32, c_int64, c_size_t, c_uint64, c_void_p
+from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int32, c_int64, c_size_t, c_uint32, c_uint64, c_void_p
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 # LAPLACE_HIP_LIB names a VARIANT build of the same library (A/B and timing probes under tools/): the product library in
@@ -51,6 +51,7 @@ class SpmmExStruct(Structure):
 MI_SPMM_SHORT_ROWS, MI_SPMM_SPLIT_ROWS = 1, 2
 MI_ERR_UNSUPPORTED = -4
 MI_ERR_WORKSPACE = -3
+MI_TOPK_ITEMS_PREPARED = 1
 
 
 class GemmProblem(Structure):
@@ -207,6 +208,8 @@ _PROTOTYPES = {
     "mi_topk_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int64]),
     "mi_topk_excl_f32": (c_int32, [c_int64, c_int64, c_int64, c_int64, P, P, c_int64, P, c_int64, P, P, P, P, P,
                                    c_size_t, P]),
+    "mi_topk_excl_ex_f32": (c_int32, [c_int64, c_int64, c_int64, c_int64, P, P, c_int64, P, c_int64, P, P, P, P, P,
+                                      c_size_t, c_uint32, P]),
     "mi_topk_prefilter_scores_workspace_bytes": (c_size_t, [c_int64, c_int64]),
     "mi_topk_prefilter_scores_f32": (c_int32, [c_int64, c_int64, c_int64, P, P, c_int64, P, c_int64, P, P, P, c_size_t, P]),
     "mi_segment_max_f32": (c_int32, [c_int64, c_int64, P, P, P, c_int64, P, c_int64, P, P]),

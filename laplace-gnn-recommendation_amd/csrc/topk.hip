@@ -1311,7 +1311,7 @@ static void topk_split_launch(int64_t n_rows, int64_t n_pad, const float* T, int
 template <int D>
 static int topk_prefilter_launch(FusedArgs& a, MiArena& ar, const float* Is, float* sample_scores, uint32_t* thr,
                                  const int32_t* excl_ptr, const int32_t* excl_idx, int k, int kpow2, float* scores,
-                                 int64_t* out_idx, float* out_score, int n_cu, hipStream_t s) {
+                                 int64_t* out_idx, float* out_score, int n_cu, bool items_ready, hipStream_t s) {
     const int64_t strips = mi_ceil_div(a.n_q, 256), q_pad = strips * 256;
     const int64_t panels = mi_ceil_div(a.n_items, 64), i_pad = panels * 64;
     uint2* Ib = reinterpret_cast<uint2*>(ar.take<float>((size_t)i_pad * 128));
@@ -1323,10 +1323,12 @@ static int topk_prefilter_launch(FusedArgs& a, MiArena& ar, const float* Is, flo
     unsigned long long* pre = ar.take<unsigned long long>((size_t)q_pad * kPreCap);
     int* pre_cnt = ar.take<int>((size_t)q_pad * 512);
     if (!Ib || !Ub || !Sb || !thrf || !epsv || !n2max || !pre || !pre_cnt) return MI_ERR_WORKSPACE;
-    MI_HIP(hipMemsetAsync(n2max, 0, sizeof(uint32_t), s));
-    topk_split_launch<D>(a.n_items, i_pad, a.I, a.ldi, nullptr, Ib, n2max, kSplitItems, nullptr, nullptr, n_cu, s);
+    if (!items_ready) {   // the item side: the same for every chunk of a call (MI_TOPK_ITEMS_PREPARED)
+        MI_HIP(hipMemsetAsync(n2max, 0, sizeof(uint32_t), s));
+        topk_split_launch<D>(a.n_items, i_pad, a.I, a.ldi, nullptr, Ib, n2max, kSplitItems, nullptr, nullptr, n_cu, s);
+        topk_split_launch<D>(kSample, kSample, Is, D, nullptr, Sb, n2max, kSplitPlain, nullptr, nullptr, n_cu, s);
+    }
     topk_split_launch<D>(a.n_q, q_pad, a.U, a.ldu, a.uid, Ub, n2max, kSplitQueries, thrf, epsv, n_cu, s);
-    topk_split_launch<D>(kSample, kSample, Is, D, nullptr, Sb, n2max, kSplitPlain, nullptr, nullptr, n_cu, s);
     PreArgs pa;
     memset(&pa, 0, sizeof(pa));
     pa.n_q = a.n_q; pa.n_items = a.n_items;
@@ -1396,7 +1398,15 @@ int mi_topk_excl_f32(int64_t n_q, int64_t n_items, int64_t d, int64_t k, const i
                      const float* user_emb, int64_t ldu, const float* item_emb, int64_t ldi,
                      const int32_t* excl_ptr, const int32_t* excl_idx, int64_t* out_idx,
                      float* out_score, void* ws, size_t ws_bytes, mi_stream_t stream) {
-    MI_CHECK_ARG(n_q >= 0 && n_items >= 0 && d > 0 && k > 0);
+    return mi_topk_excl_ex_f32(n_q, n_items, d, k, uid, user_emb, ldu, item_emb, ldi, excl_ptr, excl_idx, out_idx, out_score, ws, ws_bytes,
+                               0u, stream);
+}
+
+int mi_topk_excl_ex_f32(int64_t n_q, int64_t n_items, int64_t d, int64_t k, const int64_t* uid,
+                        const float* user_emb, int64_t ldu, const float* item_emb, int64_t ldi,
+                        const int32_t* excl_ptr, const int32_t* excl_idx, int64_t* out_idx,
+                        float* out_score, void* ws, size_t ws_bytes, uint32_t flags, mi_stream_t stream) {
+    MI_CHECK_ARG(n_q >= 0 && n_items >= 0 && d > 0 && k > 0 && (flags & ~(uint32_t)MI_TOPK_ITEMS_PREPARED) == 0);
     if (n_q == 0) return 0;
     if (k > kMaxK) return MI_ERR_UNSUPPORTED;
     if (n_items >= INT32_MAX) return MI_ERR_TOO_LARGE;
@@ -1420,19 +1430,24 @@ int mi_topk_excl_f32(int64_t n_q, int64_t n_items, int64_t d, int64_t k, const i
         int* cnt = ar.take<int>((size_t)n_q);
         unsigned long long* cand = ar.take<unsigned long long>((size_t)n_q * kCap);
         if (!Is || !sample_scores || !bitmap || !thr || !cnt || !cand) return MI_ERR_WORKSPACE;
-        hipLaunchKernelGGL(gather_sample_rows_kernel, dim3(kSample), dim3(64), 0, s, n_items, (int)d, item_emb, ldi, Is);
+        const bool pre_path = topk_prefilter_on() && (d == 128 || d == 64) && k <= kPreMaxK && topk_prefilter_usable(d);
+        // MI_TOPK_ITEMS_PREPARED: the item side of the prefilter (sample rows, the bf16 split of the item table and of the
+        // sample, the largest |item|^2) is still in `ws` from the previous call: nothing of it is recomputed
+        const bool items_ready = pre_path && (flags & MI_TOPK_ITEMS_PREPARED) != 0;
+        if (!items_ready)
+            hipLaunchKernelGGL(gather_sample_rows_kernel, dim3(kSample), dim3(64), 0, s, n_items, (int)d, item_emb, ldi, Is);
         FusedArgs a;
         a.n_q = n_q; a.n_items = n_items; a.d = (int)d; a.uid = uid;
         a.U = user_emb; a.ldu = ldu; a.I = item_emb; a.ldi = ldi;
-        if (topk_prefilter_on() && (d == 128 || d == 64) && k <= kPreMaxK && topk_prefilter_usable(d)) {
+        if (pre_path) {
             // bf16x3 prefilter (topk_prefilter.hpp): sample scores, thresholds, lists and the exact finish all in there
             MI_HIP(hipMemsetAsync(bitmap, 0, (size_t)n_q * words * sizeof(uint32_t), s));
             a.thr = thr; a.bitmap = bitmap; a.words = words; a.cand = cand; a.cnt = cnt;
             if (d == 128)
                 return topk_prefilter_launch<128>(a, ar, Is, sample_scores, thr, excl_ptr, excl_idx, (int)k, kpow2, scores, out_idx,
-                                                  out_score, mi_cu_count(), s);
+                                                  out_score, mi_cu_count(), items_ready, s);
             return topk_prefilter_launch<64>(a, ar, Is, sample_scores, thr, excl_ptr, excl_idx, (int)k, kpow2, scores, out_idx,
-                                             out_score, mi_cu_count(), s);
+                                             out_score, mi_cu_count(), items_ready, s);
         }
         const int64_t strips = mi_ceil_div(n_q, FM);
         const int64_t capacity = 2 * (int64_t)mi_cu_count();

@@ -812,15 +812,21 @@ def topk_excl(uid: Tensor, user_emb: Tensor, item_emb: Tensor, k: int, excl: Opt
         ws_bytes = int(L.mi_topk_workspace_bytes(chunk, n_items, k))
     wss = [_ws(ws_bytes, dev) for _ in range(lanes)]
 
+    prepared = {}   # workspace -> the chunk size whose item-side tables it holds (MI_TOPK_ITEMS_PREPARED)
+
     def launch(q0: int, ws: Tensor):
         q1 = min(n_q, q0 + chunk)
         # rowptr keeps absolute offsets into excl.col, so a chunk is just a slice of rowptr
         ep = excl.rowptr[q0:q1 + 1] if excl is not None else None
         ei = excl.col if (excl is not None and excl.nnz) else None
-        check(L.mi_topk_excl_f32(q1 - q0, n_items, d, k, uid[q0:q1].data_ptr(), user_emb.data_ptr(), ldu,
-                                 item_emb.data_ptr(), ldi, _ptr(ep), _ptr(ei),
-                                 out_idx[q0:q1].data_ptr(), out_sc[q0:q1].data_ptr() if want_scores else None,
-                                 ws.data_ptr(), ws.numel(), _stream()), "mi_topk_excl_f32")
+        # from a workspace's second chunk of the same size on, the item side of the prefilter (sample rows, the bf16 split of the
+        # item table, the largest item norm: ~40 us per chunk at 100 K items) is still in it: same table, same layout
+        flags = _lib.MI_TOPK_ITEMS_PREPARED if prepared.get(id(ws)) == q1 - q0 else 0
+        check(L.mi_topk_excl_ex_f32(q1 - q0, n_items, d, k, uid[q0:q1].data_ptr(), user_emb.data_ptr(), ldu,
+                                    item_emb.data_ptr(), ldi, _ptr(ep), _ptr(ei),
+                                    out_idx[q0:q1].data_ptr(), out_sc[q0:q1].data_ptr() if want_scores else None,
+                                    ws.data_ptr(), ws.numel(), flags, _stream()), "mi_topk_excl_ex_f32")
+        prepared[id(ws)] = q1 - q0
 
     if lanes == 1:
         for q0 in range(0, n_q, chunk):
