@@ -250,6 +250,12 @@ typedef struct mi_spmm_ex {
     int32_t        hot_base;        /* first cached row of X (see hot_rows) */
     int32_t        hot_threads;     /* tuning of the hot-row launch, 0 = defaults: bits 0..11 workgroup size (256 / 512 / 1024),
                                        bits 12.. wavefronts per CU (workgroups per CU = that / wavefronts per workgroup) */
+    const uint32_t* x_bits;         /* nullable, with x_map: bit c of the array (word c / 32, bit c % 32; mi_map_live_bits_i32 writes
+                                       it) = (x_map[c] >= 0).  Saying so declares the live columns RARE (the batch's users among all
+                                       users, first backward product of the fused step): the split rows' work items then run in a
+                                       form that tests the bit before the map, gathers only live entries, writes no partial row
+                                       for a work item without any, and the fix-up skips those — same sums in the same order,
+                                       bitwise the result without the hint.  Ignored with a sweep or a row_list. */
 } mi_spmm_ex;
 #define MI_SPMM_SHORT_ROWS 1
 #define MI_SPMM_SPLIT_ROWS 2
@@ -262,6 +268,9 @@ int mi_spmm_csr_ex_f32(int64_t n_rows, int64_t d,
                        float* S, int64_t lds, float scale,
                        const mi_spmm_plan* plan, const mi_spmm_ex* ex,
                        void* ws, size_t ws_bytes, mi_stream_t stream);
+
+/* bits[w] bit b = (map[32 w + b] >= 0), w < ceil(n / 32): mi_spmm_ex.x_bits of a map. */
+int mi_map_live_bits_i32(int64_t n, const int32_t* map, uint32_t* bits, mi_stream_t stream);
 
 /* dst[i,:] = scale * ((accumulate ? dst[i,:] : 0) + src[rows[i] - row_offset,:])
  * for i in [begin_dev ? *begin_dev : 0, min(n_max, n_dev ? *n_dev : n_max)).

@@ -45,7 +45,8 @@ class SpmmSweepStruct(Structure):
 class SpmmExStruct(Structure):
     _fields_ = [("x_map", c_void_p), ("addend_map", c_void_p), ("row_list", c_void_p), ("n_list_dev", c_void_p),
                 ("n_list", c_int64), ("adam", POINTER(AdamArgs)), ("parts", c_int32), ("hot_rows", c_int32),
-                ("sweep", POINTER(SpmmSweepStruct)), ("hot_base", c_int32), ("hot_threads", c_int32)]
+                ("sweep", POINTER(SpmmSweepStruct)), ("hot_base", c_int32), ("hot_threads", c_int32),
+                ("x_bits", c_void_p)]
 
 
 MI_SPMM_SHORT_ROWS, MI_SPMM_SPLIT_ROWS = 1, 2
@@ -186,6 +187,7 @@ _PROTOTYPES = {
     "mi_spmm_plan_count_range": (c_int32, [c_int64, c_int64, P, P, c_int32, c_int32, c_int32, P, c_size_t, POINTER(SpmmPlanInfo), P]),
     "mi_spmm_plan_fill": (c_int32, [c_int64, P, POINTER(SpmmPlanInfo), POINTER(SpmmPlanStruct), P, c_size_t, P]),
     "mi_spmm_workspace_bytes": (c_size_t, [POINTER(SpmmPlanStruct), c_int64]),
+    "mi_map_live_bits_i32": (c_int32, [c_int64, c_void_p, c_void_p, c_void_p]),
     "mi_spmm_csr_f32": (c_int32, [c_int64, c_int64, P, P, P, P, c_int64, P, c_int64, P, c_int64, P, c_int64,
                                   c_float, POINTER(SpmmPlanStruct), P, c_size_t, P]),
     "mi_spmm_csr_ex_f32": (c_int32, [c_int64, c_int64, P, P, P, P, c_int64, P, c_int64, P, c_int64, P, c_int64,

@@ -103,6 +103,8 @@ struct Ex {
     const int32_t* long_index;  // [n_rows]: index into the plan's long rows, -1 for short rows (row_list mode)
     int32_t parts;              // mask of MI_SPMM_SHORT_ROWS / MI_SPMM_SPLIT_ROWS (host side only)
     int32_t hot_base, hot_rows, hot_threads;  // persistent short-row launch (host side only): hot_rows 0 = plain launch, > 0 = LDS cache rows, < 0 = no cache
+    const uint32_t* x_bits;     // bit c = (x_map[c] >= 0): "live columns are rare" — the work items run as spmm_items_xmap_kernel
+    uint8_t* slot_live;         // [plan->n_items], behind the partial rows: 0 = the work item gathered nothing and wrote no partial row
 };
 
 // Largest n over the sub-groups of the wavefront (loop bounds must be wave-uniform around __shfl).
@@ -645,6 +647,129 @@ __global__ __launch_bounds__(kBlock) void spmm_items_kernel(int64_t n_launch, in
     }
 }
 
+// Work items with a MAPPED operand whose live columns are rare (the first backward product of the fused train step: x_map
+// names the batch's 131 K users among 8 M columns).  The plain kernel above pays one dependent chain per work item
+// (descriptor -> (col, val) -> map -> rows -> store: ~3 us with ~12 entries to show for it, 2.2 ms for C4's 7.7 M work
+// items); here a sub-group takes R launch slots at once — the R descriptors, then the R first (col, val) batches, then the
+// R map look-ups each leave as one group of loads — and gathers ONLY the live entries, in list order (the dead ones add
+// 0 * 0: same bits as the plain kernel).  A workgroup serves a whole launch block of the banded plan.
+template <int LPR, int VPL, int R>
+__global__ __launch_bounds__(kBlock) void spmm_items_xmap_kernel(int64_t n_launch, int32_t banded, int d4,
+                                                                 const int4* __restrict__ items,
+                                                                 const int32_t* __restrict__ col,
+                                                                 const float* __restrict__ val,
+                                                                 const float4* __restrict__ X4, int64_t ldx4,
+                                                                 float4* __restrict__ partial,
+                                                                 const int32_t* __restrict__ x_map,
+                                                                 const uint32_t* __restrict__ x_bits,
+                                                                 uint8_t* __restrict__ slot_live, bool streaming) {
+    constexpr int NB = MI_WAVE / LPR, SG = NB * kWavesPerBlock, G = SG * R;
+    static_assert(kPlanGroup % G == 0, "a workgroup serves a whole fraction of a launch block");
+    const int lane = mi_lane();
+    const int li = lane % LPR;
+    const int sgi = (threadIdx.x / MI_WAVE) * NB + lane / LPR;
+    int64_t base;
+    if (banded) {
+        constexpr int per = kPlanGroup / G;
+        const int64_t x = blockIdx.x & 7, tq = blockIdx.x >> 3;
+        base = ((tq / per) * 8 + x) * kPlanGroup + (tq % per) * G;
+    } else {
+        base = (int64_t)blockIdx.x * G;
+    }
+    int4 it[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        const int64_t q = base + k * SG + sgi;
+        it[k] = make_int4(0, 0, 0, -1);
+        if (q < n_launch) it[k] = items[q];
+    }
+    int32_t c0[R];
+    float v0[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        const int n = it[k].w >= 0 ? it[k].z - it[k].y : 0;
+        c0[k] = -1;
+        v0[k] = 0.f;
+        if (li < n) {
+            c0[k] = __builtin_nontemporal_load(col + it[k].y + li);
+            v0[k] = __builtin_nontemporal_load(val + it[k].y + li);
+        }
+    }
+    // the 1-bit pre-test (the whole bitmap sits in every XCD's L2; the 4-byte map entries of 8 M columns do not): a dead
+    // column — almost all of them — costs no look-up beyond it
+#pragma unroll
+    for (int k = 0; k < R; ++k)
+        if (c0[k] >= 0 && !((x_bits[c0[k] >> 5] >> (c0[k] & 31)) & 1u)) c0[k] = -1;
+#pragma unroll
+    for (int k = 0; k < R; ++k)
+        if (c0[k] >= 0) c0[k] = x_map[c0[k]];
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        const int32_t slot = it[k].w;
+        const int n = slot >= 0 ? it[k].z - it[k].y : 0;
+        const int nmax = wave_max_over_subgroups<LPR>(n);
+        float4 acc[VPL];
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) acc[v] = mi_f4_zero();
+        int32_t my_c = c0[k];
+        float my_v = v0[k];
+        uint32_t any_live = 0u;   // sub-group-uniform
+        for (int b = 0; b < nmax; b += LPR) {
+            if (b > 0) {   // work items longer than a batch: the rest of the list, batch by batch
+                my_c = -1;
+                my_v = 0.f;
+                if (b + li < n) {
+                    const int32_t c = __builtin_nontemporal_load(col + it[k].y + b + li);
+                    my_c = ((x_bits[c >> 5] >> (c & 31)) & 1u) ? x_map[c] : -1;
+                    my_v = __builtin_nontemporal_load(val + it[k].y + b + li);
+                }
+            }
+            const unsigned long long live = __ballot(my_c >= 0);
+            if constexpr (LPR == 64) any_live |= (uint32_t)(live != 0ull);
+            else any_live |= (uint32_t)(((live >> ((lane / LPR) * LPR)) & ((1ull << LPR) - 1ull)) != 0ull);
+            uint32_t mine;   // this sub-group's live entries
+            if constexpr (LPR == 64) mine = (uint32_t)live;
+            else mine = (uint32_t)((live >> ((lane / LPR) * LPR)) & ((1ull << LPR) - 1ull));
+            // LPR == 64: the upper half is walked in a second round
+            for (int half = 0; half < (LPR == 64 ? 2 : 1); ++half) {
+                if (LPR == 64 && half == 1) mine = (uint32_t)(live >> 32);
+                while (__ballot(mine != 0u)) {
+                    const bool ok = mine != 0u;
+                    const int j = (ok ? __ffs((int)mine) - 1 : 0) + 32 * half;
+                    const int32_t c = __shfl(my_c, j, LPR);
+                    const float w = __shfl(my_v, j, LPR);
+                    const float4* src = X4 + (int64_t)(ok ? c : 0) * ldx4;
+#pragma unroll
+                    for (int v = 0; v < VPL; ++v) {
+                        const int e = li + v * LPR;
+                        if (ok && e < d4) mi_f4_fma(acc[v], w, src[e]);
+                    }
+                    mine &= mine - 1u;
+                }
+            }
+        }
+        if (slot >= 0) {
+            if (li == 0) slot_live[slot] = (uint8_t)any_live;
+            if (any_live) {   // a work item without a live entry writes no partial row: the fix-up reads the flag instead
+#pragma unroll
+                for (int v = 0; v < VPL; ++v) {
+                    const int e = li + v * LPR;
+                    if (e < d4) mi_store4<1>(partial + (int64_t)slot * d4 + e, acc[v], streaming);
+                }
+            }
+        }
+    }
+}
+
+// bits[w] bit b = (map[32 w + b] >= 0)
+__global__ __launch_bounds__(kBlock) void map_live_bits_kernel(int64_t n, const int32_t* __restrict__ map, uint32_t* __restrict__ bits) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const bool live = i < n && map[i] >= 0;
+    const unsigned long long b = __ballot(live);
+    const int lane = mi_lane();
+    if ((lane & 31) == 0 && i < n) bits[i >> 5] = (uint32_t)(b >> lane);
+}
+
 // Split rows, SWEEP form (mi_spmm_sweep): workgroup w serves XCD w & 7 and holds 32 consecutive streams of it; every
 // sub-group walks its own stream front to back — (col, val) read LPR at a time, coalesced; rows gathered UNROLL at a
 // time — adding each product into the accumulator its column's tag names.  A run of entries with the same tag is summed
@@ -800,7 +925,9 @@ __global__ __launch_bounds__(kBlock) void spmm_fixup_kernel(int32_t n_long, int 
             for (int v = 0; v < VPL; ++v) {
                 const int e = li + v * LPR;
                 const int32_t ss = s + u * NSG;
-                x[u][v] = (ss < se && e < d4) ? partial[(int64_t)ss * d4 + e] : mi_f4_zero();
+                bool take = ss < se && e < d4;
+                if (SPARSE && take && ex.slot_live) take = ex.slot_live[ss] != 0;   // a work item that gathered nothing (mapped operand): + 0
+                x[u][v] = take ? partial[(int64_t)ss * d4 + e] : mi_f4_zero();
             }
 #pragma unroll
         for (int u = 0; u < FU; ++u)
@@ -1065,14 +1192,33 @@ int launch_spmm_mode(int64_t n_rows, int d4, const int32_t* rowptr, const int32_
             return MI_ERR_UNSUPPORTED;
         }
     }
+    bool xmap_form = false;   // the work items ran as spmm_items_xmap_kernel: their live flags are valid
     // HYBRID plan (round 4): the hub rows in SWEEP form AND the remaining split rows as banded work items — `items` is
     // then non-null beside the sweep, its slots are absolute (they start behind the sweep's 8 * n_slots partial rows)
     if (do_split && plan && plan->n_items > 0 && (!sweep || plan->items)) {  // row_list mode still reduces every split row: hubs are few and almost always wanted
         const int64_t n_launch = plan->n_launch;
         dim3 gi((unsigned)mi_ceil_div(n_launch, SG * ITEMS_RPS));
-        hipLaunchKernelGGL((spmm_items_kernel<LPR, VPL, UNROLL, ITEMS_RPS, SPARSE>), gi, dim3(kBlock), 0, s, n_launch,
-                           plan->band > 0 ? 1 : 0, d4, reinterpret_cast<const int4*>(plan->items), col, val, X4, ldx4,
-                           partial, ex.x_map, ep.streaming);
+        bool done = false;
+        xmap_form = false;
+        if constexpr (SPARSE) {
+#ifndef MI_SPMM_XMAP_SLOTS
+#define MI_SPMM_XMAP_SLOTS 32  // launch slots per workgroup of the mapped-operand kernel (a whole launch block of a banded plan); 0 = off
+#endif
+            constexpr int XR = MI_SPMM_XMAP_SLOTS / SG;
+            if constexpr (XR >= 2) {
+                if (ex.x_map && ex.x_bits && ex.slot_live) {
+                    hipLaunchKernelGGL((spmm_items_xmap_kernel<LPR, VPL, XR>), dim3((unsigned)mi_ceil_div(n_launch, SG * XR)),
+                                       dim3(kBlock), 0, s, n_launch, plan->band > 0 ? 1 : 0, d4,
+                                       reinterpret_cast<const int4*>(plan->items), col, val, X4, ldx4, partial, ex.x_map,
+                                       ex.x_bits, ex.slot_live, ep.streaming);
+                    done = xmap_form = true;
+                }
+            }
+        }
+        if (!done)
+            hipLaunchKernelGGL((spmm_items_kernel<LPR, VPL, UNROLL, ITEMS_RPS, SPARSE>), gi, dim3(kBlock), 0, s, n_launch,
+                               plan->band > 0 ? 1 : 0, d4, reinterpret_cast<const int4*>(plan->items), col, val, X4, ldx4,
+                               partial, ex.x_map, ep.streaming);
     }
     const int64_t n_out = listed ? n_list : n_rows;
     bool short_done = false;
@@ -1132,9 +1278,11 @@ int launch_spmm_mode(int64_t n_rows, int d4, const int32_t* rowptr, const int32_
     }
     if (do_split && plan && plan->n_long_rows > 0) {
         const int64_t nf = listed ? n_list : (int64_t)plan->n_long_rows;
+        Ex exf = ex;
+        if (!xmap_form) exf.slot_live = nullptr;
         if (nf > 0)
             hipLaunchKernelGGL((spmm_fixup_kernel<LPR, VPL, SPARSE, ADAM>), dim3((unsigned)nf), dim3(kBlock), 0, s,
-                               (int32_t)nf, d4, plan->long_rows, plan->item_ptr, partial, ep, ex);
+                               (int32_t)nf, d4, plan->long_rows, plan->item_ptr, partial, ep, exf);
     }
     return mi_launch_status();
 }
@@ -1292,7 +1440,16 @@ int mi_spmm_plan_fill(int64_t n_rows, const int32_t* rowptr, const mi_spmm_plan_
 
 size_t mi_spmm_workspace_bytes(const mi_spmm_plan* plan, int64_t d) {
     if (!plan || plan->n_items <= 0) return 0;
-    return mi_align_up((size_t)plan->n_items * (size_t)d * sizeof(float), 256);
+    // the partial rows, then one live flag per work item (mapped launches with mi_spmm_ex.x_bits)
+    return mi_align_up((size_t)plan->n_items * (size_t)d * sizeof(float), 256) + mi_align_up((size_t)plan->n_items, 256);
+}
+
+int mi_map_live_bits_i32(int64_t n, const int32_t* map, uint32_t* bits, mi_stream_t stream) {
+    MI_CHECK_ARG(n >= 0 && (n == 0 || (map && bits)));
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(map_live_bits_kernel, dim3((unsigned)mi_ceil_div(n, (int64_t)kBlock)), dim3(kBlock), 0, (hipStream_t)stream, n, map,
+                       bits);
+    return mi_launch_status();
 }
 
 int mi_spmm_csr_ex_f32(int64_t n_rows, int64_t d, const int32_t* rowptr, const int32_t* col,
@@ -1310,7 +1467,7 @@ int mi_spmm_csr_ex_f32(int64_t n_rows, int64_t d, const int32_t* rowptr, const i
     MI_CHECK_ARG(!Y || (ldy % 4 == 0 && ldy >= d && mi_aligned16(Y) && Y != X));
     MI_CHECK_ARG(!S || (lds % 4 == 0 && lds >= d && mi_aligned16(S) && S != X));
     MI_CHECK_ARG(!addend || (lda % 4 == 0 && lda >= d && mi_aligned16(addend)));
-    Ex ex = {nullptr, nullptr, nullptr, nullptr, nullptr, MI_SPMM_SHORT_ROWS | MI_SPMM_SPLIT_ROWS, 0, 0, 0};
+    Ex ex = {nullptr, nullptr, nullptr, nullptr, nullptr, MI_SPMM_SHORT_ROWS | MI_SPMM_SPLIT_ROWS, 0, 0, 0, nullptr, nullptr};
     int64_t n_list = 0;
     if (exh) {
         ex.x_map = exh->x_map;
@@ -1356,6 +1513,13 @@ int mi_spmm_csr_ex_f32(int64_t n_rows, int64_t d, const int32_t* rowptr, const i
         if (!ws || ws_bytes < mi_spmm_workspace_bytes(plan, d)) return MI_ERR_WORKSPACE;
         MI_CHECK_ARG(mi_aligned16(ws) && (!plan->items || mi_aligned16(plan->items)));
         partial = reinterpret_cast<float4*>(ws);
+        // the work items of a mapped operand whose live columns are rare (x_bits): spmm_items_xmap_kernel + live flags.
+        // Not with a sweep (its slots carry no flags) and not with row_list (the fix-up then walks listed rows only — fine —
+        // but the combination has no caller and no test)
+        if (exh && exh->x_bits && ex.x_map && plan->items && !sweep && !ex.row_list) {
+            ex.x_bits = exh->x_bits;
+            ex.slot_live = reinterpret_cast<uint8_t*>(ws) + mi_align_up((size_t)plan->n_items * (size_t)d * sizeof(float), 256);
+        }
     }
     Epilogue ep;
     ep.Y = reinterpret_cast<float4*>(Y);                 ep.ldy4 = ldy / 4;

@@ -305,7 +305,8 @@ class ShardedLightGCNTrainer:
         for i in range(K):
             nxt = self.bufs[i % 2]
             if i == 0:  # input = the batch gradient: item rows gather local batch users, user rows the non-zero item rows
-                ops.spmm(self.a_items, self.gc_c, Y=nxt[U:], x_map=gmap)   # local operands only: runs beside the exchanges above
+                ops.spmm(self.a_items, self.gc_c, Y=nxt[U:], x_map=gmap,    # local operands only: runs beside the exchanges above
+                         x_rare=8 * self.batch_size <= U)
                 for w in pending:
                     if w is not None:
                         w.wait()

@@ -39,6 +39,7 @@ SPMM_EVENTS = None
 # LAPLACE_SPMM_TWO_STREAMS=0 / 1; the enqueue order of the two halves does not matter).  On by default;
 # LAPLACE_SPMM_TWO_STREAMS=0 switches it off.  (2 = split rows enqueued first: an A/B setting.)
 SPMM_TWO_STREAMS = int(os.environ.get("LAPLACE_SPMM_TWO_STREAMS", "1") or 0)
+X_RARE_BITS = os.environ.get("LAPLACE_X_RARE", "1") != "0"   # A/B: spmm(..., x_rare=True) honoured (mi_spmm_ex.x_bits)
 _SIDE = {}
 
 
@@ -492,7 +493,7 @@ def build_spmm_plan(a: DeviceCSR, chunk: int = DEFAULT_CHUNK, band: Optional[int
 def spmm(a: DeviceCSR, X: Tensor, *, Y: Optional[Tensor] = None, addend: Optional[Tensor] = None,
          S: Optional[Tensor] = None, scale: float = 1.0, x_map: Optional[Tensor] = None,
          addend_map: Optional[Tensor] = None, row_list: Optional[Tensor] = None,
-         n_list_dev: Optional[Tensor] = None, adam: Optional[dict] = None) -> None:
+         n_list_dev: Optional[Tensor] = None, adam: Optional[dict] = None, x_rare: bool = False) -> None:
     """K1/K2 — acc = A @ X; Y = acc (optional); S = scale * (addend + acc) (optional).
 
     adam = dict(p=, m=, v=, step=, lr=, beta1=, beta2=, eps=, reg_w=): S's value is the gradient of parameter
@@ -504,7 +505,9 @@ def spmm(a: DeviceCSR, X: Tensor, *, Y: Optional[Tensor] = None, addend: Optiona
 
     Sparse-operand forms (mi_spmm_csr_ex_f32): x_map int32[n_cols] — X is compact, column c reads
     X[x_map[c]], negative = an all-zero row; addend_map int32[n_rows] — addend is compact; row_list
-    int32[n] (+ n_list_dev, device int32[1]) — compute only these rows, Y/S/addend compact by list position."""
+    int32[n] (+ n_list_dev, device int32[1]) — compute only these rows, Y/S/addend compact by list position.
+    x_rare (with x_map): few columns are live (mi_spmm_ex.x_bits) — the split rows' work items test a bitmap of the map
+    first, gather only live entries and skip work items without any; bitwise the result without the hint."""
     if a.val is None:
         raise ValueError("spmm needs edge values (run gcn_norm or set val)")
     d = X.shape[1]
@@ -578,6 +581,14 @@ def spmm(a: DeviceCSR, X: Tensor, *, Y: Optional[Tensor] = None, addend: Optiona
         if hot_base < 0 or hot_rows < -1 or hot_base + max(hot_rows, 0) > X.shape[0]:
             raise ValueError(f"hot rows [{hot_base}, {hot_base + hot_rows}) lie outside X ({X.shape[0]} rows)")
 
+    x_bits = None
+    if (x_rare and X_RARE_BITS and x_map is not None and row_list is None and sweep is None and plan is not None
+            and plan.n_items > 0):
+        x_bits = getattr(a, "_x_bits", None)
+        if x_bits is None:
+            x_bits = a._x_bits = t.empty((a.n_cols + 31) // 32, dtype=t.int32, device=a.device)
+        check(L.mi_map_live_bits_i32(a.n_cols, _ptr(x_map), _ptr(x_bits), _stream()), "mi_map_live_bits_i32")
+
     def launch(parts: int, stream: int) -> None:
         exs = None
         if (x_map is not None or addend_map is not None or row_list is not None or adam_args is not None or parts
@@ -585,7 +596,7 @@ def spmm(a: DeviceCSR, X: Tensor, *, Y: Optional[Tensor] = None, addend: Optiona
             exs = SpmmExStruct(_ptr(x_map), _ptr(addend_map), _ptr(row_list), _ptr(n_list_dev),
                                row_list.numel() if row_list is not None else 0,
                                ctypes.pointer(adam_args) if adam_args is not None else None, parts, hot_rows,
-                               ctypes.pointer(sweep) if sweep is not None else None, hot_base, HOT_THREADS)
+                               ctypes.pointer(sweep) if sweep is not None else None, hot_base, HOT_THREADS, _ptr(x_bits))
         check(L.mi_spmm_csr_ex_f32(a.n_rows, d, _ptr(a.rowptr), col_ptr, val_ptr, X.data_ptr(), ldx,
                                    _ptr(Y), ldy, _ptr(addend), lda, _ptr(S), lds, float(scale),
                                    ctypes.byref(plan.struct) if plan is not None else None,

@@ -223,7 +223,9 @@ class LightGCNTrainer:
                                beta2=self.betas[1], eps=self.eps, reg_w=self.reg_w)
                 out = None if opt is not None else nxt
                 if i == 0:   # input = the compact gradient itself: skip its all-zero rows
-                    ops.spmm(adj_t, self.gc_c, addend=self.gc_c, S=out, x_map=gmap, addend_map=gmap, adam=opt)
+                    # (the split rows are the hub ITEMS': their columns are users, of which the batch names few)
+                    ops.spmm(adj_t, self.gc_c, addend=self.gc_c, S=out, x_map=gmap, addend_map=gmap, adam=opt,
+                             x_rare=8 * self.batch_size <= self.model.num_users)
                 else:
                     ops.spmm(adj_t, cur, addend=self.gc_c, S=out, addend_map=gmap, adam=opt)
                 cur = nxt

@@ -40,8 +40,8 @@ def build_spmm_plan(a, chunk=256, band=None):
 
 
 def spmm(a: DeviceCSR, X: Tensor, *, Y=None, addend=None, S=None, scale=1.0, x_map=None, addend_map=None,
-         row_list=None, n_list_dev=None, adam=None) -> None:
-    """Dense semantics of every sparse-operand form: expand, multiply, then select."""
+         row_list=None, n_list_dev=None, adam=None, x_rare=False) -> None:
+    """Dense semantics of every sparse-operand form: expand, multiply, then select (x_rare is a speed hint: ignored)."""
     d = X.shape[1]
     if x_map is not None:
         Xd = t.zeros(a.n_cols, d)

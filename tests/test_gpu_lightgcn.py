@@ -261,6 +261,57 @@ def test_spmm_sweep_plan_equals_work_item_plan(d, n_streams):
     want = (vv[b:e, None] * Xw.cpu().double()[cc[b:e]]).sum(0)
     assert (Yw[r].cpu().double() - want).abs().max() <= 1e-3
 
+@pytest.mark.parametrize("band", [0, 64])
+@pytest.mark.parametrize("d,live", [(32, 0.02), (64, 0.3), (128, 0.005), (128, 0.0), (256, 0.02), (512, 0.02)])
+def test_rare_live_columns_hint_is_bitwise_the_mapped_product(d, live, band):
+    """mi_spmm_ex.x_bits (round 4): a mapped operand whose live columns are rare — the first backward product of the fused
+    step on BASELINE configs[3], the batch's 131 K users among 8 M.  The split rows' work items then test one bit per column
+    before the map, gather only the live entries and leave out the partial rows of work items without any (the fix-up reads
+    their flag).  Same sums in the same order: bitwise the product without the hint, on both streams' halves, with work
+    items longer than a sub-group's batch, at every width class; and the dense product of the expanded operand to rounding."""
+    ops = _ops()
+    g = t.Generator().manual_seed(7 * d + band + int(1000 * live))
+    n = 6000
+    degs = t.cat([t.tensor([5000, 2600, 900]), t.randint(260, 700, (60,), generator=g)])   # 63 rows above chunk = 256
+    hub_rows = t.randperm(n, generator=g)[: degs.numel()]
+    row = t.cat([t.full((int(L),), int(r)) for r, L in zip(hub_rows, degs)] + [t.randint(0, n, (30000,), generator=g)])
+    col = t.randint(0, n, (row.numel(),), generator=g)
+    a = ops.coo_to_csr(row.to(DEV), col.to(DEV), n, n, want_perm=False)
+    a.val = (t.rand(a.nnz, generator=g) + 0.5).to(DEV)
+    a.plan = ops.build_spmm_plan(a, chunk=256, band=band, sweep=False)
+    assert a.plan.n_items > 0 and a.plan.sweep is None
+    keep = t.rand(n, generator=g) < live
+    ids = keep.nonzero().view(-1)
+    x_map = t.full((n,), -1, dtype=t.int32)
+    x_map[ids] = t.randperm(ids.numel(), generator=g).to(t.int32)      # compact rows in another order than the columns
+    Xc = t.randn(max(ids.numel(), 1), d, generator=g).to(DEV)
+    x_map = x_map.to(DEV)
+    A = t.randn(n, d, generator=g).to(DEV)
+    out = {}
+    saved = ops.SPMM_TWO_STREAMS
+    try:
+        for streams in (1, 0):
+            ops.SPMM_TWO_STREAMS = streams
+            for rare in (False, True):
+                Y, S = t.full((n, d), float("nan"), device=DEV), t.full((n, d), float("nan"), device=DEV)
+                ops.spmm(a, Xc, Y=Y, addend=A, S=S, scale=0.5, x_map=x_map, x_rare=rare)
+                out[(streams, rare)] = (Y, S)
+    finally:
+        ops.SPMM_TWO_STREAMS = saved
+    t.cuda.synchronize()
+    ref = out[(1, False)]
+    for key, (Y, S) in out.items():
+        assert t.equal(Y, ref[0]) and t.equal(S, ref[1]), key
+    X = t.zeros(n, d, device=DEV)
+    if ids.numel():
+        X[ids.to(DEV)] = Xc[x_map[ids.to(DEV)].long()]
+    Yd = t.empty(n, d, device=DEV)
+    ops.spmm(a, X, Y=Yd)
+    assert (Yd - ref[0]).abs().max() <= 1e-5 * max(float(Yd.abs().max()), 1.0)
+    if live == 0.0:
+        assert float(ref[0].abs().max()) == 0.0 and t.equal(ref[1], 0.5 * A)
+
+
 @pytest.mark.parametrize("tail_whole", [False, True])
 @pytest.mark.parametrize("d", [32, 128])
 def test_hybrid_plan_equals_the_banded_plan(d, tail_whole):

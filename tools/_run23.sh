@@ -1,0 +1,4 @@
+export TMPDIR=/tmp
+mkdir -p gpurun_out/r04w
+timeout -k 10 900 python -m pytest tests/test_gpu_lightgcn.py tests/test_gpu_full_size.py -x -q -k "not c5 and not pinsage" > gpurun_out/r04w/tests.log 2>&1; echo rc=$?; tail -n 4 gpurun_out/r04w/tests.log
+bash tools/ab_c4_env.sh "xmap-kernel||" "off|LAPLACE_HIP_LIB=$PWD/laplace-gnn-recommendation_amd/liblaplace_hip_xoff.so|" "xmap-kernel-2||"
