@@ -128,6 +128,14 @@ typedef struct mi_spmm_plan {
                               short rows; nullable (needed only by row_list launches)  */
     int32_t  band;         /* columns per band; 0 = row-major launch order           */
     int32_t  n_bands;
+    /* Optional (round 4; all three or none): the split rows' entries copied into LAUNCH order by
+     * mi_spmm_plan_pack_entries.  A work item's ~12 entries are then read from the same cache lines as its launch
+     * neighbours' instead of two lines of their own in the CSR arrays (7.7 M work items on BASELINE configs[3]: ~2 GB of
+     * line fetches per launch for 0.7 GB of entries).  epos[q] = first packed entry of launch slot q.  ecol / eval hold
+     * VALUES: when the CSR's val changes, call mi_spmm_plan_pack_entries again with values_only = 1.                    */
+    int32_t* epos;         /* device int32[n_launch]; nullable                       */
+    int32_t* ecol;         /* device int32[nnz_long]                                 */
+    float*   eval;         /* device float[nnz_long]                                 */
 } mi_spmm_plan;
 
 /* What mi_spmm_plan_count found; the caller allocates the plan arrays from it. */
@@ -157,6 +165,12 @@ int    mi_spmm_plan_count_range(int64_t n_rows, int64_t n_cols, const int32_t* r
                                 mi_spmm_plan_info* info, mi_stream_t stream);
 int    mi_spmm_plan_fill(int64_t n_rows, const int32_t* rowptr, const mi_spmm_plan_info* info,
                          mi_spmm_plan* plan, void* ws, size_t ws_bytes, mi_stream_t stream);
+/* Fills plan->epos / ecol / eval (caller-allocated: n_launch, nnz_long, nnz_long elements; nnz_long from
+ * mi_spmm_plan_info) from the filled plan and the CSR's col / val.  values_only != 0: epos and ecol are kept, eval is
+ * copied again (the adjacency was re-weighted).  ws: mi_spmm_plan_pack_workspace_bytes(plan->n_launch).  Enqueues only. */
+size_t mi_spmm_plan_pack_workspace_bytes(int64_t n_launch);
+int    mi_spmm_plan_pack_entries(const mi_spmm_plan* plan, int64_t nnz_long, const int32_t* col, const float* val,
+                                 int32_t values_only, void* ws, size_t ws_bytes, mi_stream_t stream);
 /* Bytes of partial-sum workspace mi_spmm_csr_f32 needs for this plan and width. */
 size_t mi_spmm_workspace_bytes(const mi_spmm_plan* plan, int64_t d);
 

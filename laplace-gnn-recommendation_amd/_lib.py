@@ -23,6 +23,7 @@ class SpmmPlanStruct(Structure):
         ("chunk", c_int32), ("n_long_rows", c_int32), ("n_items", c_int32), ("n_launch", c_int32),
         ("long_rows", c_void_p), ("item_ptr", c_void_p), ("items", c_void_p), ("long_index", c_void_p),
         ("band", c_int32), ("n_bands", c_int32),
+        ("epos", c_void_p), ("ecol", c_void_p), ("eval", c_void_p),
     ]
 
 
@@ -187,6 +188,8 @@ _PROTOTYPES = {
     "mi_spmm_plan_count_range": (c_int32, [c_int64, c_int64, P, P, c_int32, c_int32, c_int32, P, c_size_t, POINTER(SpmmPlanInfo), P]),
     "mi_spmm_plan_fill": (c_int32, [c_int64, P, POINTER(SpmmPlanInfo), POINTER(SpmmPlanStruct), P, c_size_t, P]),
     "mi_spmm_workspace_bytes": (c_size_t, [POINTER(SpmmPlanStruct), c_int64]),
+    "mi_spmm_plan_pack_workspace_bytes": (c_size_t, [c_int64]),
+    "mi_spmm_plan_pack_entries": (c_int32, [POINTER(SpmmPlanStruct), c_int64, c_void_p, c_void_p, c_int32, c_void_p, c_size_t, c_void_p]),
     "mi_map_live_bits_i32": (c_int32, [c_int64, c_void_p, c_void_p, c_void_p]),
     "mi_spmm_csr_f32": (c_int32, [c_int64, c_int64, P, P, P, P, c_int64, P, c_int64, P, c_int64, P, c_int64,
                                   c_float, POINTER(SpmmPlanStruct), P, c_size_t, P]),

@@ -57,7 +57,10 @@ template <int BIT>
 __device__ __forceinline__ void mi_store4(float4* p, const float4& v, bool streaming) {
     if (((MI_SPMM_SC1 >> BIT) & 1) && streaming) {
         mi_f4v x = {v.x, v.y, v.z, v.w};
-        asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(x) : "memory");
+        // s_nop: a store of more than 64 bits reads its data registers over several cycles and the hazard recogniser does not
+        // look into inline asm — without the wait states the next instruction may overwrite them (seen as run-to-run different
+        // partial rows once a kernel reused the accumulator registers right behind the store, round 4)
+        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(x) : "memory");
     } else if ((MI_SPMM_NT >> BIT) & 1) {
         mi_f4v x = {v.x, v.y, v.z, v.w};
         __builtin_nontemporal_store(x, reinterpret_cast<mi_f4v*>(p));
@@ -609,6 +612,7 @@ __global__ __launch_bounds__(1024) void spmm_rows_hot_kernel(int64_t n_rows, int
 template <int LPR, int VPL, int UNROLL, int RPS, bool SPARSE>
 __global__ __launch_bounds__(kBlock) void spmm_items_kernel(int64_t n_launch, int32_t banded, int d4,
                                                             const int4* __restrict__ items,
+                                                            const int32_t* __restrict__ epos,
                                                             const int32_t* __restrict__ col,
                                                             const float* __restrict__ val,
                                                             const float4* __restrict__ X4, int64_t ldx4,
@@ -631,12 +635,16 @@ __global__ __launch_bounds__(kBlock) void spmm_items_kernel(int64_t n_launch, in
     for (int k = 0; k < RPS; ++k) {
         const int64_t q = base + k * SG + sgi;
         int4 it = make_int4(0, 0, 0, -1);
-        if (q < n_launch) it = items[q];
+        int32_t first = 0;
+        if (q < n_launch) {
+            it = items[q];
+            first = epos ? epos[q] : it.y;   // packed plan: col / val are the plan's launch-ordered copies
+        }
         const int32_t slot = it.w;
         const int n = slot >= 0 ? it.z - it.y : 0;
         const int nmax = wave_max_over_subgroups<LPR>(n);
         float4 acc[VPL];
-        subgroup_accumulate<LPR, VPL, UNROLL, SPARSE>(col, val, X4, ldx4, d4, it.y, n, nmax, li, x_map, acc);
+        subgroup_accumulate<LPR, VPL, UNROLL, SPARSE>(col, val, X4, ldx4, d4, first, n, nmax, li, x_map, acc);
         if (slot >= 0) {
 #pragma unroll
             for (int v = 0; v < VPL; ++v) {
@@ -648,117 +656,175 @@ __global__ __launch_bounds__(kBlock) void spmm_items_kernel(int64_t n_launch, in
 }
 
 // Work items with a MAPPED operand whose live columns are rare (the first backward product of the fused train step: x_map
-// names the batch's 131 K users among 8 M columns).  The plain kernel above pays one dependent chain per work item
-// (descriptor -> (col, val) -> map -> rows -> store: ~3 us with ~12 entries to show for it, 2.2 ms for C4's 7.7 M work
-// items); here a sub-group takes R launch slots at once — the R descriptors, then the R first (col, val) batches, then the
-// R map look-ups each leave as one group of loads — and gathers ONLY the live entries, in list order (the dead ones add
-// 0 * 0: same bits as the plain kernel).  A workgroup serves a whole launch block of the banded plan.
-template <int LPR, int VPL, int R>
-__global__ __launch_bounds__(kBlock) void spmm_items_xmap_kernel(int64_t n_launch, int32_t banded, int d4,
-                                                                 const int4* __restrict__ items,
-                                                                 const int32_t* __restrict__ col,
-                                                                 const float* __restrict__ val,
-                                                                 const float4* __restrict__ X4, int64_t ldx4,
-                                                                 float4* __restrict__ partial,
-                                                                 const int32_t* __restrict__ x_map,
-                                                                 const uint32_t* __restrict__ x_bits,
-                                                                 uint8_t* __restrict__ slot_live, bool streaming) {
-    constexpr int NB = MI_WAVE / LPR, SG = NB * kWavesPerBlock, G = SG * R;
-    static_assert(kPlanGroup % G == 0, "a workgroup serves a whole fraction of a launch block");
-    const int lane = mi_lane();
-    const int li = lane % LPR;
-    const int sgi = (threadIdx.x / MI_WAVE) * NB + lane / LPR;
-    int64_t base;
-    if (banded) {
-        constexpr int per = kPlanGroup / G;
-        const int64_t x = blockIdx.x & 7, tq = blockIdx.x >> 3;
-        base = ((tq / per) * 8 + x) * kPlanGroup + (tq % per) * G;
-    } else {
-        base = (int64_t)blockIdx.x * G;
+// names the batch's 131 K users among 8 M columns; ~4 % of the split rows' entries are live, 60 % of the work items have
+// none).  The plain kernel above pays one dependent chain per work item (descriptor -> (col, val) -> map -> rows -> store:
+// ~5 us of wavefront lifetime for two work items; 2.2 ms for C4's 7.7 M).  Taking four work items per sub-group into that
+// chain (first version of this round) only moved it to 1.8 ms: the launch stays bound by wavefront lifetime x generations.
+// So this kernel does not walk work items at all.  It needs a PACKED plan (mi_spmm_plan.epos / ecol / eval: the entries in
+// launch order): a wavefront owns 64 consecutive launch slots, whose entries are ONE contiguous run of the packed arrays,
+// and scans that run in tiles of 512 entries — 8 coalesced column loads per lane in flight, then the 8 bit tests
+// (x_bits: the 1 MB bitmap of the map sits in every XCD's L2), then map and value of the few live entries — compacting the
+// live ones, in list order, into LDS with the slot each belongs to (a search over the 64 slot starts, live entries only).
+// The sub-groups then walk that short list (slot s belongs to sub-group s mod NB), four row gathers in flight, summing
+// per slot in list order — the sum the plain kernel forms, bit for bit, since a dead entry added 0 * 0 — and write a
+// partial row when the slot changes.  A slot without a live entry gets no partial row, only its flag (slot_live).
+// Measured on C4 (profiles/r04_c4_item_rows_experiments.md): alone the kernel takes about as long as the chained forms
+// (2.0 ms: 0.37 ms of scan, the rest is the walk's gather latency in the hub rows' 32-tile runs), but it keeps few loads
+// in flight and moves a seventh of the bytes, so beside the short-row kernel on the other stream it all but disappears:
+// sparse launch 6.30 -> 5.36 ms, step 52.8 -> 50.95 ms, where the chained forms got 52.8 -> 52.2.
+#ifndef MI_SPMM_XSCAN_U
+#define MI_SPMM_XSCAN_U 4   // row gathers in flight per sub-group
+#endif
+template <int LPR, int VPL>
+__global__ __launch_bounds__(kBlock) void spmm_items_xscan_kernel(int64_t n_launch, int d4, const int4* __restrict__ items,
+                                                                  const int32_t* __restrict__ epos,
+                                                                  const int32_t* __restrict__ ecol,
+                                                                  const float* __restrict__ eval,
+                                                                  const float4* __restrict__ X4, int64_t ldx4,
+                                                                  float4* __restrict__ partial,
+                                                                  const int32_t* __restrict__ x_map,
+                                                                  const uint32_t* __restrict__ x_bits,
+                                                                  uint8_t* __restrict__ slot_live, bool streaming) {
+    constexpr int NB = MI_WAVE / LPR;   // sub-groups per wavefront
+    constexpr int UNR = 8, T = UNR * MI_WAVE;
+    constexpr int U = MI_SPMM_XSCAN_U;
+    __shared__ int32_t s_first[kWavesPerBlock][MI_WAVE + 1];
+    __shared__ int32_t s_slot[kWavesPerBlock][MI_WAVE];
+    __shared__ uint8_t s_has[kWavesPerBlock][MI_WAVE];
+    __shared__ uint8_t l_slot[kWavesPerBlock][T];
+    __shared__ int32_t l_m[kWavesPerBlock][T];
+    __shared__ float l_v[kWavesPerBlock][T];
+    const int lane = mi_lane(), wave = threadIdx.x / MI_WAVE;
+    const int li = lane % LPR, g = lane / LPR;
+    const int64_t q0 = ((int64_t)blockIdx.x * kWavesPerBlock + wave) * MI_WAVE;
+    if (q0 >= n_launch) return;   // the whole wavefront; nothing below synchronises across wavefronts
+    auto wave_sync = [] {          // LDS traffic of one wavefront is in order; the compiler must not move it across
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+    const int64_t q = q0 + lane;
+    int4 it = make_int4(0, 0, 0, -1);
+    int32_t first = 0;
+    if (q < n_launch) {
+        it = items[q];
+        first = epos[q];
     }
-    int4 it[R];
+    const int32_t len = it.w >= 0 ? it.z - it.y : 0;
+    const int32_t e_begin = __shfl(first, 0, MI_WAVE);
+    int32_t e_end = q < n_launch ? first + len : 0;   // epos ascends with the slot: the run ends where the last slot ends
 #pragma unroll
-    for (int k = 0; k < R; ++k) {
-        const int64_t q = base + k * SG + sgi;
-        it[k] = make_int4(0, 0, 0, -1);
-        if (q < n_launch) it[k] = items[q];
-    }
-    int32_t c0[R];
-    float v0[R];
+    for (int m = MI_WAVE / 2; m > 0; m >>= 1) e_end = max(e_end, __shfl_xor(e_end, m, MI_WAVE));
+    s_first[wave][lane] = q < n_launch ? first : e_end;
+    if (lane == 0) s_first[wave][MI_WAVE] = e_end;
+    s_slot[wave][lane] = it.w;
+    s_has[wave][lane] = 0;
+    wave_sync();
+    int cur = -1;   // the slot (0..63 of this wavefront) whose sum this sub-group holds
+    float4 acc[VPL];
 #pragma unroll
-    for (int k = 0; k < R; ++k) {
-        const int n = it[k].w >= 0 ? it[k].z - it[k].y : 0;
-        c0[k] = -1;
-        v0[k] = 0.f;
-        if (li < n) {
-            c0[k] = __builtin_nontemporal_load(col + it[k].y + li);
-            v0[k] = __builtin_nontemporal_load(val + it[k].y + li);
+    for (int v = 0; v < VPL; ++v) acc[v] = mi_f4_zero();
+    auto flush = [&] {
+        const int32_t slot = s_slot[wave][cur];
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) {
+            const int e = li + v * LPR;
+            if (e < d4) mi_store4<1>(partial + (int64_t)slot * d4 + e, acc[v], streaming);
+            acc[v] = mi_f4_zero();
         }
-    }
-    // the 1-bit pre-test (the whole bitmap sits in every XCD's L2; the 4-byte map entries of 8 M columns do not): a dead
-    // column — almost all of them — costs no look-up beyond it
+    };
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    for (int32_t t0 = e_begin; t0 < e_end; t0 += T) {
+        // ---- scan one tile: columns, bit tests, then map + value of the live entries, compacted in list order
+        int32_t c[UNR];
+        bool live[UNR];
 #pragma unroll
-    for (int k = 0; k < R; ++k)
-        if (c0[k] >= 0 && !((x_bits[c0[k] >> 5] >> (c0[k] & 31)) & 1u)) c0[k] = -1;
+        for (int u = 0; u < UNR; ++u) {
+            const int32_t i = t0 + u * MI_WAVE + lane;
+            c[u] = i < e_end ? __builtin_nontemporal_load(ecol + i) : -1;
+        }
 #pragma unroll
-    for (int k = 0; k < R; ++k)
-        if (c0[k] >= 0) c0[k] = x_map[c0[k]];
+        for (int u = 0; u < UNR; ++u) live[u] = c[u] >= 0 && ((x_bits[c[u] >> 5] >> (c[u] & 31)) & 1u);
+        int32_t mm[UNR];
+        float vv[UNR];
 #pragma unroll
-    for (int k = 0; k < R; ++k) {
-        const int32_t slot = it[k].w;
-        const int n = slot >= 0 ? it[k].z - it[k].y : 0;
-        const int nmax = wave_max_over_subgroups<LPR>(n);
-        float4 acc[VPL];
-#pragma unroll
-        for (int v = 0; v < VPL; ++v) acc[v] = mi_f4_zero();
-        int32_t my_c = c0[k];
-        float my_v = v0[k];
-        uint32_t any_live = 0u;   // sub-group-uniform
-        for (int b = 0; b < nmax; b += LPR) {
-            if (b > 0) {   // work items longer than a batch: the rest of the list, batch by batch
-                my_c = -1;
-                my_v = 0.f;
-                if (b + li < n) {
-                    const int32_t c = __builtin_nontemporal_load(col + it[k].y + b + li);
-                    my_c = ((x_bits[c >> 5] >> (c & 31)) & 1u) ? x_map[c] : -1;
-                    my_v = __builtin_nontemporal_load(val + it[k].y + b + li);
-                }
-            }
-            const unsigned long long live = __ballot(my_c >= 0);
-            if constexpr (LPR == 64) any_live |= (uint32_t)(live != 0ull);
-            else any_live |= (uint32_t)(((live >> ((lane / LPR) * LPR)) & ((1ull << LPR) - 1ull)) != 0ull);
-            uint32_t mine;   // this sub-group's live entries
-            if constexpr (LPR == 64) mine = (uint32_t)live;
-            else mine = (uint32_t)((live >> ((lane / LPR) * LPR)) & ((1ull << LPR) - 1ull));
-            // LPR == 64: the upper half is walked in a second round
-            for (int half = 0; half < (LPR == 64 ? 2 : 1); ++half) {
-                if (LPR == 64 && half == 1) mine = (uint32_t)(live >> 32);
-                while (__ballot(mine != 0u)) {
-                    const bool ok = mine != 0u;
-                    const int j = (ok ? __ffs((int)mine) - 1 : 0) + 32 * half;
-                    const int32_t c = __shfl(my_c, j, LPR);
-                    const float w = __shfl(my_v, j, LPR);
-                    const float4* src = X4 + (int64_t)(ok ? c : 0) * ldx4;
-#pragma unroll
-                    for (int v = 0; v < VPL; ++v) {
-                        const int e = li + v * LPR;
-                        if (ok && e < d4) mi_f4_fma(acc[v], w, src[e]);
-                    }
-                    mine &= mine - 1u;
-                }
+        for (int u = 0; u < UNR; ++u) {
+            mm[u] = -1;
+            vv[u] = 0.f;
+            if (live[u]) {
+                mm[u] = x_map[c[u]];
+                vv[u] = __builtin_nontemporal_load(eval + t0 + u * MI_WAVE + lane);
             }
         }
-        if (slot >= 0) {
-            if (li == 0) slot_live[slot] = (uint8_t)any_live;
-            if (any_live) {   // a work item without a live entry writes no partial row: the fix-up reads the flag instead
+        int cnt = 0;   // wavefront-uniform
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const unsigned long long b = __ballot(live[u]);
+            if (live[u]) {
+                const int32_t i = t0 + u * MI_WAVE + lane;
+                int lo = 0, hi = MI_WAVE;   // the LAST slot whose start is <= i: of a run of slots with equal starts (padding,
+                while (hi - lo > 1) {       // empty work items) all but the last are empty, so this one owns entry i
+                    const int mid = (lo + hi) >> 1;
+                    if (s_first[wave][mid] <= i) lo = mid; else hi = mid;
+                }
+                const int pos = cnt + __popcll(b & lt_mask);
+                l_slot[wave][pos] = (uint8_t)lo;
+                l_m[wave][pos] = mm[u];
+                l_v[wave][pos] = vv[u];
+                s_has[wave][lo] = 1;
+            }
+            cnt += __popcll(b);
+        }
+        wave_sync();
+        // ---- walk the tile's live list: sub-group g takes the entries of slots s with s % NB == g, in order
+        int idx = 0;   // sub-group-uniform cursor
+        while (__ballot(idx < cnt) != 0ull) {
+            // the next LPR list entries: which are this sub-group's?
+            const int p = idx + li;
+            const bool own = p < cnt && (int)(l_slot[wave][p] & (NB - 1)) == g;
+            unsigned long long ob = __ballot(own);
+            if constexpr (LPR < 64) ob = (ob >> (g * LPR)) & ((1ull << LPR) - 1ull);
+            int e[U];
+            bool ok[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                ok[u] = ob != 0ull;
+                e[u] = ok[u] ? idx + __ffsll((long long)ob) - 1 : 0;
+                ob &= ob - 1ull;
+            }
+            // the cursor moves behind the U-th own entry, or over the whole window when it held fewer (idx >= cnt ends the walk)
+            const int next = ob != 0ull ? e[U - 1] + 1 : idx + LPR;
+            float w[U];
+            int sl[U];
+            float4 x[U][VPL];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int32_t m = ok[u] ? l_m[wave][e[u]] : 0;
+                w[u] = ok[u] ? l_v[wave][e[u]] : 0.f;
+                sl[u] = ok[u] ? (int)l_slot[wave][e[u]] : 0;
+                const float4* src = X4 + (int64_t)m * ldx4;
 #pragma unroll
                 for (int v = 0; v < VPL; ++v) {
-                    const int e = li + v * LPR;
-                    if (e < d4) mi_store4<1>(partial + (int64_t)slot * d4 + e, acc[v], streaming);
+                    const int el = li + v * LPR;
+                    x[u][v] = (ok[u] && el < d4) ? src[el] : mi_f4_zero();
                 }
             }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (ok[u]) {
+                    if (sl[u] != cur) {
+                        if (cur >= 0) flush();
+                        cur = sl[u];
+                    }
+#pragma unroll
+                    for (int v = 0; v < VPL; ++v) mi_f4_fma(acc[v], w[u], x[u][v]);
+                }
+            }
+            idx = next;
         }
+        wave_sync();   // the list is rewritten by the next tile
     }
+    if (cur >= 0) flush();
+    if (it.w >= 0) slot_live[it.w] = s_has[wave][lane];
 }
 
 // bits[w] bit b = (map[32 w + b] >= 0)
@@ -917,22 +983,34 @@ __global__ __launch_bounds__(kBlock) void spmm_fixup_kernel(int32_t n_long, int 
 #pragma unroll
     for (int v = 0; v < VPL; ++v) acc[v] = mi_f4_zero();
     constexpr int FU = MI_SPMM_FIXUP_UNROLL / VPL;  // partial rows in flight per lane
-    for (int32_t s = sb + sg; s < se; s += NSG * FU) {
-        float4 x[FU][VPL];
+    constexpr int kTile = 2048;                      // a multiple of NSG * FU: the tiles cut the walk below between two of its trips
+    static_assert(kTile % (NSG * FU) == 0, "tile = whole trips");
+    __shared__ uint8_t live_sh[SPARSE ? kTile : 1];
+    const bool flagged = SPARSE && ex.slot_live != nullptr;   // mapped operand with x_bits: a work item that gathered nothing wrote no partial row
+    for (int32_t t0 = sb; t0 < se; t0 += kTile) {
+        const int32_t t1 = min(se, t0 + kTile);
+        if (flagged) {   // block-uniform: the row's flags of this tile, one coalesced read, instead of a flag load in front of every row load
+            __syncthreads();
+            for (int32_t i = t0 + (int32_t)threadIdx.x; i < t1; i += kBlock) live_sh[i - t0] = ex.slot_live[i];
+            __syncthreads();
+        }
+        for (int32_t s = t0 + sg; s < t1; s += NSG * FU) {
+            float4 x[FU][VPL];
 #pragma unroll
-        for (int u = 0; u < FU; ++u)
+            for (int u = 0; u < FU; ++u)
 #pragma unroll
-            for (int v = 0; v < VPL; ++v) {
-                const int e = li + v * LPR;
-                const int32_t ss = s + u * NSG;
-                bool take = ss < se && e < d4;
-                if (SPARSE && take && ex.slot_live) take = ex.slot_live[ss] != 0;   // a work item that gathered nothing (mapped operand): + 0
-                x[u][v] = take ? partial[(int64_t)ss * d4 + e] : mi_f4_zero();
-            }
+                for (int v = 0; v < VPL; ++v) {
+                    const int e = li + v * LPR;
+                    const int32_t ss = s + u * NSG;
+                    bool take = ss < t1 && e < d4;
+                    if (SPARSE && flagged && take) take = live_sh[ss - t0] != 0;
+                    x[u][v] = take ? partial[(int64_t)ss * d4 + e] : mi_f4_zero();
+                }
 #pragma unroll
-        for (int u = 0; u < FU; ++u)
+            for (int u = 0; u < FU; ++u)
 #pragma unroll
-            for (int v = 0; v < VPL; ++v) acc[v] = mi_f4_add(acc[v], x[u][v]);
+                for (int v = 0; v < VPL; ++v) acc[v] = mi_f4_add(acc[v], x[u][v]);
+        }
     }
 #pragma unroll
     for (int m = MI_WAVE / 2; m >= LPR; m >>= 1)
@@ -1143,6 +1221,29 @@ __global__ void plan_items_kernel(int32_t n_seg, int32_t banded, const uint64_t*
     items[pos] = make_int4(r, p, end, s);
 }
 
+// mi_spmm_plan_pack_entries: entries of launch slot q -> [epos[q], epos[q] + len) of the packed arrays
+__global__ void plan_item_len_kernel(int64_t n, const int4* __restrict__ items, int32_t* __restrict__ len) {
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n) return;
+    const int4 it = items[q];
+    len[q] = it.w >= 0 ? it.z - it.y : 0;
+}
+__global__ __launch_bounds__(256) void plan_pack_kernel(int64_t n, const int4* __restrict__ items, const int32_t* __restrict__ epos,
+                                                        int32_t nnz_long, const int32_t* __restrict__ col,
+                                                        const float* __restrict__ val, int32_t* __restrict__ ecol,
+                                                        float* __restrict__ eval) {
+    const int64_t q = (int64_t)blockIdx.x * 8 + threadIdx.x / 32;
+    if (q >= n) return;
+    const int4 it = items[q];
+    if (it.w < 0) return;
+    const int32_t len = it.z - it.y, first = epos[q];
+    if (first < 0 || first + len > nnz_long) return;   // a plan / nnz_long mismatch writes nothing out of bounds
+    for (int i = threadIdx.x % 32; i < len; i += 32) {
+        if (ecol) ecol[first + i] = col[it.y + i];
+        eval[first + i] = val[it.y + i];
+    }
+}
+
 #ifndef MI_SPMM_BAND_MIN_PER
 #define MI_SPMM_BAND_MIN_PER 1   // entries a band cut of a split row should hold on average (plan_seg_flags_kernel); 1 = every row cuts at `band`
 #endif
@@ -1198,27 +1299,24 @@ int launch_spmm_mode(int64_t n_rows, int d4, const int32_t* rowptr, const int32_
     if (do_split && plan && plan->n_items > 0 && (!sweep || plan->items)) {  // row_list mode still reduces every split row: hubs are few and almost always wanted
         const int64_t n_launch = plan->n_launch;
         dim3 gi((unsigned)mi_ceil_div(n_launch, SG * ITEMS_RPS));
+        const int32_t* ecol = plan->epos ? plan->ecol : col;   // packed plan: the work items read the plan's launch-ordered copies
+        const float* eval = plan->epos ? plan->eval : val;
         bool done = false;
         xmap_form = false;
         if constexpr (SPARSE) {
-#ifndef MI_SPMM_XMAP_SLOTS
-#define MI_SPMM_XMAP_SLOTS 32  // launch slots per workgroup of the mapped-operand kernel (a whole launch block of a banded plan); 0 = off
-#endif
-            constexpr int XR = MI_SPMM_XMAP_SLOTS / SG;
-            if constexpr (XR >= 2) {
-                if (ex.x_map && ex.x_bits && ex.slot_live) {
-                    hipLaunchKernelGGL((spmm_items_xmap_kernel<LPR, VPL, XR>), dim3((unsigned)mi_ceil_div(n_launch, SG * XR)),
-                                       dim3(kBlock), 0, s, n_launch, plan->band > 0 ? 1 : 0, d4,
-                                       reinterpret_cast<const int4*>(plan->items), col, val, X4, ldx4, partial, ex.x_map,
-                                       ex.x_bits, ex.slot_live, ep.streaming);
-                    done = xmap_form = true;
-                }
+            // a mapped operand declared rare-live (x_bits) on a packed plan: the scan form
+            if (ex.x_map && ex.x_bits && ex.slot_live && plan->epos) {
+                hipLaunchKernelGGL((spmm_items_xscan_kernel<LPR, VPL>),
+                                   dim3((unsigned)mi_ceil_div(n_launch, (int64_t)(kWavesPerBlock * MI_WAVE))), dim3(kBlock), 0, s,
+                                   n_launch, d4, reinterpret_cast<const int4*>(plan->items), plan->epos, plan->ecol, plan->eval,
+                                   X4, ldx4, partial, ex.x_map, ex.x_bits, ex.slot_live, ep.streaming);
+                done = xmap_form = true;
             }
         }
         if (!done)
             hipLaunchKernelGGL((spmm_items_kernel<LPR, VPL, UNROLL, ITEMS_RPS, SPARSE>), gi, dim3(kBlock), 0, s, n_launch,
-                               plan->band > 0 ? 1 : 0, d4, reinterpret_cast<const int4*>(plan->items), col, val, X4, ldx4,
-                               partial, ex.x_map, ep.streaming);
+                               plan->band > 0 ? 1 : 0, d4, reinterpret_cast<const int4*>(plan->items), plan->epos, ecol, eval,
+                               X4, ldx4, partial, ex.x_map, ep.streaming);
     }
     const int64_t n_out = listed ? n_list : n_rows;
     bool short_done = false;
@@ -1438,6 +1536,34 @@ int mi_spmm_plan_fill(int64_t n_rows, const int32_t* rowptr, const mi_spmm_plan_
     return mi_launch_status();
 }
 
+size_t mi_spmm_plan_pack_workspace_bytes(int64_t n_launch) {
+    const size_t n = (size_t)(n_launch > 0 ? n_launch : 0) + 1;
+    return 2 * mi_align_up(n * sizeof(int32_t), 256) + plan_tmp_bytes((int64_t)n);
+}
+
+int mi_spmm_plan_pack_entries(const mi_spmm_plan* plan, int64_t nnz_long, const int32_t* col, const float* val,
+                              int32_t values_only, void* ws, size_t ws_bytes, mi_stream_t stream) {
+    MI_CHECK_ARG(plan && plan->items && plan->epos && plan->ecol && plan->eval && val && (values_only || col));
+    MI_CHECK_ARG(plan->n_launch > 0 && nnz_long >= 0 && nnz_long < INT32_MAX && mi_aligned16(plan->items));
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t n = plan->n_launch;
+    if (!values_only) {
+        MiArena ar(ws, ws_bytes);
+        int32_t* len = ar.take<int32_t>((size_t)n + 1);
+        const size_t tmp_bytes = plan_tmp_bytes(n + 1);
+        char* tmp = ar.take<char>(tmp_bytes);
+        if (!len || !tmp) return MI_ERR_WORKSPACE;
+        hipLaunchKernelGGL(plan_item_len_kernel, plan_grid(n), dim3(256), 0, s, n, reinterpret_cast<const int4*>(plan->items), len);
+        size_t tb = tmp_bytes;
+        MI_HIP(rocprim::exclusive_scan(tmp, tb, len, plan->epos, 0, (size_t)n, rocprim::plus<int32_t>(), s));
+    }
+    constexpr int kPerBlock = 256 / 32;   // one 32-lane group per launch slot
+    hipLaunchKernelGGL(plan_pack_kernel, dim3((unsigned)mi_ceil_div(n, (int64_t)kPerBlock)), dim3(256), 0, s, n,
+                       reinterpret_cast<const int4*>(plan->items), plan->epos, (int32_t)nnz_long, col, val,
+                       values_only ? nullptr : plan->ecol, plan->eval);
+    return mi_launch_status();
+}
+
 size_t mi_spmm_workspace_bytes(const mi_spmm_plan* plan, int64_t d) {
     if (!plan || plan->n_items <= 0) return 0;
     // the partial rows, then one live flag per work item (mapped launches with mi_spmm_ex.x_bits)
@@ -1510,6 +1636,7 @@ int mi_spmm_csr_ex_f32(int64_t n_rows, int64_t d, const int32_t* rowptr, const i
         MI_CHECK_ARG(plan->item_ptr && plan->long_rows && (sweep || plan->items));
         MI_CHECK_ARG(!plan->items || plan->n_launch >= own_items);
         MI_CHECK_ARG(!plan->items || plan->band == 0 || plan->n_launch % (8 * kPlanGroup) == 0);
+        MI_CHECK_ARG(!plan->epos || (plan->items && plan->ecol && plan->eval));
         if (!ws || ws_bytes < mi_spmm_workspace_bytes(plan, d)) return MI_ERR_WORKSPACE;
         MI_CHECK_ARG(mi_aligned16(ws) && (!plan->items || mi_aligned16(plan->items)));
         partial = reinterpret_cast<float4*>(ws);

@@ -39,6 +39,7 @@ SPMM_EVENTS = None
 # LAPLACE_SPMM_TWO_STREAMS=0 / 1; the enqueue order of the two halves does not matter).  On by default;
 # LAPLACE_SPMM_TWO_STREAMS=0 switches it off.  (2 = split rows enqueued first: an A/B setting.)
 SPMM_TWO_STREAMS = int(os.environ.get("LAPLACE_SPMM_TWO_STREAMS", "1") or 0)
+PACK_ENTRIES = os.environ.get("LAPLACE_SPMM_PACK", "1") != "0"   # A/B: banded plans carry launch-ordered copies of their entries
 X_RARE_BITS = os.environ.get("LAPLACE_X_RARE", "1") != "0"   # A/B: spmm(..., x_rare=True) honoured (mi_spmm_ex.x_bits)
 _SIDE = {}
 
@@ -129,6 +130,9 @@ class SpmmPlan:
     sweep: Optional[SpmmSweepStruct] = None       # split rows in SWEEP form (mi_spmm_sweep); tensors kept in sweep_t
     sweep_t: tuple = ()
     wide: Optional["SpmmPlan"] = None             # work-item plan of the same adjacency for widths the sweep form lacks
+    packed: tuple = ()                            # (epos, ecol, eval): the split rows' entries in launch order (mi_spmm_plan_pack_entries)
+    packed_of: tuple = ()                         # (val.data_ptr(), val._version) the packed values were copied from
+    nnz_long: int = 0
 
     @property
     def n_long_rows(self) -> int:
@@ -487,7 +491,27 @@ def build_spmm_plan(a: DeviceCSR, chunk: int = DEFAULT_CHUNK, band: Optional[int
     st.long_index = long_index.data_ptr()
     check(L.mi_spmm_plan_fill(a.n_rows, _ptr(a.rowptr), ctypes.byref(info), ctypes.byref(st), ws.data_ptr(), ws.numel(),
                               _stream()), "mi_spmm_plan_fill")
-    return SpmmPlan(st, long_rows, item_ptr, items, long_index)
+    plan = SpmmPlan(st, long_rows, item_ptr, items, long_index)
+    plan.nnz_long = int(info.nnz_long)
+    del ws
+    if PACK_ENTRIES and nlaunch > 0 and plan.nnz_long > 0 and a.val is not None:
+        _pack_plan_entries(a, plan, values_only=False)
+    return plan
+
+
+def _pack_plan_entries(a: DeviceCSR, plan: SpmmPlan, values_only: bool) -> None:
+    """The split rows' (col, val) copied into launch order (mi_spmm_plan.epos / ecol / eval): a banded plan's work items are
+    launched band by band, so in the CSR arrays every work item's ~12 entries sit in two cache lines of their own."""
+    L = _lib.lib()
+    dev, st = a.device, plan.struct
+    if not values_only:
+        plan.packed = (t.empty(int(st.n_launch), dtype=t.int32, device=dev), t.empty(plan.nnz_long, dtype=t.int32, device=dev),
+                       t.empty(plan.nnz_long, dtype=t.float32, device=dev))
+        st.epos, st.ecol, st.eval = (x.data_ptr() for x in plan.packed)
+    ws = _ws(L.mi_spmm_plan_pack_workspace_bytes(int(st.n_launch)), dev)
+    check(L.mi_spmm_plan_pack_entries(ctypes.byref(st), plan.nnz_long, _ptr(a.col), _ptr(a.val), 1 if values_only else 0,
+                                      ws.data_ptr(), ws.numel(), _stream()), "mi_spmm_plan_pack_entries")
+    plan.packed_of = (a.val.data_ptr(), a.val._version)
 
 
 def spmm(a: DeviceCSR, X: Tensor, *, Y: Optional[Tensor] = None, addend: Optional[Tensor] = None,
@@ -560,6 +584,8 @@ def spmm(a: DeviceCSR, X: Tensor, *, Y: Optional[Tensor] = None, addend: Optiona
             plan.wide = build_spmm_plan(a, chunk=int(plan.struct.chunk), sweep=False)
         plan = plan.wide
     L = _lib.lib()
+    if plan is not None and plan.packed and plan.packed_of != (a.val.data_ptr(), a.val._version):
+        _pack_plan_entries(a, plan, values_only=True)     # the adjacency was re-weighted since the plan copied its values
     ws_ptr, ws_bytes = None, 0
     if plan is not None and plan.n_items > 0:
         if d not in plan.partial:

@@ -79,6 +79,43 @@ def test_c4_full_size_propagate_properties(c4_graph):
     assert int(deg.max()) > 1_000_000 and worst > 0.0                  # the hubs of this graph really are 10^6-entry rows
 
 
+def test_c4_full_size_mapped_product_with_rare_live_columns(c4_graph):
+    """The first backward product of the fused step at configs[3]'s size: the adjacency times a compact batch gradient through
+    x_map (131 072 sampled edges' users, their items, uniform negatives).  The rare-live-columns form (mi_spmm_ex.x_bits:
+    spmm_items_xmap_kernel + live flags) must be bitwise the plain mapped product and bitwise reproducible — at THIS size the
+    outputs are streamed (sc1 stores through inline asm), a path no small test reaches: the form's first version passed every
+    small test and differed run to run here (a missing wait state behind the store)."""
+    from laplace_amd import ops, synthetic as S
+    ei, inter, adj = c4_graph
+    U, I, B = S.C4.num_users, S.C4.num_items, 131_072
+    n, d = adj.n_rows, 128
+    us, ps, ns = ops.sample_bpr_batch(inter.csr(), inter.row_of_edge(), B, I, seed=5, step=3)
+    gmap, nodes, cnt = ops.batch_nodes(us, ps, ns, U, n)
+    g = t.Generator(device=DEV).manual_seed(1)
+    Xc = t.randn(3 * B, d, device=DEV, generator=g) * 0.1
+    outs = []
+    for rare in (False, True, True):
+        o = t.full((n, d), float("nan"), device=DEV)
+        ops.spmm(adj, Xc, addend=Xc, S=o, x_map=gmap, addend_map=gmap, x_rare=rare)
+        outs.append(o)
+    t.cuda.synchronize()
+    assert t.equal(outs[1], outs[2])          # reproducible
+    assert t.equal(outs[1], outs[0])          # the hint changes no bit
+    # a handful of hub rows against float64 of the expanded operand
+    deg = (adj.rowptr[1:] - adj.rowptr[:-1])
+    for r in deg.cpu().topk(6).indices.tolist() + [U + 5000, U + 50_000]:
+        b, e = int(adj.rowptr[r]), int(adj.rowptr[r + 1])
+        cols = adj.col[b:e].long()
+        m = gmap[cols].long()
+        live = m >= 0
+        want = (adj.val[b:e][live].double()[:, None] * Xc[m[live]].double()).sum(0)
+        ar = int(gmap[r])
+        if ar >= 0:
+            want = want + Xc[ar].double()
+        assert (outs[1][r].double() - want).abs().max() <= 1e-5 + 1e-6 * float(live.sum()) ** 0.5, r
+    del outs
+
+
 def test_c4_full_size_sampler_and_one_fused_step(c4_graph):
     """bench.py --config c4 at N = 1: on-device sampling of the global batch (131 072), one fused train step under the
     locality order; rows without gradient stay put, no parameter moves by more than lr (Adam's first step)."""

@@ -261,6 +261,69 @@ def test_spmm_sweep_plan_equals_work_item_plan(d, n_streams):
     want = (vv[b:e, None] * Xw.cpu().double()[cc[b:e]]).sum(0)
     assert (Yw[r].cpu().double() - want).abs().max() <= 1e-3
 
+@pytest.mark.parametrize("d", [32, 128, 512])
+def test_packed_plan_entries_are_the_same_product_and_follow_a_reweighting(d):
+    """mi_spmm_plan.epos / ecol / eval (round 4): a banded plan's work items read launch-ordered COPIES of the split rows' entries.
+    The product is bitwise the one read from the CSR arrays (dense, mapped, row-list forms); the copies hold values, so a
+    re-weighted adjacency (val changed in place, or replaced) must be seen by the next product."""
+    ops = _ops()
+    g = t.Generator().manual_seed(d)
+    n = 5000
+    degs = t.cat([t.tensor([4000, 1500]), t.randint(260, 600, (40,), generator=g)])
+    hub_rows = t.randperm(n, generator=g)[: degs.numel()]
+    row = t.cat([t.full((int(L),), int(r)) for r, L in zip(hub_rows, degs)] + [t.randint(0, n, (20000,), generator=g)])
+    col = t.randint(0, n, (row.numel(),), generator=g)
+    a = ops.coo_to_csr(row.to(DEV), col.to(DEV), n, n, want_perm=False)
+    a.val = (t.rand(a.nnz, generator=g) + 0.5).to(DEV)
+    X = t.randn(n, d, generator=g).to(DEV)
+    keep = t.rand(n, generator=g) < 0.2
+    x_map = t.where(keep, t.cumsum(keep.int(), 0) - 1, t.full((n,), -1)).to(t.int32).to(DEV)
+    Xc = X[keep.to(DEV)].contiguous()
+    rows = t.cat([hub_rows[:10], t.randint(0, n, (200,), generator=g)]).to(t.int32).to(DEV)
+
+    def products(plan):
+        a.plan = plan
+        Y = t.full((n, d), float("nan"), device=DEV)
+        Ym = t.full((n, d), float("nan"), device=DEV)
+        Yl = t.full((rows.numel(), d), float("nan"), device=DEV)
+        ops.spmm(a, X, Y=Y)
+        ops.spmm(a, Xc, Y=Ym, x_map=x_map)
+        ops.spmm(a, X, Y=Yl, row_list=rows)
+        return Y, Ym, Yl
+
+    saved = ops.PACK_ENTRIES
+    try:
+        ops.PACK_ENTRIES = False
+        plain = ops.build_spmm_plan(a, chunk=256, band=64, sweep=False)
+        ops.PACK_ENTRIES = True
+        packed = ops.build_spmm_plan(a, chunk=256, band=64, sweep=False)
+    finally:
+        ops.PACK_ENTRIES = saved
+    assert not plain.packed and len(packed.packed) == 3 and packed.nnz_long >= int(degs.sum())
+    epos, ecol, ev = packed.packed
+    items = packed.items.view(-1, 4).cpu()
+    real = items[:, 3] >= 0
+    lens = (items[:, 2] - items[:, 1])[real]
+    assert int(lens.sum()) == packed.nnz_long and int(epos.cpu()[real].max()) + int(lens[epos.cpu()[real].argmax()]) == packed.nnz_long
+    q = int(real.nonzero()[7])                                           # one work item's copy, entry by entry
+    b, e, p0 = int(items[q, 1]), int(items[q, 2]), int(epos[q])
+    assert t.equal(ecol[p0:p0 + e - b], a.col[b:e]) and t.equal(ev[p0:p0 + e - b], a.val[b:e])
+    want = products(plain)
+    got = products(packed)
+    for w_, g_ in zip(want, got):
+        assert t.equal(w_, g_)
+    # re-weighting in place, then by replacement: the packed values follow
+    a.val.mul_(1.5)
+    got2 = products(packed)
+    want2 = products(plain)
+    for w_, g_ in zip(want2, got2):
+        assert t.equal(w_, g_)
+    assert not t.equal(got2[0], got[0])
+    a.val = (a.val * 0.25 + 0.1).contiguous()
+    for w_, g_ in zip(products(plain), products(packed)):
+        assert t.equal(w_, g_)
+
+
 @pytest.mark.parametrize("band", [0, 64])
 @pytest.mark.parametrize("d,live", [(32, 0.02), (64, 0.3), (128, 0.005), (128, 0.0), (256, 0.02), (512, 0.02)])
 def test_rare_live_columns_hint_is_bitwise_the_mapped_product(d, live, band):
