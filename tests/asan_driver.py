@@ -196,6 +196,21 @@ def main():
         st.n_items = n_items
         L.mi_spmm_workspace_bytes(ctypes.byref(st), dd)
     assert L.mi_spmm_workspace_bytes(None, 128) == 0
+    # round 4: the packed-entries and live-bits entry points reject bad descriptors before they enqueue or read anything
+    for n in (0, 1, 7_726_979, -4):
+        L.mi_spmm_plan_pack_workspace_bytes(n)
+    f0 = Fake()
+    st = _lib.SpmmPlanStruct()
+    assert L.mi_spmm_plan_pack_entries(None, 10, f0(64), f0(64), 0, f0(1 << 20), 1 << 20, None) == BAD_ARG
+    assert L.mi_spmm_plan_pack_entries(ctypes.byref(st), 10, f0(64), f0(64), 0, f0(1 << 20), 1 << 20, None) == BAD_ARG   # no items / epos
+    st.items, st.epos, st.ecol, st.eval, st.n_launch = f0(4096), f0(1024), f0(1024), f0(1024), 0
+    assert L.mi_spmm_plan_pack_entries(ctypes.byref(st), 10, f0(64), f0(64), 0, f0(1 << 20), 1 << 20, None) == BAD_ARG   # n_launch = 0
+    st.n_launch = 256
+    assert L.mi_spmm_plan_pack_entries(ctypes.byref(st), -1, f0(64), f0(64), 0, f0(1 << 20), 1 << 20, None) == BAD_ARG
+    assert L.mi_spmm_plan_pack_entries(ctypes.byref(st), 10, None, f0(64), 0, f0(1 << 20), 1 << 20, None) == BAD_ARG    # col needed unless values_only
+    assert L.mi_spmm_plan_pack_entries(ctypes.byref(st), 10, f0(64), f0(64), 0, f0(256), 256, None) == -3                # MI_ERR_WORKSPACE
+    assert L.mi_map_live_bits_i32(-1, f0(64), f0(64), None) == BAD_ARG and L.mi_map_live_bits_i32(5, None, f0(64), None) == BAD_ARG
+    assert L.mi_map_live_bits_i32(0, None, None, None) == 0
     for v in (0, 1, 128, 131072, -5):
         L.mi_bpr_workspace_bytes(v); L.mi_batch_nodes_workspace_bytes(v); L.mi_batchnorm_workspace_bytes(v)
     for m, n, k in ((1, 1, 1), (64, 64, 8192), (30000, 128, 84), (0, 5, 5), (-1, 2, 3), (128, 170, 1 << 20)):
