@@ -325,7 +325,7 @@ def test_packed_plan_entries_are_the_same_product_and_follow_a_reweighting(d):
 
 
 @pytest.mark.parametrize("band", [0, 64])
-@pytest.mark.parametrize("d,live", [(32, 0.02), (64, 0.3), (128, 0.005), (128, 0.0), (256, 0.02), (512, 0.02)])
+@pytest.mark.parametrize("d,live", [(32, 0.02), (64, 0.3), (128, 0.005), (128, 0.0), (128, 1.0), (256, 0.02), (512, 0.02), (512, 0.9)])
 def test_rare_live_columns_hint_is_bitwise_the_mapped_product(d, live, band):
     """mi_spmm_ex.x_bits (round 4): a mapped operand whose live columns are rare — the first backward product of the fused
     step on BASELINE configs[3], the batch's 131 K users among 8 M.  The split rows' work items then test one bit per column
