@@ -266,10 +266,11 @@ typedef struct mi_spmm_ex {
                                        bits 12.. wavefronts per CU (workgroups per CU = that / wavefronts per workgroup) */
     const uint32_t* x_bits;         /* nullable, with x_map: bit c of the array (word c / 32, bit c % 32; mi_map_live_bits_i32 writes
                                        it) = (x_map[c] >= 0).  Saying so declares the live columns RARE (the batch's users among all
-                                       users, first backward product of the fused step): the split rows' work items then run in a
-                                       form that tests the bit before the map, gathers only live entries, writes no partial row
-                                       for a work item without any, and the fix-up skips those — same sums in the same order,
-                                       bitwise the result without the hint.  Ignored with a sweep or a row_list. */
+                                       users: first backward product of the fused step).  On a PACKED plan (epos / ecol / eval) the
+                                       split rows' work items are then not walked one by one: wavefronts scan the packed entries,
+                                       test the bit before the map, gather only the live entries in list order, write no partial
+                                       row for a work item without any, and the fix-up skips those — same sums in the same order,
+                                       bitwise the result without the hint.  Ignored with a sweep, a row_list or an unpacked plan. */
 } mi_spmm_ex;
 #define MI_SPMM_SHORT_ROWS 1
 #define MI_SPMM_SPLIT_ROWS 2

@@ -106,7 +106,7 @@ struct Ex {
     const int32_t* long_index;  // [n_rows]: index into the plan's long rows, -1 for short rows (row_list mode)
     int32_t parts;              // mask of MI_SPMM_SHORT_ROWS / MI_SPMM_SPLIT_ROWS (host side only)
     int32_t hot_base, hot_rows, hot_threads;  // persistent short-row launch (host side only): hot_rows 0 = plain launch, > 0 = LDS cache rows, < 0 = no cache
-    const uint32_t* x_bits;     // bit c = (x_map[c] >= 0): "live columns are rare" — the work items run as spmm_items_xmap_kernel
+    const uint32_t* x_bits;     // bit c = (x_map[c] >= 0): "live columns are rare" — on a packed plan the work items run as spmm_items_xscan_kernel
     uint8_t* slot_live;         // [plan->n_items], behind the partial rows: 0 = the work item gathered nothing and wrote no partial row
 };
 
@@ -1293,7 +1293,7 @@ int launch_spmm_mode(int64_t n_rows, int d4, const int32_t* rowptr, const int32_
             return MI_ERR_UNSUPPORTED;
         }
     }
-    bool xmap_form = false;   // the work items ran as spmm_items_xmap_kernel: their live flags are valid
+    bool xmap_form = false;   // the work items ran as spmm_items_xscan_kernel: their live flags are valid
     // HYBRID plan (round 4): the hub rows in SWEEP form AND the remaining split rows as banded work items — `items` is
     // then non-null beside the sweep, its slots are absolute (they start behind the sweep's 8 * n_slots partial rows)
     if (do_split && plan && plan->n_items > 0 && (!sweep || plan->items)) {  // row_list mode still reduces every split row: hubs are few and almost always wanted
@@ -1640,10 +1640,10 @@ int mi_spmm_csr_ex_f32(int64_t n_rows, int64_t d, const int32_t* rowptr, const i
         if (!ws || ws_bytes < mi_spmm_workspace_bytes(plan, d)) return MI_ERR_WORKSPACE;
         MI_CHECK_ARG(mi_aligned16(ws) && (!plan->items || mi_aligned16(plan->items)));
         partial = reinterpret_cast<float4*>(ws);
-        // the work items of a mapped operand whose live columns are rare (x_bits): spmm_items_xmap_kernel + live flags.
+        // the work items of a mapped operand whose live columns are rare (x_bits): spmm_items_xscan_kernel + live flags (packed plans).
         // Not with a sweep (its slots carry no flags) and not with row_list (the fix-up then walks listed rows only — fine —
         // but the combination has no caller and no test)
-        if (exh && exh->x_bits && ex.x_map && plan->items && !sweep && !ex.row_list) {
+        if (exh && exh->x_bits && ex.x_map && plan->items && plan->epos && !sweep && !ex.row_list) {
             ex.x_bits = exh->x_bits;
             ex.slot_live = reinterpret_cast<uint8_t*>(ws) + mi_align_up((size_t)plan->n_items * (size_t)d * sizeof(float), 256);
         }

@@ -82,7 +82,7 @@ def test_c4_full_size_propagate_properties(c4_graph):
 def test_c4_full_size_mapped_product_with_rare_live_columns(c4_graph):
     """The first backward product of the fused step at configs[3]'s size: the adjacency times a compact batch gradient through
     x_map (131 072 sampled edges' users, their items, uniform negatives).  The rare-live-columns form (mi_spmm_ex.x_bits:
-    spmm_items_xmap_kernel + live flags) must be bitwise the plain mapped product and bitwise reproducible — at THIS size the
+    spmm_items_xscan_kernel + live flags) must be bitwise the plain mapped product and bitwise reproducible — at THIS size the
     outputs are streamed (sc1 stores through inline asm), a path no small test reaches: the form's first version passed every
     small test and differed run to run here (a missing wait state behind the store)."""
     from laplace_amd import ops, synthetic as S
