@@ -600,20 +600,43 @@ __global__ __launch_bounds__(kBlock) void topk_refine_finalize_kernel(FusedArgs 
                 return;
             }
             if (ok) {
-                // exact scores: the k-ordered fma chain, bit for bit the f32 MFMA's and the oracle's
-                for (int i = tid; i < n2; i += kBlock) {
-                    const uint32_t item = surv[i];
-                    const float4* it = reinterpret_cast<const float4*>(a.I + (int64_t)item * a.ldi);
-                    float acc = 0.f;
-                    for (int c4 = 0; c4 < a.d / 4; ++c4) {
-                        const float4 w = it[c4];
-                        const float4 uu = *reinterpret_cast<const float4*>(urow + 4 * c4);
-                        acc = fmaf(uu.x, w.x, acc);
-                        acc = fmaf(uu.y, w.y, acc);
-                        acc = fmaf(uu.z, w.z, acc);
-                        acc = fmaf(uu.w, w.w, acc);
+                // exact scores: the k-ordered fma chain, bit for bit the f32 MFMA's and the oracle's.  TWO rows per thread and
+                // trip (i and i + kBlock), their loads in flight together: at k = 256 the survivors are kk + a few (~270-280), and
+                // a second trip for the two dozen beyond kBlock paid a full round of memory latency with one wavefront a third full
+                for (int base = 0; base < n2; base += 2 * kBlock) {
+                    const int i0 = base + tid, i1 = i0 + kBlock;
+                    const bool h0 = i0 < n2, h1 = i1 < n2;
+                    const uint32_t item0 = h0 ? surv[i0] : 0u, item1 = h1 ? surv[i1] : 0u;
+                    const float4* it0 = reinterpret_cast<const float4*>(a.I + (int64_t)item0 * a.ldi);
+                    const float4* it1 = reinterpret_cast<const float4*>(a.I + (int64_t)item1 * a.ldi);
+                    float acc0 = 0.f, acc1 = 0.f;
+                    if (__ballot(h1) == 0ull) {   // wavefront-uniform: nothing in the second half
+                        if (h0)
+                            for (int c4 = 0; c4 < a.d / 4; ++c4) {
+                                const float4 w = it0[c4];
+                                const float4 uu = *reinterpret_cast<const float4*>(urow + 4 * c4);
+                                acc0 = fmaf(uu.x, w.x, acc0);
+                                acc0 = fmaf(uu.y, w.y, acc0);
+                                acc0 = fmaf(uu.z, w.z, acc0);
+                                acc0 = fmaf(uu.w, w.w, acc0);
+                            }
+                    } else {
+                        for (int c4 = 0; c4 < a.d / 4; ++c4) {
+                            const float4 w0 = h0 ? it0[c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+                            const float4 w1 = h1 ? it1[c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+                            const float4 uu = *reinterpret_cast<const float4*>(urow + 4 * c4);
+                            acc0 = fmaf(uu.x, w0.x, acc0);
+                            acc0 = fmaf(uu.y, w0.y, acc0);
+                            acc0 = fmaf(uu.z, w0.z, acc0);
+                            acc0 = fmaf(uu.w, w0.w, acc0);
+                            acc1 = fmaf(uu.x, w1.x, acc1);
+                            acc1 = fmaf(uu.y, w1.y, acc1);
+                            acc1 = fmaf(uu.z, w1.z, acc1);
+                            acc1 = fmaf(uu.w, w1.w, acc1);
+                        }
                     }
-                    sh.cand[i] = composite(score_key(acc), item);
+                    if (h0) sh.cand[i0] = composite(score_key(acc0), item0);
+                    if (h1) sh.cand[i1] = composite(score_key(acc1), item1);
                 }
                 __syncthreads();
 #if defined(MI_REFINE_PROBE) && MI_REFINE_PROBE == 4
