@@ -261,6 +261,50 @@ def test_spmm_sweep_plan_equals_work_item_plan(d, n_streams):
     want = (vv[b:e, None] * Xw.cpu().double()[cc[b:e]]).sum(0)
     assert (Yw[r].cpu().double() - want).abs().max() <= 1e-3
 
+def test_streaming_stores_equal_cached_stores():
+    """Outputs of 64 MB and more leave through write-through (sc1) stores issued from inline asm (mi_store4); smaller ones through
+    plain stores.  Round 4 found the asm form short of the wait states a 128-bit store needs before its data registers are
+    reused — invisible to every test below that size.  Here one product is large enough to stream (150 K x 128 floats = 77 MB)
+    and the same rows computed as two row slices are not: every row's sum is formed the same way (a plan cuts a row by its own
+    entries), so the two must agree bit for bit — dense, mapped with and without the rare-live hint — and repeat bit for bit."""
+    ops = _ops()
+    g = t.Generator().manual_seed(11)
+    n, d = 150_000, 128
+    degs = t.cat([t.tensor([30000, 9000, 4000]), t.randint(260, 900, (300,), generator=g)])
+    hub_rows = t.randperm(n, generator=g)[: degs.numel()]
+    row = t.cat([t.full((int(L),), int(r)) for r, L in zip(hub_rows, degs)] + [t.randint(0, n, (1_200_000,), generator=g)])
+    col = t.randint(0, n, (row.numel(),), generator=g)
+    a = ops.coo_to_csr(row.to(DEV), col.to(DEV), n, n, want_perm=False)
+    a.val = (t.rand(a.nnz, generator=g) + 0.5).to(DEV)
+    a.plan = ops.build_spmm_plan(a, chunk=256, band=16384, sweep=False)
+    halves = [ops.row_slice(a, 0, n // 2), ops.row_slice(a, n // 2, n)]
+    for h in halves:
+        h.plan = ops.build_spmm_plan(h, chunk=256, band=16384, sweep=False)
+    assert a.plan.n_items > 1000 and all(h.plan.n_items > 100 for h in halves)
+    X = (t.randn(n, d, generator=g) * 0.1).to(DEV)
+    keep = t.rand(n, generator=g) < 0.03
+    x_map = t.where(keep, t.cumsum(keep.int(), 0) - 1, t.full((n,), -1)).to(t.int32).to(DEV)
+    Xc = X[keep.to(DEV)].contiguous()
+
+    def whole(**kw):
+        Y = t.full((n, d), float("nan"), device=DEV)
+        ops.spmm(a, kw.pop("X"), Y=Y, **kw)
+        return Y
+
+    def sliced(**kw):
+        Y = t.full((n, d), float("nan"), device=DEV)
+        Xin = kw.pop("X")
+        ops.spmm(halves[0], Xin, Y=Y[: n // 2], **kw)
+        ops.spmm(halves[1], Xin, Y=Y[n // 2:], **kw)
+        return Y
+
+    for kw in (dict(X=X), dict(X=Xc, x_map=x_map), dict(X=Xc, x_map=x_map, x_rare=True)):
+        big, big2, small = whole(**dict(kw)), whole(**dict(kw)), sliced(**dict(kw))
+        t.cuda.synchronize()
+        assert t.equal(big, big2), sorted(kw)
+        assert t.equal(big, small), sorted(kw)
+
+
 @pytest.mark.parametrize("d", [32, 128, 512])
 def test_packed_plan_entries_are_the_same_product_and_follow_a_reweighting(d):
     """mi_spmm_plan.epos / ecol / eval (round 4): a banded plan's work items read launch-ordered COPIES of the split rows' entries.
