@@ -119,10 +119,18 @@ def run(users=1_371_980, items=105_542, edges=31_800_000, lightgcn_steps=300, li
     native = NativeRankerStep(ranker, opt)   # what training.train_with_dataloader runs per batch: one C call per iteration
     fused = FusedRankerStep(ranker, opt)
 
+    path = {"native": 0, "fused": 0}
+    declined = {}
+
     def step(batch):
         lab = batch[Constants.edge_key]
         loss = native.step(batch.x_dict, batch.edge_index_dict, lab.edge_label_index, lab.edge_label)
-        return loss if loss is not None else fused.step(*select_properties(batch))
+        if loss is not None:
+            path["native"] += 1
+            return loss
+        path["fused"] += 1
+        declined[native.declined] = declined.get(native.declined, 0) + 1
+        return fused.step(*select_properties(batch))
 
     for _ in range(5):
         step(next(it))
@@ -140,6 +148,7 @@ def run(users=1_371_980, items=105_542, edges=31_800_000, lightgcn_steps=300, li
     out["ranker_ms_per_iteration"] = round(1e3 * dt / max(ranker_iters, 1), 3)
     out["ranker_positive_edges_per_s"] = round(pos / dt)
     out["ranker_loss_last"] = round(float(rl.detach()), 4)
+    out["ranker_iteration_path"] = dict(path, **({"declined": declined} if declined else {}))
 
     # 5. evaluation of the held-out users: device-built samples with the matchers' candidates, inference, top-12
     t0 = time.perf_counter()
