@@ -208,15 +208,28 @@ class DeviceGraphSampler:
         data[Constants.rev_edge_key].edge_label_index = label3[1:3]
         data[Constants.rev_edge_key].edge_label = labels
         data._blocks = blocks + [xc, xa]  # the storages behind every tensor of the batch (the iterator's record_stream calls)
+        data._seed_users, data._user_ptr = seeds, user_ptr   # per-sample structure (run_submission.make_predictions' sync-free path)
+        data._max_candidates = int(self.max_neg)             # capacity of a sample's label-0 list
         return data
+
+    def iter_users(self, users: Tensor) -> Iterator[HeteroData]:
+        """The batches of `users` (int64, in this order, batch_size at a time) through the same pipelined iterator as an epoch:
+        batch i is sampled with Philox step self.step + i, exactly what sample(users[i * B:(i + 1) * B], step=self.step + i)
+        returns — evaluation of a subset of the customers (a submission shard, held-out users) without a host wait per batch."""
+        self._order_override = users.detach().to("cpu", t.int64).contiguous()
+        return iter(self)
 
     def __iter__(self) -> Iterator[HeteroData]:
         """One epoch: every user once, shuffled (DataLoader(shuffle=True) semantics).  With `prefetch` (default)
         sampling runs three batches ahead on a side stream while the consumer trains on batch i: nothing of the
         sampler sits between two steps.  Same batches, same order, same Philox steps as the serial loop."""
         g = t.Generator(device="cpu").manual_seed(self.seed + self.step)
-        order = t.randperm(self.num_users, generator=g) if self.shuffle else t.arange(self.num_users)
-        batches = [order[b:b + self.batch_size] for b in range(0, self.num_users, self.batch_size)]
+        order = getattr(self, "_order_override", None)
+        self._order_override = None
+        if order is None:
+            order = t.randperm(self.num_users, generator=g) if self.shuffle else t.arange(self.num_users)
+        n_order = int(order.numel())
+        batches = [order[b:b + self.batch_size] for b in range(0, n_order, self.batch_size)]
         if not getattr(self, "prefetch", True) or not batches:
             for seeds in batches:
                 yield self.sample(seeds)
@@ -235,7 +248,7 @@ class DeviceGraphSampler:
         # the epoch's seed order goes to the device ONCE (round 4: a 24-element host-to-device copy per batch was 40 us of the
         # loop's host time — the loop is host-bound, tools/prof_host_native.py); a batch's seeds are a view of it
         order_dev = order.to(self.device, t.int64)
-        batches_dev = [order_dev[b:b + self.batch_size] for b in range(0, self.num_users, self.batch_size)]
+        batches_dev = [order_dev[b:b + self.batch_size] for b in range(0, n_order, self.batch_size)]
 
         side_raw = side.cuda_stream
 

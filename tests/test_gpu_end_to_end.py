@@ -128,6 +128,58 @@ def test_candidate_generation_feeds_the_ranker():
     assert 0.0 <= MAPatK(gt, preds, k=cfg.k) <= 1.0
 
 
+def test_device_built_inference_batches_pipelined_and_selected_without_host_waits():
+    """run_submission.make_predictions on device-built evaluation samples (round 4): `DeviceGraphSampler.iter_users` yields the
+    batches of a user subset through the pipelined iterator — the same batches `sample(users[i*B:(i+1)*B], step=i)` builds —
+    and the per-customer top-k selection runs without a host read (rows by searchsorted over the samples' node offsets).
+    Same customers, same predictions as the generic selection path on the same batches."""
+    from types import SimpleNamespace
+    from laplace_amd import run_submission as RS, synthetic as S
+    from laplace_amd.data.device_sampler import DeviceGraphSampler
+    from laplace_amd.data.matching import PopularItemsMatcher
+    from laplace_amd.model.encoder_decoder import Encoder_Decoder_Model
+    from laplace_amd.model.layers import get_SAGEConv_layers, get_linear_layers
+    from laplace_amd.utils.constants import Constants
+    from laplace_amd.utils.get_info import get_feature_info
+    spec = S.SyntheticSpec(20_000, 3_000, 300_000, seed=5, zipf_s=1.0, communities=8, community_mix=0.8)
+    hetero, users_adj, articles_adj = S.generate_hetero(spec, feature_signal=True)
+    cfg = SimpleNamespace(k=12, num_neighbors=16, n_hop_neighbors=2, positive_edges_ratio=0.5, negative_edges_ratio=3.0, batch_size=32,
+                          num_gnn_layers=2, hidden_layer_size=32, encoder_layer_output_size=16, conv_agg_type="add", num_linear_layers=2,
+                          heterogeneous_prop_agg_type="sum", batch_norm=True, p_dropout_edges=0.0, p_dropout_features=0.0)
+    matchers = [PopularItemsMatcher.from_adjacency(articles_adj, 40)]
+    ev = DeviceGraphSampler(cfg, hetero, users_adj, articles_adj, device=DEV, seed=4, train=False, matchers=matchers, shuffle=False)
+    g = t.Generator().manual_seed(0)
+    users = t.randperm(20_000, generator=g)[:200]                      # 7 batches, the last one short
+    ev.step = 0
+    piped = list(ev.iter_users(users))
+    assert len(piped) == 7 and ev.step == 7
+    for i, b in enumerate(piped):
+        ref = ev.sample(users[32 * i:32 * i + 32], step=i)
+        for key in (Constants.node_user, Constants.node_item):
+            assert t.equal(b[key].n_id, ref[key].n_id) and t.equal(b[key].x, ref[key].x)
+        assert t.equal(b[Constants.edge_key].edge_index, ref[Constants.edge_key].edge_index)
+        assert t.equal(b[Constants.edge_key].edge_label_index, ref[Constants.edge_key].edge_label_index)
+        assert t.equal(b[Constants.edge_key].edge_label, ref[Constants.edge_key].edge_label)
+        assert t.equal(b._seed_users.cpu(), users[32 * i:32 * i + 32])
+    t.manual_seed(3)
+    model = Encoder_Decoder_Model(get_SAGEConv_layers(2, 32, 16, "add"), get_linear_layers(2, 32, 32, 1), get_feature_info(hetero),
+                                  piped[0].metadata(), True, "sum", True, 0.0, 0.0).to(DEV)
+    model.initialize_encoder_input_size(piped[0])
+    with t.no_grad():
+        ev.step = 0
+        c_fast, p_fast = RS.make_predictions(model, ev.iter_users(users), k=12, device=DEV)
+        saved = RS.FAST_SELECT
+        try:
+            RS.FAST_SELECT = False
+            ev.step = 0
+            c_slow, p_slow = RS.make_predictions(model, ev.iter_users(users), k=12, device=DEV)
+        finally:
+            RS.FAST_SELECT = saved
+    assert t.equal(c_fast, users) and t.equal(c_slow, users)
+    assert p_fast.shape == (200, 12) and t.equal(p_fast, p_slow)
+    assert int((p_fast >= 0).sum()) > 200 * 6                          # real candidates were ranked
+
+
 def test_configs3_chain_at_one_tenth_scale_keeps_its_ranking_quality_across_the_hand_off():
     """BASELINE configs[3] ("LightGCN candidate-gen + GNN ranker end-to-end") — the chain bench.py's `e2e_c3` block runs at the
     full H&M shape (tools/e2e_hm_scale.py::run), here at 1/10 of it (137 198 x 10 554 x 3.18 M, planted structure, one held-out

@@ -156,13 +156,10 @@ def run(users=1_371_980, items=105_542, edges=31_800_000, lightgcn_steps=300, li
     stage["eval_sampler_setup_s"] = round(time.perf_counter() - t0, 2)
     eval_u, eval_i = held[0], held[1]
 
-    def eval_batches():
-        for k, lo in enumerate(range(0, eval_u.numel(), ranker_batch)):
-            yield ev.sample(eval_u[lo:lo + ranker_batch], step=k)
-
     sync()
     t0 = time.perf_counter()
-    customers, preds = RS.make_predictions(ranker, eval_batches(), k=12, device=dev)
+    ev.step = 0
+    customers, preds = RS.make_predictions(ranker, ev.iter_users(eval_u), k=12, device=dev)   # sampling pipelined, no host wait per batch
     sync()
     dt = time.perf_counter() - t0
     stage["eval_inference_s"] = round(dt, 2)

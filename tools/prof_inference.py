@@ -47,4 +47,9 @@ with t.no_grad():
     print("make_predictions on a fixed batch (forward + selection + .cpu()): %.3f ms" % timed(lambda i: RS.make_predictions(model, [b], k=12, device=dev)))
     t0 = time.perf_counter()
     c, p = RS.make_predictions(model, (ev.sample(eval_u[128 * i:128 * i + 128], step=i) for i in range(N)), k=12, device=dev)
-    sync(); print("the loop: %.3f ms / batch; nodes per batch %s" % (1e3 * (time.perf_counter() - t0) / N, {k: v.shape[0] for k, v in b.x_dict.items()}))
+    sync(); print("the loop, one ev.sample per batch: %.3f ms / batch; nodes per batch %s" % (1e3 * (time.perf_counter() - t0) / N, {k: v.shape[0] for k, v in b.x_dict.items()}))
+    ev.step = 0
+    t0 = time.perf_counter()
+    c2, p2 = RS.make_predictions(model, ev.iter_users(eval_u), k=12, device=dev)
+    sync(); print("the loop, ev.iter_users (sampling pipelined): %.3f ms / batch = %.0f users/s; same predictions: %s" % (
+        1e3 * (time.perf_counter() - t0) / N, 128 * N / (time.perf_counter() - t0), bool(t.equal(p, p2))))
