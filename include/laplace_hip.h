@@ -687,6 +687,11 @@ typedef struct mi_ranker_batch {
      * aux_stream: a hipStream_t; ev_fork / ev_join: two hipEvent_t (timing disabled) owned by the caller and used by no one
      * else while the call is in flight.  All three null = everything on `stream`.  Results do not depend on it. */
     void *aux_stream, *ev_fork, *ev_join;
+    /* INFERENCE (round 4; model(x, edge_index, edge_label_index) under model.eval(): run_submission.py:55-58): non-null =
+     * forward only, in evaluation mode — no dropout, BatchNorm with its running statistics (required) — and the decoder's
+     * output per label edge goes to logits[n_label].  label / label_f32 / loss, every gradient pointer of the model and its
+     * parameter list are then neither required nor read; nothing of the model is written. */
+    float* logits;
 } mi_ranker_batch;
 int64_t mi_ranker_sizeof(int32_t which);  /* sizeof of: 0 model, 1 batch, 2 conv, 3 norm, 4 linear, 5 param (binding self-check) */
 size_t mi_ranker_step_workspace_bytes(const mi_ranker_model* model, const mi_ranker_batch* batch);

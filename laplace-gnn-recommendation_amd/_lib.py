@@ -108,7 +108,8 @@ class RankerBatch(Structure):
     _fields_ = [("n_nodes", c_int64 * 2), ("x", c_void_p * 2), ("by_customer_ptr", c_void_p), ("by_customer_col", c_void_p),
                 ("by_article_ptr", c_void_p), ("by_article_col", c_void_p), ("nnz", c_int64), ("n_label", c_int64),
                 ("label_row", c_void_p), ("label_col", c_void_p), ("label", c_void_p), ("seed", c_uint64), ("step", c_uint64),
-                ("loss", c_void_p), ("label_f32", c_void_p), ("aux_stream", c_void_p), ("ev_fork", c_void_p), ("ev_join", c_void_p)]
+                ("loss", c_void_p), ("label_f32", c_void_p), ("aux_stream", c_void_p), ("ev_fork", c_void_p), ("ev_join", c_void_p),
+                ("logits", c_void_p)]
 
 
 MI_PINSAGE_MAX_LAYERS = 4

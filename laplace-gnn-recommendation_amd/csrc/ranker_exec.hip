@@ -254,7 +254,11 @@ int Exec::run() {
     const int L = M.n_enc_layers, LD = M.n_dec_layers;
     const int64_t n[2] = {B.n_nodes[0], B.n_nodes[1]};
     const int64_t nnz = B.nnz, nl = B.n_label;
-    const bool drop = M.p_dropout > 0.f;
+    // INFERENCE (batch->logits non-null, round 4): the forward launches only, in evaluation mode — no dropout, BatchNorm with
+    // its running statistics — and the decoder's output per label edge written to batch->logits; gradient, optimizer, label
+    // and loss fields are neither required nor read.
+    const bool infer = B.logits != nullptr;
+    const bool drop = M.p_dropout > 0.f && !infer;
     // relation r: src / dst type, forward CSR (rows = dst), backward CSR (rows = src)
     const int src_of[2] = {0, 1}, dst_of[2] = {1, 0};
     const int32_t* fptr[2] = {B.by_article_ptr, B.by_customer_ptr};
@@ -280,19 +284,20 @@ int Exec::run() {
             for (int c = 0; c < M.n_cols[t]; ++c)
                 if (M.dims[t][c] < 1 || M.dims[t][c] > 4096 || M.table_rows[t][c] < 1 || !M.tables[t][c]) return MI_ERR_BAD_ARG;
         }
-        if (!B.by_customer_ptr || !B.by_article_ptr || !B.label_row || !B.label_col || (!B.label && !B.label_f32) || !B.loss) return MI_ERR_BAD_ARG;
+        if (!B.by_customer_ptr || !B.by_article_ptr || !B.label_row || !B.label_col) return MI_ERR_BAD_ARG;
+        if (!infer && ((!B.label && !B.label_f32) || !B.loss)) return MI_ERR_BAD_ARG;
         if (nnz > 0 && (!B.by_customer_col || !B.by_article_col)) return MI_ERR_BAD_ARG;
         for (int l = 0; l < L; ++l)
             for (int r = 0; r < 2; ++r) {
                 const mi_ranker_conv& cv = M.conv[l][r];
                 if (cv.c_src < 1 || cv.c_dst < 1 || cv.c_out < 1 || cv.c_src > 4096 || cv.c_dst > 4096 || cv.c_out > 4096) return MI_ERR_UNSUPPORTED;
-                if (!cv.w_l || !cv.w_r || !cv.gw_l || !cv.gw_r || (cv.b_l && !cv.gb_l)) return MI_ERR_BAD_ARG;
+                if (!cv.w_l || !cv.w_r || (!infer && (!cv.gw_l || !cv.gw_r || (cv.b_l && !cv.gb_l)))) return MI_ERR_BAD_ARG;
             }
         for (int j = 0; j < LD; ++j) {
             const mi_ranker_linear& ln = M.dec[j];
-            if (ln.in < 1 || ln.out < 1 || ln.in > 4096 || ln.out > 4096 || !ln.w || !ln.gw || (ln.b && !ln.gb)) return MI_ERR_BAD_ARG;
+            if (ln.in < 1 || ln.out < 1 || ln.in > 4096 || ln.out > 4096 || !ln.w || (!infer && (!ln.gw || (ln.b && !ln.gb)))) return MI_ERR_BAD_ARG;
         }
-        for (int i = 0; i < M.n_params; ++i) {
+        for (int i = 0; i < M.n_params && !infer; ++i) {
             const mi_ranker_param& q = M.params[i];
             if (!q.p || !q.g || !q.m || !q.v || q.n < 0 || !mi_aligned16(q.p) || !mi_aligned16(q.g) || !mi_aligned16(q.m) || !mi_aligned16(q.v))
                 return MI_ERR_UNSUPPORTED;
@@ -387,8 +392,8 @@ int Exec::run() {
         for (int r = 0; r < 2; ++r) {
             const mi_ranker_conv& cv = M.conv[l][r];
             const int st = src_of[r], dt = dst_of[r];
-            if (mode == CHECK && (cv.c_src != cw[st] || cv.c_dst != cw[dt] || !cv.w_l || !cv.w_r || !cv.gw_l || !cv.gw_r ||
-                                  (cv.b_l && !cv.gb_l) || cv.c_src % 4 || cv.c_dst % 4 || cv.c_out % 4))
+            if (mode == CHECK && (cv.c_src != cw[st] || cv.c_dst != cw[dt] || !cv.w_l || !cv.w_r ||
+                                  (!infer && (!cv.gw_l || !cv.gw_r || (cv.b_l && !cv.gb_l))) || cv.c_src % 4 || cv.c_dst % 4 || cv.c_out % 4))
                 return MI_ERR_UNSUPPORTED;
             agg[l][r] = take(n[dt], cv.c_src);
             out[l][r] = take(n[dt], cv.c_out);
@@ -420,13 +425,14 @@ int Exec::run() {
             bn_ws[t] = take_bytes(bn_ws_bytes);
             on(t);
             const mi_ranker_norm& bn = M.norm[t];
-            if (mode == CHECK && ((bn.gamma && (!bn.beta || !bn.g_gamma || !bn.g_beta)) || C > 512)) return MI_ERR_UNSUPPORTED;
+            if (mode == CHECK && ((bn.gamma && (!bn.beta || (!infer && (!bn.g_gamma || !bn.g_beta)))) || C > 512)) return MI_ERR_UNSUPPORTED;
+            if (mode == CHECK && infer && (!bn.running_mean || !bn.running_var)) return MI_ERR_UNSUPPORTED;   // evaluation mode needs the statistics
             z[t] = take(n[t], C);
             bn_mean[t] = take(C, 1);
             bn_inv[t] = take(C, 1);
         }
         bool done = false;
-        if (go() && twin()) {
+        if (go() && twin() && !infer) {
             mi_pairs::BnSide q[2];
             for (int t = 0; t < kTypes; ++t) {
                 const mi_ranker_norm& bn = M.norm[t];
@@ -440,7 +446,7 @@ int Exec::run() {
             on(t);
             if (go())
                 ok(mi_batchnorm_fwd_f32(n[t], C, zpre[t], C, bn.gamma, bn.beta, bn.running_mean, bn.running_var, bn.momentum, bn.eps,
-                                        1, bn_mean[t], bn_inv[t], z[t], C, bn_ws[t], bn_ws_bytes, (mi_stream_t)cur));
+                                        infer ? 0 : 1, bn_mean[t], bn_inv[t], z[t], C, bn_ws[t], bn_ws_bytes, (mi_stream_t)cur));
         }
         on(1);
         join();
@@ -460,14 +466,14 @@ int Exec::run() {
     for (int j = 0; j < LD; ++j) {
         const mi_ranker_linear& ln = M.dec[j];
         const bool last = j == LD - 1;
-        if (mode == CHECK && (ln.in != hw || !ln.w || !ln.gw || (ln.b && !ln.gb) || (last && ln.out != 1))) return MI_ERR_UNSUPPORTED;
+        if (mode == CHECK && (ln.in != hw || !ln.w || (!infer && (!ln.gw || (ln.b && !ln.gb))) || (last && ln.out != 1))) return MI_ERR_UNSUPPORTED;
         din[j] = h;
         if (!last && drop) {
             din[j] = take(nl, hw);
             if (j == 0 && mode == LAUNCH && gc_fused) din[j] = h;   // h already holds the dropped rows (the spare buffer stays unused)
             else dropout(h, din[j], nl * hw, (uint32_t)(64 + j));
         }
-        dout[j] = take(nl, ln.out);
+        dout[j] = (infer && last) ? B.logits : take(nl, ln.out);
         const size_t need = mi_gemm_workspace_bytes(nl, ln.out, hw);
         char* w = need ? take_bytes(need) : nullptr;
         if (go())
@@ -475,6 +481,7 @@ int Exec::run() {
         h = dout[j];
         hw = ln.out;
     }
+    if (infer) return oom ? MI_ERR_WORKSPACE : rc;   // the logits are where the caller asked for them
     // ---- loss (b9)
     float* dlogits = take(nl, 1);
     if (go()) ok(mi_bce_logits_f32(nl, h, B.label_f32 ? B.label_f32 : label_f, B.loss, dlogits, (mi_stream_t)s));

@@ -70,6 +70,23 @@ class NativeRankerStep:
     # ------------------------------------------------------------------------------------------
     @staticmethod
     def unsupported_reason(model, optimizer) -> Optional[str]:
+        why = NativeRankerStep.model_unsupported_reason(model)
+        if why:
+            return why
+        if type(optimizer) is not t.optim.Adam or len(optimizer.param_groups) != 1:
+            return "optimizer other than a single-group torch.optim.Adam"
+        g = optimizer.param_groups[0]
+        if g.get("amsgrad") or g.get("weight_decay", 0) or g.get("maximize") or g.get("capturable") or g.get("differentiable"):
+            return "Adam options (amsgrad / weight_decay / maximize / capturable)"
+        if isinstance(g["lr"], Tensor):
+            return "tensor learning rate"
+        if len(g["params"]) > _lib.MI_RANKER_MAX_PARAMS or any(p.dtype != t.float32 or not p.is_cuda for p in g["params"]):
+            return "parameter list"
+        return None
+
+    @staticmethod
+    def model_unsupported_reason(model) -> Optional[str]:
+        """The model half of unsupported_reason (NativeRankerForward has no optimizer)."""
         if not isinstance(model, Encoder_Decoder_Model):
             return "not an Encoder_Decoder_Model"
         enc, dec = model.encoder, model.decoder
@@ -97,15 +114,6 @@ class NativeRankerStep:
         for tables in model.embedding_layers.values():
             if len(tables) > _lib.MI_RANKER_MAX_COLS:
                 return "more categorical columns than the executor takes"
-        if type(optimizer) is not t.optim.Adam or len(optimizer.param_groups) != 1:
-            return "optimizer other than a single-group torch.optim.Adam"
-        g = optimizer.param_groups[0]
-        if g.get("amsgrad") or g.get("weight_decay", 0) or g.get("maximize") or g.get("capturable") or g.get("differentiable"):
-            return "Adam options (amsgrad / weight_decay / maximize / capturable)"
-        if isinstance(g["lr"], Tensor):
-            return "tensor learning rate"
-        if len(g["params"]) > _lib.MI_RANKER_MAX_PARAMS or any(p.dtype != t.float32 or not p.is_cuda for p in g["params"]):
-            return "parameter list"
         return None
 
     @classmethod
@@ -387,3 +395,152 @@ class NativeRankerStep:
             for s in steps:                 # the default Adam's host scalars
                 s += 1
         return loss
+
+
+class NativeRankerForward:
+    """model(x_dict, edge_index_dict, edge_label_index) under model.eval() as ONE C call (mi_ranker_step_f32 with
+    mi_ranker_batch.logits set: the executor's forward launches only, no dropout, BatchNorm with its running statistics).
+    run_submission.make_predictions' loop is bound by the Python side of the op-by-op forward (0.69 of a 1.2 ms batch of 128
+    customers, tools/prof_inference.py); this is that forward without it.  `logits(...)` returns the decoder's output per label
+    edge as float32[n_label], or None when the executor does not take the model / batch (the caller runs the model itself)."""
+
+    def __init__(self, model: Encoder_Decoder_Model):
+        why = NativeRankerStep.model_unsupported_reason(model)
+        if not why and model.batch_normalize:
+            for bn in (model.encoder_layer_norm_customer, model.encoder_layer_norm_article):
+                if not bn.track_running_stats or bn.running_mean is None:
+                    why = "BatchNorm without running statistics"
+        if not why and not all(p.is_cuda and p.dtype == t.float32 for p in model.parameters()):
+            why = "parameters not float32 on the GPU"
+        if why:
+            raise ValueError(f"NativeRankerForward: {why}")
+        self.model = model
+        self._desc: Optional[RankerModel] = None
+        self._ptrs = None
+        self._ws: Optional[Tensor] = None
+        self.declined: Optional[str] = None
+
+    @classmethod
+    def supports(cls, model) -> bool:
+        try:
+            cls(model)
+            return True
+        except ValueError:
+            return False
+
+    def _tensors(self):
+        """Every tensor the descriptor points into, in a fixed order (its pointers are the descriptor's identity)."""
+        model = self.model
+        out = []
+        for key in (Constants.node_user, Constants.node_item):
+            out += list(model.embedding_layers[key])
+        for convs in model.encoder.layers:
+            for et in (Constants.edge_key, Constants.rev_edge_key):
+                conv = convs[_key(tuple(et))]
+                out += [conv.lin_l.weight, conv.lin_r.weight] + ([conv.lin_l.bias] if conv.lin_l.bias is not None else [])
+        for bn in (model.encoder_layer_norm_customer, model.encoder_layer_norm_article):
+            out += [x for x in (bn.weight, bn.bias, bn.running_mean, bn.running_var) if x is not None]
+        for layer in model.decoder.layers:
+            out += [layer.weight] + ([layer.bias] if layer.bias is not None else [])
+        return out
+
+    def _build(self) -> RankerModel:
+        model = self.model
+        enc, dec = model.encoder, model.decoder
+        d = RankerModel()
+        d.n_enc_layers, d.n_dec_layers = len(enc.layers), len(dec.layers)
+        first = next(iter(enc.layers[0].values()))
+        d.aggr = 1 if first.aggr == "mean" else 0
+        d.batch_normalize = 1 if model.batch_normalize else 0
+        d.max_norm = 1.0
+        for ti, key in enumerate((Constants.node_user, Constants.node_item)):
+            tables = model.embedding_layers[key]
+            d.n_cols[ti] = len(tables)
+            for c, tb in enumerate(tables):
+                if not tb.is_contiguous():
+                    raise ValueError("embedding tables must be contiguous")
+                d.tables[ti][c], d.table_rows[ti][c], d.dims[ti][c] = tb.data_ptr(), int(tb.shape[0]), int(tb.shape[1])
+        for l, convs in enumerate(enc.layers):
+            for r, et in enumerate((Constants.edge_key, Constants.rev_edge_key)):
+                conv = convs[_key(tuple(et))]
+                cv = d.conv[l][r]
+                cv.w_l, cv.w_r = conv.lin_l.weight.data_ptr(), conv.lin_r.weight.data_ptr()
+                if conv.lin_l.bias is not None:
+                    cv.b_l = conv.lin_l.bias.data_ptr()
+                cv.c_out, cv.c_src = (int(x) for x in conv.lin_l.weight.shape)
+                cv.c_dst = int(conv.lin_r.weight.shape[1])
+        for ti, bn in enumerate((model.encoder_layer_norm_customer, model.encoder_layer_norm_article)):
+            nm = d.norm[ti]
+            if bn.weight is not None:
+                nm.gamma, nm.beta = bn.weight.data_ptr(), bn.bias.data_ptr()
+            if bn.track_running_stats and bn.running_mean is not None:
+                nm.running_mean, nm.running_var = bn.running_mean.data_ptr(), bn.running_var.data_ptr()
+            nm.momentum, nm.eps = float(bn.momentum if bn.momentum is not None else 0.1), float(bn.eps)
+        for j, layer in enumerate(dec.layers):
+            ln = d.dec[j]
+            ln.w = layer.weight.data_ptr()
+            if layer.bias is not None:
+                ln.b = layer.bias.data_ptr()
+            ln.out, ln.in_ = (int(x) for x in layer.weight.shape)
+        d.n_params = 0
+        d.p_dropout = 0.0
+        return d
+
+    def logits(self, x_dict: Dict[str, Tensor], edge_index_dict: dict, edge_label_index: Tensor) -> Optional[Tensor]:
+        self.declined = None
+        ei = None
+        for k, v in edge_index_dict.items():
+            if tuple(k) == tuple(Constants.edge_key):
+                ei = v
+        xc, xa = x_dict.get(Constants.node_user), x_dict.get(Constants.node_item)
+        if ei is None or xc is None or xa is None or edge_label_index.dtype != t.int64 or xc.dtype != t.int64 or xa.dtype != t.int64:
+            self.declined = "no buys relation, or features / label index not int64"
+            return None
+        if not xc.is_cuda:
+            self.declined = "batch not on the GPU"
+            return None
+        ptrs = tuple(x.data_ptr() for x in self._tensors())
+        if self._desc is None or ptrs != self._ptrs:     # a table / weight / buffer was replaced (load_state_dict keeps storages; .to() does not)
+            self._desc, self._ptrs = self._build(), ptrs
+        d = self._desc
+        n_c, n_a = int(xc.shape[0]), int(xa.shape[0])
+        pre = getattr(ei, "_sorted_csr", None)
+        if pre is not None and pre[0].n_rows == n_c and pre[1].n_rows == n_a:
+            by_c, by_a = pre
+        else:
+            src, dst = ei[0].contiguous(), ei[1].contiguous()
+            by_c = ops.coo_to_csr(src, dst, n_c, n_a, want_perm=False)
+            by_a = ops.coo_to_csr(dst, src, n_a, n_c, want_perm=False)
+        xc, xa = xc.contiguous(), xa.contiguous()
+        row, col = edge_label_index[0].contiguous(), edge_label_index[1].contiguous()
+        n_lab = int(row.numel())
+        if n_lab == 0:
+            return t.empty(0, dtype=t.float32, device=xc.device)
+        ones = _ones4(max(n_c, n_a, n_lab), xc.device)
+        d.ones4, d.n_ones = ones.data_ptr(), int(ones.shape[0])
+        out = t.empty(n_lab, dtype=t.float32, device=xc.device)
+        b = RankerBatch()
+        b.n_nodes[0], b.n_nodes[1] = n_c, n_a
+        b.x[0], b.x[1] = xc.data_ptr(), xa.data_ptr()
+        b.by_customer_ptr, b.by_customer_col = by_c.rowptr.data_ptr(), (by_c.col.data_ptr() if by_c.nnz else by_c.rowptr.data_ptr())
+        b.by_article_ptr, b.by_article_col = by_a.rowptr.data_ptr(), (by_a.col.data_ptr() if by_a.nnz else by_a.rowptr.data_ptr())
+        b.nnz, b.n_label = by_c.nnz, n_lab
+        b.label_row, b.label_col = row.data_ptr(), col.data_ptr()
+        b.logits = out.data_ptr()
+        L = _lib.lib()
+        for attempt in (0, 1):
+            if self._ws is None or attempt == 1:
+                need = int(L.mi_ranker_step_workspace_bytes(ctypes.byref(d), ctypes.byref(b)))
+                if need == 0:
+                    self.declined = "mi_ranker_step_f32: shape outside the executor's"
+                    return None
+                self._ws = t.empty(int(need * 1.25) + (1 << 20), dtype=t.uint8, device=xc.device)
+            rc = L.mi_ranker_step_f32(ctypes.byref(d), ctypes.byref(b), self._ws.data_ptr(), self._ws.numel(), _lib.current_stream())
+            if rc != _lib.MI_ERR_WORKSPACE:
+                break
+        if rc == _lib.MI_ERR_UNSUPPORTED:
+            self.declined = "mi_ranker_step_f32: MI_ERR_UNSUPPORTED (shape outside the executor's)"
+            return None
+        _lib.check(rc, "mi_ranker_step_f32 (inference)")
+        self._keep = (xc, xa, row, col, ones, by_c, by_a)   # until the next call: the launches may still be reading them
+        return out

@@ -59,7 +59,8 @@ def build_model(config: Config, full_data, first_batch, state_dict: Optional[dic
     return model
 
 
-FAST_SELECT = True   # tests switch it off to compare the two selection paths
+FAST_SELECT = True      # tests switch these off to compare the paths
+NATIVE_FORWARD = True   # the model's evaluation forward as one C call where the executor takes the model
 
 
 @t.no_grad()
@@ -69,11 +70,18 @@ def make_predictions(model, dataloader, k: int, device: str = "cuda") -> Tuple[T
     are articles the customer already bought)."""
     model.eval()
     customers, predictions = [], []
+    native = None
+    if NATIVE_FORWARD and str(device).startswith("cuda"):
+        from .ranker_native import NativeRankerForward
+        if NativeRankerForward.supports(model):
+            native = NativeRankerForward(model)      # the forward as one C call (mi_ranker_batch.logits); declines fall to model(...)
     for batch in dataloader:
         seeds, user_ptr = getattr(batch, "_seed_users", None), getattr(batch, "_user_ptr", None)
         batch = batch.to(device)
         x, edge_index_dict, edge_label_index, edge_label = select_properties(batch)
-        scores = model(x, edge_index_dict, edge_label_index).view(-1)
+        scores = native.logits(x, edge_index_dict, edge_label_index) if native is not None else None
+        if scores is None:
+            scores = model(x, edge_index_dict, edge_label_index).view(-1)
         if seeds is not None and user_ptr is not None and FAST_SELECT:
             # a device-built batch (data/device_sampler.py): sample s owns the customer nodes [user_ptr[s], user_ptr[s + 1]) and its
             # label edges are contiguous, so the row of a label edge is a searchsorted away and nothing below needs a host read —
