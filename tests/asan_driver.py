@@ -139,6 +139,27 @@ def main():
         run(f"ranker valid {kw}", *rk, *ranker_case(**kw), want=0)
     for kw in (dict(), dict(hidden=64), dict(hidden=128, layers=1, sizes=((93, 93, 0),))):
         run(f"pinsage valid {kw}", *pn, *pinsage_case(**kw), want=0)
+    # ---- inference descriptors (round 4: mi_ranker_batch.logits): no gradient pointers, no parameter list, no labels / loss
+    def inference_case(**kw):
+        d, b, f = ranker_case(**kw)
+        b.logits, b.loss, b.label, b.label_f32 = f(4 * int(b.n_label)), None, None, None
+        for l in range(int(d.n_enc_layers)):
+            for r in range(2):
+                d.conv[l][r].gw_l = d.conv[l][r].gw_r = d.conv[l][r].gb_l = None
+        for t_ in range(2):
+            d.norm[t_].g_gamma = d.norm[t_].g_beta = None
+        for j in range(int(d.n_dec_layers)):
+            d.dec[j].gw = d.dec[j].gb = None
+        d.n_params = 0
+        return d, b, f
+    for kw in (dict(), dict(mean=True), dict(n_c=32_000, n_a=9_000, nnz=46_000, n_label=3_000)):
+        run(f"ranker inference valid {kw}", *rk, *inference_case(**kw), want=0)
+    d, b, f = inference_case()
+    d.norm[1].running_mean = None
+    run("ranker inference without running statistics", *rk, d, b, f, want=UNSUPPORTED)
+    d, b, f = inference_case()
+    d.dec[0].w = None
+    run("ranker inference without a decoder weight", *rk, d, b, f, want=UNSUPPORTED)
     # ---- truncated / out-of-range descriptors: counts beyond the fixed arrays, negative sizes, missing pointers
     def mut(case, **fields):
         d, b, f = case
