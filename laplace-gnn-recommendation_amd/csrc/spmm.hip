@@ -347,7 +347,7 @@ __global__ __launch_bounds__(kBlock) void spmm_rows_pair_kernel(RowsSide a, Rows
     ep.streaming = MI_PICK(ep.streaming);
     ep.p = nullptr; ep.ldp4 = 0; ep.m = nullptr; ep.v = nullptr; ep.reg_w = nullptr;
     ep.adam = MiAdamConsts{};
-    const Ex ex = {nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0};
+    const Ex ex = {nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, nullptr, nullptr};
     spmm_rows_body<LPR, 1, UNROLL, MI_SPMM_ROWS_RPS, false, false>(first ? blockIdx.x : blockIdx.x - split, first ? split : gridDim.x - split,
                                                                   MI_PICK(n_out), MI_PICK(d4), MI_PICK(rowptr), MI_PICK(col), MI_PICK(val),
                                                                   MI_PICK(X4), MI_PICK(ldx4), ep, INT32_MAX, ex, 1);
