@@ -296,20 +296,21 @@ def roofline_block(events, nnz: int, n_rows: int, D: int, steps: int, traffic, t
             "dense_with_adam_epilogue_avg_ms": (sum(fused_ms) / len(fused_ms)) if fused_ms else None}
 
 
-def offline_traffic(default_workload: bool):
-    """profiles/traffic.json (tools/prof_bench.sh): used only when the live passes are off or failed; refused when the
-    kernels or the host code that shapes their launches changed since it was collected."""
-    tf = os.path.join(ROOT, "profiles", "traffic.json")
+def offline_traffic(default_workload: bool, config: str = "c4"):
+    """profiles/traffic.json (tools/prof_bench.sh on the DEFAULT configuration, BASELINE configs[3]; traffic_c2.json for
+    --config c2): used only when the live passes are off or failed; refused when the kernels or the host code that shapes
+    their launches changed since it was collected."""
+    tf = os.path.join(ROOT, "profiles", "traffic.json" if config == "c4" else f"traffic_{config}.json")
     if not (os.path.exists(tf) and default_workload):
         return None, None
     try:
         tj = json.load(open(tf))
         if tj.get("kernel_source_hash") == kernel_source_hash():
             return tj.get("spmm_hbm_bytes_per_launch"), (
-                f"profiles/traffic.json <- {tj.get('source')}: offline rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on "
+                f"{os.path.basename(tf)} <- {tj.get('source')}: offline rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on "
                 f"the code with hash {tj.get('kernel_source_hash')} (matches this build); (2*FETCH_SIZE+WRITE_SIZE)*1024 per "
                 f"MI355X_MICROARCH.md; counts L2 misses incl. Infinity-Cache hits, i.e. an upper bound on HBM bytes")
-        return None, "profiles/traffic.json is stale (kernel or launch code changed since it was collected): not used"
+        return None, f"profiles/{os.path.basename(tf)} is stale (kernel or launch code changed since it was collected): not used"
     except Exception:
         return None, None
 
@@ -594,7 +595,7 @@ def main():
     tl = _leg("import_and_graph_setup", tl)
     spec, ei, U, I, D, K, B = w["spec"], w["ei"], w["U"], w["I"], w["D"], w["K"], w["B"]
     model, inter, adj, trainer, strong = w["model"], w["inter"], w["adj"], w["trainer"], w["strong"]
-    default_workload = args.config == "c2" and not custom_size and (D, K) == (128, 3)
+    default_workload = not custom_size and (D, K) == (128, 3)   # the sizes the offline traffic files were collected on
     nnz, n_rows = trainer.adj_fwd.nnz, trainer.adj_fwd.n_rows
     t.cuda.synchronize()
 
@@ -623,7 +624,7 @@ def main():
             if traffic is None:
                 traffic_src = f"live PMC passes failed ({traffic_src})"
         if traffic is None and world == 1:
-            off, off_src = offline_traffic(default_workload)
+            off, off_src = offline_traffic(default_workload, args.config)
             if off is not None:
                 traffic, traffic_src = off, off_src
             elif off_src and not traffic_src:
