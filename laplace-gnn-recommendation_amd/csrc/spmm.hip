@@ -32,7 +32,18 @@
 namespace {
 
 #ifndef MI_SPMM_UNROLL
-#define MI_SPMM_UNROLL 8   // row loads in flight per lane (VPL = 1); round-1 A/B: 4 -> 8 gains 2 % with sub-group rows
+#define MI_SPMM_UNROLL 4   // row loads in flight per lane (VPL = 1).  Round 1 (row per wavefront half, C2): 4 -> 8 gained 2 %.  Round 4, on
+                           // today's kernels (tools/exp_c4.py, bench.py --config c2 / c4, same loss to the last digit): 8 -> 4 takes the C2
+                           // step 5.209 -> 5.005 ms (dense launch 0.893 -> 0.851, sparse 0.515 -> 0.488) and C4's dense launch 9.15-9.22 ->
+                           // 9.06-9.12 ms; 2 loses (C4 54.1 ms / step, C2 5.30).  The short-row kernel WITH the Adam epilogue keeps 8
+                           // (C4's Adam launch 12.0-12.15 vs 12.3 ms at 4; same-box triples of the C4 step: mixed 50.84 / all-8 51.21 /
+                           // all-4 51.12 and 51.79 / 51.84 / 52.05 ms)
+#endif
+#ifndef MI_SPMM_UNROLL_ADAM
+#define MI_SPMM_UNROLL_ADAM 8
+#endif
+#ifndef MI_SPMM_UNROLL_PAIR
+#define MI_SPMM_UNROLL_PAIR 8   // the ranker's plan-less twin launches (spmm_rows_pair_kernel): measured at 8 (profiles/r04_ranker_native_timeline.txt)
 #endif
 #ifndef MI_SPMM_ROWS_RPS
 #define MI_SPMM_ROWS_RPS 1  // rows a sub-group handles in sequence; A/B on C2: 1: 1.373 ms, 2: 1.408, 4: 1.397.  Two rows walked
@@ -1264,7 +1275,8 @@ template <int LPR, int VPL, bool SPARSE, bool ADAM>
 int launch_spmm_mode(int64_t n_rows, int d4, const int32_t* rowptr, const int32_t* col, const float* val,
                      const float4* X4, int64_t ldx4, const Epilogue& ep, const mi_spmm_plan* plan,
                      float4* partial, const Ex& ex, int64_t n_list, hipStream_t s, const mi_spmm_sweep* sweep) {
-    constexpr int UNROLL = (VPL == 1) ? MI_SPMM_UNROLL : MI_SPMM_UNROLL / 2;
+    constexpr int UNROLL = (VPL == 1) ? MI_SPMM_UNROLL : 4;                                        // work items, sweep
+    constexpr int UNROLL_ROWS = (VPL == 1) ? (ADAM ? MI_SPMM_UNROLL_ADAM : MI_SPMM_UNROLL) : 4;   // the short-row kernel (the one that carries the Adam epilogue)
     constexpr int SG = (MI_WAVE / LPR) * kWavesPerBlock;
     constexpr int ROWS_RPS = MI_SPMM_ROWS_RPS;
 #ifndef MI_SPMM_ITEMS_SLOTS
@@ -1371,7 +1383,7 @@ int launch_spmm_mode(int64_t n_rows, int d4, const int32_t* rowptr, const int32_
     if (do_short && n_out > 0 && !short_done) {
         dim3 gr((unsigned)mi_ceil_div(n_out, SG * ROWS_RPS));
         if (MI_SPMM_XCD_RANGES && !listed) gr.x = (gr.x + 7u) / 8u * 8u;
-        hipLaunchKernelGGL((spmm_rows_kernel<LPR, VPL, UNROLL, ROWS_RPS, SPARSE, ADAM>), gr, dim3(kBlock), 0, s, n_out, d4,
+        hipLaunchKernelGGL((spmm_rows_kernel<LPR, VPL, UNROLL_ROWS, ROWS_RPS, SPARSE, ADAM>), gr, dim3(kBlock), 0, s, n_out, d4,
                            rowptr, col, val, X4, ldx4, ep, chunk, ex, plan ? 0 : 1);
     }
     if (do_split && plan && plan->n_long_rows > 0) {
@@ -1716,7 +1728,7 @@ template <int LPR>
 static int launch_rows_pair(const RowsSide& a, const RowsSide& b, hipStream_t s) {
     constexpr int SG = (MI_WAVE / LPR) * kWavesPerBlock;
     const unsigned ga = (unsigned)mi_ceil_div(a.n_out, SG * MI_SPMM_ROWS_RPS), gb = (unsigned)mi_ceil_div(b.n_out, SG * MI_SPMM_ROWS_RPS);
-    hipLaunchKernelGGL((spmm_rows_pair_kernel<LPR, MI_SPMM_UNROLL>), dim3(ga + gb), dim3(kBlock), 0, s, a, b, ga);
+    hipLaunchKernelGGL((spmm_rows_pair_kernel<LPR, MI_SPMM_UNROLL_PAIR>), dim3(ga + gb), dim3(kBlock), 0, s, a, b, ga);
     return mi_launch_status();
 }
 
